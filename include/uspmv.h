@@ -1,0 +1,206 @@
+/*
+ * uspmv.h -- C ABI of the MI355X-native SELL-C-sigma SpMV / SpMMV engine (libuspmv.so).
+ *
+ * Drop-in boundary for the scs/crs kernel path of RRZE-HPC/Ultimate-SpMV.  The reference has no
+ * FFI; its seam is the C++ function-pointer type SpmvKernel::OnePrecFuncPtr / MultiPrecFuncPtr
+ * (code/classes_structs.hpp:283-333) and the free functions of code/interface.hpp.  Every entry
+ * point below names the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; indices are 32-bit (`IT = int`, code/main.cpp:1711-1718),
+ *     sizes 64-bit (`ST = long`, code/classes_structs.hpp:31);
+ *   - every function returns a uspmv_status (0 = success) and NEVER calls exit(); the text of
+ *     the last failure of the calling thread is available from uspmv_last_error();
+ *   - pointers prefixed d_ are device (HBM) pointers of the current HIP device; all others are
+ *     host pointers;  `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - device entry points are asynchronous with respect to the host (the reference's launchers
+ *     call cudaDeviceSynchronize, code/classes_structs.hpp:1032-1034; callers that need that
+ *     behaviour call uspmv_stream_synchronize);
+ *   - there is NO CPU fallback: device entry points fail with USPMV_ERR_NO_DEVICE / USPMV_ERR_HIP
+ *     when no gfx950 device is usable.
+ */
+#ifndef USPMV_H
+#define USPMV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    USPMV_OK = 0,
+    USPMV_ERR_INVALID = 1,     /* bad argument (NULL, negative size, unknown enum ...)        */
+    USPMV_ERR_IO = 2,          /* file cannot be opened / parsed                               */
+    USPMV_ERR_UNSUPPORTED = 3, /* valid request the engine does not implement                  */
+    USPMV_ERR_OVERFLOW = 4,    /* a 32-bit index would overflow (code/utilities.hpp:1959-1962) */
+    USPMV_ERR_NO_DEVICE = 5,   /* no HIP device visible                                        */
+    USPMV_ERR_HIP = 6,         /* a HIP runtime call failed                                    */
+    USPMV_ERR_ALLOC = 7
+} uspmv_status;
+
+typedef enum { USPMV_F64 = 0, USPMV_F32 = 1 } uspmv_dtype;            /* -dp / -sp              */
+typedef enum { USPMV_COLWISE = 0, USPMV_ROWWISE = 1 } uspmv_layout;   /* Makefile:26-31         */
+typedef enum { USPMV_SEG_ROWS = 0, USPMV_SEG_NNZ = 1 } uspmv_seg;     /* -seg_rows / -seg_nnz   */
+
+typedef struct uspmv_coo uspmv_coo_t;     /* host COO,           MtxData  code/classes_structs.hpp:1169-1238 */
+typedef struct uspmv_scs uspmv_scs_t;     /* host SELL-C-sigma,  ScsData  code/classes_structs.hpp:1313-1339 */
+typedef struct uspmv_dmat uspmv_dmat_t;   /* device-resident SCS (what assign_spmv_kernel_gpu_data
+                                             uploads, code/utilities.hpp:3721-3811)                         */
+typedef struct uspmv_halo uspmv_halo_t;   /* per-rank halo description (ContextData,
+                                             code/classes_structs.hpp:156-184)                             */
+
+const char *uspmv_status_string(int status);
+const char *uspmv_last_error(void);
+const char *uspmv_version(void);
+
+/* ------------------------------------------------------------------ L1: COO / MatrixMarket */
+/* read_mtx (code/utilities.hpp:2148-2309) + mm_read_unsymmetric_sparse (code/mmio.h:132-263):
+ * real / integer / pattern (= 0.01) coordinate files, general or symmetric (expanded), entries
+ * stable-sorted by row. */
+int uspmv_read_mtx(const char *path, uspmv_coo_t **out);
+/* MtxData filled by a host application (API_doc.md:7-9).  Arrays are copied. */
+int uspmv_coo_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *I, const int32_t *J,
+                     const double *values, uspmv_coo_t **out);
+int uspmv_coo_dims(const uspmv_coo_t *m, int64_t *n_rows, int64_t *n_cols, int64_t *nnz);
+/* borrowed pointers, valid until uspmv_coo_free */
+int uspmv_coo_arrays(const uspmv_coo_t *m, const int32_t **I, const int32_t **J, const double **values);
+void uspmv_coo_free(uspmv_coo_t *m);
+
+/* Deterministic synthetic matrices for the BASELINE configurations whose SuiteSparse files are
+ * not available offline: 27-point stencil with `dof` unknowns per grid node on
+ * an nx*ny*nz grid, rows [row_begin,row_end) only (so that every rank of a distributed run
+ * generates just its block; column indices stay global).  Symmetric pattern and values
+ * v(i,j) = hash(min,max,seed) in [-1,1), diagonal 27*dof + u.  magnitude_decades > 0 spreads the
+ * off-diagonal magnitudes log-uniformly over that many decades (HV15R-class, for -ap splits). */
+int uspmv_gen_stencil27(int64_t nx, int64_t ny, int64_t nz, int dof, uint64_t seed, double magnitude_decades,
+                        int64_t row_begin, int64_t row_end, uspmv_coo_t **out);
+
+/* ------------------------------------------------------------------ L2: format conversion */
+/* convert_to_scs (code/utilities.hpp:1842-2104; library twin code/interface.hpp:401-656).
+ * fixed_permutation may be NULL (sigma-window sort by descending row length, std::sort tie order
+ * reproduced) or an old->new row map of n_rows entries (:1911-1928).  dtype selects VT. */
+int uspmv_convert_to_scs(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dtype,
+                         const int32_t *fixed_permutation, uspmv_scs_t **out);
+/* meta[8] = C, sigma, n_rows, n_cols, n_rows_padded, n_chunks, n_elements, nnz */
+int uspmv_scs_meta(const uspmv_scs_t *s, int64_t meta[8]);
+int uspmv_scs_dtype(const uspmv_scs_t *s, int *dtype);
+/* borrowed pointers (chunk_ptrs[n_chunks+1], chunk_lengths[n_chunks], col_idxs/values[n_elements],
+ * old_to_new_idx/new_to_old_idx[n_rows]); any argument may be NULL */
+int uspmv_scs_arrays(const uspmv_scs_t *s, const int32_t **chunk_ptrs, const int32_t **chunk_lengths,
+                     const int32_t **col_idxs, const void **values, const int32_t **old_to_new_idx,
+                     const int32_t **new_to_old_idx);
+/* mutable view of col_idxs (halo set-up rewrites it in place like the reference does) */
+int uspmv_scs_col_idxs_mut(uspmv_scs_t *s, int32_t **col_idxs);
+/* permute_scs_cols (code/utilities.hpp:1802-1831): col = perm[col] where col < n_rows */
+int uspmv_permute_scs_cols(uspmv_scs_t *s, const int32_t *perm);
+void uspmv_scs_free(uspmv_scs_t *s);
+/* apply_permutation (code/utilities.hpp:1768-1782): out[i] = in[perm[i]], host vectors */
+int uspmv_apply_permutation(void *out, const void *in, const int32_t *perm, int64_t n, int dtype);
+/* partition_precisions, ap[dp_sp] non-equilibrated branch (code/utilities.hpp:2899-2911):
+ * |v| >= threshold_1 -> dp, else sp (values rounded to float), COO order kept. */
+int uspmv_partition_precisions(const uspmv_coo_t *m, double threshold_1, uspmv_coo_t **dp, uspmv_coo_t **sp);
+
+/* ------------------------------------------------------------------ L3: device kernels    */
+int uspmv_device_count(int *count);
+int uspmv_set_device(int device);
+int uspmv_stream_synchronize(void *stream);
+
+/* H2D staging of one SCS struct (assign_spmv_kernel_gpu_data, code/utilities.hpp:3721-3811). */
+int uspmv_dmat_upload(const uspmv_scs_t *s, uspmv_dmat_t **out);
+/* Wrap arrays that already live in HBM (owned by the caller, e.g. a framework allocator). */
+int uspmv_dmat_wrap(int64_t C, int64_t n_chunks, int64_t n_elements, int dtype, const int32_t *d_chunk_ptrs,
+                    const int32_t *d_chunk_lengths, const int32_t *d_col_idxs, const void *d_values,
+                    uspmv_dmat_t **out);
+void uspmv_dmat_free(uspmv_dmat_t *m);
+/* Mark a C = 1 struct as "crs" (uspmv <mtx> crs): uspmv_spmv then uses the CRS kernel (several lanes
+ * per row, twin of spmv_omp_csr) instead of the generic SELL kernel (twin of spmv_omp_scs). */
+int uspmv_dmat_set_crs(uspmv_dmat_t *m, int on);
+
+/* y = A x.  Replaces SpmvKernel::execute_one_prec -> spmv_gpu_scs_adv_launcher /
+ * spmv_gpu_scs_launcher / spmv_gpu_csr_launcher (code/classes_structs.hpp:997-1035,
+ * code/kernels.hpp:579-775), i.e. the GPU twins of spmv_omp_scs_adv / spmv_omp_scs /
+ * spmv_omp_csr.  d_x: padded_vec_size elements; d_y: n_rows_padded elements written. */
+int uspmv_spmv(const uspmv_dmat_t *A, const void *d_x, void *d_y, void *stream);
+/* Same over a subset of chunks (d_chunk_ids[n_ids], ascending): interior / boundary split used to
+ * overlap the halo exchange with the kernel (absent in the reference, code/main.cpp:464-468). */
+int uspmv_spmv_chunks(const uspmv_dmat_t *A, const int32_t *d_chunk_ids, int64_t n_ids, const void *d_x,
+                      void *d_y, void *stream);
+/* Y = A X, b right-hand sides.  Replaces block_spmv_gpu_scs_{adv,general}_launcher /
+ * block_spmv_gpu_csr_launcher, which the reference only stubs on GPU (code/kernels.hpp:777-844);
+ * semantics = block_spmv_omp_scs_general (code/kernels.hpp:306-398).  ld = vec_length of the
+ * colwise layout (ignored for rowwise). */
+int uspmv_spmmv(const uspmv_dmat_t *A, const void *d_X, void *d_Y, int b, int64_t ld, int layout, void *stream);
+/* Adaptive precision dp+sp.  Replaces execute_two_prec -> spmv_gpu_ap_scs_adv_launcher
+ * (code/classes_structs.hpp:1037-1075, code/ap_kernels.hpp:821-953); numerics follow the CPU
+ * kernel scs_ap_impl_cpu (code/ap_kernels.hpp:24-82): both parts accumulated in double from the
+ * double x, y = dp_sum + sp_sum.  dp and sp must share C and n_chunks. */
+int uspmv_spmv_ap(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const double *d_x, double *d_y, void *stream);
+
+/* Raw-array forms with the argument lists of the library kernels of code/interface.hpp
+ * (uspmv_scs_gpu :1766-1793, uspmv_scs_c_gpu :1835-1867, uspmv_csr_gpu :1741-1760). */
+int uspmv_scs_gpu_f64(int64_t C, int64_t n_chunks, const int32_t *d_chunk_ptrs, const int32_t *d_chunk_lengths,
+                      const int32_t *d_col_idxs, const double *d_values, const double *d_x, double *d_y,
+                      void *stream);
+int uspmv_scs_gpu_f32(int64_t C, int64_t n_chunks, const int32_t *d_chunk_ptrs, const int32_t *d_chunk_lengths,
+                      const int32_t *d_col_idxs, const float *d_values, const float *d_x, float *d_y,
+                      void *stream);
+int uspmv_csr_gpu_f64(int64_t n_rows, const int32_t *d_row_ptrs, const int32_t *d_col_idxs,
+                      const double *d_values, const double *d_x, double *d_y, void *stream);
+int uspmv_csr_gpu_f32(int64_t n_rows, const int32_t *d_row_ptrs, const int32_t *d_col_idxs,
+                      const float *d_values, const float *d_x, float *d_y, void *stream);
+
+/* Device apply_permutation: d_out[i] = d_in[d_perm[i]] (code/utilities.hpp:1768-1782). */
+int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_perm, int64_t n, int dtype,
+                                void *stream);
+
+/* Kernel-variant selection for A/B measurements (DESIGN.md "variants").  key/value pairs:
+ *   "unroll" 1|2|4|8, "nontemporal" 0|1, "xcd_remap" 0|1, "block" 64|128|256|512,
+ *   "spmv_variant" 0 (lane per row, bit-exact) | 1 (two lanes per row, C=32 only). */
+int uspmv_set_tuning(const char *key, int value);
+int uspmv_get_tuning(const char *key, int *value);
+
+/* ------------------------------------------------------------------ L4: halo exchange     */
+/* seg_work_sharing_arr (code/mpi_funcs.hpp:424-622), seg-rows and seg-nnz: wsa[P+1]. */
+int uspmv_seg_work_sharing_arr(const uspmv_coo_t *total, int seg_method, int P, int32_t *wsa);
+/* seg_mtx_struct + localize_row_idx (code/mpi_funcs.hpp:636-674, :862-877): rows
+ * [wsa[rank], wsa[rank+1]) with process-local row ids and GLOBAL column ids. */
+int uspmv_seg_local_coo(const uspmv_coo_t *total, const int32_t *wsa, int rank, uspmv_coo_t **out);
+/* collect_local_needed_heri (code/mpi_funcs.hpp:242-415): discovers remote columns of the local
+ * SCS struct (scanned in storage order, padding entries included), rewrites col_idxs to
+ * local + halo numbering, and records per owner which of ITS local rows this rank needs. */
+int uspmv_halo_discover(uspmv_scs_t *local_scs, const int32_t *wsa, int rank, int P, uspmv_halo_t **out);
+/* n_halo = recv_counts_cumsum.back(); recv_counts_cumsum[P+1]; recv_idxs grouped by owner rank
+ * ascending with recv_counts[P] entries each (borrowed pointers). */
+int uspmv_halo_meta(const uspmv_halo_t *h, int64_t *n_halo, const int32_t **recv_counts_cumsum,
+                    const int32_t **recv_idxs, const int32_t **recv_counts);
+void uspmv_halo_free(uspmv_halo_t *h);
+/* Chunk ids whose columns are all local (< n_local) and the rest (touch the halo region). Arrays
+ * are malloc'ed; release with uspmv_free. */
+int uspmv_scs_split_chunks(const uspmv_scs_t *s, int64_t n_local, int32_t **interior, int64_t *n_interior,
+                           int32_t **boundary, int64_t *n_boundary);
+void uspmv_free(void *p);
+/* Send-buffer gather for ALL neighbours in one launch over the concatenated index list:
+ * d_send[i] = d_x[d_perm[d_send_idxs[i]] + block_offset].  Replaces pack_send_buf /
+ * pack_d_send_buf (code/classes_structs.hpp:786-855, code/kernels.hpp:554-577: one launch +
+ * device sync per neighbour). */
+int uspmv_pack_send_buf(const void *d_x, const int32_t *d_perm, const int32_t *d_send_idxs, int64_t n,
+                        int64_t block_offset, void *d_send, int dtype, void *stream);
+
+/* ------------------------------------------------------------------ measurement helpers   */
+/* Device STREAM kernels (copy: a=b, triad: a=b+s*c, read: sum-reduce b) used as the roofline
+ * denominator measured in the same run.  n = number of doubles. */
+int uspmv_stream_copy(double *d_a, const double *d_b, int64_t n, void *stream);
+int uspmv_stream_triad(double *d_a, const double *d_b, const double *d_c, double s, int64_t n, void *stream);
+int uspmv_stream_read(const double *d_b, int64_t n, double *d_partial, void *stream);
+/* Time `reps` back-to-back launches of one entry point with HIP events on `stream`;
+ * what: 0 spmv(A,x,y) 1 stream_copy 2 stream_triad 3 stream_read 4 spmv_ap(A,B,x,y)
+ *       5 spmmv(A,X,Y,b,ld,layout).  Returns the average milliseconds per launch. */
+int uspmv_time_launches(int what, int reps, const uspmv_dmat_t *A, const uspmv_dmat_t *B, const void *d_x,
+                        void *d_y, int64_t n, int b, int64_t ld, int layout, void *stream, double *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* USPMV_H */

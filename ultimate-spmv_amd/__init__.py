@@ -1,0 +1,17 @@
+"""uspmv-mi355x: MI355X-native SELL-C-sigma SpMV / SpMMV engine.
+
+The product is the C-ABI shared library ``libuspmv.so`` (host data layer in C++, hand-written
+HIP kernels for gfx950; see include/uspmv.h).  This package is only the thin ctypes front-end used
+by tests/, bench.py and __graft_entry__.py, plus the torch.distributed (RCCL) halo-exchange
+driver.  It never imports anything from ``oracle/`` and has no CPU fallback: device entry points
+raise UspmvError when the HIP extension or a GPU is missing.
+
+The directory name contains a hyphen (repository convention), so import it through
+``__graft_entry__.load_package()`` (module name ``ultimate_spmv_amd``).
+"""
+from .binding import (  # noqa: F401
+    COLWISE, F32, F64, ROWWISE, SEG_NNZ, SEG_ROWS, Coo, DeviceMatrix, HaloPlan, Scs, UspmvError, apply_permutation,
+    build_library, convert_to_scs, device_count, gen_stencil27, get_tuning, lib, library_path, pack_send_buf,
+    partition_precisions, permute_scs_cols, read_mtx, seg_work_sharing_arr, set_tuning, spmmv, spmv, spmv_ap,
+    spmv_chunks, uspmv_csr_gpu, uspmv_scs_gpu,
+)

@@ -1,0 +1,416 @@
+"""ctypes front-end of libuspmv.so (include/uspmv.h).
+
+Names follow the reference's library API (code/interface.hpp, API_doc.md:7-24): MtxData -> Coo,
+ScsData -> Scs, convert_to_scs, partition_precisions, apply_permutation, permute_scs_cols,
+uspmv_scs_gpu, uspmv_csr_gpu.  Device vectors are torch tensors (torch is used for device memory,
+streams and torch.distributed only); their raw pointers are handed to the C ABI.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+F64, F32 = 0, 1
+COLWISE, ROWWISE = 0, 1
+SEG_ROWS, SEG_NNZ = 0, 1
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+
+class UspmvError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(f"libuspmv status {status}: {text}")
+        self.status = status
+
+
+def library_path():
+    return os.path.join(_HERE, "libuspmv.so")
+
+
+def build_library(force=False):
+    """Compile libuspmv.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", _HERE, "all"])
+    return library_path()
+
+
+# every symbol include/uspmv.h declares: name -> (restype, argtypes)
+_SIGS = {
+    "uspmv_status_string": (C.c_char_p, [C.c_int]),
+    "uspmv_last_error": (C.c_char_p, []),
+    "uspmv_version": (C.c_char_p, []),
+    "uspmv_read_mtx": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "uspmv_coo_create": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "uspmv_coo_dims": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "uspmv_coo_arrays": (C.c_int, [_vp, C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_f64p)]),
+    "uspmv_coo_free": (None, [_vp]),
+    "uspmv_gen_stencil27": (C.c_int, [_i64, _i64, _i64, C.c_int, C.c_uint64, C.c_double, _i64, _i64, C.POINTER(_vp)]),
+    "uspmv_convert_to_scs": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, C.POINTER(_vp)]),
+    "uspmv_scs_meta": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "uspmv_scs_dtype": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "uspmv_scs_arrays": (C.c_int, [_vp, C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_vp),
+                                   C.POINTER(_i32p), C.POINTER(_i32p)]),
+    "uspmv_scs_col_idxs_mut": (C.c_int, [_vp, C.POINTER(_i32p)]),
+    "uspmv_permute_scs_cols": (C.c_int, [_vp, _vp]),
+    "uspmv_scs_free": (None, [_vp]),
+    "uspmv_apply_permutation": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int]),
+    "uspmv_partition_precisions": (C.c_int, [_vp, C.c_double, C.POINTER(_vp), C.POINTER(_vp)]),
+    "uspmv_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "uspmv_set_device": (C.c_int, [C.c_int]),
+    "uspmv_stream_synchronize": (C.c_int, [_vp]),
+    "uspmv_dmat_upload": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "uspmv_dmat_wrap": (C.c_int, [_i64, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "uspmv_dmat_free": (None, [_vp]),
+    "uspmv_dmat_set_crs": (C.c_int, [_vp, C.c_int]),
+    "uspmv_spmv": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "uspmv_spmv_chunks": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "uspmv_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp]),
+    "uspmv_spmv_ap": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "uspmv_scs_gpu_f64": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "uspmv_scs_gpu_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "uspmv_csr_gpu_f64": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "uspmv_csr_gpu_f32": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "uspmv_apply_permutation_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
+    "uspmv_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "uspmv_get_tuning": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "uspmv_seg_work_sharing_arr": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "uspmv_seg_local_coo": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp)]),
+    "uspmv_halo_discover": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "uspmv_halo_meta": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_i32p)]),
+    "uspmv_halo_free": (None, [_vp]),
+    "uspmv_scs_split_chunks": (C.c_int, [_vp, _i64, C.POINTER(_i32p), C.POINTER(_i64), C.POINTER(_i32p),
+                                         C.POINTER(_i64)]),
+    "uspmv_free": (None, [_vp]),
+    "uspmv_pack_send_buf": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, C.c_int, _vp]),
+    "uspmv_stream_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "uspmv_stream_triad": (C.c_int, [_vp, _vp, _vp, C.c_double, _i64, _vp]),
+    "uspmv_stream_read": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "uspmv_time_launches": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _i64, C.c_int, _i64, C.c_int, _vp,
+                                      C.POINTER(C.c_double)]),
+}
+
+
+def lib():
+    """Load libuspmv.so.  Fails loudly (no fallback) when the extension has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise UspmvError(-1, f"{path} is missing: build it with __graft_entry__.build() "
+                                 f"(make -C ultimate-spmv_amd); there is no CPU fallback")
+        L = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            f.restype, f.argtypes = res, args
+        _LIB = L
+    return _LIB
+
+
+def _ck(rc):
+    if rc != 0:
+        raise UspmvError(rc, lib().uspmv_last_error().decode())
+
+
+def _np_ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+def _view(ptr, n, dtype, owner=None):
+    """numpy view of library-owned memory; `owner` (the Python wrapper whose handle owns the
+    memory) is pinned on the ctypes pointer, which the array keeps alive through .base."""
+    if n == 0:
+        return np.zeros(0, dtype)
+    ptr._uspmv_owner = owner
+    return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype)
+
+
+# ---------------------------------------------------------------------------------------- COO
+class Coo:
+    """Host COO matrix (MtxData, code/classes_structs.hpp:1169-1238)."""
+
+    def __init__(self, handle):
+        self.h = handle
+        a, b, c = _i64(), _i64(), _i64()
+        _ck(lib().uspmv_coo_dims(handle, C.byref(a), C.byref(b), C.byref(c)))
+        self.n_rows, self.n_cols, self.nnz = a.value, b.value, c.value
+
+    @classmethod
+    def from_arrays(cls, n_rows, n_cols, I, J, values):
+        I = np.ascontiguousarray(I, np.int32); J = np.ascontiguousarray(J, np.int32)
+        v = np.ascontiguousarray(values, np.float64)
+        h = _vp()
+        _ck(lib().uspmv_coo_create(n_rows, n_cols, len(I), _np_ptr(I), _np_ptr(J), _np_ptr(v), C.byref(h)))
+        return cls(h)
+
+    def arrays(self):
+        """(I, J, values) as numpy views borrowed from the library (valid while self lives)."""
+        I, J, v = _i32p(), _i32p(), _f64p()
+        _ck(lib().uspmv_coo_arrays(self.h, C.byref(I), C.byref(J), C.byref(v)))
+        return (_view(I, self.nnz, np.int32, self), _view(J, self.nnz, np.int32, self),
+                _view(v, self.nnz, np.float64, self))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.uspmv_coo_free(self.h)
+            self.h = None
+
+
+def read_mtx(path):
+    h = _vp()
+    _ck(lib().uspmv_read_mtx(os.fsencode(path), C.byref(h)))
+    return Coo(h)
+
+
+def gen_stencil27(nx, ny, nz, dof=1, seed=0x5EED, magnitude_decades=0.0, row_begin=0, row_end=None):
+    n = nx * ny * nz * dof
+    h = _vp()
+    _ck(lib().uspmv_gen_stencil27(nx, ny, nz, dof, seed, magnitude_decades, row_begin,
+                                  n if row_end is None else row_end, C.byref(h)))
+    return Coo(h)
+
+
+# ---------------------------------------------------------------------------------------- SCS
+class Scs:
+    """Host SELL-C-sigma matrix (ScsData, code/classes_structs.hpp:1313-1339)."""
+
+    def __init__(self, handle):
+        self.h = handle
+        m = (_i64 * 8)()
+        _ck(lib().uspmv_scs_meta(handle, m))
+        (self.C, self.sigma, self.n_rows, self.n_cols, self.n_rows_padded, self.n_chunks, self.n_elements,
+         self.nnz) = [int(v) for v in m]
+        d = C.c_int()
+        _ck(lib().uspmv_scs_dtype(handle, C.byref(d)))
+        self.dtype = d.value
+
+    @property
+    def np_dtype(self):
+        return np.float64 if self.dtype == F64 else np.float32
+
+    def arrays(self):
+        """dict of numpy views borrowed from the library (valid while self lives)."""
+        cp, cl, ci, o2n, n2o = _i32p(), _i32p(), _i32p(), _i32p(), _i32p()
+        va = _vp()
+        _ck(lib().uspmv_scs_arrays(self.h, C.byref(cp), C.byref(cl), C.byref(ci), C.byref(va), C.byref(o2n),
+                                   C.byref(n2o)))
+        vp = C.cast(va, C.POINTER(C.c_double if self.dtype == F64 else C.c_float))
+        return dict(chunk_ptrs=_view(cp, self.n_chunks + 1, np.int32, self),
+                    chunk_lengths=_view(cl, self.n_chunks, np.int32, self),
+                    col_idxs=_view(ci, self.n_elements, np.int32, self),
+                    values=_view(vp, self.n_elements, self.np_dtype, self),
+                    old_to_new_idx=_view(o2n, self.n_rows, np.int32, self),
+                    new_to_old_idx=_view(n2o, self.n_rows, np.int32, self))
+
+    def split_chunks(self, n_local):
+        """(interior chunk ids, boundary chunk ids): boundary chunks touch a column >= n_local."""
+        a, b = _i32p(), _i32p()
+        na, nb = _i64(), _i64()
+        _ck(lib().uspmv_scs_split_chunks(self.h, n_local, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
+        ia = _view(a, na.value, np.int32).copy()
+        ib = _view(b, nb.value, np.int32).copy()
+        lib().uspmv_free(a); lib().uspmv_free(b)
+        return ia, ib
+
+    def __del__(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.uspmv_scs_free(self.h)
+            self.h = None
+
+
+def convert_to_scs(coo, Cc, sigma, dtype=F64, fixed_permutation=None):
+    fp = None if fixed_permutation is None else np.ascontiguousarray(fixed_permutation, np.int32)
+    h = _vp()
+    _ck(lib().uspmv_convert_to_scs(coo.h, Cc, sigma, dtype, _np_ptr(fp), C.byref(h)))
+    return Scs(h)
+
+
+def permute_scs_cols(scs, perm):
+    perm = np.ascontiguousarray(perm, np.int32)
+    _ck(lib().uspmv_permute_scs_cols(scs.h, _np_ptr(perm)))
+
+
+def apply_permutation(vec, perm):
+    """out[i] = vec[perm[i]] on the host (numpy float64 / float32)."""
+    vec = np.ascontiguousarray(vec); perm = np.ascontiguousarray(perm, np.int32)
+    dt = {np.dtype(np.float64): F64, np.dtype(np.float32): F32}[vec.dtype]
+    out = np.empty(len(perm), vec.dtype)
+    _ck(lib().uspmv_apply_permutation(_np_ptr(out), _np_ptr(vec), _np_ptr(perm), len(perm), dt))
+    return out
+
+
+def partition_precisions(coo, threshold_1):
+    dp, sp = _vp(), _vp()
+    _ck(lib().uspmv_partition_precisions(coo.h, threshold_1, C.byref(dp), C.byref(sp)))
+    return Coo(dp), Coo(sp)
+
+
+# ---------------------------------------------------------------------------------------- halo set-up
+def seg_work_sharing_arr(coo, method, P):
+    wsa = np.zeros(P + 1, np.int32)
+    m = {"seg-rows": SEG_ROWS, "seg-nnz": SEG_NNZ}.get(method, method)
+    _ck(lib().uspmv_seg_work_sharing_arr(coo.h, m, P, _np_ptr(wsa)))
+    return wsa
+
+
+def seg_local_coo(coo, wsa, rank):
+    wsa = np.ascontiguousarray(wsa, np.int32)
+    h = _vp()
+    _ck(lib().uspmv_seg_local_coo(coo.h, _np_ptr(wsa), rank, C.byref(h)))
+    return Coo(h)
+
+
+class HaloPlan:
+    """Result of collect_local_needed_heri on one rank (code/mpi_funcs.hpp:242-415)."""
+
+    def __init__(self, scs, wsa, rank, P):
+        wsa = np.ascontiguousarray(wsa, np.int32)
+        h = _vp()
+        _ck(lib().uspmv_halo_discover(scs.h, _np_ptr(wsa), rank, P, C.byref(h)))
+        self.h, self.P, self.rank = h, P, rank
+        n = _i64()
+        cum, idx, cnt = _i32p(), _i32p(), _i32p()
+        _ck(lib().uspmv_halo_meta(h, C.byref(n), C.byref(cum), C.byref(idx), C.byref(cnt)))
+        self.n_halo = n.value
+        self.recv_counts_cumsum = _view(cum, P + 1, np.int32).copy()
+        self.recv_counts = _view(cnt, P, np.int32).copy()
+        self.recv_idxs = _view(idx, self.n_halo, np.int32).copy()
+        self.n_local = int(wsa[rank + 1] - wsa[rank])
+
+    def recv_idxs_of(self, owner):
+        o = int(self.recv_counts[:owner].sum())
+        return self.recv_idxs[o:o + int(self.recv_counts[owner])]
+
+    def __del__(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.uspmv_halo_free(self.h)
+            self.h = None
+
+
+# ---------------------------------------------------------------------------------------- device
+def device_count():
+    n = C.c_int()
+    _ck(lib().uspmv_device_count(C.byref(n)))
+    return n.value
+
+
+def set_tuning(**kw):
+    for k, v in kw.items():
+        _ck(lib().uspmv_set_tuning(k.encode(), int(v)))
+
+
+def get_tuning(key):
+    v = C.c_int()
+    _ck(lib().uspmv_get_tuning(key.encode(), C.byref(v)))
+    return v.value
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+    return getattr(stream, "cuda_stream", stream)
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+class DeviceMatrix:
+    """SELL-C-sigma matrix resident in HBM (what assign_spmv_kernel_gpu_data stages,
+    code/utilities.hpp:3721-3811).  Arrays are torch tensors owned by this object."""
+
+    def __init__(self, scs, device="cuda", crs=False):
+        import torch
+        a = scs.arrays()
+        self.C, self.n_chunks, self.n_elements, self.dtype = scs.C, scs.n_chunks, scs.n_elements, scs.dtype
+        self.n_rows, self.n_rows_padded, self.nnz = scs.n_rows, scs.n_rows_padded, scs.nnz
+        self.torch_dtype = torch.float64 if scs.dtype == F64 else torch.float32
+        dev = torch.device(device)
+        self.chunk_ptrs = torch.from_numpy(a["chunk_ptrs"].copy()).to(dev)
+        self.chunk_lengths = torch.from_numpy(a["chunk_lengths"].copy()).to(dev)
+        self.col_idxs = torch.from_numpy(a["col_idxs"]).to(dev)      # H2D straight from library memory
+        self.values = torch.from_numpy(a["values"]).to(dev)
+        h = _vp()
+        _ck(lib().uspmv_dmat_wrap(self.C, self.n_chunks, self.n_elements, self.dtype, _dp(self.chunk_ptrs),
+                                  _dp(self.chunk_lengths), _dp(self.col_idxs), _dp(self.values), C.byref(h)))
+        self.h = h
+        if crs:
+            _ck(lib().uspmv_dmat_set_crs(h, 1))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.uspmv_dmat_free(self.h)
+            self.h = None
+
+
+def spmv(A, x, y, stream=None):
+    """y = A x on the device (x: padded_vec_size, y: n_rows_padded elements)."""
+    assert x.dtype == A.torch_dtype and y.dtype == A.torch_dtype and y.numel() >= A.n_rows_padded
+    _ck(lib().uspmv_spmv(A.h, _dp(x), _dp(y), _stream_ptr(stream)))
+    return y
+
+
+def spmv_chunks(A, chunk_ids, x, y, stream=None):
+    assert chunk_ids.dtype.is_floating_point is False and x.dtype == A.torch_dtype
+    _ck(lib().uspmv_spmv_chunks(A.h, _dp(chunk_ids), chunk_ids.numel(), _dp(x), _dp(y), _stream_ptr(stream)))
+    return y
+
+
+def spmmv(A, X, Y, b, ld, layout=COLWISE, stream=None):
+    assert X.dtype == A.torch_dtype and Y.dtype == A.torch_dtype
+    _ck(lib().uspmv_spmmv(A.h, _dp(X), _dp(Y), b, ld, layout, _stream_ptr(stream)))
+    return Y
+
+
+def spmv_ap(A_dp, A_sp, x, y, stream=None):
+    _ck(lib().uspmv_spmv_ap(A_dp.h, A_sp.h, _dp(x), _dp(y), _stream_ptr(stream)))
+    return y
+
+
+def uspmv_scs_gpu(Cc, n_chunks, chunk_ptrs, chunk_lengths, col_idxs, values, x, y, stream=None):
+    """Raw-array form, argument list of uspmv_scs_gpu (code/interface.hpp:1766-1793)."""
+    import torch
+    f = lib().uspmv_scs_gpu_f64 if values.dtype == torch.float64 else lib().uspmv_scs_gpu_f32
+    _ck(f(Cc, n_chunks, _dp(chunk_ptrs), _dp(chunk_lengths), _dp(col_idxs), _dp(values), _dp(x), _dp(y),
+          _stream_ptr(stream)))
+    return y
+
+
+def uspmv_csr_gpu(n_rows, row_ptrs, col_idxs, values, x, y, stream=None):
+    """Raw-array form, argument list of uspmv_csr_gpu (code/interface.hpp:1741-1760)."""
+    import torch
+    f = lib().uspmv_csr_gpu_f64 if values.dtype == torch.float64 else lib().uspmv_csr_gpu_f32
+    _ck(f(n_rows, _dp(row_ptrs), _dp(col_idxs), _dp(values), _dp(x), _dp(y), _stream_ptr(stream)))
+    return y
+
+
+def apply_permutation_dev(out, vec, perm, stream=None):
+    import torch
+    dt = F64 if vec.dtype == torch.float64 else F32
+    _ck(lib().uspmv_apply_permutation_dev(_dp(out), _dp(vec), _dp(perm), perm.numel(), dt, _stream_ptr(stream)))
+    return out
+
+
+def pack_send_buf(x, perm, send_idxs, out, block_offset=0, stream=None):
+    """out[i] = x[perm[send_idxs[i]] + block_offset] for the concatenated send list (one launch)."""
+    import torch
+    dt = F64 if x.dtype == torch.float64 else F32
+    _ck(lib().uspmv_pack_send_buf(_dp(x), _dp(perm), _dp(send_idxs), send_idxs.numel(), block_offset, _dp(out), dt,
+                                  _stream_ptr(stream)))
+    return out
+
+
+def time_launches(what, reps, A=None, B=None, x=None, y=None, n=0, b=1, ld=0, layout=COLWISE, stream=None):
+    """Average ms per launch of `reps` back-to-back launches, HIP events on the launch stream."""
+    ms = C.c_double()
+    _ck(lib().uspmv_time_launches(what, reps, A.h if A is not None else None, B.h if B is not None else None,
+                                  _dp(x), _dp(y), n, b, ld, layout, _stream_ptr(stream), C.byref(ms)))
+    return ms.value

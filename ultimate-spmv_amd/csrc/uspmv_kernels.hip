@@ -1,0 +1,744 @@
+// Hand-written HIP kernels for gfx950 (CDNA4, MI355X) and the device half of the C ABI.
+// Written for 64-lane wavefronts and the 8-XCD / per-XCD-L2 memory system; no CUDA path exists.
+//
+// Kernels (reference CPU twin each one reproduces, paths relative to the reference root):
+//   scs_spmv_rows      spmv_omp_scs / scs_impl_cpu<C>            code/kernels.hpp:159-258
+//   scs_spmv_split2    same maths, two lanes per row (C = 32)     (tolerance variant)
+//   csr_spmv_vector    spmv_omp_csr                               code/kernels.hpp:22-63
+//   scs_spmmv_rows     block_spmv_omp_scs_general                 code/kernels.hpp:306-398
+//   scs_spmv_ap_rows   scs_ap_impl_cpu<C>                         code/ap_kernels.hpp:24-82
+//   gather_kernel      pack_send_buf / apply_permutation          code/classes_structs.hpp:813-818,
+//                                                                 code/utilities.hpp:1768-1782
+//
+// Data layout in HBM (identical to the reference's ScsData, code/classes_structs.hpp:1313-1339):
+// element (row-in-chunk i, slot j) of chunk c at chunk_ptrs[c] + j*C + i.  A wavefront that owns
+// 64/C consecutive chunks (lane <-> row) therefore reads, per slot j, 64/C contiguous segments
+// of C*sizeof(VT) bytes of `values` and C*4 bytes of `col_idxs`: the matrix stream is perfectly
+// coalesced and read exactly once; it is issued with non-temporal loads so that it does not
+// evict the x vector, whose irregular 8-byte gathers are served by the XCD's L2 / the
+// Infinity Cache.  One lane walks one row in slot order j = 0,1,2,... with one fused
+// multiply-add per element, which is bit-for-bit the summation the reference's CPU kernels
+// perform (g++ -O3 contracts `tmp += a*b` to an FMA).
+//
+// Workgroup -> chunk mapping: hardware deals workgroups round-robin over the 8 XCDs; with
+// xcd_remap the logical block id is permuted so that every XCD walks its own contiguous eighth of
+// the chunk range -- the x window of a region is then fetched into one L2 instead of eight.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
+#include "../host/uspmv_internal.hpp"
+
+struct uspmv_dmat {
+    int64_t C = 0, n_chunks = 0, n_elements = 0;
+    int dtype = USPMV_F64;
+    const int32_t *chunk_ptrs = nullptr, *chunk_lengths = nullptr, *col_idxs = nullptr;
+    const void *values = nullptr;
+    bool owns = false;
+    bool crs = false;
+};
+
+namespace {
+
+struct Tuning {
+    int unroll = 4;
+    int nontemporal = 1;
+    int xcd_remap = 1;
+    int block = 256;
+    int spmv_variant = 0;
+    int csr_lanes = 0;  // 0 = choose from average row length
+};
+Tuning g_tune;
+
+#define HIP_TRY(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return uspmv::fail(USPMV_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                               __FILE__, __LINE__);                                                \
+    } while (0)
+
+int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        return uspmv::fail(USPMV_ERR_NO_DEVICE, "no HIP device is visible (hipGetDeviceCount: %s); "
+                           "libuspmv has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    }
+    return USPMV_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_stream(const T *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// logical block id: every XCD (blocks b, b+8, b+16, ... share one) gets a contiguous range
+__device__ __forceinline__ unsigned remap_block(unsigned b, unsigned nb, bool remap) {
+    if (!remap || nb < 16) return b;
+    const unsigned xcd = b & 7u, q = nb >> 3, r = nb & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+// ------------------------------------------------------------------------------------------
+// SELL-C-sigma SpMV, one lane per row.  CT > 0: compile-time C; CT == 0: C passed at run time.
+// IDS: virtual chunk v -> chunk_ids[v] (interior / boundary subsets).
+template <typename VT, int CT, int U, bool NT, bool IDS>
+__global__ void scs_spmv_rows(const long n_work_chunks, const int C_rt, const int *__restrict__ chunk_ptrs,
+                              const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
+                              const VT *__restrict__ values, const VT *__restrict__ x, VT *__restrict__ y,
+                              const int *__restrict__ chunk_ids, const int xcd_remap) {
+    const int C = CT > 0 ? CT : C_rt;
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap != 0);
+    const long vrow = (long)lb * blockDim.x + threadIdx.x;
+    const long vc = vrow / C;
+    const int i = (int)(vrow - vc * C);
+    if (vc >= n_work_chunks) return;
+    const long c = IDS ? (long)chunk_ids[vc] : vc;
+    const long cs = chunk_ptrs[c];
+    const int L = chunk_lengths[c];
+    const VT *vp = values + cs + i;
+    const int *cp = col_idxs + cs + i;
+    VT acc = VT(0);
+    int j = 0;
+    for (; j + U <= L; j += U) {
+        VT v[U];
+        int ci[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = ld_stream<NT>(vp + (long)(j + u) * C);
+            ci[u] = ld_stream<NT>(cp + (long)(j + u) * C);
+        }
+        VT xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = x[ci[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = fma_t(v[u], xv[u], acc);
+    }
+    for (; j < L; ++j) {
+        const VT v = ld_stream<NT>(vp + (long)j * C);
+        const int ci = ld_stream<NT>(cp + (long)j * C);
+        acc = fma_t(v, x[ci], acc);
+    }
+    y[c * C + i] = acc;
+}
+
+// C = 32, one wavefront per chunk, two lanes per row: lane l owns row l & 31 and the slots
+// j == (l >> 5) (mod 2), so every wave-instruction of the matrix stream is one contiguous
+// 512-byte (values) / 256-byte (col_idxs) segment.  The two partial sums are combined with one
+// cross-lane add: NOT the sequential chain -> compared against the oracle with a tolerance.
+template <typename VT, int U, bool NT>
+__global__ void scs_spmv_split2(const long n_chunks, const int *__restrict__ chunk_ptrs,
+                                const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
+                                const VT *__restrict__ values, const VT *__restrict__ x, VT *__restrict__ y,
+                                const int xcd_remap) {
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap != 0);
+    const long c = ((long)lb * blockDim.x + threadIdx.x) >> 6;
+    if (c >= n_chunks) return;
+    const int lane = threadIdx.x & 63;
+    const long cs = chunk_ptrs[c];
+    const int L = chunk_lengths[c];
+    const VT *vp = values + cs + lane;   // slot pair t: element index t*64 + lane
+    const int *cp = col_idxs + cs + lane;
+    const int h = lane >> 5;
+    const int T = (L + 1 - h) >> 1;       // number of slots j = 2t + h < L
+    VT acc = VT(0);
+    int t = 0;
+    for (; t + U <= T; t += U) {
+        VT v[U];
+        int ci[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = ld_stream<NT>(vp + (long)(t + u) * 64);
+            ci[u] = ld_stream<NT>(cp + (long)(t + u) * 64);
+        }
+        VT xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = x[ci[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = fma_t(v[u], xv[u], acc);
+    }
+    for (; t < T; ++t) {
+        const VT v = ld_stream<NT>(vp + (long)t * 64);
+        const int ci = ld_stream<NT>(cp + (long)t * 64);
+        acc = fma_t(v, x[ci], acc);
+    }
+    const VT other = __shfl_xor(acc, 32, 64);
+    if (h == 0) y[c * 32 + lane] = acc + other;
+}
+
+// CRS SpMV: G lanes per row (G = power of two <= 64), lane-strided partial sums, shuffle
+// reduction.  The reference's own loop is `omp simd`-reassociated (code/kernels.hpp:49), so
+// there is no canonical order to be bit-exact with; compared with a tolerance.
+template <typename VT, int G, bool NT>
+__global__ void csr_spmv_vector(const long n_rows, const int *__restrict__ row_ptrs,
+                                const int *__restrict__ col_idxs, const VT *__restrict__ values,
+                                const VT *__restrict__ x, VT *__restrict__ y) {
+    const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long row = gt / G;
+    const int g = (int)(gt % G);
+    VT acc = VT(0);
+    if (row < n_rows) {
+        const int b = row_ptrs[row], e = row_ptrs[row + 1];
+        for (int k = b + g; k < e; k += G) acc = fma_t(ld_stream<NT>(values + k), x[ld_stream<NT>(col_idxs + k)], acc);
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (row < n_rows && g == 0) y[row] = acc;
+}
+
+// SELL-C-sigma SpMMV (block of b vectors), one lane per row, VB vectors per pass held in registers.
+// colwise: X[col + v*ld], Y[row + v*ld];  rowwise: X[col*b + v], Y[row*b + v].
+template <typename VT, int VB, bool ROWWISE, bool NT>
+__global__ void scs_spmmv_rows(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
+                               const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
+                               const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
+                               const int b, const long ld, const int xcd_remap) {
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap != 0);
+    const long row = (long)lb * blockDim.x + threadIdx.x;
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    if (c >= n_chunks) return;
+    const long cs = chunk_ptrs[c];
+    const int L = chunk_lengths[c];
+    const VT *vp = values + cs + i;
+    const int *cp = col_idxs + cs + i;
+    for (int v0 = 0; v0 < b; v0 += VB) {
+        VT acc[VB];
+#pragma unroll
+        for (int v = 0; v < VB; ++v) acc[v] = VT(0);
+        for (int j = 0; j < L; ++j) {
+            const VT a = ld_stream<NT>(vp + (long)j * C);
+            const long col = ld_stream<NT>(cp + (long)j * C);
+#pragma unroll
+            for (int v = 0; v < VB; ++v) {
+                if (v0 + v < b) {
+                    const VT xv = ROWWISE ? X[col * b + v0 + v] : X[col + (long)(v0 + v) * ld];
+                    acc[v] = fma_t(a, xv, acc[v]);
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {
+            if (v0 + v < b) {
+                if (ROWWISE) Y[row * b + v0 + v] = acc[v];
+                else Y[row + (long)(v0 + v) * ld] = acc[v];
+            }
+        }
+    }
+}
+
+// Adaptive precision dp+sp, one lane per row: the dp chain, then the sp chain (float value widened,
+// times the DOUBLE x, accumulated in double), y = dp + sp  (code/ap_kernels.hpp:59-75).
+template <int U, bool NT>
+__global__ void scs_spmv_ap_rows(const long n_chunks, const int C, const int *__restrict__ dp_cp,
+                                 const int *__restrict__ dp_cl, const int *__restrict__ dp_ci,
+                                 const double *__restrict__ dp_va, const int *__restrict__ sp_cp,
+                                 const int *__restrict__ sp_cl, const int *__restrict__ sp_ci,
+                                 const float *__restrict__ sp_va, const double *__restrict__ x,
+                                 double *__restrict__ y, const int xcd_remap) {
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap != 0);
+    const long row = (long)lb * blockDim.x + threadIdx.x;
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    if (c >= n_chunks) return;
+    double dt = 0.0, st = 0.0;
+    {
+        const long cs = dp_cp[c];
+        const int L = dp_cl[c];
+        const double *vp = dp_va + cs + i;
+        const int *cp = dp_ci + cs + i;
+        int j = 0;
+        for (; j + U <= L; j += U) {
+            double v[U]; int ci[U]; double xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { v[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = x[ci[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dt = __builtin_fma(v[u], xv[u], dt);
+        }
+        for (; j < L; ++j) dt = __builtin_fma(ld_stream<NT>(vp + (long)j * C), x[ld_stream<NT>(cp + (long)j * C)], dt);
+    }
+    {
+        const long cs = sp_cp[c];
+        const int L = sp_cl[c];
+        const float *vp = sp_va + cs + i;
+        const int *cp = sp_ci + cs + i;
+        int j = 0;
+        for (; j + U <= L; j += U) {
+            float v[U]; int ci[U]; double xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { v[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = x[ci[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) st = __builtin_fma((double)v[u], xv[u], st);
+        }
+        for (; j < L; ++j) st = __builtin_fma((double)ld_stream<NT>(vp + (long)j * C), x[ld_stream<NT>(cp + (long)j * C)], st);
+    }
+    y[row] = dt + st;
+}
+
+// out[i] = in[perm[idx ? idx[i] : i] + offset]   (pack_send_buf with idx, apply_permutation without)
+template <typename VT>
+__global__ void gather_kernel(VT *__restrict__ out, const VT *__restrict__ in, const int *__restrict__ perm,
+                              const int *__restrict__ idx, const long n, const long offset) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[(long)perm[idx ? idx[i] : (int)i] + offset];
+}
+
+// STREAM-style calibrators: 16 bytes per lane, grid-stride.
+__global__ void stream_copy_kernel(double2 *__restrict__ a, const double2 *__restrict__ b, const long n2) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) a[i] = b[i];
+}
+__global__ void stream_triad_kernel(double2 *__restrict__ a, const double2 *__restrict__ b,
+                                    const double2 *__restrict__ c, const double s, const long n2) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+        double2 bb = b[i], cc = c[i];
+        a[i] = make_double2(bb.x + s * cc.x, bb.y + s * cc.y);
+    }
+}
+__global__ void stream_read_kernel(const double2 *__restrict__ b, const long n2, double *__restrict__ partial) {
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+        const double *pb = (const double *)(b + i);
+        acc += __builtin_nontemporal_load(pb) + __builtin_nontemporal_load(pb + 1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) partial[((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6] = acc;
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+inline unsigned grid_for(long work_items, int block) { return (unsigned)((work_items + block - 1) / block); }
+
+template <typename VT, int CT, int U, bool NT>
+void launch_rows_ids(bool ids, unsigned grid, int block, hipStream_t st, long nwc, int C, const uspmv_dmat *A,
+                     const VT *x, VT *y, const int *chunk_ids) {
+    if (ids)
+        hipLaunchKernelGGL((scs_spmv_rows<VT, CT, U, NT, true>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
+                           A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+    else
+        hipLaunchKernelGGL((scs_spmv_rows<VT, CT, U, NT, false>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
+                           A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+}
+
+template <typename VT, int CT, int U>
+void launch_rows_nt(bool ids, unsigned grid, int block, hipStream_t st, long nwc, int C, const uspmv_dmat *A,
+                    const VT *x, VT *y, const int *chunk_ids) {
+    if (g_tune.nontemporal) launch_rows_ids<VT, CT, U, true>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids);
+    else launch_rows_ids<VT, CT, U, false>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids);
+}
+
+template <typename VT, int CT>
+void launch_rows_unroll(bool ids, unsigned grid, int block, hipStream_t st, long nwc, int C, const uspmv_dmat *A,
+                        const VT *x, VT *y, const int *chunk_ids) {
+    switch (g_tune.unroll) {
+        case 1: launch_rows_nt<VT, CT, 1>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
+        case 2: launch_rows_nt<VT, CT, 2>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
+        case 8: launch_rows_nt<VT, CT, 8>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
+        default: launch_rows_nt<VT, CT, 4>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
+    }
+}
+
+template <typename VT>
+int launch_spmv_scs(const uspmv_dmat *A, const int *chunk_ids, long n_ids, const VT *x, VT *y, hipStream_t st) {
+    const bool ids = chunk_ids != nullptr;
+    const long nwc = ids ? n_ids : A->n_chunks;
+    if (nwc == 0) return USPMV_OK;
+    const int C = (int)A->C;
+    const int block = g_tune.block;
+    if (!ids && C == 32 && g_tune.spmv_variant == 1) {
+        const unsigned grid = grid_for(nwc * 64, block);
+        if (g_tune.nontemporal)
+            hipLaunchKernelGGL((scs_spmv_split2<VT, 4, true>), dim3(grid), dim3(block), 0, st, nwc, A->chunk_ptrs,
+                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, g_tune.xcd_remap);
+        else
+            hipLaunchKernelGGL((scs_spmv_split2<VT, 4, false>), dim3(grid), dim3(block), 0, st, nwc, A->chunk_ptrs,
+                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, g_tune.xcd_remap);
+    } else {
+        const unsigned grid = grid_for(nwc * C, block);
+        switch (C) {  // host-side dispatch on C (the reference switches inside the __global__, code/kernels.hpp:735-753)
+            case 1: launch_rows_unroll<VT, 1>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
+            case 2: launch_rows_unroll<VT, 2>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
+            case 4: launch_rows_unroll<VT, 4>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
+            case 8: launch_rows_unroll<VT, 8>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
+            case 16: launch_rows_unroll<VT, 16>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
+            case 32: launch_rows_unroll<VT, 32>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
+            case 64: launch_rows_unroll<VT, 64>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
+            case 128: launch_rows_unroll<VT, 128>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
+            default: launch_rows_unroll<VT, 0>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+template <typename VT, int G>
+void launch_csr_g(long n_rows, const int *rp, const int *ci, const VT *va, const VT *x, VT *y, hipStream_t st) {
+    const unsigned grid = grid_for(n_rows * G, 256);
+    if (g_tune.nontemporal)
+        hipLaunchKernelGGL((csr_spmv_vector<VT, G, true>), dim3(grid), dim3(256), 0, st, n_rows, rp, ci, va, x, y);
+    else
+        hipLaunchKernelGGL((csr_spmv_vector<VT, G, false>), dim3(grid), dim3(256), 0, st, n_rows, rp, ci, va, x, y);
+}
+
+template <typename VT>
+int launch_csr(long n_rows, long nnz_hint, const int *rp, const int *ci, const VT *va, const VT *x, VT *y,
+               hipStream_t st) {
+    if (n_rows == 0) return USPMV_OK;
+    int G = g_tune.csr_lanes;
+    if (G <= 0) {
+        const double avg = nnz_hint > 0 ? (double)nnz_hint / (double)n_rows : 16.0;
+        G = 2;
+        while (G < 64 && G < avg / 2) G <<= 1;
+    }
+    switch (G) {
+        case 1: launch_csr_g<VT, 1>(n_rows, rp, ci, va, x, y, st); break;
+        case 2: launch_csr_g<VT, 2>(n_rows, rp, ci, va, x, y, st); break;
+        case 4: launch_csr_g<VT, 4>(n_rows, rp, ci, va, x, y, st); break;
+        case 8: launch_csr_g<VT, 8>(n_rows, rp, ci, va, x, y, st); break;
+        case 16: launch_csr_g<VT, 16>(n_rows, rp, ci, va, x, y, st); break;
+        case 32: launch_csr_g<VT, 32>(n_rows, rp, ci, va, x, y, st); break;
+        default: launch_csr_g<VT, 64>(n_rows, rp, ci, va, x, y, st); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+template <typename VT, int VB>
+void launch_spmmv_vb(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int layout, hipStream_t st) {
+    const int block = g_tune.block;
+    const unsigned grid = grid_for(A->n_chunks * A->C, block);
+    const bool nt = g_tune.nontemporal != 0;
+#define SPMMV_LAUNCH(RW, NTV)                                                                                     \
+    hipLaunchKernelGGL((scs_spmmv_rows<VT, VB, RW, NTV>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks,      \
+                       (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, b, ld, \
+                       g_tune.xcd_remap)
+    if (layout == USPMV_ROWWISE) { if (nt) SPMMV_LAUNCH(true, true); else SPMMV_LAUNCH(true, false); }
+    else { if (nt) SPMMV_LAUNCH(false, true); else SPMMV_LAUNCH(false, false); }
+#undef SPMMV_LAUNCH
+}
+
+template <typename VT>
+int launch_spmmv(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int layout, hipStream_t st) {
+    if (A->n_chunks == 0) return USPMV_OK;
+    if (b <= 1) launch_spmmv_vb<VT, 1>(A, X, Y, b, ld, layout, st);
+    else if (b <= 2) launch_spmmv_vb<VT, 2>(A, X, Y, b, ld, layout, st);
+    else if (b <= 4) launch_spmmv_vb<VT, 4>(A, X, Y, b, ld, layout, st);
+    else launch_spmmv_vb<VT, 8>(A, X, Y, b, ld, layout, st);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int check_dmat(const uspmv_dmat *A, const char *who) {
+    if (!A) return uspmv::fail(USPMV_ERR_INVALID, "%s: NULL matrix", who);
+    if (A->C < 1 || A->n_chunks < 0) return uspmv::fail(USPMV_ERR_INVALID, "%s: corrupt matrix handle", who);
+    if (A->n_chunks * A->C > INT32_MAX) return uspmv::fail(USPMV_ERR_OVERFLOW, "%s: padded rows exceed int32", who);
+    return USPMV_OK;
+}
+
+}  // namespace
+
+// ============================================================================================ C ABI
+extern "C" {
+
+int uspmv_device_count(int *count) {
+    if (!count) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_device_count: NULL argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return USPMV_OK;
+}
+
+int uspmv_set_device(int device) {
+    if (int rc = require_device()) return rc;
+    HIP_TRY(hipSetDevice(device));
+    return USPMV_OK;
+}
+
+int uspmv_stream_synchronize(void *stream) {
+    if (int rc = require_device()) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return USPMV_OK;
+}
+
+int uspmv_set_tuning(const char *key, int value) {
+    if (!key) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_set_tuning: NULL key");
+    if (!strcmp(key, "unroll")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8) return uspmv::fail(USPMV_ERR_INVALID, "unroll must be 1|2|4|8");
+        g_tune.unroll = value;
+    } else if (!strcmp(key, "nontemporal")) g_tune.nontemporal = value != 0;
+    else if (!strcmp(key, "xcd_remap")) g_tune.xcd_remap = value != 0;
+    else if (!strcmp(key, "block")) {
+        if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
+            return uspmv::fail(USPMV_ERR_INVALID, "block must be 64|128|256|512|1024");
+        g_tune.block = value;
+    } else if (!strcmp(key, "spmv_variant")) {
+        if (value != 0 && value != 1) return uspmv::fail(USPMV_ERR_INVALID, "spmv_variant must be 0|1");
+        g_tune.spmv_variant = value;
+    } else if (!strcmp(key, "csr_lanes")) {
+        if (value < 0 || value > 64 || (value & (value - 1))) return uspmv::fail(USPMV_ERR_INVALID, "csr_lanes must be 0 or a power of two <= 64");
+        g_tune.csr_lanes = value;
+    } else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_set_tuning: unknown key '%s'", key);
+    return USPMV_OK;
+}
+
+int uspmv_get_tuning(const char *key, int *value) {
+    if (!key || !value) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_get_tuning: NULL argument");
+    if (!strcmp(key, "unroll")) *value = g_tune.unroll;
+    else if (!strcmp(key, "nontemporal")) *value = g_tune.nontemporal;
+    else if (!strcmp(key, "xcd_remap")) *value = g_tune.xcd_remap;
+    else if (!strcmp(key, "block")) *value = g_tune.block;
+    else if (!strcmp(key, "spmv_variant")) *value = g_tune.spmv_variant;
+    else if (!strcmp(key, "csr_lanes")) *value = g_tune.csr_lanes;
+    else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_get_tuning: unknown key '%s'", key);
+    return USPMV_OK;
+}
+
+int uspmv_dmat_upload(const uspmv_scs_t *s, uspmv_dmat_t **out) {
+    if (!s || !out) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_upload: NULL argument");
+    if (int rc = require_device()) return rc;
+    auto *A = new uspmv_dmat;
+    A->C = s->C; A->n_chunks = s->n_chunks; A->n_elements = s->n_elements; A->dtype = s->dtype; A->owns = true;
+    const size_t vsz = s->dtype == USPMV_F64 ? 8 : 4;
+    void *cp = nullptr, *cl = nullptr, *ci = nullptr, *va = nullptr;
+    const size_t ne = (size_t)std::max<int64_t>(s->n_elements, 1);
+    hipError_t e;
+    if ((e = hipMalloc(&cp, sizeof(int32_t) * (size_t)(s->n_chunks + 1))) != hipSuccess ||
+        (e = hipMalloc(&cl, sizeof(int32_t) * (size_t)std::max<int64_t>(s->n_chunks, 1))) != hipSuccess ||
+        (e = hipMalloc(&ci, sizeof(int32_t) * ne)) != hipSuccess || (e = hipMalloc(&va, vsz * ne)) != hipSuccess) {
+        (void)hipFree(cp); (void)hipFree(cl); (void)hipFree(ci); (void)hipFree(va);
+        delete A;
+        return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_upload: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    A->chunk_ptrs = (const int32_t *)cp; A->chunk_lengths = (const int32_t *)cl;
+    A->col_idxs = (const int32_t *)ci; A->values = va;
+    e = hipMemcpy(cp, s->chunk_ptrs.data(), sizeof(int32_t) * (size_t)(s->n_chunks + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(cl, s->chunk_lengths.data(), sizeof(int32_t) * (size_t)s->n_chunks, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ci, s->col_idxs.data(), sizeof(int32_t) * (size_t)s->n_elements, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(va, s->values_ptr(), vsz * (size_t)s->n_elements, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        uspmv_dmat_free(A);
+        return uspmv::fail(USPMV_ERR_HIP, "uspmv_dmat_upload: hipMemcpy failed: %s", hipGetErrorString(e));
+    }
+    *out = A;
+    return USPMV_OK;
+}
+
+int uspmv_dmat_wrap(int64_t C, int64_t n_chunks, int64_t n_elements, int dtype, const int32_t *d_chunk_ptrs,
+                    const int32_t *d_chunk_lengths, const int32_t *d_col_idxs, const void *d_values,
+                    uspmv_dmat_t **out) {
+    if (!out || C < 1 || n_chunks < 0 || n_elements < 0 || (dtype != USPMV_F64 && dtype != USPMV_F32) ||
+        !d_chunk_ptrs || (n_chunks > 0 && !d_chunk_lengths) || (n_elements > 0 && (!d_col_idxs || !d_values)))
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_wrap: bad argument");
+    auto *A = new uspmv_dmat;
+    A->C = C; A->n_chunks = n_chunks; A->n_elements = n_elements; A->dtype = dtype;
+    A->chunk_ptrs = d_chunk_ptrs; A->chunk_lengths = d_chunk_lengths; A->col_idxs = d_col_idxs; A->values = d_values;
+    A->owns = false;
+    *out = A;
+    return USPMV_OK;
+}
+
+void uspmv_dmat_free(uspmv_dmat_t *A) {
+    if (!A) return;
+    if (A->owns) {
+        (void)hipFree((void *)A->chunk_ptrs); (void)hipFree((void *)A->chunk_lengths);
+        (void)hipFree((void *)A->col_idxs); (void)hipFree((void *)A->values);
+    }
+    delete A;
+}
+
+int uspmv_dmat_set_crs(uspmv_dmat_t *A, int on) {
+    if (!A) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_set_crs: NULL matrix");
+    if (on && A->C != 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_set_crs: crs needs C = 1 (got %lld)", (long long)A->C);
+    A->crs = on != 0;
+    return USPMV_OK;
+}
+
+int uspmv_spmv(const uspmv_dmat_t *A, const void *d_x, void *d_y, void *stream) {
+    if (int rc = check_dmat(A, "uspmv_spmv")) return rc;
+    if (!d_x || !d_y) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv: NULL vector");
+    if (int rc = require_device()) return rc;
+    if (A->crs) {
+        if (A->dtype == USPMV_F64)
+            return launch_csr<double>((long)A->n_chunks, (long)A->n_elements, A->chunk_ptrs, A->col_idxs,
+                                      (const double *)A->values, (const double *)d_x, (double *)d_y, (hipStream_t)stream);
+        return launch_csr<float>((long)A->n_chunks, (long)A->n_elements, A->chunk_ptrs, A->col_idxs,
+                                 (const float *)A->values, (const float *)d_x, (float *)d_y, (hipStream_t)stream);
+    }
+    if (A->dtype == USPMV_F64) return launch_spmv_scs<double>(A, nullptr, 0, (const double *)d_x, (double *)d_y, (hipStream_t)stream);
+    return launch_spmv_scs<float>(A, nullptr, 0, (const float *)d_x, (float *)d_y, (hipStream_t)stream);
+}
+
+int uspmv_spmv_chunks(const uspmv_dmat_t *A, const int32_t *d_chunk_ids, int64_t n_ids, const void *d_x, void *d_y,
+                      void *stream) {
+    if (int rc = check_dmat(A, "uspmv_spmv_chunks")) return rc;
+    if (n_ids < 0 || n_ids > A->n_chunks || (n_ids > 0 && !d_chunk_ids) || !d_x || !d_y)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_chunks: bad argument");
+    if (int rc = require_device()) return rc;
+    if (n_ids == 0) return USPMV_OK;
+    if (A->dtype == USPMV_F64) return launch_spmv_scs<double>(A, d_chunk_ids, n_ids, (const double *)d_x, (double *)d_y, (hipStream_t)stream);
+    return launch_spmv_scs<float>(A, d_chunk_ids, n_ids, (const float *)d_x, (float *)d_y, (hipStream_t)stream);
+}
+
+int uspmv_spmmv(const uspmv_dmat_t *A, const void *d_X, void *d_Y, int b, int64_t ld, int layout, void *stream) {
+    if (int rc = check_dmat(A, "uspmv_spmmv")) return rc;
+    if (!d_X || !d_Y || b < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmmv: bad argument");
+    if (layout != USPMV_COLWISE && layout != USPMV_ROWWISE) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmmv: unknown layout %d", layout);
+    if (layout == USPMV_COLWISE && ld < A->n_chunks * A->C)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmmv: ld=%lld smaller than n_rows_padded=%lld", (long long)ld,
+                           (long long)(A->n_chunks * A->C));
+    if (int rc = require_device()) return rc;
+    if (A->dtype == USPMV_F64) return launch_spmmv<double>(A, (const double *)d_X, (double *)d_Y, b, (long)ld, layout, (hipStream_t)stream);
+    return launch_spmmv<float>(A, (const float *)d_X, (float *)d_Y, b, (long)ld, layout, (hipStream_t)stream);
+}
+
+int uspmv_spmv_ap(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const double *d_x, double *d_y, void *stream) {
+    if (int rc = check_dmat(dp, "uspmv_spmv_ap")) return rc;
+    if (int rc = check_dmat(sp, "uspmv_spmv_ap")) return rc;
+    if (dp->dtype != USPMV_F64 || sp->dtype != USPMV_F32)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_ap: expects a double and a float struct");
+    if (dp->C != sp->C || dp->n_chunks != sp->n_chunks)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_ap: dp and sp structs must share C and n_chunks");
+    if (!d_x || !d_y) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_ap: NULL vector");
+    if (int rc = require_device()) return rc;
+    if (dp->n_chunks == 0) return USPMV_OK;
+    const int block = g_tune.block;
+    const unsigned grid = grid_for(dp->n_chunks * dp->C, block);
+#define AP_LAUNCH(NTV)                                                                                               \
+    hipLaunchKernelGGL((scs_spmv_ap_rows<4, NTV>), dim3(grid), dim3(block), 0, (hipStream_t)stream, (long)dp->n_chunks, \
+                       (int)dp->C, dp->chunk_ptrs, dp->chunk_lengths, dp->col_idxs, (const double *)dp->values,      \
+                       sp->chunk_ptrs, sp->chunk_lengths, sp->col_idxs, (const float *)sp->values, d_x, d_y,         \
+                       g_tune.xcd_remap)
+    if (g_tune.nontemporal) AP_LAUNCH(true); else AP_LAUNCH(false);
+#undef AP_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+#define RAW_SCS(SUF, VT, DT)                                                                                        \
+    int uspmv_scs_gpu_##SUF(int64_t C, int64_t n_chunks, const int32_t *cp, const int32_t *cl, const int32_t *ci,   \
+                            const VT *va, const VT *x, VT *y, void *stream) {                                       \
+        if (C < 1 || n_chunks < 0 || !cp || (n_chunks > 0 && (!cl || !ci || !va || !x || !y)))                      \
+            return uspmv::fail(USPMV_ERR_INVALID, "uspmv_scs_gpu_" #SUF ": bad argument");                          \
+        if (int rc = require_device()) return rc;                                                                   \
+        uspmv_dmat A;                                                                                               \
+        A.C = C; A.n_chunks = n_chunks; A.dtype = DT; A.chunk_ptrs = cp; A.chunk_lengths = cl; A.col_idxs = ci;     \
+        A.values = va;                                                                                              \
+        if (int rc = check_dmat(&A, "uspmv_scs_gpu_" #SUF)) return rc;                                              \
+        return launch_spmv_scs<VT>(&A, nullptr, 0, x, y, (hipStream_t)stream);                                      \
+    }                                                                                                               \
+    int uspmv_csr_gpu_##SUF(int64_t n_rows, const int32_t *rp, const int32_t *ci, const VT *va, const VT *x, VT *y, \
+                            void *stream) {                                                                         \
+        if (n_rows < 0 || !rp || (n_rows > 0 && (!x || !y)))                                                        \
+            return uspmv::fail(USPMV_ERR_INVALID, "uspmv_csr_gpu_" #SUF ": bad argument");                          \
+        if (int rc = require_device()) return rc;                                                                   \
+        return launch_csr<VT>((long)n_rows, 0, rp, ci, va, x, y, (hipStream_t)stream);                              \
+    }
+RAW_SCS(f64, double, USPMV_F64)
+RAW_SCS(f32, float, USPMV_F32)
+#undef RAW_SCS
+
+int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_perm, int64_t n, int dtype,
+                                void *stream) {
+    if (!d_out || !d_in || !d_perm || n < 0) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_apply_permutation_dev: bad argument");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return USPMV_OK;
+    const unsigned grid = grid_for(n, 256);
+    if (dtype == USPMV_F64)
+        hipLaunchKernelGGL((gather_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (double *)d_out,
+                           (const double *)d_in, d_perm, (const int *)nullptr, (long)n, 0L);
+    else if (dtype == USPMV_F32)
+        hipLaunchKernelGGL((gather_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (float *)d_out,
+                           (const float *)d_in, d_perm, (const int *)nullptr, (long)n, 0L);
+    else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_apply_permutation_dev: unknown dtype %d", dtype);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int uspmv_pack_send_buf(const void *d_x, const int32_t *d_perm, const int32_t *d_send_idxs, int64_t n,
+                        int64_t block_offset, void *d_send, int dtype, void *stream) {
+    if (n < 0 || (n > 0 && (!d_x || !d_perm || !d_send_idxs || !d_send)))
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_pack_send_buf: bad argument");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return USPMV_OK;
+    const unsigned grid = grid_for(n, 256);
+    if (dtype == USPMV_F64)
+        hipLaunchKernelGGL((gather_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (double *)d_send,
+                           (const double *)d_x, d_perm, d_send_idxs, (long)n, (long)block_offset);
+    else if (dtype == USPMV_F32)
+        hipLaunchKernelGGL((gather_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (float *)d_send,
+                           (const float *)d_x, d_perm, d_send_idxs, (long)n, (long)block_offset);
+    else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_pack_send_buf: unknown dtype %d", dtype);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int uspmv_stream_copy(double *a, const double *b, int64_t n, void *stream) {
+    if (!a || !b || n < 0 || (n & 1)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_stream_copy: bad argument (n must be even)");
+    if (int rc = require_device()) return rc;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (double2 *)a, (const double2 *)b, (long)(n / 2));
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int uspmv_stream_triad(double *a, const double *b, const double *c, double s, int64_t n, void *stream) {
+    if (!a || !b || !c || n < 0 || (n & 1)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_stream_triad: bad argument (n must be even)");
+    if (int rc = require_device()) return rc;
+    hipLaunchKernelGGL(stream_triad_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (double2 *)a, (const double2 *)b, (const double2 *)c, s, (long)(n / 2));
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int uspmv_stream_read(const double *b, int64_t n, double *partial, void *stream) {
+    if (!b || !partial || n < 0 || (n & 1)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_stream_read: bad argument (n must be even; partial needs 8192 doubles)");
+    if (int rc = require_device()) return rc;
+    hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const double2 *)b, (long)(n / 2), partial);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int uspmv_time_launches(int what, int reps, const uspmv_dmat_t *A, const uspmv_dmat_t *B, const void *d_x, void *d_y,
+                        int64_t n, int b, int64_t ld, int layout, void *stream, double *avg_ms) {
+    if (reps < 1 || !avg_ms) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_time_launches: bad argument");
+    if (int rc = require_device()) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = USPMV_OK;
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int r = 0; r < reps && rc == USPMV_OK; ++r) {
+        switch (what) {
+            case 0: rc = uspmv_spmv(A, d_x, d_y, stream); break;
+            case 1: rc = uspmv_stream_copy((double *)d_y, (const double *)d_x, n, stream); break;
+            case 2: rc = uspmv_stream_triad((double *)d_y, (const double *)d_x, (const double *)d_x, 3.0, n, stream); break;
+            case 3: rc = uspmv_stream_read((const double *)d_x, n, (double *)d_y, stream); break;
+            case 4: rc = uspmv_spmv_ap(A, B, (const double *)d_x, (double *)d_y, stream); break;
+            case 5: rc = uspmv_spmmv(A, d_x, d_y, b, ld, layout, stream); break;
+            default: rc = uspmv::fail(USPMV_ERR_INVALID, "uspmv_time_launches: unknown kind %d", what);
+        }
+    }
+    hipError_t e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc != USPMV_OK) return rc;
+    if (e != hipSuccess) return uspmv::fail(USPMV_ERR_HIP, "uspmv_time_launches: %s", hipGetErrorString(e));
+    *avg_ms = (double)ms / reps;
+    return USPMV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// Internal definitions shared by the host data layer and the HIP C-ABI layer of libuspmv.so.
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "uspmv.h"
+
+// COO matrix, 0-based, entries stable-sorted by row when produced by uspmv_read_mtx
+// (role of MtxData<double,int>, reference code/classes_structs.hpp:1169-1238).
+struct uspmv_coo {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    std::vector<int32_t> I, J;
+    std::vector<double> values;
+};
+
+// SELL-C-sigma matrix on the host (role of ScsData<VT,int>, code/classes_structs.hpp:1313-1339).
+// Element (row-in-chunk i, slot j) of chunk c lives at chunk_ptrs[c] + j*C + i (column-major
+// inside a chunk); padding entries have value 0 and column 0.
+struct uspmv_scs {
+    int64_t C = 0, sigma = 0, n_rows = 0, n_cols = 0, n_rows_padded = 0, n_chunks = 0, n_elements = 0, nnz = 0;
+    int dtype = USPMV_F64;
+    std::vector<int32_t> chunk_ptrs, chunk_lengths, col_idxs, old_to_new_idx, new_to_old_idx;
+    std::vector<double> values_f64;
+    std::vector<float> values_f32;
+    const void *values_ptr() const {
+        return dtype == USPMV_F64 ? (const void *)values_f64.data() : (const void *)values_f32.data();
+    }
+};
+
+// Per-rank halo description (role of ContextData, code/classes_structs.hpp:156-184).
+struct uspmv_halo {
+    int P = 0, rank = 0;
+    int64_t n_local = 0, n_halo = 0;
+    std::vector<int32_t> recv_counts_cumsum;  // P+1, assembled as code/mpi_funcs.hpp:403-414
+    std::vector<int32_t> recv_counts;         // P
+    std::vector<int32_t> recv_idxs;           // grouped by owner ascending, owner-local row ids
+};
+
+namespace uspmv {
+int fail(int status, const char *fmt, ...);  // records the thread-local error text, returns status
+}
