@@ -1,0 +1,313 @@
+"""Parity of the HIP path (through the C ABI of libuspmv.so) with the oracle and with the golden
+vectors of the genuine reference.  Integer work: bit-exact.  Floating point: the lane-per-row
+kernels are bit-exact (same FMA chain as the reference's CPU kernels); kernels that split a row
+over lanes (two-lane SELL variant, CRS) are held to
+    |y - y_ref| <= tol * sum_j |a_ij x_j|,   tol = 1e-13 (dp) / 1e-5 (sp)
+the reference's own max_rel_error constants (code/utilities.hpp:35-47)."""
+import hashlib
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ADV_CS, GOLDEN, block_x, golden, make_x, mtx_path
+
+pytestmark = pytest.mark.gpu
+TOL = {"f64": 1e-13, "f32": 1e-5}
+FULL = ["FDM-2d-16", "impcol_e", "matrix1", "myBigMat", "mySymmMat", "matrix_band_klein", "bcsstk13"]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(pkg):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    assert pkg.device_count() >= 1
+    torch.cuda.set_device(0)
+    yield torch
+    pkg.set_tuning(unroll=4, nontemporal=1, xcd_remap=1, block=256, spmv_variant=0, csr_lanes=0)
+
+
+def sha(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _dev(t, a):
+    return t.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _prep(pkg, coo, Cc, sg, dtype, x_orig):
+    """Reference flow on the host (convert, permute cols, permute x) -> (scs, arrays, x_perm padded)."""
+    s = pkg.convert_to_scs(coo, Cc, sg, dtype)
+    a = s.arrays()
+    pkg.permute_scs_cols(s, a["old_to_new_idx"])
+    a = s.arrays()
+    xp = np.zeros(s.n_rows_padded, s.np_dtype)
+    xp[:s.n_rows] = pkg.apply_permutation(x_orig.astype(s.np_dtype), a["new_to_old_idx"])
+    return s, a, xp
+
+
+@pytest.mark.parametrize("name", FULL)
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_spmv_golden_bitexact_all_variants(pkg, torch_cuda, name, dt):
+    t = torch_cuda
+    g = golden(f"scs_{name}.npz")
+    m = pkg.read_mtx(mtx_path(name))
+    s = pkg.convert_to_scs(m, int(g["C"]), int(g["sigma"]), pkg.F64 if dt == "f64" else pkg.F32)
+    pkg.permute_scs_cols(s, s.arrays()["old_to_new_idx"])
+    A = pkg.DeviceMatrix(s)
+    x = _dev(t, g[f"{dt}_x_perm"])
+    for unroll in (1, 2, 4, 8):
+        for nt in (0, 1):
+            for xcd in (0, 1):
+                for block in (64, 256, 1024):
+                    pkg.set_tuning(unroll=unroll, nontemporal=nt, xcd_remap=xcd, block=block, spmv_variant=0)
+                    y = t.full((s.n_rows_padded,), -7.0, dtype=x.dtype, device="cuda")
+                    pkg.spmv(A, x, y)
+                    assert np.array_equal(y.cpu().numpy(), g[f"{dt}_y_perm"]), (unroll, nt, xcd, block)
+    pkg.set_tuning(unroll=4, nontemporal=1, xcd_remap=1, block=256)
+    # raw-array entry point with the interface.hpp argument list
+    y = t.zeros(s.n_rows_padded, dtype=x.dtype, device="cuda")
+    pkg.uspmv_scs_gpu(s.C, s.n_chunks, A.chunk_ptrs, A.chunk_lengths, A.col_idxs, A.values, x, y)
+    assert np.array_equal(y.cpu().numpy(), g[f"{dt}_y_perm"])
+    yo = pkg.apply_permutation(y.cpu().numpy(), g[f"{dt}_old_to_new"])
+    assert np.array_equal(yo, g[f"{dt}_y_orig"])
+
+
+def test_spmv_grid_vs_oracle_and_reference_hashes(pkg, orc, torch_cuda):
+    """C x sigma grid of scripts/validate_master.sh:16-23 (+ C = 1, 128): bit-exact vs the oracle on
+    the same arrays and vs the sha1 of the reference's y."""
+    t = torch_cuda
+    grid = json.load(open(os.path.join(GOLDEN, "scs_grid_sha1.json")))
+    mats = {}
+    n = 0
+    for key, ent in grid.items():
+        name, Cc, sg = key.split("|")
+        Cc, sg = int(Cc), int(sg)
+        if name == "bcsstk13" and sg not in (1, 64, 512):
+            continue
+        m = mats.setdefault(name, pkg.read_mtx(mtx_path(name)))
+        x0 = make_x(m.n_rows)
+        for dt, code in (("f64", pkg.F64), ("f32", pkg.F32)):
+            s, a, xp = _prep(pkg, m, Cc, sg, code, x0)
+            A = pkg.DeviceMatrix(s)
+            y = t.zeros(s.n_rows_padded, dtype=A.torch_dtype, device="cuda")
+            pkg.spmv(A, _dev(t, xp), y)
+            yh = y.cpu().numpy()
+            y_or = orc.spmv_scs(Cc, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+            assert np.array_equal(yh, y_or), (key, dt)
+            assert sha(yh) == ent[dt]["y_perm"], (key, dt)
+            n += 1
+    assert n > 300
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_spmv_two_lane_variant_tolerance(pkg, orc, torch_cuda, dt):
+    t = torch_cuda
+    for name in ("bcsstk13", "impcol_e"):
+        g = golden(f"scs_{name}.npz")
+        m = pkg.read_mtx(mtx_path(name))
+        s, a, xp = _prep(pkg, m, 32, 512, pkg.F64 if dt == "f64" else pkg.F32, g["x"])
+        A = pkg.DeviceMatrix(s)
+        y = t.zeros(s.n_rows_padded, dtype=A.torch_dtype, device="cuda")
+        pkg.set_tuning(spmv_variant=1)
+        pkg.spmv(A, _dev(t, xp), y)
+        pkg.set_tuning(spmv_variant=0)
+        bound = orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], np.abs(a["values"]),
+                             np.abs(xp)).astype(np.float64)
+        err = np.abs(y.cpu().numpy().astype(np.float64) - g[f"{dt}_y_perm"].astype(np.float64))
+        assert np.all(err <= TOL[dt] * bound + 1e-300)
+
+
+@pytest.mark.parametrize("name", ["FDM-2d-16", "impcol_e", "matrix1", "bcsstk13"])
+def test_crs(pkg, orc, torch_cuda, name):
+    t = torch_cuda
+    c = golden("csr.npz")
+    m = pkg.read_mtx(mtx_path(name))
+    x0 = make_x(m.n_rows)
+    for dt, code in (("f64", pkg.F64), ("f32", pkg.F32)):
+        s, a, xp = _prep(pkg, m, 1, 1, code, x0)
+        assert np.array_equal(a["chunk_ptrs"], c[f"{name}_{dt}_row_ptrs"])
+        bound = orc.spmv_csr(s.n_rows, a["chunk_ptrs"], a["col_idxs"], np.abs(a["values"]), np.abs(xp)).astype(np.float64)
+        ref = c[f"{name}_{dt}_y"].astype(np.float64)
+        x = _dev(t, xp)
+        A = pkg.DeviceMatrix(s, crs=True)
+        for lanes in (0, 1, 2, 8, 64):
+            pkg.set_tuning(csr_lanes=lanes)
+            y = t.zeros(s.n_rows, dtype=A.torch_dtype, device="cuda")
+            pkg.spmv(A, x, y)
+            assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= TOL[dt] * bound + 1e-300), (dt, lanes)
+        pkg.set_tuning(csr_lanes=0)
+        y = t.zeros(s.n_rows, dtype=A.torch_dtype, device="cuda")
+        pkg.uspmv_csr_gpu(s.n_rows, A.chunk_ptrs, A.col_idxs, A.values, x, y)
+        assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= TOL[dt] * bound + 1e-300)
+        # the generic SELL kernel at C = 1 is the sequential chain: bit-exact with the oracle
+        A1 = pkg.DeviceMatrix(s)
+        pkg.spmv(A1, x, y)
+        assert np.array_equal(y.cpu().numpy(), orc.spmv_csr(s.n_rows, a["chunk_ptrs"], a["col_idxs"], a["values"], xp))
+
+
+@pytest.mark.parametrize("name", ["FDM-2d-16", "impcol_e", "bcsstk13"])
+def test_spmmv_golden_bitexact(pkg, orc, torch_cuda, name):
+    t = torch_cuda
+    g = golden(f"scs_{name}.npz")
+    sp = golden("spmmv.npz")
+    m = pkg.read_mtx(mtx_path(name))
+    for dt, code in (("f64", pkg.F64), ("f32", pkg.F32)):
+        s, a, xp = _prep(pkg, m, int(g["C"]), int(g["sigma"]), code, g["x"])
+        A = pkg.DeviceMatrix(s)
+        ld = s.n_rows_padded
+        for b in (2, 8):
+            for rowwise in (0, 1):
+                X = block_x(xp, ld, b, ld, rowwise)
+                Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
+                pkg.spmmv(A, _dev(t, X), Y, b, ld, pkg.ROWWISE if rowwise else pkg.COLWISE)
+                assert np.array_equal(Y.cpu().numpy(), sp[f"{name}_{dt}_b{b}_{'row' if rowwise else 'col'}_Y"]), (dt, b, rowwise)
+        for b in (1, 3, 5, 13):     # widths without a golden: vs the oracle, colwise ld > n_rows_padded too
+            for rowwise in (0, 1):
+                ld2 = ld + 7
+                X = block_x(xp, ld, b, ld2, rowwise)
+                Y = t.zeros(b * ld2, dtype=A.torch_dtype, device="cuda")
+                pkg.spmmv(A, _dev(t, X), Y, b, ld2, pkg.ROWWISE if rowwise else pkg.COLWISE)
+                Yo = orc.spmmv_scs(s.C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, b, ld2, rowwise)
+                got = Y.cpu().numpy()
+                if rowwise:
+                    assert np.array_equal(got[:ld * b], Yo[:ld * b])
+                else:
+                    assert np.array_equal(got, Yo)
+
+
+@pytest.mark.parametrize("name", ["bcsstk13", "impcol_e", "FDM-2d-16", "matrix1"])
+def test_ap_golden_bitexact(pkg, torch_cuda, name):
+    t = torch_cuda
+    a = golden("ap.npz")
+    p = name + "_"
+    m = pkg.read_mtx(mtx_path(name))
+    dp, sp = pkg.partition_precisions(m, float(a[p + "th"]))
+    Cc, sg = int(a[p + "C"]), int(a[p + "sigma"])
+    ds = pkg.convert_to_scs(dp, Cc, sg, pkg.F64)
+    perm = ds.arrays()["old_to_new_idx"].copy()
+    ss = pkg.convert_to_scs(sp, Cc, sg, pkg.F32, fixed_permutation=perm)
+    pkg.permute_scs_cols(ds, perm); pkg.permute_scs_cols(ss, perm)
+    Ad, As = pkg.DeviceMatrix(ds), pkg.DeviceMatrix(ss)
+    y = t.zeros(ds.n_rows_padded, dtype=t.float64, device="cuda")
+    pkg.spmv_ap(Ad, As, _dev(t, a[p + "x_perm"]), y)
+    key = "y_perm_adv" if Cc in ADV_CS else "y_perm_gen"   # matrix1 (C=10): generic kernel reads the float x
+    if Cc in ADV_CS:
+        assert np.array_equal(y.cpu().numpy(), a[p + key])
+        assert np.array_equal(pkg.apply_permutation(y.cpu().numpy(), perm), a[p + "y_orig_adv"])
+    else:
+        assert np.allclose(y.cpu().numpy(), a[p + key], rtol=1e-6, atol=0)
+    with pytest.raises(pkg.UspmvError):
+        pkg.spmv_ap(As, Ad, _dev(t, a[p + "x_perm"]), y)      # wrong precision order
+
+
+def test_chunk_subsets_pack_and_permutation(pkg, orc, torch_cuda):
+    t = torch_cuda
+    from ultimate_spmv_amd import binding as B
+    h = golden("halo.npz")
+    key = "bcsstk13_C32_s512_seg-nnz_P4"
+    tot = pkg.read_mtx(mtx_path("bcsstk13"))
+    wsa = pkg.seg_work_sharing_arr(tot, "seg-nnz", 4)
+    xg = make_x(tot.n_rows)
+    ys = []
+    for r in range(4):
+        loc = B.seg_local_coo(tot, wsa, r)
+        s = pkg.convert_to_scs(loc, 32, 512)
+        plan = pkg.HaloPlan(s, wsa, r, 4)
+        a = s.arrays()
+        pkg.permute_scs_cols(s, a["old_to_new_idx"])
+        A = pkg.DeviceMatrix(s)
+        inner, bnd = s.split_chunks(plan.n_local)
+        x = _dev(t, h[f"{key}_r{r}_x_local"])
+        y = t.full((s.n_rows_padded,), np.nan, dtype=t.float64, device="cuda")
+        pkg.spmv_chunks(A, _dev(t, inner), x, y)
+        assert int(t.isnan(y).sum()) == len(bnd) * 32
+        pkg.spmv_chunks(A, _dev(t, bnd), x, y)
+        y2 = t.zeros_like(y)
+        pkg.spmv(A, x, y2)
+        assert t.equal(y, y2)
+        ys.append(pkg.apply_permutation(y.cpu().numpy(), a["old_to_new_idx"]))
+        # what this rank would send to everybody who asks for all of its rows, twice over
+        idx = np.concatenate([np.arange(plan.n_local), np.arange(plan.n_local)[::-1]]).astype(np.int32)
+        out = t.zeros(len(idx), dtype=t.float64, device="cuda")
+        pkg.pack_send_buf(x, _dev(t, a["old_to_new_idx"]), _dev(t, idx), out)
+        assert np.array_equal(out.cpu().numpy(), orc.pack_send_buf(h[f"{key}_r{r}_x_local"], a["old_to_new_idx"], idx))
+        assert np.array_equal(out.cpu().numpy()[:plan.n_local], xg[wsa[r]:wsa[r + 1]])
+        o = t.zeros(s.n_rows, dtype=t.float64, device="cuda")
+        B.apply_permutation_dev(o, y, _dev(t, a["old_to_new_idx"]))
+        assert np.array_equal(o.cpu().numpy(), ys[-1])
+    assert np.array_equal(np.concatenate(ys), h[key + "_y_global"])
+
+
+def test_argument_errors(pkg, torch_cuda):
+    t = torch_cuda
+    s = pkg.convert_to_scs(pkg.gen_stencil27(4, 4, 4), 32, 512)
+    A = pkg.DeviceMatrix(s)
+    x = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
+    with pytest.raises(pkg.UspmvError):
+        pkg.spmmv(A, x, x, 2, s.n_rows_padded - 1)              # ld too small
+    with pytest.raises(pkg.UspmvError):
+        pkg.spmmv(A, x, x, 0, s.n_rows_padded)
+    with pytest.raises(pkg.UspmvError):
+        pkg.set_tuning(unroll=3)
+    rc = pkg.lib().uspmv_spmv(A.h, None, None, None)
+    assert rc == 1
+    with pytest.raises(pkg.UspmvError):
+        pkg.DeviceMatrix(s, crs=True)                           # crs needs C = 1
+
+
+@pytest.mark.parametrize("shape,C,sigma", [((40, 40, 40), 32, 512), ((33, 17, 9), 64, 128), ((64, 64, 64), 128, 1),
+                                           ((50, 20, 20), 16, 64), ((21, 21, 21), 3, 7)])
+def test_synthetic_vs_oracle(pkg, orc, torch_cuda, shape, C, sigma):
+    t = torch_cuda
+    m = pkg.gen_stencil27(*shape)
+    x0 = make_x(m.n_rows)
+    for code in (pkg.F64, pkg.F32):
+        s, a, xp = _prep(pkg, m, C, sigma, code, x0)
+        A = pkg.DeviceMatrix(s)
+        y = t.zeros(s.n_rows_padded, dtype=A.torch_dtype, device="cuda")
+        pkg.spmv(A, _dev(t, xp), y)
+        assert np.array_equal(y.cpu().numpy(), orc.spmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp))
+
+
+def test_full_size_nlpkkt200_class(pkg, orc, torch_cuda):
+    """BASELINE config 2 size (27-pt stencil on 253^3, n = 16.2M, nnz = 4.3e8, SELL-32-512 dp):
+    bit-exact against the oracle on the same arrays, plus size-independent properties:
+    linearity A(2x) == 2 A x exactly, row sums A*1 against a numpy segment sum (tolerance), and
+    un-permuting y reproduces the COO-order CSR product on a sample of rows."""
+    t = torch_cuda
+    n1 = int(os.environ.get("USPMV_FULL_N", "253"))
+    t0 = time.time()
+    m = pkg.gen_stencil27(n1, n1, n1)
+    s = pkg.convert_to_scs(m, 32, 512)
+    a = s.arrays()
+    pkg.permute_scs_cols(s, a["old_to_new_idx"])
+    a = s.arrays()
+    print(f"\n[full] n={m.n_rows} nnz={m.nnz} n_el={s.n_elements} gen+convert {time.time() - t0:.1f}s", flush=True)
+    x0 = make_x(m.n_rows)
+    xp = np.zeros(s.n_rows_padded)
+    xp[:s.n_rows] = pkg.apply_permutation(x0, a["new_to_old_idx"])
+    A = pkg.DeviceMatrix(s)
+    x = _dev(t, xp)
+    y = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
+    pkg.spmv(A, x, y)
+    yh = y.cpu().numpy()
+    t0 = time.time()
+    y_or = orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+    print(f"[full] oracle SpMV {time.time() - t0:.1f}s", flush=True)
+    assert np.array_equal(yh, y_or)
+    y2 = t.zeros_like(y)
+    pkg.spmv(A, 2.0 * x, y2)
+    assert t.equal(y2, 2.0 * y)
+    # sample of rows against the row-sorted COO (original numbering)
+    I, J, V = m.arrays()
+    yo = pkg.apply_permutation(yh, a["old_to_new_idx"])
+    rows = np.random.default_rng(0).integers(0, m.n_rows, 2000)
+    starts = np.searchsorted(I, rows, side="left"); ends = np.searchsorted(I, rows, side="right")
+    for r, b, e in zip(rows, starts, ends):
+        acc = 0.0
+        for k in range(b, e):
+            acc = float(np.float64(V[k]) * np.float64(x0[J[k]]) + acc)   # not fused: tolerance
+        assert abs(acc - yo[r]) <= 1e-13 * float(np.abs(V[b:e] * x0[J[b:e]]).sum())

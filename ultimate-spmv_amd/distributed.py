@@ -1,0 +1,207 @@
+"""One-process-per-GPU distributed SpMV: 1-D row blocks + halo exchange of x over RCCL/xGMI.
+
+Replaces the reference's MPI path -- init_local_structs (code/main.cpp:1075-1334),
+collect_comm_info (code/mpi_funcs.hpp:1061-1124) and SpmvKernel::init_halo_exchange /
+finalize_halo_exchange (code/classes_structs.hpp:857-995) -- with a design for xGMI:
+
+  * the halo region of x on rank r is ordered by owner rank ascending (reference numbering,
+    code/mpi_funcs.hpp:357-401), which is exactly the output layout of an all-to-all-v.  So the
+    whole exchange is ONE `all_to_all_single` whose output tensor IS the tail of x
+    (x[n_local : n_local + n_halo]) -- no per-neighbour launches, no receive staging;
+  * the send side is ONE gather kernel over the concatenated send list (uspmv_pack_send_buf)
+    instead of one launch + device sync per neighbour (code/classes_structs.hpp:793-806);
+  * the exchange runs on a side stream while the kernel processes the chunks that touch no halo
+    column (interior); the boundary chunks follow once the halo has landed.  The reference waits
+    for the whole exchange before the kernel starts (code/main.cpp:464-468).
+
+torch.distributed is used as plumbing only (backend "nccl" == RCCL on ROCm; "gloo" for the CPU
+tests, which inject their own pack / kernel callables because the product has no CPU kernels).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import binding as B
+
+
+def seg_from_row_counts(row_nnz, method, P):
+    """work_sharing_arr from per-row entry counts only (equivalent to uspmv_seg_work_sharing_arr /
+    code/mpi_funcs.hpp:446-493 on the row-sorted COO, without materialising the global matrix)."""
+    row_nnz = np.asarray(row_nnz, np.int64)
+    n = len(row_nnz)
+    ptr = np.concatenate([[0], np.cumsum(row_nnz)])
+    nnz = int(ptr[-1])
+    last_row_p1 = int(np.flatnonzero(row_nnz)[-1]) + 1
+    wsa = np.zeros(P + 1, np.int64)
+    if method in ("seg-rows", B.SEG_ROWS):
+        wsa[1:] = np.arange(1, P + 1) * (n // P)
+    else:
+        per = nnz // P
+        g = np.arange(1, P + 1) * (per + 1) - 1          # entry index at which the k-th cut happens
+        ok = g < nnz
+        rows = np.searchsorted(ptr, g[ok], side="right") - 1
+        wsa[1:][ok] = rows + 1
+    wsa[P] = last_row_p1
+    if P > 1 and wsa[P - 1] == wsa[P]:
+        wsa[1:P] -= 1
+    if np.any(np.diff(wsa) < 0):
+        raise B.UspmvError(1, "seg_from_row_counts: flaw in work_sharing_arr")
+    return wsa.astype(np.int32)
+
+
+class DistSpmv:
+    """Per-rank state of the distributed SELL-C-sigma SpMV.
+
+    local_coo: rows [wsa[rank], wsa[rank+1]) with process-local row ids and GLOBAL column ids
+    (uspmv_seg_local_coo / uspmv_gen_stencil27(row_begin,row_end)).
+    """
+
+    def __init__(self, local_coo, wsa, C, sigma, dtype=B.F64, device=None, group=None, overlap=True,
+                 pack_fn=None, spmv_fn=None, spmv_chunks_fn=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.P = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.wsa = np.ascontiguousarray(wsa, np.int32)
+        assert len(self.wsa) == self.P + 1
+        self.device = torch.device(device if device is not None else "cuda")
+        self.on_gpu = self.device.type == "cuda"
+        self.overlap = bool(overlap)
+        self._pack_fn, self._spmv_fn, self._spmv_chunks_fn = pack_fn, spmv_fn, spmv_chunks_fn
+        self.tdtype = torch.float64 if dtype == B.F64 else torch.float32
+
+        # ---- local SELL-C-sigma + halo discovery (order as code/main.cpp:1128, :1271-1308)
+        scs = B.convert_to_scs(local_coo, C, sigma, dtype)
+        self.plan = B.HaloPlan(scs, self.wsa, self.rank, self.P)        # rewrites col_idxs
+        a = scs.arrays()
+        B.permute_scs_cols(scs, a["old_to_new_idx"])
+        self.scs = scs
+        self.n_local = self.plan.n_local
+        self.n_halo = self.plan.n_halo
+        self.scs_padding = scs.n_rows_padded - scs.n_rows
+        self.per_vector_padding = max(self.scs_padding, self.n_halo)     # code/main.cpp:1406-1412
+        self.padded_vec_size = self.n_local + self.per_vector_padding
+        self.old_to_new = a["old_to_new_idx"].copy()
+        self.new_to_old = a["new_to_old_idx"].copy()
+        self.interior_ids, self.boundary_ids = scs.split_chunks(self.n_local)
+
+        # ---- who sends what to whom (collect_comm_idxs / organize_cumsums, code/mpi_funcs.hpp:117-232)
+        self.recv_counts = self.plan.recv_counts.astype(np.int64)
+        cdev = self.device if self._needs_device_comm() else torch.device("cpu")
+        self.send_counts = self._exchange_counts(self.recv_counts, cdev)
+        self.send_idxs = self._exchange_idxs(self.plan.recv_idxs, self.recv_counts, self.send_counts, cdev)
+        self.n_send = int(self.send_counts.sum())
+        self.recv_splits = [int(v) for v in self.recv_counts]
+        self.send_splits = [int(v) for v in self.send_counts]
+
+        # ---- device-resident state
+        if self.on_gpu:
+            self.A = B.DeviceMatrix(scs, self.device)
+        self.d_perm = torch.from_numpy(self.old_to_new).to(self.device)
+        self.d_send_idxs = torch.from_numpy(self.send_idxs.astype(np.int32)).to(self.device)
+        self.d_interior = torch.from_numpy(self.interior_ids).to(self.device)
+        self.d_boundary = torch.from_numpy(self.boundary_ids).to(self.device)
+        self.send_buf = torch.zeros(max(self.n_send, 1), dtype=self.tdtype, device=self.device)
+        self.comm_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+
+    # ------------------------------------------------------------------ set-up collectives
+    def _needs_device_comm(self):
+        return dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+
+    def _exchange_counts(self, recv_counts, cdev):
+        if self.P == 1:
+            return np.zeros(1, np.int64)
+        t_in = torch.from_numpy(recv_counts.copy()).to(cdev)
+        t_out = torch.empty_like(t_in)
+        dist.all_to_all_single(t_out, t_in, group=self.group)
+        return t_out.cpu().numpy()
+
+    def _exchange_idxs(self, recv_idxs, recv_counts, send_counts, cdev):
+        """Tell every owner WHICH of its local rows this rank needs (index all-to-all,
+        code/mpi_funcs.hpp:143-171).  Returns the concatenated send list ordered by destination."""
+        if self.P == 1:
+            return np.zeros(0, np.int32)
+        t_in = torch.from_numpy(np.ascontiguousarray(recv_idxs, np.int32)).to(cdev)
+        t_out = torch.empty(int(send_counts.sum()), dtype=torch.int32, device=cdev)
+        dist.all_to_all_single(t_out, t_in, [int(v) for v in send_counts], [int(v) for v in recv_counts],
+                               group=self.group)
+        return t_out.cpu().numpy()
+
+    # ------------------------------------------------------------------ vectors
+    def new_x(self, x_local_orig):
+        """Device x of padded_vec_size elements: permuted local part (apply_permutation with
+        new_to_old_idx, code/main.cpp:86-93), zero padding / halo tail."""
+        xp = B.apply_permutation(np.ascontiguousarray(x_local_orig, self.scs.np_dtype), self.new_to_old)
+        x = torch.zeros(self.padded_vec_size, dtype=self.tdtype, device=self.device)
+        x[:self.n_local] = torch.from_numpy(xp).to(self.device)
+        return x
+
+    def new_y(self):
+        return torch.zeros(self.padded_vec_size, dtype=self.tdtype, device=self.device)
+
+    def y_to_original_order(self, y):
+        """copy_back_result (code/utilities.hpp:3862): y_orig[i] = y[old_to_new_idx[i]]."""
+        return B.apply_permutation(y.detach().cpu().numpy(), self.old_to_new)
+
+    # ------------------------------------------------------------------ hot path
+    def _pack(self, x):
+        if self.n_send == 0:
+            return
+        if self._pack_fn is not None:
+            self._pack_fn(x, self.d_perm, self.d_send_idxs, self.send_buf)
+        else:
+            B.pack_send_buf(x, self.d_perm, self.d_send_idxs, self.send_buf)
+
+    def halo_begin(self, x):
+        """Pack + post the all-to-all-v that lands directly in x[n_local : n_local + n_halo]."""
+        if self.P == 1:
+            return None
+        if self.on_gpu and self.overlap:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            ctx = torch.cuda.stream(self.comm_stream)
+        else:
+            ctx = _Null()
+        with ctx:
+            self._pack(x)
+            out = x[self.n_local:self.n_local + self.n_halo]
+            return dist.all_to_all_single(out, self.send_buf[:self.n_send], self.recv_splits, self.send_splits,
+                                          group=self.group, async_op=True)
+
+    def halo_end(self, work):
+        if work is not None:
+            work.wait()          # nccl: orders the current stream after the collective; gloo: blocks
+            if self.on_gpu and self.overlap:
+                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+
+    def _spmv_all(self, x, y):
+        if self._spmv_fn is not None:
+            return self._spmv_fn(self, x, y)
+        return B.spmv(self.A, x, y)
+
+    def _spmv_ids(self, ids, x, y):
+        if ids.numel() == 0:
+            return y
+        if self._spmv_chunks_fn is not None:
+            return self._spmv_chunks_fn(self, ids, x, y)
+        return B.spmv_chunks(self.A, ids, x, y)
+
+    def spmv(self, x, y, comm_halos=True):
+        """One distributed SpMV step: halo exchange (optional, -comm_halos) + local kernel."""
+        if self.P == 1 or not comm_halos:
+            return self._spmv_all(x, y)
+        work = self.halo_begin(x)
+        if self.overlap:
+            self._spmv_ids(self.d_interior, x, y)
+            self.halo_end(work)
+            self._spmv_ids(self.d_boundary, x, y)
+        else:
+            self.halo_end(work)
+            self._spmv_all(x, y)
+        return y
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
