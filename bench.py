@@ -53,13 +53,34 @@ def stencil_row_counts(nx, ny, nz):
     return (sz[:, None, None] * sy[None, :, None] * sx[None, None, :]).reshape(-1)
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def set_omp_threads(n):
+    """libgomp is shared by libuspmv.so (host set-up) and the reference/oracle kernels."""
+    import ctypes
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
+
+
 def cpu_baseline(scs_arrays, C, n_chunks, nnz, x, seconds):
     """Reference CPU kernel timed on the host cores (rank 0, N = 1): the genuine scs_impl_cpu<32>
     from oracle/_ref when present (kind "reference"), else the oracle's C port (kind "port")."""
     from oracle import refshim
     a = scs_arrays
-    cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = usable_cores()
+    set_omp_threads(cores)
     if refshim.available("colwise"):
         kind = "reference"
         L = refshim.lib("colwise")
@@ -108,6 +129,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    set_omp_threads(int(os.environ.get("OMP_NUM_THREADS", usable_cores())))
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         pkg.set_tuning(**{k: int(v)})
@@ -166,7 +188,7 @@ def main():
     achieved = bytes_local / (k_ms * 1e-3) / 1e9
     nstream = 1 << 27  # 1 GiB per array
     sa = torch.empty(nstream, dtype=torch.float64, device=dev)
-    sb = torch.ones(nstream, dtype=torch.float64, device=dev)
+    sb = torch.ones(2 * nstream, dtype=torch.float64, device=dev)
     part = torch.empty(8192, dtype=torch.float64, device=dev)
     B.time_launches(1, 3, x=sb, y=sa, n=nstream)
     copy_gbs = 16.0 * nstream / (B.time_launches(1, 20, x=sb, y=sa, n=nstream) * 1e-3) / 1e9

@@ -156,8 +156,11 @@ int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_
                                 void *stream);
 
 /* Kernel-variant selection for A/B measurements (DESIGN.md "variants").  key/value pairs:
- *   "unroll" 1|2|4|8, "nontemporal" 0|1, "xcd_remap" 0|1, "block" 64|128|256|512,
- *   "spmv_variant" 0 (lane per row, bit-exact) | 1 (two lanes per row, C=32 only). */
+ *   "unroll" 1|2|4|8, "nontemporal" 0|1, "block" 64|128|256|512|1024,
+ *   "xcd_remap" 0 (hardware order) | 1 (one contiguous eighth of the grid per XCD) | G >= 2 (groups
+ *   of G consecutive workgroups per XCD), "spmv_variant" 0 (lane per row, bit-exact) | 1 (two lanes
+ *   per row, C=32 only), "csr_lanes" 0 (auto) | 1..64 lanes per row of the CRS kernel,
+ *   "ablate" 0 | 1 | 2 (measurement only: gathers collapsed / removed, results are wrong). */
 int uspmv_set_tuning(const char *key, int value);
 int uspmv_get_tuning(const char *key, int *value);
 
@@ -196,7 +199,9 @@ int uspmv_stream_triad(double *d_a, const double *d_b, const double *d_c, double
 int uspmv_stream_read(const double *d_b, int64_t n, double *d_partial, void *stream);
 /* Time `reps` back-to-back launches of one entry point with HIP events on `stream`;
  * what: 0 spmv(A,x,y) 1 stream_copy 2 stream_triad 3 stream_read 4 spmv_ap(A,B,x,y)
- *       5 spmmv(A,X,Y,b,ld,layout).  Returns the average milliseconds per launch. */
+ *       5 spmmv(A,X,Y,b,ld,layout).  Returns the average milliseconds per launch.
+ * For the STREAM kinds d_x is the source (n doubles; 2n for the triad: b = d_x, c = d_x + n) and d_y
+ * the destination (n doubles; 8192 for the read kernel's partial sums). */
 int uspmv_time_launches(int what, int reps, const uspmv_dmat_t *A, const uspmv_dmat_t *B, const void *d_x,
                         void *d_y, int64_t n, int b, int64_t ld, int layout, void *stream, double *avg_ms);
 

@@ -26,7 +26,7 @@ def torch_cuda(pkg):
     assert pkg.device_count() >= 1
     torch.cuda.set_device(0)
     yield torch
-    pkg.set_tuning(unroll=4, nontemporal=1, xcd_remap=1, block=256, spmv_variant=0, csr_lanes=0)
+    pkg.set_tuning(unroll=8, nontemporal=1, xcd_remap=0, block=256, spmv_variant=0, csr_lanes=0)
 
 
 def sha(a):
@@ -66,7 +66,7 @@ def test_spmv_golden_bitexact_all_variants(pkg, torch_cuda, name, dt):
                     y = t.full((s.n_rows_padded,), -7.0, dtype=x.dtype, device="cuda")
                     pkg.spmv(A, x, y)
                     assert np.array_equal(y.cpu().numpy(), g[f"{dt}_y_perm"]), (unroll, nt, xcd, block)
-    pkg.set_tuning(unroll=4, nontemporal=1, xcd_remap=1, block=256)
+    pkg.set_tuning(unroll=8, nontemporal=1, xcd_remap=0, block=256)
     # raw-array entry point with the interface.hpp argument list
     y = t.zeros(s.n_rows_padded, dtype=x.dtype, device="cuda")
     pkg.uspmv_scs_gpu(s.C, s.n_chunks, A.chunk_ptrs, A.chunk_lengths, A.col_idxs, A.values, x, y)

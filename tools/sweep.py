@@ -63,7 +63,7 @@ def main():
     for med, mn, k in rows:
         print(f"{med:10.4f} {mn:8.4f} {bytes_ / med / 1e6:8.0f} {2 * s.nnz / med / 1e6:8.0f}  {k}")
     n = 1 << 27
-    sa = torch.empty(n, dtype=torch.float64, device="cuda"); sb = torch.ones(n, dtype=torch.float64, device="cuda")
+    sa = torch.empty(n, dtype=torch.float64, device="cuda"); sb = torch.ones(2 * n, dtype=torch.float64, device="cuda")
     part = torch.empty(8192, dtype=torch.float64, device="cuda")
     for what, nm, bpe in ((1, "copy", 16), (2, "triad", 24), (3, "read", 8)):
         B.time_launches(what, 3, x=sb, y=sa if what != 3 else part, n=n)

@@ -102,6 +102,14 @@ def lib():
     """Load libuspmv.so.  Fails loudly (no fallback) when the extension has not been built."""
     global _LIB
     if _LIB is None:
+        # torch (when installed) must be imported BEFORE libuspmv.so is loaded: torch ships its
+        # own HIP/HSA runtime and publishes it RTLD_GLOBAL; loaded first, it is the one runtime the
+        # whole process (torch + libuspmv kernels + RCCL) shares.  Loaded second, the process ends up
+        # with two HSA runtimes and the later one finds no device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = library_path()
         if not os.path.exists(path):
             raise UspmvError(-1, f"{path} is missing: build it with __graft_entry__.build() "

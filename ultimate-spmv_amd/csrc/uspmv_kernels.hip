@@ -43,12 +43,14 @@ struct uspmv_dmat {
 namespace {
 
 struct Tuning {
-    int unroll = 4;
+    // defaults = fastest of the interleaved sweep on the nlpkkt200-class matrix (profiles/r01_sweep253.txt)
+    int unroll = 8;
     int nontemporal = 1;
-    int xcd_remap = 1;
+    int xcd_remap = 0;
     int block = 256;
     int spmv_variant = 0;
     int csr_lanes = 0;  // 0 = choose from average row length
+    int ablate = 0;     // measurement only
 };
 Tuning g_tune;
 
@@ -80,24 +82,37 @@ __device__ __forceinline__ T ld_stream(const T *p) {
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// logical block id: every XCD (blocks b, b+8, b+16, ... share one) gets a contiguous range
-__device__ __forceinline__ unsigned remap_block(unsigned b, unsigned nb, bool remap) {
-    if (!remap || nb < 16) return b;
-    const unsigned xcd = b & 7u, q = nb >> 3, r = nb & 7u;
-    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (b >> 3);
+// logical block id.  Hardware deals blocks round-robin over the 8 XCDs (b, b+8, b+16, ... share
+// one).  mode 0: identity.  mode 1: every XCD walks one contiguous eighth of the grid.
+// mode G >= 2: groups of G consecutive logical blocks per XCD, the 8 groups of a super-block
+// of 8*G blocks being processed concurrently (keeps all XCDs inside one moving DRAM window while
+// neighbouring blocks -- which share x lines -- share an L2).
+__device__ __forceinline__ unsigned remap_block(unsigned b, unsigned nb, int mode) {
+    if (mode == 0 || nb < 16) return b;
+    if (mode == 1) {
+        const unsigned xcd = b & 7u, q = nb >> 3, r = nb & 7u;
+        const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        return base + (b >> 3);
+    }
+    const unsigned G = (unsigned)mode, SG = 8u * G;
+    const unsigned full = (nb / SG) * SG;
+    if (b >= full) return b;
+    const unsigned sup = b / SG, rem = b - sup * SG;
+    return sup * SG + (rem & 7u) * G + (rem >> 3);
 }
 
 // ------------------------------------------------------------------------------------------
 // SELL-C-sigma SpMV, one lane per row.  CT > 0: compile-time C; CT == 0: C passed at run time.
 // IDS: virtual chunk v -> chunk_ids[v] (interior / boundary subsets).
-template <typename VT, int CT, int U, bool NT, bool IDS>
+// ABL != 0: measurement-only ablations (WRONG results): 1 = every gather hits one 512-byte window
+// of x (keeps the instruction stream, removes L1 misses), 2 = no gather at all.
+template <typename VT, int CT, int U, bool NT, bool IDS, int ABL = 0>
 __global__ void scs_spmv_rows(const long n_work_chunks, const int C_rt, const int *__restrict__ chunk_ptrs,
                               const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                               const VT *__restrict__ values, const VT *__restrict__ x, VT *__restrict__ y,
                               const int *__restrict__ chunk_ids, const int xcd_remap) {
     const int C = CT > 0 ? CT : C_rt;
-    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap != 0);
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
     const long vrow = (long)lb * blockDim.x + threadIdx.x;
     const long vc = vrow / C;
     const int i = (int)(vrow - vc * C);
@@ -119,14 +134,14 @@ __global__ void scs_spmv_rows(const long n_work_chunks, const int C_rt, const in
         }
         VT xv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) xv[u] = x[ci[u]];
+        for (int u = 0; u < U; ++u) xv[u] = ABL == 0 ? x[ci[u]] : ABL == 1 ? x[ci[u] & 63] : (VT)ci[u];
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = fma_t(v[u], xv[u], acc);
     }
     for (; j < L; ++j) {
         const VT v = ld_stream<NT>(vp + (long)j * C);
         const int ci = ld_stream<NT>(cp + (long)j * C);
-        acc = fma_t(v, x[ci], acc);
+        acc = fma_t(v, ABL == 0 ? x[ci] : ABL == 1 ? x[ci & 63] : (VT)ci, acc);
     }
     y[c * C + i] = acc;
 }
@@ -140,7 +155,7 @@ __global__ void scs_spmv_split2(const long n_chunks, const int *__restrict__ chu
                                 const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                                 const VT *__restrict__ values, const VT *__restrict__ x, VT *__restrict__ y,
                                 const int xcd_remap) {
-    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap != 0);
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
     const long c = ((long)lb * blockDim.x + threadIdx.x) >> 6;
     if (c >= n_chunks) return;
     const int lane = threadIdx.x & 63;
@@ -202,7 +217,7 @@ __global__ void scs_spmmv_rows(const long n_chunks, const int C, const int *__re
                                const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                                const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
                                const int b, const long ld, const int xcd_remap) {
-    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap != 0);
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
     const long row = (long)lb * blockDim.x + threadIdx.x;
     const long c = row / C;
     const int i = (int)(row - c * C);
@@ -245,7 +260,7 @@ __global__ void scs_spmv_ap_rows(const long n_chunks, const int C, const int *__
                                  const int *__restrict__ sp_cl, const int *__restrict__ sp_ci,
                                  const float *__restrict__ sp_va, const double *__restrict__ x,
                                  double *__restrict__ y, const int xcd_remap) {
-    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap != 0);
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
     const long row = (long)lb * blockDim.x + threadIdx.x;
     const long c = row / C;
     const int i = (int)(row - c * C);
@@ -367,6 +382,16 @@ int launch_spmv_scs(const uspmv_dmat *A, const int *chunk_ids, long n_ids, const
                                A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, g_tune.xcd_remap);
     } else {
         const unsigned grid = grid_for(nwc * C, block);
+        if (g_tune.ablate && C == 32 && !ids) {  // measurement-only (results are wrong by construction)
+            if (g_tune.ablate == 1)
+                hipLaunchKernelGGL((scs_spmv_rows<VT, 32, 8, true, false, 1>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
+                                   A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+            else
+                hipLaunchKernelGGL((scs_spmv_rows<VT, 32, 8, true, false, 2>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
+                                   A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+            HIP_TRY(hipGetLastError());
+            return USPMV_OK;
+        }
         switch (C) {  // host-side dispatch on C (the reference switches inside the __global__, code/kernels.hpp:735-753)
             case 1: launch_rows_unroll<VT, 1>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
             case 2: launch_rows_unroll<VT, 2>(ids, grid, block, st, nwc, C, A, x, y, chunk_ids); break;
@@ -479,7 +504,10 @@ int uspmv_set_tuning(const char *key, int value) {
         if (value != 1 && value != 2 && value != 4 && value != 8) return uspmv::fail(USPMV_ERR_INVALID, "unroll must be 1|2|4|8");
         g_tune.unroll = value;
     } else if (!strcmp(key, "nontemporal")) g_tune.nontemporal = value != 0;
-    else if (!strcmp(key, "xcd_remap")) g_tune.xcd_remap = value != 0;
+    else if (!strcmp(key, "xcd_remap")) {
+        if (value < 0 || value > 65536) return uspmv::fail(USPMV_ERR_INVALID, "xcd_remap must be 0, 1 or a group size <= 65536");
+        g_tune.xcd_remap = value;
+    } else if (!strcmp(key, "ablate")) g_tune.ablate = value;
     else if (!strcmp(key, "block")) {
         if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
             return uspmv::fail(USPMV_ERR_INVALID, "block must be 64|128|256|512|1024");
@@ -502,6 +530,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "block")) *value = g_tune.block;
     else if (!strcmp(key, "spmv_variant")) *value = g_tune.spmv_variant;
     else if (!strcmp(key, "csr_lanes")) *value = g_tune.csr_lanes;
+    else if (!strcmp(key, "ablate")) *value = g_tune.ablate;
     else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_get_tuning: unknown key '%s'", key);
     return USPMV_OK;
 }
@@ -723,7 +752,7 @@ int uspmv_time_launches(int what, int reps, const uspmv_dmat_t *A, const uspmv_d
         switch (what) {
             case 0: rc = uspmv_spmv(A, d_x, d_y, stream); break;
             case 1: rc = uspmv_stream_copy((double *)d_y, (const double *)d_x, n, stream); break;
-            case 2: rc = uspmv_stream_triad((double *)d_y, (const double *)d_x, (const double *)d_x, 3.0, n, stream); break;
+            case 2: rc = uspmv_stream_triad((double *)d_y, (const double *)d_x, (const double *)d_x + n, 3.0, n, stream); break;
             case 3: rc = uspmv_stream_read((const double *)d_x, n, (double *)d_y, stream); break;
             case 4: rc = uspmv_spmv_ap(A, B, (const double *)d_x, (double *)d_y, stream); break;
             case 5: rc = uspmv_spmmv(A, d_x, d_y, b, ld, layout, stream); break;
