@@ -137,6 +137,12 @@ int uspmv_spmmv(const uspmv_dmat_t *A, const void *d_X, void *d_Y, int b, int64_
  * kernel scs_ap_impl_cpu (code/ap_kernels.hpp:24-82): both parts accumulated in double from the
  * double x, y = dp_sum + sp_sum.  dp and sp must share C and n_chunks. */
 int uspmv_spmv_ap(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const double *d_x, double *d_y, void *stream);
+/* Generic-C variant of the reference, spmv_omp_scs_ap / spmv_gpu_ap_scs (code/ap_kernels.hpp:562-634,
+ * :721-816; selected for C outside {2,4,...,128}, code/classes_structs.hpp:630-636): the sp part
+ * multiplies with the FLOAT copy of x (d_x_sp), the float product being rounded before it is added
+ * to the double accumulator. */
+int uspmv_spmv_ap_generic(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const double *d_x, const float *d_x_sp,
+                          double *d_y, void *stream);
 
 /* Raw-array forms with the argument lists of the library kernels of code/interface.hpp
  * (uspmv_scs_gpu :1766-1793, uspmv_scs_c_gpu :1835-1867, uspmv_csr_gpu :1741-1760). */

@@ -58,14 +58,16 @@ def test_spmv_golden_bitexact_all_variants(pkg, torch_cuda, name, dt):
     pkg.permute_scs_cols(s, s.arrays()["old_to_new_idx"])
     A = pkg.DeviceMatrix(s)
     x = _dev(t, g[f"{dt}_x_perm"])
-    for unroll in (1, 2, 4, 8):
-        for nt in (0, 1):
-            for xcd in (0, 1):
-                for block in (64, 256, 1024):
-                    pkg.set_tuning(unroll=unroll, nontemporal=nt, xcd_remap=xcd, block=block, spmv_variant=0)
-                    y = t.full((s.n_rows_padded,), -7.0, dtype=x.dtype, device="cuda")
-                    pkg.spmv(A, x, y)
-                    assert np.array_equal(y.cpu().numpy(), g[f"{dt}_y_perm"]), (unroll, nt, xcd, block)
+    for variant in (0, 2):          # lane-per-row kernels: plain and software-pipelined, both bit-exact
+        for unroll in (1, 2, 4, 8):
+            for nt in (0, 1):
+                for xcd in (0, 1, 3):
+                    for block in (64, 256, 1024):
+                        pkg.set_tuning(unroll=unroll, nontemporal=nt, xcd_remap=xcd, block=block, spmv_variant=variant)
+                        y = t.full((s.n_rows_padded,), -7.0, dtype=x.dtype, device="cuda")
+                        pkg.spmv(A, x, y)
+                        assert np.array_equal(y.cpu().numpy(), g[f"{dt}_y_perm"]), (variant, unroll, nt, xcd, block)
+    pkg.set_tuning(spmv_variant=0)
     pkg.set_tuning(unroll=8, nontemporal=1, xcd_remap=0, block=256)
     # raw-array entry point with the interface.hpp argument list
     y = t.zeros(s.n_rows_padded, dtype=x.dtype, device="cuda")
@@ -92,12 +94,15 @@ def test_spmv_grid_vs_oracle_and_reference_hashes(pkg, orc, torch_cuda):
         for dt, code in (("f64", pkg.F64), ("f32", pkg.F32)):
             s, a, xp = _prep(pkg, m, Cc, sg, code, x0)
             A = pkg.DeviceMatrix(s)
-            y = t.zeros(s.n_rows_padded, dtype=A.torch_dtype, device="cuda")
-            pkg.spmv(A, _dev(t, xp), y)
-            yh = y.cpu().numpy()
             y_or = orc.spmv_scs(Cc, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
-            assert np.array_equal(yh, y_or), (key, dt)
-            assert sha(yh) == ent[dt]["y_perm"], (key, dt)
+            for variant in (0, 2):
+                pkg.set_tuning(spmv_variant=variant)
+                y = t.full((s.n_rows_padded,), 3.0, dtype=A.torch_dtype, device="cuda")
+                pkg.spmv(A, _dev(t, xp), y)
+                yh = y.cpu().numpy()
+                assert np.array_equal(yh, y_or), (key, dt, variant)
+                assert sha(yh) == ent[dt]["y_perm"], (key, dt, variant)
+            pkg.set_tuning(spmv_variant=0)
             n += 1
     assert n > 300
 
@@ -197,8 +202,10 @@ def test_ap_golden_bitexact(pkg, torch_cuda, name):
     if Cc in ADV_CS:
         assert np.array_equal(y.cpu().numpy(), a[p + key])
         assert np.array_equal(pkg.apply_permutation(y.cpu().numpy(), perm), a[p + "y_orig_adv"])
-    else:
-        assert np.allclose(y.cpu().numpy(), a[p + key], rtol=1e-6, atol=0)
+    # generic-C variant (float x for the sp part): bit-exact with the reference's spmv_omp_scs_ap
+    xs = _dev(t, a[p + "x_perm"].astype(np.float32))
+    pkg.spmv_ap(Ad, As, _dev(t, a[p + "x_perm"]), y, x_sp=xs)
+    assert np.array_equal(y.cpu().numpy(), a[p + "y_perm_gen"])
     with pytest.raises(pkg.UspmvError):
         pkg.spmv_ap(As, Ad, _dev(t, a[p + "x_perm"]), y)      # wrong precision order
 
@@ -221,6 +228,7 @@ def test_chunk_subsets_pack_and_permutation(pkg, orc, torch_cuda):
         A = pkg.DeviceMatrix(s)
         inner, bnd = s.split_chunks(plan.n_local)
         x = _dev(t, h[f"{key}_r{r}_x_local"])
+        pkg.set_tuning(spmv_variant=2 if r % 2 else 0)
         y = t.full((s.n_rows_padded,), np.nan, dtype=t.float64, device="cuda")
         pkg.spmv_chunks(A, _dev(t, inner), x, y)
         assert int(t.isnan(y).sum()) == len(bnd) * 32
@@ -238,6 +246,7 @@ def test_chunk_subsets_pack_and_permutation(pkg, orc, torch_cuda):
         o = t.zeros(s.n_rows, dtype=t.float64, device="cuda")
         B.apply_permutation_dev(o, y, _dev(t, a["old_to_new_idx"]))
         assert np.array_equal(o.cpu().numpy(), ys[-1])
+    pkg.set_tuning(spmv_variant=0)
     assert np.array_equal(np.concatenate(ys), h[key + "_y_global"])
 
 
@@ -267,9 +276,13 @@ def test_synthetic_vs_oracle(pkg, orc, torch_cuda, shape, C, sigma):
     for code in (pkg.F64, pkg.F32):
         s, a, xp = _prep(pkg, m, C, sigma, code, x0)
         A = pkg.DeviceMatrix(s)
-        y = t.zeros(s.n_rows_padded, dtype=A.torch_dtype, device="cuda")
-        pkg.spmv(A, _dev(t, xp), y)
-        assert np.array_equal(y.cpu().numpy(), orc.spmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp))
+        y_or = orc.spmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+        for variant in (0, 2):
+            pkg.set_tuning(spmv_variant=variant)
+            y = t.full((s.n_rows_padded,), 1.0, dtype=A.torch_dtype, device="cuda")
+            pkg.spmv(A, _dev(t, xp), y)
+            assert np.array_equal(y.cpu().numpy(), y_or), variant
+        pkg.set_tuning(spmv_variant=0)
 
 
 def test_full_size_nlpkkt200_class(pkg, orc, torch_cuda):

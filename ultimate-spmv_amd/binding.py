@@ -74,6 +74,7 @@ _SIGS = {
     "uspmv_spmv_chunks": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "uspmv_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp]),
     "uspmv_spmv_ap": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "uspmv_spmv_ap_generic": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "uspmv_scs_gpu_f64": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "uspmv_scs_gpu_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "uspmv_csr_gpu_f64": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -378,8 +379,12 @@ def spmmv(A, X, Y, b, ld, layout=COLWISE, stream=None):
     return Y
 
 
-def spmv_ap(A_dp, A_sp, x, y, stream=None):
-    _ck(lib().uspmv_spmv_ap(A_dp.h, A_sp.h, _dp(x), _dp(y), _stream_ptr(stream)))
+def spmv_ap(A_dp, A_sp, x, y, stream=None, x_sp=None):
+    """Adaptive precision dp+sp.  x_sp (float copy of x) selects the reference's generic-C variant."""
+    if x_sp is None:
+        _ck(lib().uspmv_spmv_ap(A_dp.h, A_sp.h, _dp(x), _dp(y), _stream_ptr(stream)))
+    else:
+        _ck(lib().uspmv_spmv_ap_generic(A_dp.h, A_sp.h, _dp(x), _dp(x_sp), _dp(y), _stream_ptr(stream)))
     return y
 
 

@@ -79,6 +79,15 @@ __device__ __forceinline__ T ld_stream(const T *p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
 }
+// y store.  A y vector is ~2 % of the bytes of an SpMV, but its HBM write stream costs 15-18 % of the
+// kernel when it goes through the write-back L2 (profiles/r01_microbench.txt: 0.74 ms without the
+// store, 0.88 ms with plain stores, 0.83 ms write-through).  Relaxed agent-scope atomic stores
+// compile to `global_store_dword[x2] ... sc1` (write-through, line not kept in L2).
+template <bool WT, typename T>
+__device__ __forceinline__ void st_y(T *p, T v) {
+    if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
@@ -143,7 +152,91 @@ __global__ void scs_spmv_rows(const long n_work_chunks, const int C_rt, const in
         const int ci = ld_stream<NT>(cp + (long)j * C);
         acc = fma_t(v, ABL == 0 ? x[ci] : ABL == 1 ? x[ci & 63] : (VT)ci, acc);
     }
-    y[c * C + i] = acc;
+    st_y<NT>(y + (c * C + i), acc);
+}
+
+// Software-pipelined form of scs_spmv_rows (same lane <-> row mapping, same FMA chain, bit-exact):
+//   * the loop runs over wave-uniform batches of U slots up to the longest chunk of the wave; a
+//     lane past the end of its own chunk re-reads its last slot (clamped index, always in bounds)
+//     and its accumulate is predicated off -- so the ragged tail is ONE masked batch instead of up
+//     to U-1 dependent single-slot round trips;
+//   * the matrix stream of batch k+1 is issued BEHIND the x gathers of batch k.  vmcnt retires in
+//     order, so the gathers (issued first) are waited for with the 2*U prefetch loads still in
+//     flight: while a wave waits for its gathers it already has its next 64*U*12 bytes coming.
+//     The steady-state body is straight-line code (no divergent branch), which is what lets the
+//     compiler emit the counted s_waitcnt vmcnt(2*U + ...) instead of vmcnt(0).
+// Dependent memory round trips per wave: 2 + ceil(L/U) instead of 2 + 2*(L/U) + 2*(L%U).
+template <typename VT, int CT, int U, bool NT, bool IDS>
+__global__ void scs_spmv_rows_pipe(const long n_work_chunks, const int C_rt, const int *__restrict__ chunk_ptrs,
+                                   const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
+                                   const VT *__restrict__ values, const VT *__restrict__ x, VT *__restrict__ y,
+                                   const int *__restrict__ chunk_ids, const int xcd_remap) {
+    const int C = CT > 0 ? CT : C_rt;
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+    const long vrow = (long)lb * blockDim.x + threadIdx.x;
+    const long vc = vrow / C;
+    const int i = (int)(vrow - vc * C);
+    const bool valid = vc < n_work_chunks;
+    long c = 0;
+    int cs = 0, L = 0;
+    if (valid) {
+        c = IDS ? (long)chunk_ids[vc] : vc;
+        cs = chunk_ptrs[c];
+        L = chunk_lengths[c];
+    }
+    int Lmax = L;  // longest chunk of this wavefront (wave-uniform)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, o, 64));
+    Lmax = __builtin_amdgcn_readfirstlane(Lmax);
+    VT acc = VT(0);
+    if (Lmax > 0) {
+        // lanes with an empty chunk (or past the grid) stream element 0 of the arrays: always valid
+        const long base = L > 0 ? (long)cs + i : 0;
+        const int last = L > 0 ? L - 1 : 0;
+        const VT *vp = values + base;
+        const int *cp = col_idxs + base;
+        VT v0[U];
+        int c0[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long o = (long)(u < last ? u : last) * C;
+            v0[u] = ld_stream<NT>(vp + o);
+            c0[u] = ld_stream<NT>(cp + o);
+        }
+        int j = 0;
+        for (; j + U < Lmax; j += U) {
+            VT xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = x[c0[u]];
+            __builtin_amdgcn_sched_barrier(0);  // gathers first: they are what the FMAs below wait for
+            VT v1[U];
+            int c1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jj = j + U + u;
+                const long o = (long)(jj < last ? jj : last) * C;
+                v1[u] = ld_stream<NT>(vp + o);
+                c1[u] = ld_stream<NT>(cp + o);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the FMA block (hipcc sinks it otherwise)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const VT t = fma_t(v0[u], xv[u], acc);
+                acc = (j + u < L) ? t : acc;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { v0[u] = v1[u]; c0[u] = c1[u]; }
+        }
+        VT xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = x[c0[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const VT t = fma_t(v0[u], xv[u], acc);
+            acc = (j + u < L) ? t : acc;
+        }
+    }
+    if (valid) st_y<NT>(y + (c * C + i), acc);
 }
 
 // C = 32, one wavefront per chunk, two lanes per row: lane l owns row l & 31 and the slots
@@ -187,7 +280,7 @@ __global__ void scs_spmv_split2(const long n_chunks, const int *__restrict__ chu
         acc = fma_t(v, x[ci], acc);
     }
     const VT other = __shfl_xor(acc, 32, 64);
-    if (h == 0) y[c * 32 + lane] = acc + other;
+    if (h == 0) st_y<NT>(y + (c * 32 + lane), acc + other);
 }
 
 // CRS SpMV: G lanes per row (G = power of two <= 64), lane-strided partial sums, shuffle
@@ -244,8 +337,8 @@ __global__ void scs_spmmv_rows(const long n_chunks, const int C, const int *__re
 #pragma unroll
         for (int v = 0; v < VB; ++v) {
             if (v0 + v < b) {
-                if (ROWWISE) Y[row * b + v0 + v] = acc[v];
-                else Y[row + (long)(v0 + v) * ld] = acc[v];
+                if (ROWWISE) st_y<NT>(Y + (row * b + v0 + v), acc[v]);
+                else st_y<NT>(Y + (row + (long)(v0 + v) * ld), acc[v]);
             }
         }
     }
@@ -253,13 +346,15 @@ __global__ void scs_spmmv_rows(const long n_chunks, const int C, const int *__re
 
 // Adaptive precision dp+sp, one lane per row: the dp chain, then the sp chain (float value widened,
 // times the DOUBLE x, accumulated in double), y = dp + sp  (code/ap_kernels.hpp:59-75).
-template <int U, bool NT>
+// SPX: the generic-C reference kernel spmv_omp_scs_ap multiplies the sp values with the FLOAT copy
+// of x (float product, rounded, then widened and added; code/ap_kernels.hpp:619-623).
+template <int U, bool NT, bool SPX>
 __global__ void scs_spmv_ap_rows(const long n_chunks, const int C, const int *__restrict__ dp_cp,
                                  const int *__restrict__ dp_cl, const int *__restrict__ dp_ci,
                                  const double *__restrict__ dp_va, const int *__restrict__ sp_cp,
                                  const int *__restrict__ sp_cl, const int *__restrict__ sp_ci,
                                  const float *__restrict__ sp_va, const double *__restrict__ x,
-                                 double *__restrict__ y, const int xcd_remap) {
+                                 const float *__restrict__ x_sp, double *__restrict__ y, const int xcd_remap) {
     const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
     const long row = (long)lb * blockDim.x + threadIdx.x;
     const long c = row / C;
@@ -290,17 +385,31 @@ __global__ void scs_spmv_ap_rows(const long n_chunks, const int C, const int *__
         const int *cp = sp_ci + cs + i;
         int j = 0;
         for (; j + U <= L; j += U) {
-            float v[U]; int ci[U]; double xv[U];
+            float v[U]; int ci[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) { v[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
+            if constexpr (SPX) {
+                float xs[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) xv[u] = x[ci[u]];
+                for (int u = 0; u < U; ++u) xs[u] = x_sp[ci[u]];
 #pragma unroll
-            for (int u = 0; u < U; ++u) st = __builtin_fma((double)v[u], xv[u], st);
+                for (int u = 0; u < U; ++u) st = st + (double)__fmul_rn(v[u], xs[u]);
+            } else {
+                double xv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = x[ci[u]];
+#pragma unroll
+                for (int u = 0; u < U; ++u) st = __builtin_fma((double)v[u], xv[u], st);
+            }
         }
-        for (; j < L; ++j) st = __builtin_fma((double)ld_stream<NT>(vp + (long)j * C), x[ld_stream<NT>(cp + (long)j * C)], st);
+        for (; j < L; ++j) {
+            const float v = ld_stream<NT>(vp + (long)j * C);
+            const int ci = ld_stream<NT>(cp + (long)j * C);
+            if constexpr (SPX) st = st + (double)__fmul_rn(v, x_sp[ci]);
+            else st = __builtin_fma((double)v, x[ci], st);
+        }
     }
-    y[row] = dt + st;
+    st_y<NT>(y + row, dt + st);
 }
 
 // out[i] = in[perm[idx ? idx[i] : i] + offset]   (pack_send_buf with idx, apply_permutation without)
@@ -339,6 +448,15 @@ inline unsigned grid_for(long work_items, int block) { return (unsigned)((work_i
 template <typename VT, int CT, int U, bool NT>
 void launch_rows_ids(bool ids, unsigned grid, int block, hipStream_t st, long nwc, int C, const uspmv_dmat *A,
                      const VT *x, VT *y, const int *chunk_ids) {
+    if (g_tune.spmv_variant == 2) {
+        if (ids)
+            hipLaunchKernelGGL((scs_spmv_rows_pipe<VT, CT, U, NT, true>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
+                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+        else
+            hipLaunchKernelGGL((scs_spmv_rows_pipe<VT, CT, U, NT, false>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
+                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+        return;
+    }
     if (ids)
         hipLaunchKernelGGL((scs_spmv_rows<VT, CT, U, NT, true>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
                            A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
@@ -513,7 +631,7 @@ int uspmv_set_tuning(const char *key, int value) {
             return uspmv::fail(USPMV_ERR_INVALID, "block must be 64|128|256|512|1024");
         g_tune.block = value;
     } else if (!strcmp(key, "spmv_variant")) {
-        if (value != 0 && value != 1) return uspmv::fail(USPMV_ERR_INVALID, "spmv_variant must be 0|1");
+        if (value < 0 || value > 2) return uspmv::fail(USPMV_ERR_INVALID, "spmv_variant must be 0|1|2");
         g_tune.spmv_variant = value;
     } else if (!strcmp(key, "csr_lanes")) {
         if (value < 0 || value > 64 || (value & (value - 1))) return uspmv::fail(USPMV_ERR_INVALID, "csr_lanes must be 0 or a power of two <= 64");
@@ -633,27 +751,39 @@ int uspmv_spmmv(const uspmv_dmat_t *A, const void *d_X, void *d_Y, int b, int64_
     return launch_spmmv<float>(A, (const float *)d_X, (float *)d_Y, b, (long)ld, layout, (hipStream_t)stream);
 }
 
-int uspmv_spmv_ap(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const double *d_x, double *d_y, void *stream) {
-    if (int rc = check_dmat(dp, "uspmv_spmv_ap")) return rc;
-    if (int rc = check_dmat(sp, "uspmv_spmv_ap")) return rc;
+static int spmv_ap_impl(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const double *d_x, const float *d_x_sp,
+                        double *d_y, void *stream, const char *who) {
+    if (int rc = check_dmat(dp, who)) return rc;
+    if (int rc = check_dmat(sp, who)) return rc;
     if (dp->dtype != USPMV_F64 || sp->dtype != USPMV_F32)
-        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_ap: expects a double and a float struct");
+        return uspmv::fail(USPMV_ERR_INVALID, "%s: expects a double and a float struct", who);
     if (dp->C != sp->C || dp->n_chunks != sp->n_chunks)
-        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_ap: dp and sp structs must share C and n_chunks");
-    if (!d_x || !d_y) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_ap: NULL vector");
+        return uspmv::fail(USPMV_ERR_INVALID, "%s: dp and sp structs must share C and n_chunks", who);
+    if (!d_x || !d_y) return uspmv::fail(USPMV_ERR_INVALID, "%s: NULL vector", who);
     if (int rc = require_device()) return rc;
     if (dp->n_chunks == 0) return USPMV_OK;
     const int block = g_tune.block;
     const unsigned grid = grid_for(dp->n_chunks * dp->C, block);
-#define AP_LAUNCH(NTV)                                                                                               \
-    hipLaunchKernelGGL((scs_spmv_ap_rows<4, NTV>), dim3(grid), dim3(block), 0, (hipStream_t)stream, (long)dp->n_chunks, \
-                       (int)dp->C, dp->chunk_ptrs, dp->chunk_lengths, dp->col_idxs, (const double *)dp->values,      \
-                       sp->chunk_ptrs, sp->chunk_lengths, sp->col_idxs, (const float *)sp->values, d_x, d_y,         \
-                       g_tune.xcd_remap)
-    if (g_tune.nontemporal) AP_LAUNCH(true); else AP_LAUNCH(false);
+#define AP_LAUNCH(NTV, SPXV)                                                                                         \
+    hipLaunchKernelGGL((scs_spmv_ap_rows<4, NTV, SPXV>), dim3(grid), dim3(block), 0, (hipStream_t)stream,            \
+                       (long)dp->n_chunks, (int)dp->C, dp->chunk_ptrs, dp->chunk_lengths, dp->col_idxs,              \
+                       (const double *)dp->values, sp->chunk_ptrs, sp->chunk_lengths, sp->col_idxs,                  \
+                       (const float *)sp->values, d_x, d_x_sp, d_y, g_tune.xcd_remap)
+    if (d_x_sp) { if (g_tune.nontemporal) AP_LAUNCH(true, true); else AP_LAUNCH(false, true); }
+    else { if (g_tune.nontemporal) AP_LAUNCH(true, false); else AP_LAUNCH(false, false); }
 #undef AP_LAUNCH
     HIP_TRY(hipGetLastError());
     return USPMV_OK;
+}
+
+int uspmv_spmv_ap(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const double *d_x, double *d_y, void *stream) {
+    return spmv_ap_impl(dp, sp, d_x, nullptr, d_y, stream, "uspmv_spmv_ap");
+}
+
+int uspmv_spmv_ap_generic(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const double *d_x, const float *d_x_sp,
+                          double *d_y, void *stream) {
+    if (!d_x_sp) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_ap_generic: NULL float x");
+    return spmv_ap_impl(dp, sp, d_x, d_x_sp, d_y, stream, "uspmv_spmv_ap_generic");
 }
 
 #define RAW_SCS(SUF, VT, DT)                                                                                        \
