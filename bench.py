@@ -196,6 +196,13 @@ def main():
     read_gbs = 8.0 * nstream / (B.time_launches(3, 20, x=sb, y=part, n=nstream) * 1e-3) / 1e9
     del sa, sb
 
+    traffic = None
+    if not args.mtx:
+        key = f"stencil27-{args.grid}x{args.grid}x{args.grid * world if args.scaling == 'weak' else args.grid}-c{args.chunk}-s{args.sigma}-f64-n{world}"
+        try:  # HBM bytes per launch measured with rocprofv3 PMC passes of this very command (profiles/)
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}).get("traffic_bytes")
+        except (OSError, ValueError):
+            traffic = None
     out = {
         "metric": "SpMV GFLOP/s (SELL-32-512 dp; achieved HBM GB/s in roofline)",
         "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -206,7 +213,7 @@ def main():
                    "partition": args.seg if world > 1 else "none", "halo_overlap": (not args.no_overlap) and world > 1,
                    "tuning": {k: pkg.get_tuning(k) for k in ("unroll", "nontemporal", "xcd_remap", "block", "spmv_variant")}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "scs_spmv_rows<double,32>", "kernel_ms": round(k_ms, 5),
                      "algorithmic_bytes_per_launch": int(bytes_local),
                      "frac_of_stream_copy": round(achieved / copy_gbs, 4),

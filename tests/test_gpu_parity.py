@@ -26,7 +26,7 @@ def torch_cuda(pkg):
     assert pkg.device_count() >= 1
     torch.cuda.set_device(0)
     yield torch
-    pkg.set_tuning(unroll=8, nontemporal=1, xcd_remap=0, block=256, spmv_variant=0, csr_lanes=0)
+    pkg.set_tuning(unroll=8, nontemporal=1, xcd_remap=0, block=256, spmv_variant=0, csr_lanes=0, tail_batch=0)
 
 
 def sha(a):
@@ -63,11 +63,13 @@ def test_spmv_golden_bitexact_all_variants(pkg, torch_cuda, name, dt):
             for nt in (0, 1):
                 for xcd in (0, 1, 3):
                     for block in (64, 256, 1024):
-                        pkg.set_tuning(unroll=unroll, nontemporal=nt, xcd_remap=xcd, block=block, spmv_variant=variant)
-                        y = t.full((s.n_rows_padded,), -7.0, dtype=x.dtype, device="cuda")
-                        pkg.spmv(A, x, y)
-                        assert np.array_equal(y.cpu().numpy(), g[f"{dt}_y_perm"]), (variant, unroll, nt, xcd, block)
-    pkg.set_tuning(spmv_variant=0)
+                        for tail in (0, 1):
+                            pkg.set_tuning(unroll=unroll, nontemporal=nt, xcd_remap=xcd, block=block, spmv_variant=variant,
+                                           tail_batch=tail)
+                            y = t.full((s.n_rows_padded,), -7.0, dtype=x.dtype, device="cuda")
+                            pkg.spmv(A, x, y)
+                            assert np.array_equal(y.cpu().numpy(), g[f"{dt}_y_perm"]), (variant, unroll, nt, xcd, block, tail)
+    pkg.set_tuning(spmv_variant=0, tail_batch=0)
     pkg.set_tuning(unroll=8, nontemporal=1, xcd_remap=0, block=256)
     # raw-array entry point with the interface.hpp argument list
     y = t.zeros(s.n_rows_padded, dtype=x.dtype, device="cuda")
@@ -163,13 +165,16 @@ def test_spmmv_golden_bitexact(pkg, orc, torch_cuda, name):
         s, a, xp = _prep(pkg, m, int(g["C"]), int(g["sigma"]), code, g["x"])
         A = pkg.DeviceMatrix(s)
         ld = s.n_rows_padded
-        for b in (2, 8):
-            for rowwise in (0, 1):
-                X = block_x(xp, ld, b, ld, rowwise)
-                Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
-                pkg.spmmv(A, _dev(t, X), Y, b, ld, pkg.ROWWISE if rowwise else pkg.COLWISE)
-                assert np.array_equal(Y.cpu().numpy(), sp[f"{name}_{dt}_b{b}_{'row' if rowwise else 'col'}_Y"]), (dt, b, rowwise)
-        for b in (1, 3, 5, 13):     # widths without a golden: vs the oracle, colwise ld > n_rows_padded too
+        for variant in (0, 1):       # 0: row-major panel kernel (+ re-layout for colwise), 1: generic kernel
+            pkg.set_tuning(spmmv_variant=variant)
+            for b in (2, 8):
+                for rowwise in (0, 1):
+                    X = block_x(xp, ld, b, ld, rowwise)
+                    Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
+                    pkg.spmmv(A, _dev(t, X), Y, b, ld, pkg.ROWWISE if rowwise else pkg.COLWISE)
+                    assert np.array_equal(Y.cpu().numpy(), sp[f"{name}_{dt}_b{b}_{'row' if rowwise else 'col'}_Y"]), (dt, b, rowwise, variant)
+        pkg.set_tuning(spmmv_variant=0)
+        for b in (1, 3, 4, 5, 13, 16):     # widths without a golden: vs the oracle, colwise ld > n_rows_padded too
             for rowwise in (0, 1):
                 ld2 = ld + 7
                 X = block_x(xp, ld, b, ld2, rowwise)
@@ -181,6 +186,22 @@ def test_spmmv_golden_bitexact(pkg, orc, torch_cuda, name):
                     assert np.array_equal(got[:ld * b], Yo[:ld * b])
                 else:
                     assert np.array_equal(got, Yo)
+
+
+def test_crs_spmmv_golden(pkg, torch_cuda):
+    """block_spmv_omp_csr (code/kernels.hpp:68-154): C = 1 structs through uspmv_spmmv, b = 4, both layouts."""
+    t = torch_cuda
+    c = golden("csr.npz")
+    for name in ("FDM-2d-16", "impcol_e", "matrix1", "bcsstk13"):
+        m = pkg.read_mtx(mtx_path(name))
+        for dt, code in (("f64", pkg.F64), ("f32", pkg.F32)):
+            s, a, xp = _prep(pkg, m, 1, 1, code, make_x(m.n_rows))
+            A = pkg.DeviceMatrix(s)
+            for rowwise in (0, 1):
+                X = block_x(xp, s.n_rows, 4, s.n_rows, rowwise)
+                Y = t.zeros(4 * s.n_rows, dtype=A.torch_dtype, device="cuda")
+                pkg.spmmv(A, _dev(t, X), Y, 4, s.n_rows, pkg.ROWWISE if rowwise else pkg.COLWISE)
+                assert np.array_equal(Y.cpu().numpy(), c[f"{name}_{dt}_Yb4_{'row' if rowwise else 'col'}"]), (name, dt, rowwise)
 
 
 @pytest.mark.parametrize("name", ["bcsstk13", "impcol_e", "FDM-2d-16", "matrix1"])

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Single-GPU BASELINE configurations 2-4 (synthetic stand-ins): kernel time (HIP events),
+GF/s, algorithmic GB/s, and a full-size parity check against the oracle.  One JSON line per config."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="2,3,4")
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink grids for quick runs")
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+    import torch
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    from ultimate_spmv_amd import binding as B
+    from oracle import oracle as orc
+    torch.cuda.set_device(0)
+    t = torch
+
+    def prep(coo, dtype, fixed=None):
+        s = pkg.convert_to_scs(coo, 32, 512, dtype, fixed_permutation=fixed)
+        return s
+
+    for cfg in args.configs.split(","):
+        t0 = time.time()
+        if cfg == "2":
+            g = int(253 * args.scale)
+            coo = pkg.gen_stencil27(g, g, g)
+            s = prep(coo, pkg.F64)
+            a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
+            A = pkg.DeviceMatrix(s)
+            xp = np.zeros(s.n_rows_padded); xp[:s.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(s.n_rows) % 1000), a["new_to_old_idx"])
+            x = t.from_numpy(xp).cuda(); y = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
+            pkg.spmv(A, x, y)
+            ok = None if args.no_check else bool(np.array_equal(y.cpu().numpy(), orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)))
+            ms = B.time_launches(0, args.reps, A=A, x=x, y=y)
+            byts = s.n_elements * 12 + 8 * s.n_chunks + 8 * s.n_rows + 8 * s.n_rows_padded
+            out = dict(config=2, workload=f"nlpkkt200-class stencil27 {g}^3 scs -c 32 -s 512 -dp", n=s.n_rows, nnz=s.nnz, b=1)
+            flops = 2.0 * s.nnz
+        elif cfg == "3":
+            g = int(111 * args.scale)
+            coo = pkg.gen_stencil27(g, g, g, dof=3)
+            s = prep(coo, pkg.F64)
+            a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
+            A = pkg.DeviceMatrix(s)
+            b, ld = 8, s.n_rows_padded
+            xp = np.zeros(ld); xp[:s.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(s.n_rows) % 1000), a["new_to_old_idx"])
+            res = {}
+            for lay, nm in ((pkg.COLWISE, "colwise"), (pkg.ROWWISE, "rowwise")):
+                X = np.zeros(b * ld)
+                for v in range(b):
+                    col = xp * (1.0 + v / 8.0)
+                    if lay == pkg.ROWWISE: X[np.arange(ld) * b + v] = col
+                    else: X[v * ld:(v + 1) * ld] = col
+                dX = t.from_numpy(X).cuda(); dY = t.zeros(b * ld, dtype=t.float64, device="cuda")
+                pkg.spmmv(A, dX, dY, b, ld, lay)
+                okl = None if args.no_check else bool(np.array_equal(dY.cpu().numpy(), orc.spmmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, b, ld, lay == pkg.ROWWISE)))
+                res[nm] = (B.time_launches(5, args.reps, A=A, x=dX, y=dY, b=b, ld=ld, layout=lay), okl)
+            ms, ok = res["colwise"]
+            byts = s.n_elements * 12 + 8 * s.n_chunks + b * 8 * s.n_rows + b * 8 * s.n_rows_padded
+            out = dict(config=3, workload=f"Queen_4147-class stencil27 {g}^3 x 3 dof scs -c 32 -s 512 -dp -block_vec_size 8", n=s.n_rows, nnz=s.nnz, b=b,
+                       rowwise_ms=round(res["rowwise"][0], 5), rowwise_bitexact=res["rowwise"][1])
+            flops = 2.0 * s.nnz * b
+        else:
+            g = int(74 * args.scale)
+            coo = pkg.gen_stencil27(g, g, g, dof=5, magnitude_decades=10.0)
+            dp, sp = pkg.partition_precisions(coo, 1e-3)
+            ds = prep(dp, pkg.F64)
+            perm = ds.arrays()["old_to_new_idx"].copy()
+            ss = prep(sp, pkg.F32, fixed=perm)
+            pkg.permute_scs_cols(ds, perm); pkg.permute_scs_cols(ss, perm)
+            da, sa = ds.arrays(), ss.arrays()
+            Ad, As = pkg.DeviceMatrix(ds), pkg.DeviceMatrix(ss)
+            xp = np.zeros(ds.n_rows_padded); xp[:ds.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(ds.n_rows) % 1000), da["new_to_old_idx"])
+            x = t.from_numpy(xp).cuda(); y = t.zeros(ds.n_rows_padded, dtype=t.float64, device="cuda")
+            pkg.spmv_ap(Ad, As, x, y)
+            ok = None if args.no_check else bool(np.array_equal(y.cpu().numpy(), orc.spmv_scs_ap_adv(
+                32, ds.n_chunks, (da["chunk_ptrs"], da["chunk_lengths"], da["col_idxs"], da["values"]),
+                (sa["chunk_ptrs"], sa["chunk_lengths"], sa["col_idxs"], sa["values"]), xp)))
+            ms = B.time_launches(4, args.reps, A=Ad, B=As, x=x, y=y)
+            byts = 12 * ds.n_elements + 8 * ss.n_elements + 16 * ds.n_chunks + 8 * (ds.n_rows + ds.n_rows_padded)
+            out = dict(config=4, workload=f"HV15R-class stencil27 {g}^3 x 5 dof, |a_ij| log-uniform over 10 decades, scs -c 32 -s 512 -ap[dp_sp] -ap_threshold_1 1e-3",
+                       n=ds.n_rows, nnz=coo.nnz, dp_nnz=dp.nnz, sp_nnz=sp.nnz, dp_elements=ds.n_elements, sp_elements=ss.n_elements, b=1)
+            # same matrix in plain dp for comparison
+            s = prep(coo, pkg.F64); a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"])
+            A = pkg.DeviceMatrix(s)
+            out["plain_dp_ms"] = round(B.time_launches(0, args.reps, A=A, x=x, y=y), 5)
+            flops = 2.0 * coo.nnz
+        out.update(kernel_ms=round(ms, 5), gflops=round(flops / ms / 1e6, 1), algorithmic_GBs=round(byts / ms / 1e6, 1),
+                   frac_of_8TBs=round(byts / ms / 1e6 / 8000, 4), bitexact_vs_oracle=ok, setup_s=round(time.time() - t0, 1))
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

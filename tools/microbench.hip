@@ -170,6 +170,51 @@ __global__ void k_sell_burst(const double *__restrict__ v, const int *__restrict
     }
 }
 
+// chip-scale write combining: persistent workgroups (one per CU, WAVES waves) walk groups of 8*WAVES/4
+// chunks block-cyclically, park y in LDS and flush M groups at a time.  All workgroups progress at
+// the same rate, so the flushes of the whole chip coincide: HBM sees long pure-read phases separated
+// by short pure-write bursts instead of a continuous read/write mix.
+template <int U, int M, int STORE>
+__global__ void __launch_bounds__(1024) k_sell_wc(const double *__restrict__ v, const int *__restrict__ c, const int *__restrict__ cptr,
+                          const int *__restrict__ clen, long n_chunks, double *__restrict__ y) {
+    extern __shared__ double ybuf[];                       // M * blockDim.x doubles
+    const long nrows = n_chunks * 32;
+    const long ngroups = (nrows + blockDim.x - 1) / blockDim.x;
+    long g = blockIdx.x;
+    while (g < ngroups) {
+        int m = 0;
+        long g0 = g;
+        for (; m < M && g < ngroups; ++m, g += gridDim.x) {
+            const long row = g * blockDim.x + threadIdx.x;
+            const long ch = row >> 5; const int i = row & 31;
+            double acc = 0;
+            if (ch < n_chunks) {
+                const long cs = cptr[ch];
+                const int L = clen[ch];
+                const double *vp = v + cs + i; const int *cp = c + cs + i;
+                int j = 0;
+                for (; j + U <= L; j += U) {
+                    double a[U]; int b[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { a[u] = ldnt(vp + (long)(j + u) * 32); b[u] = ldnt(cp + (long)(j + u) * 32); }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc = __builtin_fma(a[u], (double)b[u], acc);
+                }
+                for (; j < L; ++j) acc = __builtin_fma(ldnt(vp + (long)j * 32), (double)ldnt(cp + (long)j * 32), acc);
+            }
+            ybuf[m * blockDim.x + threadIdx.x] = acc;       // each lane re-reads only its own slots: no barrier needed
+        }
+        for (int k = 0; k < m; ++k) {
+            const long row = (g0 + (long)k * gridDim.x) * blockDim.x + threadIdx.x;
+            if (row < nrows) {
+                const double r = ybuf[k * blockDim.x + threadIdx.x];
+                if (STORE == 1) y[row] = r;
+                else asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(y + row), "v"(r) : "memory");
+            }
+        }
+    }
+}
+
 // slot-blocked SELL: lane = row, per step one double2 (2 slots) + one int2, chunk stored [j/2][i][j%2]
 template <int U, bool NT>
 __global__ void k_sell_b2(const double2 *__restrict__ v, const int2 *__restrict__ c, long n_chunks, int L2, double *out) {
@@ -232,9 +277,11 @@ int main() {
         const int gfull = (int)((n_chunks * 32 + 255) / 256);
         S(8, true, false, gfull);
 #define M(U, META, STORE, FMA) rep("sell U=" #U " meta=" #META " store=" #STORE " fma=" #FMA, timeit([&] { hipLaunchKernelGGL((k_sell_meta<U, true, META, STORE, FMA>), dim3(gfull), dim3(256), 0, 0, v, c, cptr, clen, n_chunks, (int)L, y, out); }, 20), gb)
-        M(8, true, 1, true); M(8, true, 4, true); M(8, true, 10, true); M(8, true, 11, true);
+        M(8, true, 1, true); M(8, true, 4, true);
+#define WC(U, M, STORE, G, T) rep("sell-wc U=" #U " M=" #M " store=" #STORE " grid=" #G " threads=" #T, timeit([&] { hipLaunchKernelGGL((k_sell_wc<U, M, STORE>), dim3(G), dim3(T), M * T * 8, 0, v, c, cptr, clen, n_chunks, y); }, 20), gb)
+        WC(4, 16, 4, 256, 1024); WC(4, 1, 4, 256, 1024); WC(4, 4, 4, 256, 1024); WC(4, 19, 4, 256, 1024); WC(4, 16, 1, 256, 1024); WC(2, 16, 4, 256, 1024); WC(4, 16, 4, 512, 512); WC(4, 16, 4, 1024, 256); WC(4, 8, 4, 2048, 256); WC(4, 1, 4, 2048, 256); WC(9, 16, 4, 256, 1024); WC(3, 16, 4, 256, 1024);
 #define BU(G, STORE) rep("sell-burst G=" #G " store=" #STORE, timeit([&] { hipLaunchKernelGGL((k_sell_burst<8, G, STORE>), dim3((unsigned)((n_chunks * 32 + G * 256 - 1) / (G * 256))), dim3(256), 0, 0, v, c, cptr, clen, n_chunks, y); }, 20), gb)
-        BU(1, 1); BU(4, 1); BU(16, 1); BU(16, 4); BU(32, 1); BU(32, 4);
+        BU(32, 4);
 #define B2(U, NT) rep("sell slot-blocked-2 (L=28) U=" #U " nt=" #NT, timeit([&] { hipLaunchKernelGGL((k_sell_b2<U, NT>), dim3(gfull), dim3(256), 0, 0, (const double2 *)v, (const int2 *)c, n_chunks, 14, out); }, 20), gb28)
 
         printf("----\n");

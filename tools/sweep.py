@@ -54,7 +54,7 @@ def main():
     res = {json.dumps(v, sort_keys=True): [] for v in var}
     for r in range(args.rounds):
         for v in var:
-            pkg.set_tuning(spmv_variant=0, unroll=8, nontemporal=1, xcd_remap=0, block=256, ablate=0)  # keys are sticky
+            pkg.set_tuning(spmv_variant=0, unroll=8, nontemporal=1, xcd_remap=0, block=256, ablate=0, tail_batch=0)  # keys are sticky
             pkg.set_tuning(**v)
             B.time_launches(0, 2, A=A, x=x, y=y)
             res[json.dumps(v, sort_keys=True)].append(B.time_launches(0, args.reps, A=A, x=x, y=y))

@@ -26,8 +26,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstring>
-#include <mutex>
 
 #include "../host/uspmv_internal.hpp"
 
@@ -38,6 +38,10 @@ struct uspmv_dmat {
     const void *values = nullptr;
     bool owns = false;
     bool crs = false;
+    // scratch for the internal row-major copies of column-major block vectors (uspmv_spmmv); grown
+    // on demand, released with the handle.  Not thread-safe per handle, like the reference's kernel object.
+    mutable void *ws = nullptr;
+    mutable size_t ws_bytes = 0;
 };
 
 namespace {
@@ -51,6 +55,8 @@ struct Tuning {
     int spmv_variant = 0;
     int csr_lanes = 0;  // 0 = choose from average row length
     int ablate = 0;     // measurement only
+    int tail_batch = 0;     // ragged tail of a chunk as one predicated batch
+    int spmmv_variant = 0;  // 0 = row-major panel kernel (+ re-layout for colwise), 1 = generic kernel
 };
 Tuning g_tune;
 
@@ -115,7 +121,7 @@ __device__ __forceinline__ unsigned remap_block(unsigned b, unsigned nb, int mod
 // IDS: virtual chunk v -> chunk_ids[v] (interior / boundary subsets).
 // ABL != 0: measurement-only ablations (WRONG results): 1 = every gather hits one 512-byte window
 // of x (keeps the instruction stream, removes L1 misses), 2 = no gather at all.
-template <typename VT, int CT, int U, bool NT, bool IDS, int ABL = 0>
+template <typename VT, int CT, int U, bool NT, bool IDS, int ABL = 0, bool TAILB = false>
 __global__ void scs_spmv_rows(const long n_work_chunks, const int C_rt, const int *__restrict__ chunk_ptrs,
                               const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                               const VT *__restrict__ values, const VT *__restrict__ x, VT *__restrict__ y,
@@ -147,10 +153,33 @@ __global__ void scs_spmv_rows(const long n_work_chunks, const int C_rt, const in
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = fma_t(v[u], xv[u], acc);
     }
-    for (; j < L; ++j) {
-        const VT v = ld_stream<NT>(vp + (long)j * C);
-        const int ci = ld_stream<NT>(cp + (long)j * C);
-        acc = fma_t(v, ABL == 0 ? x[ci] : ABL == 1 ? x[ci & 63] : (VT)ci, acc);
+    if (TAILB) {
+        // ragged tail (< U slots) as ONE predicated batch: all its loads issue back to back under the
+        // lane mask, then all its gathers -- 2 dependent round trips instead of 2 per leftover slot
+        if (j < L) {
+            VT v[U];
+            int ci[U];
+            VT xv[U];
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u) {
+                v[u] = VT(0); ci[u] = 0;
+                if (j + u < L) { v[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
+            }
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u) {
+                xv[u] = VT(0);
+                if (j + u < L) xv[u] = ABL == 0 ? x[ci[u]] : ABL == 1 ? x[ci[u] & 63] : (VT)ci[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u)
+                if (j + u < L) acc = fma_t(v[u], xv[u], acc);
+        }
+    } else {
+        for (; j < L; ++j) {
+            const VT v = ld_stream<NT>(vp + (long)j * C);
+            const int ci = ld_stream<NT>(cp + (long)j * C);
+            acc = fma_t(v, ABL == 0 ? x[ci] : ABL == 1 ? x[ci & 63] : (VT)ci, acc);
+        }
     }
     st_y<NT>(y + (c * C + i), acc);
 }
@@ -344,6 +373,92 @@ __global__ void scs_spmmv_rows(const long n_chunks, const int C, const int *__re
     }
 }
 
+// SpMMV with ROW-MAJOR block vectors of compile-time width B (X[col*B + v]): one lane per row, B
+// accumulators per lane.  Per slot a lane reads its whole X row -- B*sizeof(VT) contiguous bytes --
+// with 16-byte loads, so one wave-instruction moves 1 KiB of X instead of 512 B of eight-byte
+// column gathers: 1 + 1 + B*sizeof(VT)/16 vector-memory instructions per 64 non-zeros (the
+// column-major form needs 2 + B, each fetching a whole 64-byte sector per lane for 8 useful bytes).
+// Every (row, v) accumulator is still the slot-ordered FMA chain of block_spmv_omp_scs_general.
+template <typename VT, int B, int U, bool NT>
+__global__ void scs_spmmv_rowmajor(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
+                                   const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
+                                   const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
+                                   const int xcd_remap) {
+    constexpr int VW = 16 / (int)sizeof(VT);  // elements per 16-byte load
+    constexpr int NV = B / VW;
+    typedef VT vec_t __attribute__((ext_vector_type(VW)));
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+    const long row = (long)lb * blockDim.x + threadIdx.x;
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    if (c >= n_chunks) return;
+    const long cs = chunk_ptrs[c];
+    const int L = chunk_lengths[c];
+    const VT *vp = values + cs + i;
+    const int *cp = col_idxs + cs + i;
+    VT acc[B];
+#pragma unroll
+    for (int v = 0; v < B; ++v) acc[v] = VT(0);
+    int j = 0;
+    for (; j + U <= L; j += U) {
+        VT a[U];
+        int ci[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
+        vec_t xr[U][NV];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const vec_t *xp = (const vec_t *)(X + (long)ci[u] * B);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) xr[u][k] = xp[k];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+#pragma unroll
+                for (int w = 0; w < VW; ++w) acc[k * VW + w] = fma_t(a[u], xr[u][k][w], acc[k * VW + w]);
+    }
+    for (; j < L; ++j) {
+        const VT a = ld_stream<NT>(vp + (long)j * C);
+        const vec_t *xp = (const vec_t *)(X + (long)ld_stream<NT>(cp + (long)j * C) * B);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const vec_t xv = xp[k];
+#pragma unroll
+            for (int w = 0; w < VW; ++w) acc[k * VW + w] = fma_t(a, xv[w], acc[k * VW + w]);
+        }
+    }
+    vec_t *yp = (vec_t *)(Y + row * B);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        vec_t t;
+#pragma unroll
+        for (int w = 0; w < VW; ++w) t[w] = acc[k * VW + w];
+        yp[k] = t;
+    }
+}
+
+// colwise (b vectors of leading dimension ld) <-> row-major (n rows of B) re-layout, one lane per row
+template <typename VT, int B, bool TO_ROWMAJOR>
+__global__ void block_vector_relayout(const VT *__restrict__ in, VT *__restrict__ out, const long n, const long ld) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    if (TO_ROWMAJOR) {
+        VT t[B];
+#pragma unroll
+        for (int v = 0; v < B; ++v) t[v] = in[r + (long)v * ld];
+#pragma unroll
+        for (int v = 0; v < B; ++v) out[r * B + v] = t[v];
+    } else {
+        VT t[B];
+#pragma unroll
+        for (int v = 0; v < B; ++v) t[v] = in[r * B + v];
+#pragma unroll
+        for (int v = 0; v < B; ++v) out[r + (long)v * ld] = t[v];
+    }
+}
+
 // Adaptive precision dp+sp, one lane per row: the dp chain, then the sp chain (float value widened,
 // times the DOUBLE x, accumulated in double), y = dp + sp  (code/ap_kernels.hpp:59-75).
 // SPX: the generic-C reference kernel spmv_omp_scs_ap multiplies the sp values with the FLOAT copy
@@ -361,53 +476,73 @@ __global__ void scs_spmv_ap_rows(const long n_chunks, const int C, const int *__
     const int i = (int)(row - c * C);
     if (c >= n_chunks) return;
     double dt = 0.0, st = 0.0;
-    {
-        const long cs = dp_cp[c];
-        const int L = dp_cl[c];
-        const double *vp = dp_va + cs + i;
-        const int *cp = dp_ci + cs + i;
-        int j = 0;
-        for (; j + U <= L; j += U) {
-            double v[U]; int ci[U]; double xv[U];
+    const long dcs = dp_cp[c], scs_ = sp_cp[c];
+    const int Ld = dp_cl[c], Ls = sp_cl[c];
+    const double *dvp = dp_va + dcs + i;
+    const int *dcp = dp_ci + dcs + i;
+    const float *svp = sp_va + scs_ + i;
+    const int *scp = sp_ci + scs_ + i;
+    int jd = 0, js = 0;
+    // fused part: one dp batch and one sp batch per trip -- the two accumulators are independent
+    // chains, so their streams and gathers are issued together (twice the bytes in flight per
+    // wave); each chain still runs in slot order, i.e. bit-identical to dp-then-sp.
+    for (; jd + U <= Ld && js + U <= Ls; jd += U, js += U) {
+        double dv[U]; int dci[U]; float sv[U]; int sci[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { v[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
+        for (int u = 0; u < U; ++u) {
+            dv[u] = ld_stream<NT>(dvp + (long)(jd + u) * C); dci[u] = ld_stream<NT>(dcp + (long)(jd + u) * C);
+            sv[u] = ld_stream<NT>(svp + (long)(js + u) * C); sci[u] = ld_stream<NT>(scp + (long)(js + u) * C);
+        }
+        double dx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dx[u] = x[dci[u]];
+        if constexpr (SPX) {
+            float sx[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) sx[u] = x_sp[sci[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { dt = __builtin_fma(dv[u], dx[u], dt); st = st + (double)__fmul_rn(sv[u], sx[u]); }
+        } else {
+            double sx[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) sx[u] = x[sci[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { dt = __builtin_fma(dv[u], dx[u], dt); st = __builtin_fma((double)sv[u], sx[u], st); }
+        }
+    }
+    for (; jd + U <= Ld; jd += U) {
+        double v[U]; int ci[U]; double xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { v[u] = ld_stream<NT>(dvp + (long)(jd + u) * C); ci[u] = ld_stream<NT>(dcp + (long)(jd + u) * C); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = x[ci[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dt = __builtin_fma(v[u], xv[u], dt);
+    }
+    for (; jd < Ld; ++jd) dt = __builtin_fma(ld_stream<NT>(dvp + (long)jd * C), x[ld_stream<NT>(dcp + (long)jd * C)], dt);
+    for (; js + U <= Ls; js += U) {
+        float v[U]; int ci[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { v[u] = ld_stream<NT>(svp + (long)(js + u) * C); ci[u] = ld_stream<NT>(scp + (long)(js + u) * C); }
+        if constexpr (SPX) {
+            float xs[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) xs[u] = x_sp[ci[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) st = st + (double)__fmul_rn(v[u], xs[u]);
+        } else {
+            double xv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) xv[u] = x[ci[u]];
 #pragma unroll
-            for (int u = 0; u < U; ++u) dt = __builtin_fma(v[u], xv[u], dt);
+            for (int u = 0; u < U; ++u) st = __builtin_fma((double)v[u], xv[u], st);
         }
-        for (; j < L; ++j) dt = __builtin_fma(ld_stream<NT>(vp + (long)j * C), x[ld_stream<NT>(cp + (long)j * C)], dt);
     }
-    {
-        const long cs = sp_cp[c];
-        const int L = sp_cl[c];
-        const float *vp = sp_va + cs + i;
-        const int *cp = sp_ci + cs + i;
-        int j = 0;
-        for (; j + U <= L; j += U) {
-            float v[U]; int ci[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) { v[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
-            if constexpr (SPX) {
-                float xs[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) xs[u] = x_sp[ci[u]];
-#pragma unroll
-                for (int u = 0; u < U; ++u) st = st + (double)__fmul_rn(v[u], xs[u]);
-            } else {
-                double xv[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) xv[u] = x[ci[u]];
-#pragma unroll
-                for (int u = 0; u < U; ++u) st = __builtin_fma((double)v[u], xv[u], st);
-            }
-        }
-        for (; j < L; ++j) {
-            const float v = ld_stream<NT>(vp + (long)j * C);
-            const int ci = ld_stream<NT>(cp + (long)j * C);
-            if constexpr (SPX) st = st + (double)__fmul_rn(v, x_sp[ci]);
-            else st = __builtin_fma((double)v, x[ci], st);
-        }
+    for (; js < Ls; ++js) {
+        const float v = ld_stream<NT>(svp + (long)js * C);
+        const int ci = ld_stream<NT>(scp + (long)js * C);
+        if constexpr (SPX) st = st + (double)__fmul_rn(v, x_sp[ci]);
+        else st = __builtin_fma((double)v, x[ci], st);
     }
     st_y<NT>(y + row, dt + st);
 }
@@ -454,6 +589,15 @@ void launch_rows_ids(bool ids, unsigned grid, int block, hipStream_t st, long nw
                                A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
         else
             hipLaunchKernelGGL((scs_spmv_rows_pipe<VT, CT, U, NT, false>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
+                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+        return;
+    }
+    if (g_tune.tail_batch && U > 1) {
+        if (ids)
+            hipLaunchKernelGGL((scs_spmv_rows<VT, CT, U, NT, true, 0, true>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
+                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+        else
+            hipLaunchKernelGGL((scs_spmv_rows<VT, CT, U, NT, false, 0, true>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
                                A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
         return;
     }
@@ -572,13 +716,64 @@ void launch_spmmv_vb(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, in
 #undef SPMMV_LAUNCH
 }
 
+template <typename VT, int B>
+void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, hipStream_t st) {
+    const int block = g_tune.block;
+    const unsigned grid = grid_for(A->n_chunks * A->C, block);
+    constexpr int U = (B * (int)sizeof(VT) >= 64) ? 2 : 4;
+    if (g_tune.nontemporal)
+        hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, true>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, (int)A->C,
+                           A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, g_tune.xcd_remap);
+    else
+        hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, false>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, (int)A->C,
+                           A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, g_tune.xcd_remap);
+}
+
+// B-specialised path: row-major kernel, with a re-layout on both sides for column-major callers.
+// Returns false when (b, dtype) has no specialisation (caller falls back to the generic kernel).
+template <typename VT, int B>
+int spmmv_fast(const uspmv_dmat *A, const VT *X, VT *Y, long ld, int layout, hipStream_t st) {
+    if (layout == USPMV_ROWWISE) {
+        launch_spmmv_rowmajor<VT, B>(A, X, Y, st);
+        return USPMV_OK;
+    }
+    const long n_pad = A->n_chunks * A->C;
+    const size_t need = sizeof(VT) * (size_t)B * (size_t)(ld + n_pad);
+    if (A->ws_bytes < need) {
+        if (A->ws) (void)hipFree(A->ws);
+        A->ws = nullptr; A->ws_bytes = 0;
+        hipError_t e = hipMalloc(&A->ws, need);
+        if (e != hipSuccess) return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_spmmv: workspace of %zu bytes: %s", need, hipGetErrorString(e));
+        A->ws_bytes = need;
+    }
+    VT *Xr = (VT *)A->ws, *Yr = Xr + (size_t)B * ld;
+    hipLaunchKernelGGL((block_vector_relayout<VT, B, true>), dim3(grid_for(ld, 256)), dim3(256), 0, st, X, Xr, ld, ld);
+    launch_spmmv_rowmajor<VT, B>(A, Xr, Yr, st);
+    hipLaunchKernelGGL((block_vector_relayout<VT, B, false>), dim3(grid_for(n_pad, 256)), dim3(256), 0, st, (const VT *)Yr, Y, n_pad, ld);
+    return USPMV_OK;
+}
+
 template <typename VT>
 int launch_spmmv(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int layout, hipStream_t st) {
     if (A->n_chunks == 0) return USPMV_OK;
-    if (b <= 1) launch_spmmv_vb<VT, 1>(A, X, Y, b, ld, layout, st);
-    else if (b <= 2) launch_spmmv_vb<VT, 2>(A, X, Y, b, ld, layout, st);
-    else if (b <= 4) launch_spmmv_vb<VT, 4>(A, X, Y, b, ld, layout, st);
-    else launch_spmmv_vb<VT, 8>(A, X, Y, b, ld, layout, st);
+    int rc = -1;
+    if (g_tune.spmmv_variant == 0 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0)) {
+        constexpr int VW = 16 / (int)sizeof(VT);
+        switch (b) {
+            case 2: if (VW <= 2) rc = spmmv_fast<VT, 2>(A, X, Y, ld, layout, st); break;
+            case 4: rc = spmmv_fast<VT, 4>(A, X, Y, ld, layout, st); break;
+            case 8: rc = spmmv_fast<VT, 8>(A, X, Y, ld, layout, st); break;
+            case 16: rc = spmmv_fast<VT, 16>(A, X, Y, ld, layout, st); break;
+            default: break;
+        }
+    }
+    if (rc > 0) return rc;
+    if (rc < 0) {  // generic width / layout
+        if (b <= 1) launch_spmmv_vb<VT, 1>(A, X, Y, b, ld, layout, st);
+        else if (b <= 2) launch_spmmv_vb<VT, 2>(A, X, Y, b, ld, layout, st);
+        else if (b <= 4) launch_spmmv_vb<VT, 4>(A, X, Y, b, ld, layout, st);
+        else launch_spmmv_vb<VT, 8>(A, X, Y, b, ld, layout, st);
+    }
     HIP_TRY(hipGetLastError());
     return USPMV_OK;
 }
@@ -626,6 +821,8 @@ int uspmv_set_tuning(const char *key, int value) {
         if (value < 0 || value > 65536) return uspmv::fail(USPMV_ERR_INVALID, "xcd_remap must be 0, 1 or a group size <= 65536");
         g_tune.xcd_remap = value;
     } else if (!strcmp(key, "ablate")) g_tune.ablate = value;
+    else if (!strcmp(key, "spmmv_variant")) g_tune.spmmv_variant = value != 0;
+    else if (!strcmp(key, "tail_batch")) g_tune.tail_batch = value != 0;
     else if (!strcmp(key, "block")) {
         if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
             return uspmv::fail(USPMV_ERR_INVALID, "block must be 64|128|256|512|1024");
@@ -649,6 +846,8 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmv_variant")) *value = g_tune.spmv_variant;
     else if (!strcmp(key, "csr_lanes")) *value = g_tune.csr_lanes;
     else if (!strcmp(key, "ablate")) *value = g_tune.ablate;
+    else if (!strcmp(key, "spmmv_variant")) *value = g_tune.spmmv_variant;
+    else if (!strcmp(key, "tail_batch")) *value = g_tune.tail_batch;
     else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_get_tuning: unknown key '%s'", key);
     return USPMV_OK;
 }
@@ -699,6 +898,7 @@ int uspmv_dmat_wrap(int64_t C, int64_t n_chunks, int64_t n_elements, int dtype, 
 
 void uspmv_dmat_free(uspmv_dmat_t *A) {
     if (!A) return;
+    if (A->ws) (void)hipFree(A->ws);
     if (A->owns) {
         (void)hipFree((void *)A->chunk_ptrs); (void)hipFree((void *)A->chunk_lengths);
         (void)hipFree((void *)A->col_idxs); (void)hipFree((void *)A->values);
@@ -764,13 +964,17 @@ static int spmv_ap_impl(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const do
     if (dp->n_chunks == 0) return USPMV_OK;
     const int block = g_tune.block;
     const unsigned grid = grid_for(dp->n_chunks * dp->C, block);
-#define AP_LAUNCH(NTV, SPXV)                                                                                         \
-    hipLaunchKernelGGL((scs_spmv_ap_rows<4, NTV, SPXV>), dim3(grid), dim3(block), 0, (hipStream_t)stream,            \
+#define AP_LAUNCH_U(UU, NTV, SPXV)                                                                                   \
+    hipLaunchKernelGGL((scs_spmv_ap_rows<UU, NTV, SPXV>), dim3(grid), dim3(block), 0, (hipStream_t)stream,           \
                        (long)dp->n_chunks, (int)dp->C, dp->chunk_ptrs, dp->chunk_lengths, dp->col_idxs,              \
                        (const double *)dp->values, sp->chunk_ptrs, sp->chunk_lengths, sp->col_idxs,                  \
                        (const float *)sp->values, d_x, d_x_sp, d_y, g_tune.xcd_remap)
+#define AP_LAUNCH(NTV, SPXV)                                                                                         \
+    do { if (g_tune.unroll >= 8) AP_LAUNCH_U(8, NTV, SPXV); else if (g_tune.unroll == 4) AP_LAUNCH_U(4, NTV, SPXV);  \
+         else AP_LAUNCH_U(2, NTV, SPXV); } while (0)
     if (d_x_sp) { if (g_tune.nontemporal) AP_LAUNCH(true, true); else AP_LAUNCH(false, true); }
     else { if (g_tune.nontemporal) AP_LAUNCH(true, false); else AP_LAUNCH(false, false); }
+#undef AP_LAUNCH_U
 #undef AP_LAUNCH
     HIP_TRY(hipGetLastError());
     return USPMV_OK;
