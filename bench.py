@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--tune", default="", help="key=value,... forwarded to uspmv_set_tuning")
+    ap.add_argument("--no-tlc", action="store_true", help="skip the tile-local-column plan (plain gather kernel)")
     return ap.parse_args()
 
 
@@ -152,7 +153,7 @@ def main():
         loc = pkg.gen_stencil27(g, g, nz, row_begin=int(wsa[rank]), row_end=int(wsa[rank + 1]))
         workload = (f"nlpkkt200-class synthetic (27-pt stencil {g}x{g}x{nz}, n={n_global}, nnz={total_nnz}) "
                     f"scs -c {args.chunk} -s {args.sigma} -dp" + (f" -{args.seg.replace('-', '_')} -comm_halos 1" if world > 1 else ""))
-    d = DistSpmv(loc, wsa, args.chunk, args.sigma, B.F64, device=dev, overlap=not args.no_overlap)
+    d = DistSpmv(loc, wsa, args.chunk, args.sigma, B.F64, device=dev, overlap=not args.no_overlap, tlc=not args.no_tlc)
     del loc
     x = d.new_x(np.full(d.n_local, 5.0))          # DefaultValues::x (code/classes_structs.hpp:1799-1800)
     y = d.new_y()
@@ -211,10 +212,13 @@ def main():
         "config": {"workload": workload, "C": args.chunk, "sigma": args.sigma, "n_rows": n_global, "nnz": total_nnz,
                    "beta": round(s.nnz / s.n_elements, 6), "x": "5.0 (DefaultValues)",
                    "partition": args.seg if world > 1 else "none", "halo_overlap": (not args.no_overlap) and world > 1,
-                   "tuning": {k: pkg.get_tuning(k) for k in ("unroll", "nontemporal", "xcd_remap", "block", "spmv_variant")}},
+                   "kernel": "tile-local-column (LDS-staged x, 16-bit local indices)" if d.use_tiles or (world == 1 and d.A.tlc_staged) else "lane-per-row gather",
+                   "tlc_tiles_staged": [d.A.tlc_staged, d.A.tlc_tiles],
+                   "tuning": {k: pkg.get_tuning(k) for k in ("unroll", "nontemporal", "xcd_remap", "block", "spmv_variant", "tlc")}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "scs_spmv_rows<double,32>", "kernel_ms": round(k_ms, 5),
+                     "kernel": "scs_spmv_tlc<double,32>" if d.A.tlc_staged and pkg.get_tuning("tlc") else "scs_spmv_rows<double,32,8>",
+                     "kernel_ms": round(k_ms, 5),
                      "algorithmic_bytes_per_launch": int(bytes_local),
                      "frac_of_stream_copy": round(achieved / copy_gbs, 4),
                      "stream_same_run_GBs": {"copy": round(copy_gbs, 1), "triad": round(triad_gbs, 1), "read": round(read_gbs, 1)}},

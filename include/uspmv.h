@@ -114,6 +114,18 @@ int uspmv_dmat_wrap(int64_t C, int64_t n_chunks, int64_t n_elements, int dtype, 
                     const int32_t *d_chunk_lengths, const int32_t *d_col_idxs, const void *d_values,
                     uspmv_dmat_t **out);
 void uspmv_dmat_free(uspmv_dmat_t *m);
+/* Optional, MI355X-specific: derive a tile-local-column plan from the host struct the handle was made
+ * from: per 256-row tile the list of 16-element x lines it touches plus 16-bit LDS-local
+ * column indices.  uspmv_spmv then stages the x lines of a tile in LDS and streams 2-byte instead of
+ * 4-byte indices (results unchanged, bit for bit).  Tiles touching more than max_lines lines (0 = default
+ * 512) keep the gather path.  n_tiles / n_staged report the outcome (may be NULL). */
+int uspmv_dmat_optimize(uspmv_dmat_t *m, const uspmv_scs_t *s, int max_lines, int64_t *n_tiles, int64_t *n_staged);
+/* Rows per tile of the plan (256 | 512 | 1024; 0 = no plan).  A tile covers tile_rows/C consecutive chunks. */
+int uspmv_dmat_tile_rows(const uspmv_dmat_t *m, int *tile_rows);
+/* uspmv_spmv over a subset of tiles (d_tile_ids[n_ids]) of a handle with a plan: the interior /
+ * boundary split of the halo-overlap scheme at tile granularity. */
+int uspmv_spmv_tiles(const uspmv_dmat_t *A, const int32_t *d_tile_ids, int64_t n_ids, const void *d_x, void *d_y,
+                     void *stream);
 /* Mark a C = 1 struct as "crs" (uspmv <mtx> crs): uspmv_spmv then uses the CRS kernel (several lanes
  * per row, twin of spmv_omp_csr) instead of the generic SELL kernel (twin of spmv_omp_scs). */
 int uspmv_dmat_set_crs(uspmv_dmat_t *m, int on);
@@ -166,6 +178,8 @@ int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_
  *   "xcd_remap" 0 (hardware order) | 1 (one contiguous eighth of the grid per XCD) | G >= 2 (groups
  *   of G consecutive workgroups per XCD), "spmv_variant" 0 (lane per row, bit-exact) | 1 (two lanes
  *   per row, C=32 only), "csr_lanes" 0 (auto) | 1..64 lanes per row of the CRS kernel,
+ *   "tlc" 1|0 use the tile-local-column kernel when the handle has a plan, "tail_batch" 0|1,
+ *   "spmmv_variant" 0 (row-major panel kernel) | 1 (generic),
  *   "ablate" 0 | 1 | 2 (measurement only: gathers collapsed / removed, results are wrong). */
 int uspmv_set_tuning(const char *key, int value);
 int uspmv_get_tuning(const char *key, int *value);

@@ -26,7 +26,7 @@ def torch_cuda(pkg):
     assert pkg.device_count() >= 1
     torch.cuda.set_device(0)
     yield torch
-    pkg.set_tuning(unroll=8, nontemporal=1, xcd_remap=0, block=256, spmv_variant=0, csr_lanes=0, tail_batch=0)
+    pkg.set_tuning(unroll=8, nontemporal=1, xcd_remap=256, block=256, spmv_variant=0, csr_lanes=0, tail_batch=0, tlc=1)
 
 
 def sha(a):
@@ -70,7 +70,7 @@ def test_spmv_golden_bitexact_all_variants(pkg, torch_cuda, name, dt):
                             pkg.spmv(A, x, y)
                             assert np.array_equal(y.cpu().numpy(), g[f"{dt}_y_perm"]), (variant, unroll, nt, xcd, block, tail)
     pkg.set_tuning(spmv_variant=0, tail_batch=0)
-    pkg.set_tuning(unroll=8, nontemporal=1, xcd_remap=0, block=256)
+    pkg.set_tuning(unroll=8, nontemporal=1, xcd_remap=256, block=256)
     # raw-array entry point with the interface.hpp argument list
     y = t.zeros(s.n_rows_padded, dtype=x.dtype, device="cuda")
     pkg.uspmv_scs_gpu(s.C, s.n_chunks, A.chunk_ptrs, A.chunk_lengths, A.col_idxs, A.values, x, y)
@@ -257,6 +257,15 @@ def test_chunk_subsets_pack_and_permutation(pkg, orc, torch_cuda):
         y2 = t.zeros_like(y)
         pkg.spmv(A, x, y2)
         assert t.equal(y, y2)
+        # same split at tile granularity on a handle with a tile-local-column plan
+        At = pkg.DeviceMatrix(s, tlc=True)
+        cpt = At.tile_rows // s.C
+        tb = np.unique(bnd // cpt).astype(np.int32)
+        ti = np.setdiff1d(np.arange(At.tlc_tiles, dtype=np.int32), tb).astype(np.int32)
+        y3 = t.full((s.n_rows_padded,), np.nan, dtype=t.float64, device="cuda")
+        pkg.spmv_tiles(At, _dev(t, ti), x, y3)
+        pkg.spmv_tiles(At, _dev(t, tb), x, y3)
+        assert t.equal(y3, y2)
         ys.append(pkg.apply_permutation(y.cpu().numpy(), a["old_to_new_idx"]))
         # what this rank would send to everybody who asks for all of its rows, twice over
         idx = np.concatenate([np.arange(plan.n_local), np.arange(plan.n_local)[::-1]]).astype(np.int32)
@@ -269,6 +278,45 @@ def test_chunk_subsets_pack_and_permutation(pkg, orc, torch_cuda):
         assert np.array_equal(o.cpu().numpy(), ys[-1])
     pkg.set_tuning(spmv_variant=0)
     assert np.array_equal(np.concatenate(ys), h[key + "_y_global"])
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_tile_local_column_kernel_bitexact(pkg, orc, torch_cuda, name):
+    """uspmv_dmat_optimize: LDS-staged x tiles + 16-bit local column indices must not change a bit of y,
+    whether all, some (tiny max_lines) or no tiles can be staged; every C that divides 256."""
+    t = torch_cuda
+    g = golden(f"scs_{name}.npz")
+    m = pkg.read_mtx(mtx_path(name))
+    x0 = g["x"]
+    for code in (pkg.F64, pkg.F32):
+        for Cc, sg in ((int(g["C"]), int(g["sigma"])), (1, 1), (2, 4), (8, 64), (32, 512), (64, 64), (128, 256), (256, 256)):
+            s, a, xp = _prep(pkg, m, Cc, sg, code, x0)
+            y_or = orc.spmv_scs(Cc, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+            x = _dev(t, xp)
+            for max_lines, tile_rows in ((0, 256), (3, 256), (1, 512), (0, 512), (0, 1024), (5, 1024)):
+                pkg.set_tuning(tlc_tile_rows=tile_rows)
+                A = pkg.DeviceMatrix(s, tlc=True, tlc_max_lines=max_lines)
+                pkg.set_tuning(tlc_tile_rows=256)
+                assert A.tlc_tiles == (s.n_chunks + tile_rows // Cc - 1) // (tile_rows // Cc)
+                for nt in (0, 1):
+                    pkg.set_tuning(nontemporal=nt)
+                    y = t.full((s.n_rows_padded,), 9.0, dtype=A.torch_dtype, device="cuda")
+                    pkg.spmv(A, x, y)
+                    assert np.array_equal(y.cpu().numpy(), y_or), (name, code, Cc, sg, max_lines, nt, A.tlc_staged)
+                pkg.set_tuning(nontemporal=1)
+            # a misaligned x (not 16-byte aligned) silently takes the plain kernel
+            xo = t.zeros(s.n_rows_padded + 1, dtype=x.dtype, device="cuda")
+            xo[1:] = x
+            y = t.zeros(s.n_rows_padded, dtype=x.dtype, device="cuda")
+            pkg.spmv(A, xo[1:], y)
+            assert np.array_equal(y.cpu().numpy(), y_or)
+    if name == "bcsstk13":
+        s, a, xp = _prep(pkg, m, 32, 512, pkg.F64, x0)
+        A = pkg.DeviceMatrix(s, tlc=True)
+        assert A.tlc_staged == A.tlc_tiles > 0
+        s2 = pkg.convert_to_scs(m, 10, 3)          # C does not divide 256: no plan, still correct
+        A2 = pkg.DeviceMatrix(s2, tlc=True)
+        assert A2.tlc_tiles == 0
 
 
 def test_argument_errors(pkg, torch_cuda):
@@ -296,7 +344,7 @@ def test_synthetic_vs_oracle(pkg, orc, torch_cuda, shape, C, sigma):
     x0 = make_x(m.n_rows)
     for code in (pkg.F64, pkg.F32):
         s, a, xp = _prep(pkg, m, C, sigma, code, x0)
-        A = pkg.DeviceMatrix(s)
+        A = pkg.DeviceMatrix(s, tlc=True)
         y_or = orc.spmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
         for variant in (0, 2):
             pkg.set_tuning(spmv_variant=variant)
@@ -323,10 +371,17 @@ def test_full_size_nlpkkt200_class(pkg, orc, torch_cuda):
     x0 = make_x(m.n_rows)
     xp = np.zeros(s.n_rows_padded)
     xp[:s.n_rows] = pkg.apply_permutation(x0, a["new_to_old_idx"])
-    A = pkg.DeviceMatrix(s)
+    A = pkg.DeviceMatrix(s, tlc=True)
+    print(f"[full] tile-local-column plan: {A.tlc_staged} of {A.tlc_tiles} tiles staged", flush=True)
     x = _dev(t, xp)
     y = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
+    pkg.set_tuning(tlc=0)
     pkg.spmv(A, x, y)
+    y_plain = y.clone()
+    pkg.set_tuning(tlc=1)
+    y.zero_()
+    pkg.spmv(A, x, y)
+    assert t.equal(y, y_plain)
     yh = y.cpu().numpy()
     t0 = time.time()
     y_or = orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)

@@ -35,7 +35,10 @@ def main():
     s = pkg.convert_to_scs(m, args.c, args.s)
     a = s.arrays()
     pkg.permute_scs_cols(s, a["old_to_new_idx"])
-    A = pkg.DeviceMatrix(s)
+    ap.add_argument("--tile-rows", type=int, default=256) if False else None
+    pkg.set_tuning(tlc_tile_rows=int(os.environ.get("TLC_TILE_ROWS", "256")))
+    A = pkg.DeviceMatrix(s, tlc=True, tlc_max_lines=int(os.environ.get("TLC_MAX_LINES", "0")))
+    print(f"tlc: {A.tlc_staged} of {A.tlc_tiles} tiles staged", flush=True)
     print(f"n={s.n_rows} nnz={s.nnz} n_el={s.n_elements} beta={s.nnz / s.n_elements:.4f} setup {time.time() - t0:.1f}s", flush=True)
     x = torch.full((s.n_rows_padded,), 5.0, dtype=torch.float64, device="cuda")
     if args.xmode == "rand":
@@ -54,7 +57,7 @@ def main():
     res = {json.dumps(v, sort_keys=True): [] for v in var}
     for r in range(args.rounds):
         for v in var:
-            pkg.set_tuning(spmv_variant=0, unroll=8, nontemporal=1, xcd_remap=0, block=256, ablate=0, tail_batch=0)  # keys are sticky
+            pkg.set_tuning(spmv_variant=0, unroll=8, nontemporal=1, xcd_remap=0, block=256, ablate=0, tail_batch=0, tlc=0)  # keys are sticky
             pkg.set_tuning(**v)
             B.time_launches(0, 2, A=A, x=x, y=y)
             res[json.dumps(v, sort_keys=True)].append(B.time_launches(0, args.reps, A=A, x=x, y=y))

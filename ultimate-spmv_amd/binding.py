@@ -70,8 +70,11 @@ _SIGS = {
     "uspmv_dmat_wrap": (C.c_int, [_i64, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "uspmv_dmat_free": (None, [_vp]),
     "uspmv_dmat_set_crs": (C.c_int, [_vp, C.c_int]),
+    "uspmv_dmat_optimize": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_spmv": (C.c_int, [_vp, _vp, _vp, _vp]),
     "uspmv_spmv_chunks": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "uspmv_spmv_tiles": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "uspmv_dmat_tile_rows": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "uspmv_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp]),
     "uspmv_spmv_ap": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "uspmv_spmv_ap_generic": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
@@ -336,7 +339,7 @@ class DeviceMatrix:
     """SELL-C-sigma matrix resident in HBM (what assign_spmv_kernel_gpu_data stages,
     code/utilities.hpp:3721-3811).  Arrays are torch tensors owned by this object."""
 
-    def __init__(self, scs, device="cuda", crs=False):
+    def __init__(self, scs, device="cuda", crs=False, tlc=False, tlc_max_lines=0):
         import torch
         a = scs.arrays()
         self.C, self.n_chunks, self.n_elements, self.dtype = scs.C, scs.n_chunks, scs.n_elements, scs.dtype
@@ -351,8 +354,21 @@ class DeviceMatrix:
         _ck(lib().uspmv_dmat_wrap(self.C, self.n_chunks, self.n_elements, self.dtype, _dp(self.chunk_ptrs),
                                   _dp(self.chunk_lengths), _dp(self.col_idxs), _dp(self.values), C.byref(h)))
         self.h = h
+        self.tlc_tiles = self.tlc_staged = self.tile_rows = 0
         if crs:
             _ck(lib().uspmv_dmat_set_crs(h, 1))
+        if tlc:
+            self.optimize(scs, tlc_max_lines)
+
+    def optimize(self, scs, max_lines=0):
+        """Build the tile-local-column plan (uspmv_dmat_optimize); returns (n_tiles, n_staged_tiles)."""
+        a, b = _i64(), _i64()
+        _ck(lib().uspmv_dmat_optimize(self.h, scs.h, max_lines, C.byref(a), C.byref(b)))
+        self.tlc_tiles, self.tlc_staged = a.value, b.value
+        tr = C.c_int()
+        _ck(lib().uspmv_dmat_tile_rows(self.h, C.byref(tr)))
+        self.tile_rows = tr.value          # 0: no plan was built
+        return a.value, b.value
 
     def __del__(self):
         if getattr(self, "h", None) and _LIB is not None:
@@ -370,6 +386,11 @@ def spmv(A, x, y, stream=None):
 def spmv_chunks(A, chunk_ids, x, y, stream=None):
     assert chunk_ids.dtype.is_floating_point is False and x.dtype == A.torch_dtype
     _ck(lib().uspmv_spmv_chunks(A.h, _dp(chunk_ids), chunk_ids.numel(), _dp(x), _dp(y), _stream_ptr(stream)))
+    return y
+
+
+def spmv_tiles(A, tile_ids, x, y, stream=None):
+    _ck(lib().uspmv_spmv_tiles(A.h, _dp(tile_ids), tile_ids.numel(), _dp(x), _dp(y), _stream_ptr(stream)))
     return y
 
 

@@ -27,6 +27,8 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../host/uspmv_internal.hpp"
@@ -42,6 +44,13 @@ struct uspmv_dmat {
     // on demand, released with the handle.  Not thread-safe per handle, like the reference's kernel object.
     mutable void *ws = nullptr;
     mutable size_t ws_bytes = 0;
+    // tile-local-column plan (host/tlc_plan.cpp), device copies owned by the handle
+    bool tlc = false;
+    int tlc_max_lines = 0, tlc_tile_rows = 256;
+    int64_t tlc_x_len = 0, tlc_n_tiles = 0, tlc_staged = 0;
+    int32_t *tlc_line_ptr = nullptr, *tlc_lines = nullptr;
+    uint32_t *tlc_c16_ptrs = nullptr;
+    uint16_t *tlc_col16 = nullptr;
 };
 
 namespace {
@@ -50,11 +59,13 @@ struct Tuning {
     // defaults = fastest of the interleaved sweep on the nlpkkt200-class matrix (profiles/r01_sweep253.txt)
     int unroll = 8;
     int nontemporal = 1;
-    int xcd_remap = 0;
+    int xcd_remap = 256;  // groups of 256 consecutive workgroups per XCD (profiles/r01/sweepH.txt)
     int block = 256;
     int spmv_variant = 0;
     int csr_lanes = 0;  // 0 = choose from average row length
     int ablate = 0;     // measurement only
+    int tlc = 1;            // use the tile-local-column kernel when the handle carries a plan
+    int tlc_tile_rows = 256;  // rows (= threads) per tile used by the NEXT uspmv_dmat_optimize
     int tail_batch = 0;     // ragged tail of a chunk as one predicated batch
     int spmmv_variant = 0;  // 0 = row-major panel kernel (+ re-layout for colwise), 1 = generic kernel
 };
@@ -266,6 +277,98 @@ __global__ void scs_spmv_rows_pipe(const long n_work_chunks, const int C_rt, con
         }
     }
     if (valid) st_y<NT>(y + (c * C + i), acc);
+}
+
+// SpMV over a tile-local-column plan (host/tlc_plan.cpp).  One 256-thread workgroup = one tile of
+// 256/C chunks.  Phase 1: the workgroup copies the tile's x lines (16 elements each, listed in
+// tile_lines) into LDS with coalesced 16-byte loads.  Phase 2: lane <-> row as in scs_spmv_rows,
+// but the column stream is the 2-byte LDS-local index array (four slots per 8-byte load) and the x
+// operand comes from LDS (ds_read) instead of a 64-lane global gather.  Same slot-ordered FMA chain
+// per row -> bit-exact.  Tiles without a line list (footprint too wide) take the global-gather path.
+template <typename VT, int CT, bool NT, bool IDS>
+__global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const int C_rt, const int *__restrict__ chunk_ptrs,
+        const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const VT *__restrict__ values,
+        const VT *__restrict__ x, VT *__restrict__ y, const int *__restrict__ tile_line_ptr,
+        const int *__restrict__ tile_lines, const unsigned *__restrict__ c16_ptrs,
+        const unsigned short *__restrict__ col16, const long x_len, const int *__restrict__ tile_ids,
+        const int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tlc_smem[];
+    VT *xs = (VT *)tlc_smem;
+    constexpr int EPL = 16 / (int)sizeof(VT);   // elements per 16-byte load
+    constexpr int LPL = 16 / EPL;               // lanes that copy one 16-element line
+    typedef VT vec_t __attribute__((ext_vector_type(EPL)));
+    const int C = CT > 0 ? CT : C_rt;
+    const unsigned lbt = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+    const unsigned tile = IDS ? (unsigned)tile_ids[lbt] : lbt;
+    const int lp0 = tile_line_ptr[tile];
+    const int nl = tile_line_ptr[tile + 1] - lp0;
+    const long row = (long)tile * blockDim.x + threadIdx.x;
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    const bool valid = c < n_chunks;
+    int cs = 0, L = 0;
+    unsigned q0 = 0;
+    if (valid) { cs = chunk_ptrs[c]; L = chunk_lengths[c]; q0 = c16_ptrs[c]; }
+    VT acc = VT(0);
+    if (nl > 0) {
+        const int sub = threadIdx.x % LPL, lk = threadIdx.x / LPL;
+        for (int k = lk; k < nl; k += blockDim.x / LPL) {
+            const long idx = (long)tile_lines[lp0 + k] * 16 + sub * EPL;
+            vec_t v;
+            if (idx + EPL <= x_len) {
+                v = *(const vec_t *)(x + idx);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) v[e] = idx + e < x_len ? x[idx + e] : VT(0);
+            }
+            *(vec_t *)(xs + k * 16 + sub * EPL) = v;
+        }
+        __syncthreads();
+        if (L > 0) {
+            const VT *vp = values + (long)cs + i;
+            const unsigned long long *cq = (const unsigned long long *)(col16 + q0) + i;
+            const int ng = L >> 2;
+            int g = 0;
+            for (; g + 2 <= ng; g += 2) {
+                VT v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = ld_stream<NT>(vp + (long)(4 * g + u) * C);
+                const unsigned long long qa = ld_stream<NT>(cq + (long)g * C), qb = ld_stream<NT>(cq + (long)(g + 1) * C);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = fma_t(v[u], xs[(qa >> (16 * u)) & 0xFFFFu], acc);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = fma_t(v[4 + u], xs[(qb >> (16 * u)) & 0xFFFFu], acc);
+            }
+            for (; g < ng; ++g) {
+                VT v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = ld_stream<NT>(vp + (long)(4 * g + u) * C);
+                const unsigned long long qa = ld_stream<NT>(cq + (long)g * C);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = fma_t(v[u], xs[(qa >> (16 * u)) & 0xFFFFu], acc);
+            }
+            const int rem = L & 3;
+            if (rem) {
+                const unsigned long long qa = ld_stream<NT>(cq + (long)ng * C);
+                for (int u = 0; u < rem; ++u) acc = fma_t(ld_stream<NT>(vp + (long)(4 * ng + u) * C), xs[(qa >> (16 * u)) & 0xFFFFu], acc);
+            }
+        }
+    } else if (L > 0) {  // wide-footprint tile: 32-bit columns, global gathers
+        const VT *vp = values + (long)cs + i;
+        const int *cp = col_idxs + (long)cs + i;
+        int j = 0;
+        for (; j + 8 <= L; j += 8) {
+            VT v[8]; int ci[8]; VT xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = x[ci[u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fma_t(v[u], xv[u], acc);
+        }
+        for (; j < L; ++j) acc = fma_t(ld_stream<NT>(vp + (long)j * C), x[ld_stream<NT>(cp + (long)j * C)], acc);
+    }
+    if (valid) st_y<NT>(y + row, acc);
 }
 
 // C = 32, one wavefront per chunk, two lanes per row: lane l owns row l & 31 and the slots
@@ -628,12 +731,37 @@ void launch_rows_unroll(bool ids, unsigned grid, int block, hipStream_t st, long
 }
 
 template <typename VT>
+int launch_spmv_tlc(const uspmv_dmat *A, const int *tile_ids, long n_tiles, const VT *x, VT *y, hipStream_t st) {
+    if (n_tiles == 0) return USPMV_OK;
+    const int C = (int)A->C;
+    const unsigned grid = (unsigned)n_tiles;
+    const size_t lds = (size_t)A->tlc_max_lines * 16 * sizeof(VT);
+#define TLC_LAUNCH(CTV, NTV, IDSV)                                                                                    \
+    do {                                                                                                              \
+        auto kfn = scs_spmv_tlc<VT, CTV, NTV, IDSV>;                                                                 \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(A->tlc_tile_rows), lds, st, (long)A->n_chunks, C, A->chunk_ptrs,        \
+                           A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, A->tlc_line_ptr, A->tlc_lines,   \
+                           A->tlc_c16_ptrs, A->tlc_col16, (long)A->tlc_x_len, tile_ids, g_tune.xcd_remap);              \
+    } while (0)
+#define TLC_LAUNCH_C(NTV, IDSV) do { if (C == 32) TLC_LAUNCH(32, NTV, IDSV); else TLC_LAUNCH(0, NTV, IDSV); } while (0)
+    if (tile_ids) { if (g_tune.nontemporal) TLC_LAUNCH_C(true, true); else TLC_LAUNCH_C(false, true); }
+    else { if (g_tune.nontemporal) TLC_LAUNCH_C(true, false); else TLC_LAUNCH_C(false, false); }
+#undef TLC_LAUNCH_C
+#undef TLC_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+template <typename VT>
 int launch_spmv_scs(const uspmv_dmat *A, const int *chunk_ids, long n_ids, const VT *x, VT *y, hipStream_t st) {
     const bool ids = chunk_ids != nullptr;
     const long nwc = ids ? n_ids : A->n_chunks;
     if (nwc == 0) return USPMV_OK;
     const int C = (int)A->C;
     const int block = g_tune.block;
+    if (!ids && A->tlc && g_tune.tlc && !g_tune.ablate && g_tune.spmv_variant == 0 && ((uintptr_t)x % 16 == 0))
+        return launch_spmv_tlc<VT>(A, nullptr, A->tlc_n_tiles, x, y, st);
     if (!ids && C == 32 && g_tune.spmv_variant == 1) {
         const unsigned grid = grid_for(nwc * 64, block);
         if (g_tune.nontemporal)
@@ -823,6 +951,11 @@ int uspmv_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "ablate")) g_tune.ablate = value;
     else if (!strcmp(key, "spmmv_variant")) g_tune.spmmv_variant = value != 0;
     else if (!strcmp(key, "tail_batch")) g_tune.tail_batch = value != 0;
+    else if (!strcmp(key, "tlc")) g_tune.tlc = value != 0;
+    else if (!strcmp(key, "tlc_tile_rows")) {
+        if (value != 256 && value != 512 && value != 1024) return uspmv::fail(USPMV_ERR_INVALID, "tlc_tile_rows must be 256|512|1024");
+        g_tune.tlc_tile_rows = value;
+    }
     else if (!strcmp(key, "block")) {
         if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
             return uspmv::fail(USPMV_ERR_INVALID, "block must be 64|128|256|512|1024");
@@ -848,6 +981,8 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "ablate")) *value = g_tune.ablate;
     else if (!strcmp(key, "spmmv_variant")) *value = g_tune.spmmv_variant;
     else if (!strcmp(key, "tail_batch")) *value = g_tune.tail_batch;
+    else if (!strcmp(key, "tlc")) *value = g_tune.tlc;
+    else if (!strcmp(key, "tlc_tile_rows")) *value = g_tune.tlc_tile_rows;
     else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_get_tuning: unknown key '%s'", key);
     return USPMV_OK;
 }
@@ -896,8 +1031,49 @@ int uspmv_dmat_wrap(int64_t C, int64_t n_chunks, int64_t n_elements, int dtype, 
     return USPMV_OK;
 }
 
+static void tlc_release(uspmv_dmat_t *A) {
+    (void)hipFree(A->tlc_line_ptr); (void)hipFree(A->tlc_lines); (void)hipFree(A->tlc_c16_ptrs); (void)hipFree(A->tlc_col16);
+    A->tlc_line_ptr = A->tlc_lines = nullptr; A->tlc_c16_ptrs = nullptr; A->tlc_col16 = nullptr;
+    A->tlc = false;
+}
+
+int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
+    if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: NULL argument");
+    if (A->C != s->C || A->n_chunks != s->n_chunks || A->dtype != s->dtype)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: handle and host struct do not describe the same matrix");
+    if (int rc = require_device()) return rc;
+    if (A->tlc) tlc_release(A);
+    if (max_lines <= 0) max_lines = 512;                       // 64 KiB of doubles: 2 workgroups per CU at worst
+    const int cap = (int)(160 * 1024 / (16 * (s->dtype == USPMV_F64 ? 8 : 4)));
+    if (max_lines > cap) max_lines = cap;
+    uspmv_tlc_plan p;
+    if (int rc = uspmv_build_tlc_plan(s, max_lines, g_tune.tlc_tile_rows, &p)) return rc;
+    if (n_tiles) *n_tiles = p.n_tiles;
+    if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
+    if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] tlc plan: tile_rows=%d tiles=%lld staged=%lld max_lines=%d lines_total=%zu col16=%zu\n",
+                                         p.tile_rows, (long long)p.n_tiles, (long long)p.n_staged_tiles, p.max_lines_used, p.tile_lines.size(), p.col16.size());
+    if (!p.valid) return USPMV_OK;                              // nothing worth staging: plain kernel stays
+    auto up = [&](const void *h, size_t bytes, void **d) -> hipError_t {
+        hipError_t e = hipMalloc(d, bytes ? bytes : 4);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(p.tile_line_ptr.data(), p.tile_line_ptr.size() * 4, (void **)&A->tlc_line_ptr);
+    if (e == hipSuccess) e = up(p.tile_lines.data(), p.tile_lines.size() * 4, (void **)&A->tlc_lines);
+    if (e == hipSuccess) e = up(p.c16_ptrs.data(), p.c16_ptrs.size() * 4, (void **)&A->tlc_c16_ptrs);
+    if (e == hipSuccess) e = up(p.col16.data(), p.col16.size() * 2, (void **)&A->tlc_col16);
+    if (e != hipSuccess) {
+        tlc_release(A);
+        return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize: device copy failed: %s", hipGetErrorString(e));
+    }
+    A->tlc = true; A->tlc_tile_rows = p.tile_rows; A->tlc_max_lines = p.max_lines_used; A->tlc_x_len = p.x_len_min; A->tlc_n_tiles = p.n_tiles;
+    A->tlc_staged = p.n_staged_tiles;
+    return USPMV_OK;
+}
+
 void uspmv_dmat_free(uspmv_dmat_t *A) {
     if (!A) return;
+    if (A->tlc) tlc_release(A);
     if (A->ws) (void)hipFree(A->ws);
     if (A->owns) {
         (void)hipFree((void *)A->chunk_ptrs); (void)hipFree((void *)A->chunk_lengths);
@@ -937,6 +1113,24 @@ int uspmv_spmv_chunks(const uspmv_dmat_t *A, const int32_t *d_chunk_ids, int64_t
     if (n_ids == 0) return USPMV_OK;
     if (A->dtype == USPMV_F64) return launch_spmv_scs<double>(A, d_chunk_ids, n_ids, (const double *)d_x, (double *)d_y, (hipStream_t)stream);
     return launch_spmv_scs<float>(A, d_chunk_ids, n_ids, (const float *)d_x, (float *)d_y, (hipStream_t)stream);
+}
+
+int uspmv_spmv_tiles(const uspmv_dmat_t *A, const int32_t *d_tile_ids, int64_t n_ids, const void *d_x, void *d_y,
+                     void *stream) {
+    if (int rc = check_dmat(A, "uspmv_spmv_tiles")) return rc;
+    if (!A->tlc) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_tiles: handle has no tile-local-column plan (uspmv_dmat_optimize)");
+    if (n_ids < 0 || n_ids > A->tlc_n_tiles || (n_ids > 0 && !d_tile_ids) || !d_x || !d_y)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_tiles: bad argument");
+    if ((uintptr_t)d_x % 16) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_tiles: x must be 16-byte aligned");
+    if (int rc = require_device()) return rc;
+    if (A->dtype == USPMV_F64) return launch_spmv_tlc<double>(A, d_tile_ids, (long)n_ids, (const double *)d_x, (double *)d_y, (hipStream_t)stream);
+    return launch_spmv_tlc<float>(A, d_tile_ids, (long)n_ids, (const float *)d_x, (float *)d_y, (hipStream_t)stream);
+}
+
+int uspmv_dmat_tile_rows(const uspmv_dmat_t *A, int *tile_rows) {
+    if (!A || !tile_rows) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_tile_rows: NULL argument");
+    *tile_rows = A->tlc ? A->tlc_tile_rows : 0;
+    return USPMV_OK;
 }
 
 int uspmv_spmmv(const uspmv_dmat_t *A, const void *d_X, void *d_Y, int b, int64_t ld, int layout, void *stream) {

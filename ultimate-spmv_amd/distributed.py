@@ -57,7 +57,7 @@ class DistSpmv:
     """
 
     def __init__(self, local_coo, wsa, C, sigma, dtype=B.F64, device=None, group=None, overlap=True,
-                 pack_fn=None, spmv_fn=None, spmv_chunks_fn=None):
+                 pack_fn=None, spmv_fn=None, spmv_chunks_fn=None, tlc=True):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -94,8 +94,18 @@ class DistSpmv:
         self.send_splits = [int(v) for v in self.send_counts]
 
         # ---- device-resident state
+        self.use_tiles = False
         if self.on_gpu:
-            self.A = B.DeviceMatrix(scs, self.device)
+            self.A = B.DeviceMatrix(scs, self.device, tlc=tlc)
+            if self.A.tile_rows and self.A.tlc_staged:
+                # interior / boundary split at tile granularity (a tile = tile_rows/C chunks)
+                cpt = self.A.tile_rows // scs.C
+                n_tiles = self.A.tlc_tiles
+                bnd = np.zeros(n_tiles, bool)
+                bnd[np.unique(self.boundary_ids // cpt)] = True
+                self.interior_ids = np.flatnonzero(~bnd).astype(np.int32)
+                self.boundary_ids = np.flatnonzero(bnd).astype(np.int32)
+                self.use_tiles = True
         self.d_perm = torch.from_numpy(self.old_to_new).to(self.device)
         self.d_send_idxs = torch.from_numpy(self.send_idxs.astype(np.int32)).to(self.device)
         self.d_interior = torch.from_numpy(self.interior_ids).to(self.device)
@@ -182,6 +192,8 @@ class DistSpmv:
             return y
         if self._spmv_chunks_fn is not None:
             return self._spmv_chunks_fn(self, ids, x, y)
+        if self.use_tiles:
+            return B.spmv_tiles(self.A, ids, x, y)
         return B.spmv_chunks(self.A, ids, x, y)
 
     def spmv(self, x, y, comm_halos=True):

@@ -1,0 +1,116 @@
+// Tile-local-column (TLC) plan: an MI355X-specific device layout derived from a SELL-C-sigma
+// struct at upload time.  Nothing like it exists in the reference; the SCS arrays themselves stay
+// bit-identical to the reference's, this is an additional index structure for the SpMV kernel.
+//
+// A tile = the tile_rows/C consecutive chunks one workgroup of tile_rows (256 | 512 | 1024) threads
+// processes.  For every tile the
+// planner lists the distinct 16-element lines of x its column indices touch (sorted).  If there are
+// at most `max_lines` of them, the workgroup can stage exactly those lines into LDS with coalesced
+// 16-byte loads and every column index of the tile becomes a 16-bit LDS-local index
+//      local = (position of the line in the tile's list) * 16 + (col & 15).
+// That replaces the 4-byte global column stream by a 2-byte one (12 -> 10 bytes per non-zero in
+// double precision) and the 64-lane eight-byte global gathers by ds_read_b64.  Tiles whose
+// footprint is too wide keep the plain 32-bit gather path (n_lines = 0).
+//
+// col16 layout: per chunk, slots in groups of four, [group][row i][slot % 4], so that one lane
+// reads the four indices of its next four slots with a single 8-byte load.
+#include <algorithm>
+#include <cstring>
+
+#include "uspmv_internal.hpp"
+
+int uspmv_build_tlc_plan(const uspmv_scs *s, int max_lines, int tile_rows, uspmv_tlc_plan *p) {
+    p->valid = false;
+    const int64_t C = s->C;
+    if (tile_rows != 256 && tile_rows != 512 && tile_rows != 1024) tile_rows = 256;
+    if (C < 1 || C > tile_rows || tile_rows % C != 0 || s->n_chunks < 1) return USPMV_OK;  // unsupported shape: no plan
+    if (max_lines < 1) return USPMV_OK;
+    if (max_lines > 4096) max_lines = 4096;  // 16-bit local indices
+    const int64_t T = tile_rows / C;
+    p->tile_rows = tile_rows;
+    const int64_t n_tiles = (s->n_chunks + T - 1) / T;
+    p->chunks_per_tile = (int)T;
+    p->n_tiles = n_tiles;
+    p->c16_ptrs.assign((size_t)s->n_chunks + 1, 0);
+    int64_t tot16 = 0;
+    for (int64_t c = 0; c < s->n_chunks; ++c) {
+        p->c16_ptrs[(size_t)c] = (uint32_t)tot16;
+        tot16 += ((int64_t)(s->chunk_lengths[(size_t)c] + 3) / 4) * 4 * C;
+        if (tot16 > (int64_t)UINT32_MAX) return USPMV_OK;  // too large for 32-bit offsets: no plan
+    }
+    p->c16_ptrs[(size_t)s->n_chunks] = (uint32_t)tot16;
+    p->col16.assign((size_t)tot16, 0);
+    std::vector<std::vector<int32_t>> tile_lines((size_t)n_tiles);
+    int32_t max_col = 0;
+    const int32_t *ci = s->col_idxs.data();
+#pragma omp parallel
+    {
+        std::vector<int32_t> lines, pos;
+        int32_t my_max = 0;
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t t = 0; t < n_tiles; ++t) {
+            const int64_t c0 = t * T, c1 = std::min<int64_t>(c0 + T, s->n_chunks);
+            const int64_t e0 = s->chunk_ptrs[(size_t)c0], e1 = s->chunk_ptrs[(size_t)c1];
+            lines.clear();
+            int32_t lo = INT32_MAX, hi = -1;
+            for (int64_t k = e0; k < e1; ++k) {
+                const int32_t l = ci[k] >> 4;
+                lo = std::min(lo, l); hi = std::max(hi, l);
+                my_max = std::max(my_max, ci[k]);
+            }
+            if (hi < 0) continue;                       // tile without elements: nothing to stage
+            const int64_t range = (int64_t)hi - lo + 1;
+            const bool dense = range <= 65536;          // dense marking over the tile's line range
+            int32_t n = 0;
+            if (dense) {
+                pos.assign((size_t)range, -1);
+                for (int64_t k = e0; k < e1; ++k) pos[(size_t)((ci[k] >> 4) - lo)] = 0;
+                for (int64_t r = 0; r < range && n <= max_lines; ++r)
+                    if (pos[(size_t)r] == 0) { pos[(size_t)r] = n++; lines.push_back((int32_t)(lo + r)); }
+            } else {                                    // wide footprint: sort + unique
+                lines.resize((size_t)(e1 - e0));
+                for (int64_t k = e0; k < e1; ++k) lines[(size_t)(k - e0)] = ci[k] >> 4;
+                std::sort(lines.begin(), lines.end());
+                lines.erase(std::unique(lines.begin(), lines.end()), lines.end());
+                n = (int32_t)lines.size();
+            }
+            if (n > max_lines) continue;                // gather path for this tile
+            auto local_of = [&](int32_t col) -> uint16_t {
+                const int32_t l = col >> 4;
+                const int32_t pl = dense ? pos[(size_t)(l - lo)]
+                                         : (int32_t)(std::lower_bound(lines.begin(), lines.end(), l) - lines.begin());
+                return (uint16_t)((pl << 4) | (col & 15));
+            };
+            for (int64_t c = c0; c < c1; ++c) {
+                const int64_t cs = s->chunk_ptrs[(size_t)c], L = s->chunk_lengths[(size_t)c];
+                uint16_t *q = p->col16.data() + p->c16_ptrs[(size_t)c];
+                for (int64_t j = 0; j < L; ++j)
+                    for (int64_t i = 0; i < C; ++i)
+                        q[(j / 4) * 4 * C + i * 4 + (j % 4)] = local_of(ci[cs + j * C + i]);
+            }
+            tile_lines[(size_t)t] = lines;
+        }
+#pragma omp critical
+        max_col = std::max(max_col, my_max);
+    }
+    p->tile_line_ptr.assign((size_t)n_tiles + 1, 0);
+    int64_t tot = 0;
+    int mx = 0;
+    int64_t n_staged = 0;
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        p->tile_line_ptr[(size_t)t] = (int32_t)tot;
+        tot += (int64_t)tile_lines[(size_t)t].size();
+        mx = std::max<int>(mx, (int)tile_lines[(size_t)t].size());
+        n_staged += !tile_lines[(size_t)t].empty();
+        if (tot > INT32_MAX) return USPMV_OK;
+    }
+    p->tile_line_ptr[(size_t)n_tiles] = (int32_t)tot;
+    p->tile_lines.resize((size_t)tot);
+    for (int64_t t = 0; t < n_tiles; ++t)
+        std::copy(tile_lines[(size_t)t].begin(), tile_lines[(size_t)t].end(), p->tile_lines.begin() + p->tile_line_ptr[(size_t)t]);
+    p->max_lines_used = mx;
+    p->n_staged_tiles = n_staged;
+    p->x_len_min = (int64_t)max_col + 1;
+    p->valid = n_staged > 0;
+    return USPMV_OK;
+}

@@ -39,6 +39,18 @@ struct uspmv_halo {
     std::vector<int32_t> recv_idxs;           // grouped by owner ascending, owner-local row ids
 };
 
+// Tile-local-column plan (host copy), see host/tlc_plan.cpp
+struct uspmv_tlc_plan {
+    bool valid = false;
+    int chunks_per_tile = 0, max_lines_used = 0, tile_rows = 256;
+    int64_t n_tiles = 0, n_staged_tiles = 0, x_len_min = 0;
+    std::vector<int32_t> tile_line_ptr;   // n_tiles+1
+    std::vector<int32_t> tile_lines;      // line ids (col >> 4), sorted per tile; empty tile list = gather path
+    std::vector<uint32_t> c16_ptrs;       // n_chunks+1, offsets into col16
+    std::vector<uint16_t> col16;          // [chunk][slot/4][row][slot%4]
+};
+int uspmv_build_tlc_plan(const uspmv_scs *s, int max_lines, int tile_rows, uspmv_tlc_plan *plan);
+
 namespace uspmv {
 int fail(int status, const char *fmt, ...);  // records the thread-local error text, returns status
 }
