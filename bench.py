@@ -125,12 +125,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if os.environ.get("USPMV_BENCH_ONE_DEVICE"):   # rehearsal only: several ranks share GPU 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    set_omp_threads(int(os.environ.get("OMP_NUM_THREADS", usable_cores())))
+        if os.environ.get("USPMV_BENCH_ONE_DEVICE"):
+            dist.init_process_group("gloo", rank=rank, world_size=world)      # rehearsal: RCCL refuses duplicate GPUs
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # torchrun exports OMP_NUM_THREADS=1; the host set-up (generation, conversion, planning) is OpenMP code,
+    # so give every rank its share of the usable cores instead
+    set_omp_threads(max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         pkg.set_tuning(**{k: int(v)})
@@ -177,7 +184,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3

@@ -173,14 +173,22 @@ class DistSpmv:
         with ctx:
             self._pack(x)
             out = x[self.n_local:self.n_local + self.n_halo]
+            if self.on_gpu and not self._needs_device_comm():
+                # rehearsal path (gloo with device vectors, e.g. several ranks sharing one GPU in the
+                # tests): bounce through the host; RCCL runs take the branch below
+                h_out = torch.empty(self.n_halo, dtype=self.tdtype)
+                dist.all_to_all_single(h_out, self.send_buf[:self.n_send].cpu(), self.recv_splits, self.send_splits,
+                                       group=self.group)
+                out.copy_(h_out, non_blocking=False)
+                return None
             return dist.all_to_all_single(out, self.send_buf[:self.n_send], self.recv_splits, self.send_splits,
                                           group=self.group, async_op=True)
 
     def halo_end(self, work):
         if work is not None:
             work.wait()          # nccl: orders the current stream after the collective; gloo: blocks
-            if self.on_gpu and self.overlap:
-                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        if self.P > 1 and self.on_gpu and self.overlap:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
 
     def _spmv_all(self, x, y):
         if self._spmv_fn is not None:
