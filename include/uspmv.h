@@ -120,6 +120,10 @@ void uspmv_dmat_free(uspmv_dmat_t *m);
  * 4-byte indices (results unchanged, bit for bit).  Tiles touching more than max_lines lines (0 = default
  * 512) keep the gather path.  n_tiles / n_staged report the outcome (may be NULL). */
 int uspmv_dmat_optimize(uspmv_dmat_t *m, const uspmv_scs_t *s, int max_lines, int64_t *n_tiles, int64_t *n_staged);
+/* Same for an ap[dp_sp] pair (structs with identical row layout): one shared line list per tile, 16-bit
+ * indices for both structs; uspmv_spmv_ap then streams 10 + 6 instead of 12 + 8 bytes per non-zero. */
+int uspmv_dmat_optimize_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t *s_dp, const uspmv_scs_t *s_sp,
+                           int max_lines, int64_t *n_tiles, int64_t *n_staged);
 /* Rows per tile of the plan (256 | 512 | 1024; 0 = no plan).  A tile covers tile_rows/C consecutive chunks. */
 int uspmv_dmat_tile_rows(const uspmv_dmat_t *m, int *tile_rows);
 /* uspmv_spmv over a subset of tiles (d_tile_ids[n_ids]) of a handle with a plan: the interior /

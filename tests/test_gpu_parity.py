@@ -227,6 +227,15 @@ def test_ap_golden_bitexact(pkg, torch_cuda, name):
     xs = _dev(t, a[p + "x_perm"].astype(np.float32))
     pkg.spmv_ap(Ad, As, _dev(t, a[p + "x_perm"]), y, x_sp=xs)
     assert np.array_equal(y.cpu().numpy(), a[p + "y_perm_gen"])
+    # shared tile-local-column plan for the pair: same bits
+    for max_lines, tile_rows in ((0, 256), (2, 256), (0, 1024)):
+        pkg.set_tuning(tlc_tile_rows=tile_rows)
+        nt_, ns_ = pkg.optimize_ap(Ad, As, ds, ss, max_lines)
+        pkg.set_tuning(tlc_tile_rows=256)
+        y.fill_(7.0)
+        pkg.spmv_ap(Ad, As, _dev(t, a[p + "x_perm"]), y)
+        if Cc in ADV_CS:
+            assert np.array_equal(y.cpu().numpy(), a[p + "y_perm_adv"]), (max_lines, tile_rows, nt_, ns_)
     with pytest.raises(pkg.UspmvError):
         pkg.spmv_ap(As, Ad, _dev(t, a[p + "x_perm"]), y)      # wrong precision order
 

@@ -39,7 +39,7 @@ def main():
             coo = pkg.gen_stencil27(g, g, g)
             s = prep(coo, pkg.F64)
             a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
-            A = pkg.DeviceMatrix(s)
+            A = pkg.DeviceMatrix(s, tlc=True)
             xp = np.zeros(s.n_rows_padded); xp[:s.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(s.n_rows) % 1000), a["new_to_old_idx"])
             x = t.from_numpy(xp).cuda(); y = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
             pkg.spmv(A, x, y)
@@ -88,6 +88,11 @@ def main():
             ok = None if args.no_check else bool(np.array_equal(y.cpu().numpy(), orc.spmv_scs_ap_adv(
                 32, ds.n_chunks, (da["chunk_ptrs"], da["chunk_lengths"], da["col_idxs"], da["values"]),
                 (sa["chunk_ptrs"], sa["chunk_lengths"], sa["col_idxs"], sa["values"]), xp)))
+            ms_gather = B.time_launches(4, args.reps, A=Ad, B=As, x=x, y=y)
+            nt_, ns_ = pkg.optimize_ap(Ad, As, ds, ss)
+            y2 = t.zeros_like(y)
+            pkg.spmv_ap(Ad, As, x, y2)
+            ok = ok and bool(t.equal(y, y2)) if ok is not None else None
             ms = B.time_launches(4, args.reps, A=Ad, B=As, x=x, y=y)
             byts = 12 * ds.n_elements + 8 * ss.n_elements + 16 * ds.n_chunks + 8 * (ds.n_rows + ds.n_rows_padded)
             out = dict(config=4, workload=f"HV15R-class stencil27 {g}^3 x 5 dof, |a_ij| log-uniform over 10 decades, scs -c 32 -s 512 -ap[dp_sp] -ap_threshold_1 1e-3",
@@ -95,7 +100,10 @@ def main():
             # same matrix in plain dp for comparison
             s = prep(coo, pkg.F64); a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"])
             A = pkg.DeviceMatrix(s)
-            out["plain_dp_ms"] = round(B.time_launches(0, args.reps, A=A, x=x, y=y), 5)
+            out["gather_kernel_ms"] = round(ms_gather, 5); out["tlc_tiles_staged"] = [ns_, nt_]
+            out["plain_dp_gather_ms"] = round(B.time_launches(0, args.reps, A=A, x=x, y=y), 5)
+            A.optimize(s)
+            out["plain_dp_tlc_ms"] = round(B.time_launches(0, args.reps, A=A, x=x, y=y), 5)
             flops = 2.0 * coo.nnz
         out.update(kernel_ms=round(ms, 5), gflops=round(flops / ms / 1e6, 1), algorithmic_GBs=round(byts / ms / 1e6, 1),
                    frac_of_8TBs=round(byts / ms / 1e6 / 8000, 4), bitexact_vs_oracle=ok, setup_s=round(time.time() - t0, 1))

@@ -75,6 +75,7 @@ _SIGS = {
     "uspmv_spmv_chunks": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "uspmv_spmv_tiles": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "uspmv_dmat_tile_rows": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "uspmv_dmat_optimize_ap": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp]),
     "uspmv_spmv_ap": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "uspmv_spmv_ap_generic": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
@@ -374,6 +375,15 @@ class DeviceMatrix:
         if getattr(self, "h", None) and _LIB is not None:
             _LIB.uspmv_dmat_free(self.h)
             self.h = None
+
+
+def optimize_ap(A_dp, A_sp, scs_dp, scs_sp, max_lines=0):
+    """Shared tile-local-column plan for an ap[dp_sp] pair; returns (n_tiles, n_staged_tiles)."""
+    a, b = _i64(), _i64()
+    _ck(lib().uspmv_dmat_optimize_ap(A_dp.h, A_sp.h, scs_dp.h, scs_sp.h, max_lines, C.byref(a), C.byref(b)))
+    for A in (A_dp, A_sp):
+        A.tlc_tiles, A.tlc_staged = a.value, b.value
+    return a.value, b.value
 
 
 def spmv(A, x, y, stream=None):

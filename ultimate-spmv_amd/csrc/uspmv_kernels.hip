@@ -48,6 +48,7 @@ struct uspmv_dmat {
     bool tlc = false;
     int tlc_max_lines = 0, tlc_tile_rows = 256;
     int64_t tlc_x_len = 0, tlc_n_tiles = 0, tlc_staged = 0;
+    uint64_t tlc_plan_id = 0;   // structs planned together (ap pair) carry the same non-zero id
     int32_t *tlc_line_ptr = nullptr, *tlc_lines = nullptr;
     uint32_t *tlc_c16_ptrs = nullptr;
     uint16_t *tlc_col16 = nullptr;
@@ -369,6 +370,111 @@ __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const 
         for (; j < L; ++j) acc = fma_t(ld_stream<NT>(vp + (long)j * C), x[ld_stream<NT>(cp + (long)j * C)], acc);
     }
     if (valid) st_y<NT>(y + row, acc);
+}
+
+// Adaptive precision dp+sp over a tile-local-column plan shared by the two structs (one line list
+// per tile covering the columns of both): x lines staged once, then the dp chain (8-byte values +
+// 2-byte local indices) and the sp chain (4-byte values + 2-byte local indices), y = dp + sp.
+// 10 and 6 bytes per non-zero instead of 12 and 8; numerics of scs_ap_impl_cpu, bit-exact.
+template <int CT, bool NT>
+__global__ void __launch_bounds__(1024) scs_spmv_ap_tlc(const long n_chunks, const int C_rt,
+        const int *__restrict__ dp_cp, const int *__restrict__ dp_cl, const int *__restrict__ dp_ci, const double *__restrict__ dp_va,
+        const int *__restrict__ sp_cp, const int *__restrict__ sp_cl, const int *__restrict__ sp_ci, const float *__restrict__ sp_va,
+        const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tile_line_ptr,
+        const int *__restrict__ tile_lines, const unsigned *__restrict__ dp_c16p, const unsigned short *__restrict__ dp_c16,
+        const unsigned *__restrict__ sp_c16p, const unsigned short *__restrict__ sp_c16, const long x_len, const int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tlc_smem[];
+    double *xs = (double *)tlc_smem;
+    typedef double vec_t __attribute__((ext_vector_type(2)));
+    const int C = CT > 0 ? CT : C_rt;
+    const unsigned tile = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+    const int lp0 = tile_line_ptr[tile];
+    const int nl = tile_line_ptr[tile + 1] - lp0;
+    const long row = (long)tile * blockDim.x + threadIdx.x;
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    const bool valid = c < n_chunks;
+    int dcs = 0, Ld = 0, scs_ = 0, Ls = 0;
+    unsigned dq0 = 0, sq0 = 0;
+    if (valid) { dcs = dp_cp[c]; Ld = dp_cl[c]; scs_ = sp_cp[c]; Ls = sp_cl[c]; dq0 = dp_c16p[c]; sq0 = sp_c16p[c]; }
+    double dt = 0.0, st = 0.0;
+    if (nl > 0) {
+        const int sub = threadIdx.x & 7, lk = threadIdx.x >> 3;
+        for (int k = lk; k < nl; k += blockDim.x >> 3) {
+            const long idx = (long)tile_lines[lp0 + k] * 16 + sub * 2;
+            vec_t v;
+            if (idx + 2 <= x_len) v = *(const vec_t *)(x + idx);
+            else { v[0] = idx < x_len ? x[idx] : 0.0; v[1] = 0.0; }
+            *(vec_t *)(xs + k * 16 + sub * 2) = v;
+        }
+        __syncthreads();
+        if (Ld > 0) {
+            const double *vp = dp_va + (long)dcs + i;
+            const unsigned long long *cq = (const unsigned long long *)(dp_c16 + dq0) + i;
+            const int ng = Ld >> 2;
+            int g = 0;
+            for (; g + 2 <= ng; g += 2) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = ld_stream<NT>(vp + (long)(4 * g + u) * C);
+                const unsigned long long qa = ld_stream<NT>(cq + (long)g * C), qb = ld_stream<NT>(cq + (long)(g + 1) * C);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dt = __builtin_fma(v[u], xs[(qa >> (16 * u)) & 0xFFFFu], dt);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dt = __builtin_fma(v[4 + u], xs[(qb >> (16 * u)) & 0xFFFFu], dt);
+            }
+            for (; g < ng; ++g) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = ld_stream<NT>(vp + (long)(4 * g + u) * C);
+                const unsigned long long qa = ld_stream<NT>(cq + (long)g * C);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dt = __builtin_fma(v[u], xs[(qa >> (16 * u)) & 0xFFFFu], dt);
+            }
+            const int rem = Ld & 3;
+            if (rem) {
+                const unsigned long long qa = ld_stream<NT>(cq + (long)ng * C);
+                for (int u = 0; u < rem; ++u) dt = __builtin_fma(ld_stream<NT>(vp + (long)(4 * ng + u) * C), xs[(qa >> (16 * u)) & 0xFFFFu], dt);
+            }
+        }
+        if (Ls > 0) {
+            const float *vp = sp_va + (long)scs_ + i;
+            const unsigned long long *cq = (const unsigned long long *)(sp_c16 + sq0) + i;
+            const int ng = Ls >> 2;
+            int g = 0;
+            for (; g + 2 <= ng; g += 2) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = ld_stream<NT>(vp + (long)(4 * g + u) * C);
+                const unsigned long long qa = ld_stream<NT>(cq + (long)g * C), qb = ld_stream<NT>(cq + (long)(g + 1) * C);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) st = __builtin_fma((double)v[u], xs[(qa >> (16 * u)) & 0xFFFFu], st);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) st = __builtin_fma((double)v[4 + u], xs[(qb >> (16 * u)) & 0xFFFFu], st);
+            }
+            for (; g < ng; ++g) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = ld_stream<NT>(vp + (long)(4 * g + u) * C);
+                const unsigned long long qa = ld_stream<NT>(cq + (long)g * C);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) st = __builtin_fma((double)v[u], xs[(qa >> (16 * u)) & 0xFFFFu], st);
+            }
+            const int rem = Ls & 3;
+            if (rem) {
+                const unsigned long long qa = ld_stream<NT>(cq + (long)ng * C);
+                for (int u = 0; u < rem; ++u) st = __builtin_fma((double)ld_stream<NT>(vp + (long)(4 * ng + u) * C), xs[(qa >> (16 * u)) & 0xFFFFu], st);
+            }
+        }
+    } else {  // wide-footprint tile: 32-bit columns, global gathers
+        const double *dvp = dp_va + (long)dcs + i;
+        const int *dcp = dp_ci + (long)dcs + i;
+        for (int j = 0; j < Ld; ++j) dt = __builtin_fma(ld_stream<NT>(dvp + (long)j * C), x[ld_stream<NT>(dcp + (long)j * C)], dt);
+        const float *svp = sp_va + (long)scs_ + i;
+        const int *scp = sp_ci + (long)scs_ + i;
+        for (int j = 0; j < Ls; ++j) st = __builtin_fma((double)ld_stream<NT>(svp + (long)j * C), x[ld_stream<NT>(scp + (long)j * C)], st);
+    }
+    if (valid) st_y<NT>(y + row, dt + st);
 }
 
 // C = 32, one wavefront per chunk, two lanes per row: lane l owns row l & 31 and the slots
@@ -760,7 +866,7 @@ int launch_spmv_scs(const uspmv_dmat *A, const int *chunk_ids, long n_ids, const
     if (nwc == 0) return USPMV_OK;
     const int C = (int)A->C;
     const int block = g_tune.block;
-    if (!ids && A->tlc && g_tune.tlc && !g_tune.ablate && g_tune.spmv_variant == 0 && ((uintptr_t)x % 16 == 0))
+    if (!ids && A->tlc && A->tlc_plan_id == 0 && g_tune.tlc && !g_tune.ablate && g_tune.spmv_variant == 0 && ((uintptr_t)x % 16 == 0))
         return launch_spmv_tlc<VT>(A, nullptr, A->tlc_n_tiles, x, y, st);
     if (!ids && C == 32 && g_tune.spmv_variant == 1) {
         const unsigned grid = grid_for(nwc * 64, block);
@@ -1034,7 +1140,7 @@ int uspmv_dmat_wrap(int64_t C, int64_t n_chunks, int64_t n_elements, int dtype, 
 static void tlc_release(uspmv_dmat_t *A) {
     (void)hipFree(A->tlc_line_ptr); (void)hipFree(A->tlc_lines); (void)hipFree(A->tlc_c16_ptrs); (void)hipFree(A->tlc_col16);
     A->tlc_line_ptr = A->tlc_lines = nullptr; A->tlc_c16_ptrs = nullptr; A->tlc_col16 = nullptr;
-    A->tlc = false;
+    A->tlc = false; A->tlc_plan_id = 0;
 }
 
 int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
@@ -1047,7 +1153,7 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     const int cap = (int)(160 * 1024 / (16 * (s->dtype == USPMV_F64 ? 8 : 4)));
     if (max_lines > cap) max_lines = cap;
     uspmv_tlc_plan p;
-    if (int rc = uspmv_build_tlc_plan(s, max_lines, g_tune.tlc_tile_rows, &p)) return rc;
+    if (int rc = uspmv_build_tlc_plan(s, nullptr, max_lines, g_tune.tlc_tile_rows, &p)) return rc;
     if (n_tiles) *n_tiles = p.n_tiles;
     if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
     if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] tlc plan: tile_rows=%d tiles=%lld staged=%lld max_lines=%d lines_total=%zu col16=%zu\n",
@@ -1068,6 +1174,47 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     }
     A->tlc = true; A->tlc_tile_rows = p.tile_rows; A->tlc_max_lines = p.max_lines_used; A->tlc_x_len = p.x_len_min; A->tlc_n_tiles = p.n_tiles;
     A->tlc_staged = p.n_staged_tiles;
+    return USPMV_OK;
+}
+
+int uspmv_dmat_optimize_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t *s_dp, const uspmv_scs_t *s_sp,
+                           int max_lines, int64_t *n_tiles, int64_t *n_staged) {
+    if (!dp || !sp || !s_dp || !s_sp) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_ap: NULL argument");
+    if (dp->C != s_dp->C || dp->n_chunks != s_dp->n_chunks || dp->dtype != USPMV_F64 || s_dp->dtype != USPMV_F64 ||
+        sp->C != s_sp->C || sp->n_chunks != s_sp->n_chunks || sp->dtype != USPMV_F32 || s_sp->dtype != USPMV_F32 ||
+        dp->C != sp->C || dp->n_chunks != sp->n_chunks)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_ap: handles / host structs do not form a dp+sp pair");
+    if (int rc = require_device()) return rc;
+    if (dp->tlc) tlc_release(dp);
+    if (sp->tlc) tlc_release(sp);
+    if (max_lines <= 0) max_lines = 512;
+    if (max_lines > 1280) max_lines = 1280;
+    uspmv_tlc_plan p;
+    if (int rc = uspmv_build_tlc_plan(s_dp, s_sp, max_lines, g_tune.tlc_tile_rows, &p)) return rc;
+    if (n_tiles) *n_tiles = p.n_tiles;
+    if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
+    if (!p.valid) return USPMV_OK;
+    auto up = [&](const void *h, size_t bytes, void **d) -> hipError_t {
+        hipError_t e = hipMalloc(d, bytes ? bytes : 4);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(p.tile_line_ptr.data(), p.tile_line_ptr.size() * 4, (void **)&dp->tlc_line_ptr);
+    if (e == hipSuccess) e = up(p.tile_lines.data(), p.tile_lines.size() * 4, (void **)&dp->tlc_lines);
+    if (e == hipSuccess) e = up(p.c16_ptrs.data(), p.c16_ptrs.size() * 4, (void **)&dp->tlc_c16_ptrs);
+    if (e == hipSuccess) e = up(p.col16.data(), p.col16.size() * 2, (void **)&dp->tlc_col16);
+    if (e == hipSuccess) e = up(p.c16_ptrs_b.data(), p.c16_ptrs_b.size() * 4, (void **)&sp->tlc_c16_ptrs);
+    if (e == hipSuccess) e = up(p.col16_b.data(), p.col16_b.size() * 2, (void **)&sp->tlc_col16);
+    if (e != hipSuccess) {
+        tlc_release(dp); tlc_release(sp);
+        return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_ap: device copy failed: %s", hipGetErrorString(e));
+    }
+    static uint64_t next_plan_id = 1;
+    const uint64_t id = next_plan_id++;
+    for (uspmv_dmat_t *A : {dp, sp}) {
+        A->tlc = true; A->tlc_tile_rows = p.tile_rows; A->tlc_max_lines = p.max_lines_used; A->tlc_x_len = p.x_len_min;
+        A->tlc_n_tiles = p.n_tiles; A->tlc_staged = p.n_staged_tiles; A->tlc_plan_id = id;
+    }
     return USPMV_OK;
 }
 
@@ -1118,7 +1265,7 @@ int uspmv_spmv_chunks(const uspmv_dmat_t *A, const int32_t *d_chunk_ids, int64_t
 int uspmv_spmv_tiles(const uspmv_dmat_t *A, const int32_t *d_tile_ids, int64_t n_ids, const void *d_x, void *d_y,
                      void *stream) {
     if (int rc = check_dmat(A, "uspmv_spmv_tiles")) return rc;
-    if (!A->tlc) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_tiles: handle has no tile-local-column plan (uspmv_dmat_optimize)");
+    if (!A->tlc || A->tlc_plan_id != 0) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_tiles: handle has no tile-local-column plan (uspmv_dmat_optimize)");
     if (n_ids < 0 || n_ids > A->tlc_n_tiles || (n_ids > 0 && !d_tile_ids) || !d_x || !d_y)
         return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_tiles: bad argument");
     if ((uintptr_t)d_x % 16) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_tiles: x must be 16-byte aligned");
@@ -1156,6 +1303,26 @@ static int spmv_ap_impl(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const do
     if (!d_x || !d_y) return uspmv::fail(USPMV_ERR_INVALID, "%s: NULL vector", who);
     if (int rc = require_device()) return rc;
     if (dp->n_chunks == 0) return USPMV_OK;
+    if (!d_x_sp && dp->tlc && sp->tlc && dp->tlc_plan_id != 0 && dp->tlc_plan_id == sp->tlc_plan_id && g_tune.tlc &&
+        ((uintptr_t)d_x % 16 == 0)) {
+        const size_t lds = (size_t)dp->tlc_max_lines * 16 * sizeof(double);
+        const int C = (int)dp->C;
+#define APT_LAUNCH(CTV, NTV)                                                                                          \
+    do {                                                                                                              \
+        auto kfn = scs_spmv_ap_tlc<CTV, NTV>;                                                                        \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)dp->tlc_n_tiles), dim3(dp->tlc_tile_rows), lds, (hipStream_t)stream,     \
+                           (long)dp->n_chunks, C, dp->chunk_ptrs, dp->chunk_lengths, dp->col_idxs, (const double *)dp->values, \
+                           sp->chunk_ptrs, sp->chunk_lengths, sp->col_idxs, (const float *)sp->values, d_x, d_y,         \
+                           dp->tlc_line_ptr, dp->tlc_lines, dp->tlc_c16_ptrs, dp->tlc_col16, sp->tlc_c16_ptrs,           \
+                           sp->tlc_col16, (long)dp->tlc_x_len, g_tune.xcd_remap);                                        \
+    } while (0)
+        if (g_tune.nontemporal) { if (C == 32) APT_LAUNCH(32, true); else APT_LAUNCH(0, true); }
+        else { if (C == 32) APT_LAUNCH(32, false); else APT_LAUNCH(0, false); }
+#undef APT_LAUNCH
+        HIP_TRY(hipGetLastError());
+        return USPMV_OK;
+    }
     const int block = g_tune.block;
     const unsigned grid = grid_for(dp->n_chunks * dp->C, block);
 #define AP_LAUNCH_U(UU, NTV, SPXV)                                                                                   \

@@ -19,11 +19,14 @@
 
 #include "uspmv_internal.hpp"
 
-int uspmv_build_tlc_plan(const uspmv_scs *s, int max_lines, int tile_rows, uspmv_tlc_plan *p) {
+int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines, int tile_rows, uspmv_tlc_plan *p) {
+    // s2 (optional): a second struct with the same row layout (the sp part of an ap[dp_sp] pair);
+    // the line list of a tile then covers the columns of both, each struct gets its own col16.
     p->valid = false;
     const int64_t C = s->C;
     if (tile_rows != 256 && tile_rows != 512 && tile_rows != 1024) tile_rows = 256;
     if (C < 1 || C > tile_rows || tile_rows % C != 0 || s->n_chunks < 1) return USPMV_OK;  // unsupported shape: no plan
+    if (s2 && (s2->C != C || s2->n_chunks != s->n_chunks)) return USPMV_OK;
     if (max_lines < 1) return USPMV_OK;
     if (max_lines > 4096) max_lines = 4096;  // 16-bit local indices
     const int64_t T = tile_rows / C;
@@ -31,18 +34,23 @@ int uspmv_build_tlc_plan(const uspmv_scs *s, int max_lines, int tile_rows, uspmv
     const int64_t n_tiles = (s->n_chunks + T - 1) / T;
     p->chunks_per_tile = (int)T;
     p->n_tiles = n_tiles;
-    p->c16_ptrs.assign((size_t)s->n_chunks + 1, 0);
-    int64_t tot16 = 0;
-    for (int64_t c = 0; c < s->n_chunks; ++c) {
-        p->c16_ptrs[(size_t)c] = (uint32_t)tot16;
-        tot16 += ((int64_t)(s->chunk_lengths[(size_t)c] + 3) / 4) * 4 * C;
-        if (tot16 > (int64_t)UINT32_MAX) return USPMV_OK;  // too large for 32-bit offsets: no plan
+    const uspmv_scs *ss[2] = {s, s2};
+    std::vector<uint32_t> *ptrs[2] = {&p->c16_ptrs, &p->c16_ptrs_b};
+    std::vector<uint16_t> *c16[2] = {&p->col16, &p->col16_b};
+    const int ns = s2 ? 2 : 1;
+    for (int w = 0; w < ns; ++w) {
+        ptrs[w]->assign((size_t)s->n_chunks + 1, 0);
+        int64_t tot16 = 0;
+        for (int64_t c = 0; c < s->n_chunks; ++c) {
+            (*ptrs[w])[(size_t)c] = (uint32_t)tot16;
+            tot16 += ((int64_t)(ss[w]->chunk_lengths[(size_t)c] + 3) / 4) * 4 * C;
+            if (tot16 > (int64_t)UINT32_MAX) return USPMV_OK;  // too large for 32-bit offsets: no plan
+        }
+        (*ptrs[w])[(size_t)s->n_chunks] = (uint32_t)tot16;
+        c16[w]->assign((size_t)tot16, 0);
     }
-    p->c16_ptrs[(size_t)s->n_chunks] = (uint32_t)tot16;
-    p->col16.assign((size_t)tot16, 0);
     std::vector<std::vector<int32_t>> tile_lines((size_t)n_tiles);
     int32_t max_col = 0;
-    const int32_t *ci = s->col_idxs.data();
 #pragma omp parallel
     {
         std::vector<int32_t> lines, pos;
@@ -50,13 +58,18 @@ int uspmv_build_tlc_plan(const uspmv_scs *s, int max_lines, int tile_rows, uspmv
 #pragma omp for schedule(dynamic, 16)
         for (int64_t t = 0; t < n_tiles; ++t) {
             const int64_t c0 = t * T, c1 = std::min<int64_t>(c0 + T, s->n_chunks);
-            const int64_t e0 = s->chunk_ptrs[(size_t)c0], e1 = s->chunk_ptrs[(size_t)c1];
             lines.clear();
             int32_t lo = INT32_MAX, hi = -1;
-            for (int64_t k = e0; k < e1; ++k) {
-                const int32_t l = ci[k] >> 4;
-                lo = std::min(lo, l); hi = std::max(hi, l);
-                my_max = std::max(my_max, ci[k]);
+            int64_t n_el = 0;
+            for (int w = 0; w < ns; ++w) {
+                const int32_t *ci = ss[w]->col_idxs.data();
+                const int64_t e0 = ss[w]->chunk_ptrs[(size_t)c0], e1 = ss[w]->chunk_ptrs[(size_t)c1];
+                n_el += e1 - e0;
+                for (int64_t k = e0; k < e1; ++k) {
+                    const int32_t l = ci[k] >> 4;
+                    lo = std::min(lo, l); hi = std::max(hi, l);
+                    my_max = std::max(my_max, ci[k]);
+                }
             }
             if (hi < 0) continue;                       // tile without elements: nothing to stage
             const int64_t range = (int64_t)hi - lo + 1;
@@ -64,12 +77,18 @@ int uspmv_build_tlc_plan(const uspmv_scs *s, int max_lines, int tile_rows, uspmv
             int32_t n = 0;
             if (dense) {
                 pos.assign((size_t)range, -1);
-                for (int64_t k = e0; k < e1; ++k) pos[(size_t)((ci[k] >> 4) - lo)] = 0;
+                for (int w = 0; w < ns; ++w) {
+                    const int32_t *ci = ss[w]->col_idxs.data();
+                    for (int64_t k = ss[w]->chunk_ptrs[(size_t)c0]; k < ss[w]->chunk_ptrs[(size_t)c1]; ++k) pos[(size_t)((ci[k] >> 4) - lo)] = 0;
+                }
                 for (int64_t r = 0; r < range && n <= max_lines; ++r)
                     if (pos[(size_t)r] == 0) { pos[(size_t)r] = n++; lines.push_back((int32_t)(lo + r)); }
             } else {                                    // wide footprint: sort + unique
-                lines.resize((size_t)(e1 - e0));
-                for (int64_t k = e0; k < e1; ++k) lines[(size_t)(k - e0)] = ci[k] >> 4;
+                lines.reserve((size_t)n_el);
+                for (int w = 0; w < ns; ++w) {
+                    const int32_t *ci = ss[w]->col_idxs.data();
+                    for (int64_t k = ss[w]->chunk_ptrs[(size_t)c0]; k < ss[w]->chunk_ptrs[(size_t)c1]; ++k) lines.push_back(ci[k] >> 4);
+                }
                 std::sort(lines.begin(), lines.end());
                 lines.erase(std::unique(lines.begin(), lines.end()), lines.end());
                 n = (int32_t)lines.size();
@@ -81,12 +100,15 @@ int uspmv_build_tlc_plan(const uspmv_scs *s, int max_lines, int tile_rows, uspmv
                                          : (int32_t)(std::lower_bound(lines.begin(), lines.end(), l) - lines.begin());
                 return (uint16_t)((pl << 4) | (col & 15));
             };
-            for (int64_t c = c0; c < c1; ++c) {
-                const int64_t cs = s->chunk_ptrs[(size_t)c], L = s->chunk_lengths[(size_t)c];
-                uint16_t *q = p->col16.data() + p->c16_ptrs[(size_t)c];
-                for (int64_t j = 0; j < L; ++j)
-                    for (int64_t i = 0; i < C; ++i)
-                        q[(j / 4) * 4 * C + i * 4 + (j % 4)] = local_of(ci[cs + j * C + i]);
+            for (int w = 0; w < ns; ++w) {
+                const int32_t *ci = ss[w]->col_idxs.data();
+                for (int64_t c = c0; c < c1; ++c) {
+                    const int64_t cs = ss[w]->chunk_ptrs[(size_t)c], L = ss[w]->chunk_lengths[(size_t)c];
+                    uint16_t *q = c16[w]->data() + (*ptrs[w])[(size_t)c];
+                    for (int64_t j = 0; j < L; ++j)
+                        for (int64_t i = 0; i < C; ++i)
+                            q[(j / 4) * 4 * C + i * 4 + (j % 4)] = local_of(ci[cs + j * C + i]);
+                }
             }
             tile_lines[(size_t)t] = lines;
         }

@@ -48,8 +48,10 @@ struct uspmv_tlc_plan {
     std::vector<int32_t> tile_lines;      // line ids (col >> 4), sorted per tile; empty tile list = gather path
     std::vector<uint32_t> c16_ptrs;       // n_chunks+1, offsets into col16
     std::vector<uint16_t> col16;          // [chunk][slot/4][row][slot%4]
+    std::vector<uint32_t> c16_ptrs_b;     // same for the optional second struct (sp part of an ap pair)
+    std::vector<uint16_t> col16_b;
 };
-int uspmv_build_tlc_plan(const uspmv_scs *s, int max_lines, int tile_rows, uspmv_tlc_plan *plan);
+int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines, int tile_rows, uspmv_tlc_plan *plan);
 
 namespace uspmv {
 int fail(int status, const char *fmt, ...);  // records the thread-local error text, returns status

@@ -45,6 +45,7 @@ struct Config {  // subset of the reference's Config (code/classes_structs.hpp:4
     std::string matrix_file_name, seg_method = "seg-rows", value_type = "dp", kernel_format = "scs";
     std::string output_filename_bench = "spmv_bench.txt";
     int layout = USPMV_COLWISE;  // run-time here; a make knob in the reference (Makefile:26-31)
+    int tlc = 1;                 // build the tile-local-column plan (MI355X-specific, results unchanged)
 };
 
 [[noreturn]] void die(const std::string &msg) {
@@ -65,7 +66,7 @@ void usage() {
             "  -seg_rows|-seg_nnz -validate <0|1> -verbose <0|1> -mode <s|b> -bench_time <float>\n"
             "  -ba_synch <0|1> -comm_halos <0|1> -par_pack <0|1> -no_pack <0|1> -print_comm_vol <0|1>\n"
             "  -equilibrate <0|1> -ap_threshold_1 <float> -ap_threshold_2 <float> -dropout <0|1>\n"
-            "  -dropout_threshold <float> -block_vec_layout <colwise|rowwise>\n");
+            "  -dropout_threshold <float> -block_vec_layout <colwise|rowwise> -tlc <0|1>\n");
 }
 
 Config parse(int argc, char **argv) {
@@ -102,6 +103,7 @@ Config parse(int argc, char **argv) {
         else if (a == "-seg_rows" || a == "-seg-rows") c.seg_method = "seg-rows";
         else if (a == "-seg_nnz" || a == "-seg-nnz") c.seg_method = "seg-nnz";
         else if (a == "-seg_metis" || a == "-seg-metis") c.seg_method = "seg-metis";
+        else if (a == "-tlc") c.tlc = atoi(need(i));
         else if (a == "-block_vec_layout") { std::string v = need(i); if (v == "colwise") c.layout = USPMV_COLWISE; else if (v == "rowwise") c.layout = USPMV_ROWWISE; else die("block_vec_layout must be colwise or rowwise."); }
         else { usage(); die("unknown argument: " + a); }
     }
@@ -214,6 +216,12 @@ int run(const Config &c, uspmv_coo_t *coo) {
     ck(uspmv_dmat_upload(scs, &r.A), "uspmv_dmat_upload");
     if (ap) ck(uspmv_dmat_upload(scs_sp, &r.A_sp), "uspmv_dmat_upload");
     if (c.kernel_format != "scs") ck(uspmv_dmat_set_crs(r.A, 1), "uspmv_dmat_set_crs");
+    if (c.tlc && c.kernel_format == "scs" && b == 1) {
+        int64_t nt = 0, ns = 0;
+        if (ap) ck(uspmv_dmat_optimize_ap(r.A, r.A_sp, scs, scs_sp, 0, &nt, &ns), "uspmv_dmat_optimize_ap");
+        else ck(uspmv_dmat_optimize(r.A, scs, 0, &nt, &ns), "uspmv_dmat_optimize");
+        printf("tile-local-column plan: %ld of %ld tiles staged in LDS\n", (long)ns, (long)nt);
+    }
     r.x = dev_alloc<VT>((size_t)b * ld);
     r.y = dev_alloc<VT>((size_t)b * ld);
     hk(hipMemcpy(r.x, hx.data(), sizeof(VT) * hx.size(), hipMemcpyHostToDevice), "hipMemcpy x");
