@@ -68,6 +68,7 @@ struct Tuning {
     int tlc = 1;            // use the tile-local-column kernel when the handle carries a plan
     int tlc_tile_rows = 256;  // rows (= threads) per tile used by the NEXT uspmv_dmat_optimize
     int tail_batch = 0;     // ragged tail of a chunk as one predicated batch
+    int spmmv_unroll = 0;   // 0 = auto (2 for 64-byte rows, else 4)
     int spmmv_variant = 0;  // 0 = row-major panel kernel (+ re-layout for colwise), 1 = generic kernel
 };
 Tuning g_tune;
@@ -950,17 +951,25 @@ void launch_spmmv_vb(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, in
 #undef SPMMV_LAUNCH
 }
 
-template <typename VT, int B>
-void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, hipStream_t st) {
+template <typename VT, int B, int U>
+void launch_spmmv_rowmajor_u(const uspmv_dmat *A, const VT *X, VT *Y, hipStream_t st) {
     const int block = g_tune.block;
     const unsigned grid = grid_for(A->n_chunks * A->C, block);
-    constexpr int U = (B * (int)sizeof(VT) >= 64) ? 2 : 4;
     if (g_tune.nontemporal)
         hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, true>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, (int)A->C,
                            A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, g_tune.xcd_remap);
     else
         hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, false>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, (int)A->C,
                            A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, g_tune.xcd_remap);
+}
+
+template <typename VT, int B>
+void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, hipStream_t st) {
+    int U = g_tune.spmmv_unroll;
+    if (U == 0) U = (B * (int)sizeof(VT) >= 64) ? 2 : 4;
+    if (U >= 4) launch_spmmv_rowmajor_u<VT, B, 4>(A, X, Y, st);
+    else if (U >= 2) launch_spmmv_rowmajor_u<VT, B, 2>(A, X, Y, st);
+    else launch_spmmv_rowmajor_u<VT, B, 1>(A, X, Y, st);
 }
 
 // B-specialised path: row-major kernel, with a re-layout on both sides for column-major callers.
@@ -1057,6 +1066,7 @@ int uspmv_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "ablate")) g_tune.ablate = value;
     else if (!strcmp(key, "spmmv_variant")) g_tune.spmmv_variant = value != 0;
     else if (!strcmp(key, "tail_batch")) g_tune.tail_batch = value != 0;
+    else if (!strcmp(key, "spmmv_unroll")) g_tune.spmmv_unroll = value;
     else if (!strcmp(key, "tlc")) g_tune.tlc = value != 0;
     else if (!strcmp(key, "tlc_tile_rows")) {
         if (value != 256 && value != 512 && value != 1024) return uspmv::fail(USPMV_ERR_INVALID, "tlc_tile_rows must be 256|512|1024");
@@ -1087,6 +1097,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "ablate")) *value = g_tune.ablate;
     else if (!strcmp(key, "spmmv_variant")) *value = g_tune.spmmv_variant;
     else if (!strcmp(key, "tail_batch")) *value = g_tune.tail_batch;
+    else if (!strcmp(key, "spmmv_unroll")) *value = g_tune.spmmv_unroll;
     else if (!strcmp(key, "tlc")) *value = g_tune.tlc;
     else if (!strcmp(key, "tlc_tile_rows")) *value = g_tune.tlc_tile_rows;
     else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_get_tuning: unknown key '%s'", key);
