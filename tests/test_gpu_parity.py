@@ -328,6 +328,80 @@ def test_tile_local_column_kernel_bitexact(pkg, orc, torch_cuda, name):
         assert A2.tlc_tiles == 0
 
 
+def _random_coo(n, per_row, rng, empty_every=0, band=None):
+    I, J = [], []
+    for r in range(n):
+        if empty_every and r % empty_every == 0:
+            continue
+        k = int(rng.integers(1, per_row + 1))
+        cols = rng.integers(0, n, k) if band is None else np.clip(r + rng.integers(-band, band + 1, k), 0, n - 1)
+        I += [r] * k
+        J += cols.tolist()
+    V = rng.standard_normal(len(I)) * 10.0 ** rng.integers(-3, 4, len(I))
+    return np.array(I, np.int32), np.array(J, np.int32), V
+
+
+@pytest.mark.parametrize("case", ["wide-random", "ragged-banded", "mostly-empty", "tiny"])
+def test_edge_shapes_all_kernels(pkg, orc, torch_cuda, case):
+    """Empty rows, all-empty chunks (chunk_lengths = 0), fewer rows than C, ragged row lengths, and
+    footprints too wide to stage (gather-fallback tiles at default settings): SpMV (plan and no plan),
+    SpMMV and AP against the oracle, bit for bit."""
+    t = torch_cuda
+    rng = np.random.default_rng(11)
+    if case == "wide-random":
+        n = 30000; I, J, V = _random_coo(n, 40, rng)
+    elif case == "ragged-banded":
+        n = 5000; I, J, V = _random_coo(n, 90, rng, empty_every=7, band=300)
+    elif case == "mostly-empty":
+        n = 4000; I, J, V = _random_coo(n, 3, rng, empty_every=1)          # no entries at all ...
+        I = np.array([5, 5, 3999], np.int32); J = np.array([0, 3999, 17], np.int32); V = np.array([2.0, -1.5, 4.0])  # ... but three
+    else:
+        n = 5; I, J, V = _random_coo(n, 4, rng)
+    m = pkg.Coo.from_arrays(n, n, I, J, V)
+    x0 = make_x(n) * np.where(np.arange(n) % 3 == 0, -1.0, 1.0)
+    for Cc, sg in ((32, 512), (8, 1), (64, 128), (1, 1)):
+        for code in (pkg.F64, pkg.F32):
+            s, a, xp = _prep(pkg, m, Cc, sg, code, x0)
+            y_or = orc.spmv_scs(Cc, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+            x = _dev(t, xp)
+            for tlc in (False, True):
+                A = pkg.DeviceMatrix(s, tlc=tlc)
+                y = t.full((s.n_rows_padded,), 5.0, dtype=A.torch_dtype, device="cuda")
+                pkg.spmv(A, x, y)
+                assert np.array_equal(y.cpu().numpy(), y_or), (case, Cc, sg, code, tlc, A.tlc_staged, A.tlc_tiles)
+            if case == "wide-random" and Cc == 32 and code == pkg.F64:
+                assert 0 <= A.tlc_staged < A.tlc_tiles          # some tiles really took the gather path
+            ld = s.n_rows_padded
+            for b, rowwise in ((4, 0), (8, 1), (3, 0)):
+                X = block_x(xp, ld, b, ld, rowwise)
+                Y = t.zeros(b * ld, dtype=A.torch_dtype, device="cuda")
+                pkg.spmmv(A, _dev(t, X), Y, b, ld, pkg.ROWWISE if rowwise else pkg.COLWISE)
+                assert np.array_equal(Y.cpu().numpy(), orc.spmmv_scs(Cc, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"],
+                                                                      a["col_idxs"], a["values"], X, b, ld, rowwise)), (case, Cc, b, rowwise)
+        # adaptive precision on the same matrix, threshold in the middle of the value range
+        dp, sp = pkg.partition_precisions(m, 1.0)
+        if dp.nnz:
+            ds = pkg.convert_to_scs(dp, Cc, sg, pkg.F64)
+            perm = ds.arrays()["old_to_new_idx"].copy()
+            try:
+                ss = pkg.convert_to_scs(sp, Cc, sg, pkg.F32, fixed_permutation=perm)
+            except pkg.UspmvError:
+                continue      # dp permutation parks a non-empty sp row on a padded slot (reference overruns here)
+            pkg.permute_scs_cols(ds, perm); pkg.permute_scs_cols(ss, perm)
+            da, sa = ds.arrays(), ss.arrays()
+            xp = np.zeros(ds.n_rows_padded); xp[:n] = pkg.apply_permutation(x0, da["new_to_old_idx"])
+            y_or = orc.spmv_scs_ap_adv(Cc, ds.n_chunks, (da["chunk_ptrs"], da["chunk_lengths"], da["col_idxs"], da["values"]),
+                                       (sa["chunk_ptrs"], sa["chunk_lengths"], sa["col_idxs"], sa["values"]), xp)
+            Ad, As = pkg.DeviceMatrix(ds), pkg.DeviceMatrix(ss)
+            y = t.zeros(ds.n_rows_padded, dtype=t.float64, device="cuda")
+            pkg.spmv_ap(Ad, As, _dev(t, xp), y)
+            assert np.array_equal(y.cpu().numpy(), y_or), (case, Cc, "ap gather")
+            pkg.optimize_ap(Ad, As, ds, ss)
+            y.fill_(1.0)
+            pkg.spmv_ap(Ad, As, _dev(t, xp), y)
+            assert np.array_equal(y.cpu().numpy(), y_or), (case, Cc, "ap tlc")
+
+
 def test_argument_errors(pkg, torch_cuda):
     t = torch_cuda
     s = pkg.convert_to_scs(pkg.gen_stencil27(4, 4, 4), 32, 512)

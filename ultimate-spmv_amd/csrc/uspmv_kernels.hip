@@ -589,11 +589,13 @@ __global__ void scs_spmmv_rows(const long n_chunks, const int C, const int *__re
 // column gathers: 1 + 1 + B*sizeof(VT)/16 vector-memory instructions per 64 non-zeros (the
 // column-major form needs 2 + B, each fetching a whole 64-byte sector per lane for 8 useful bytes).
 // Every (row, v) accumulator is still the slot-ordered FMA chain of block_spmv_omp_scs_general.
-template <typename VT, int B, int U, bool NT>
+// YCOL: write Y column-major (Y[row + v*ld]) straight from the accumulators -- per vector one
+// coalesced 64-lane store -- so that column-major callers only pay the X re-layout.
+template <typename VT, int B, int U, bool NT, bool YCOL>
 __global__ void scs_spmmv_rowmajor(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
                                    const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                                    const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
-                                   const int xcd_remap) {
+                                   const long ld, const int xcd_remap) {
     constexpr int VW = 16 / (int)sizeof(VT);  // elements per 16-byte load
     constexpr int NV = B / VW;
     typedef VT vec_t __attribute__((ext_vector_type(VW)));
@@ -639,13 +641,18 @@ __global__ void scs_spmmv_rowmajor(const long n_chunks, const int C, const int *
             for (int w = 0; w < VW; ++w) acc[k * VW + w] = fma_t(a, xv[w], acc[k * VW + w]);
         }
     }
-    vec_t *yp = (vec_t *)(Y + row * B);
+    if (YCOL) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        vec_t t;
+        for (int v = 0; v < B; ++v) st_y<NT>(Y + (row + (long)v * ld), acc[v]);
+    } else {
+        vec_t *yp = (vec_t *)(Y + row * B);
 #pragma unroll
-        for (int w = 0; w < VW; ++w) t[w] = acc[k * VW + w];
-        yp[k] = t;
+        for (int k = 0; k < NV; ++k) {
+            vec_t t;
+#pragma unroll
+            for (int w = 0; w < VW; ++w) t[w] = acc[k * VW + w];
+            yp[k] = t;
+        }
     }
 }
 
@@ -952,36 +959,36 @@ void launch_spmmv_vb(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, in
 }
 
 template <typename VT, int B, int U>
-void launch_spmmv_rowmajor_u(const uspmv_dmat *A, const VT *X, VT *Y, hipStream_t st) {
+void launch_spmmv_rowmajor_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
     const int block = g_tune.block;
     const unsigned grid = grid_for(A->n_chunks * A->C, block);
-    if (g_tune.nontemporal)
-        hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, true>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, (int)A->C,
-                           A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, g_tune.xcd_remap);
-    else
-        hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, false>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, (int)A->C,
-                           A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, g_tune.xcd_remap);
+#define RM_LAUNCH(NTV, YC)                                                                                          \
+    hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, NTV, YC>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks,  \
+                       (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld,    \
+                       g_tune.xcd_remap)
+    if (g_tune.nontemporal) { if (ycol) RM_LAUNCH(true, true); else RM_LAUNCH(true, false); }
+    else { if (ycol) RM_LAUNCH(false, true); else RM_LAUNCH(false, false); }
+#undef RM_LAUNCH
 }
 
 template <typename VT, int B>
-void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, hipStream_t st) {
+void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
     int U = g_tune.spmmv_unroll;
     if (U == 0) U = (B * (int)sizeof(VT) >= 64) ? 2 : 4;
-    if (U >= 4) launch_spmmv_rowmajor_u<VT, B, 4>(A, X, Y, st);
-    else if (U >= 2) launch_spmmv_rowmajor_u<VT, B, 2>(A, X, Y, st);
-    else launch_spmmv_rowmajor_u<VT, B, 1>(A, X, Y, st);
+    if (U >= 4) launch_spmmv_rowmajor_u<VT, B, 4>(A, X, Y, ld, ycol, st);
+    else if (U >= 2) launch_spmmv_rowmajor_u<VT, B, 2>(A, X, Y, ld, ycol, st);
+    else launch_spmmv_rowmajor_u<VT, B, 1>(A, X, Y, ld, ycol, st);
 }
 
-// B-specialised path: row-major kernel, with a re-layout on both sides for column-major callers.
-// Returns false when (b, dtype) has no specialisation (caller falls back to the generic kernel).
+// B-specialised path: row-major kernel; column-major callers get X re-laid out once into the handle's
+// scratch and Y written column-major directly by the kernel.
 template <typename VT, int B>
 int spmmv_fast(const uspmv_dmat *A, const VT *X, VT *Y, long ld, int layout, hipStream_t st) {
     if (layout == USPMV_ROWWISE) {
-        launch_spmmv_rowmajor<VT, B>(A, X, Y, st);
+        launch_spmmv_rowmajor<VT, B>(A, X, Y, ld, false, st);
         return USPMV_OK;
     }
-    const long n_pad = A->n_chunks * A->C;
-    const size_t need = sizeof(VT) * (size_t)B * (size_t)(ld + n_pad);
+    const size_t need = sizeof(VT) * (size_t)B * (size_t)ld;
     if (A->ws_bytes < need) {
         if (A->ws) (void)hipFree(A->ws);
         A->ws = nullptr; A->ws_bytes = 0;
@@ -989,10 +996,9 @@ int spmmv_fast(const uspmv_dmat *A, const VT *X, VT *Y, long ld, int layout, hip
         if (e != hipSuccess) return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_spmmv: workspace of %zu bytes: %s", need, hipGetErrorString(e));
         A->ws_bytes = need;
     }
-    VT *Xr = (VT *)A->ws, *Yr = Xr + (size_t)B * ld;
+    VT *Xr = (VT *)A->ws;
     hipLaunchKernelGGL((block_vector_relayout<VT, B, true>), dim3(grid_for(ld, 256)), dim3(256), 0, st, X, Xr, ld, ld);
-    launch_spmmv_rowmajor<VT, B>(A, Xr, Yr, st);
-    hipLaunchKernelGGL((block_vector_relayout<VT, B, false>), dim3(grid_for(n_pad, 256)), dim3(256), 0, st, (const VT *)Yr, Y, n_pad, ld);
+    launch_spmmv_rowmajor<VT, B>(A, Xr, Y, ld, true, st);
     return USPMV_OK;
 }
 

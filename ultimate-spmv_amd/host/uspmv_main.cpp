@@ -46,6 +46,7 @@ struct Config {  // subset of the reference's Config (code/classes_structs.hpp:4
     std::string output_filename_bench = "spmv_bench.txt";
     int layout = USPMV_COLWISE;  // run-time here; a make knob in the reference (Makefile:26-31)
     int tlc = 1;                 // build the tile-local-column plan (MI355X-specific, results unchanged)
+    int use_graph = 1;           // bench loop replays hipGraphs of 64 launches
 };
 
 [[noreturn]] void die(const std::string &msg) {
@@ -66,7 +67,7 @@ void usage() {
             "  -seg_rows|-seg_nnz -validate <0|1> -verbose <0|1> -mode <s|b> -bench_time <float>\n"
             "  -ba_synch <0|1> -comm_halos <0|1> -par_pack <0|1> -no_pack <0|1> -print_comm_vol <0|1>\n"
             "  -equilibrate <0|1> -ap_threshold_1 <float> -ap_threshold_2 <float> -dropout <0|1>\n"
-            "  -dropout_threshold <float> -block_vec_layout <colwise|rowwise> -tlc <0|1>\n");
+            "  -dropout_threshold <float> -block_vec_layout <colwise|rowwise> -tlc <0|1> -graph <0|1>\n");
 }
 
 Config parse(int argc, char **argv) {
@@ -104,6 +105,7 @@ Config parse(int argc, char **argv) {
         else if (a == "-seg_nnz" || a == "-seg-nnz") c.seg_method = "seg-nnz";
         else if (a == "-seg_metis" || a == "-seg-metis") c.seg_method = "seg-metis";
         else if (a == "-tlc") c.tlc = atoi(need(i));
+        else if (a == "-graph") c.use_graph = atoi(need(i));
         else if (a == "-block_vec_layout") { std::string v = need(i); if (v == "colwise") c.layout = USPMV_COLWISE; else if (v == "rowwise") c.layout = USPMV_ROWWISE; else die("block_vec_layout must be colwise or rowwise."); }
         else { usage(); die("unknown argument: " + a); }
     }
@@ -153,13 +155,14 @@ struct Run {  // everything one kernel invocation needs
     uspmv_dmat_t *A = nullptr, *A_sp = nullptr;
     void *x = nullptr, *y = nullptr;
     int b = 1; long ld = 0; int layout = USPMV_COLWISE; bool ap = false;
-    void exec() const {
+    void exec_on(void *stream) const {
         int rc;
-        if (ap) rc = uspmv_spmv_ap(A, A_sp, (const double *)x, (double *)y, nullptr);
-        else if (b > 1) rc = uspmv_spmmv(A, x, y, b, ld, layout, nullptr);
-        else rc = uspmv_spmv(A, x, y, nullptr);
+        if (ap) rc = uspmv_spmv_ap(A, A_sp, (const double *)x, (double *)y, stream);
+        else if (b > 1) rc = uspmv_spmmv(A, x, y, b, ld, layout, stream);
+        else rc = uspmv_spmv(A, x, y, stream);
         ck(rc, "kernel launch");
     }
+    void exec() const { exec_on(nullptr); }
 };
 
 template <typename VT>
@@ -203,8 +206,12 @@ int run(const Config &c, uspmv_coo_t *coo) {
     std::mt19937 engine;
     std::uniform_real_distribution<double> dist(vmin, vmax);
     for (int v = 0; v < b; ++v) {
-        for (int64_t i = 0; i < n_rows; ++i)
-            xo[(size_t)i] = c.random_init_x == '1' ? (VT)dist(engine) : c.random_init_x == 'm' ? (VT)vmean : (VT)5.0;
+        // random_init draws for every element of the padded vector, padding is zeroed afterwards
+        // (code/utilities.hpp:880-912, :955-980): consume ld draws per vector, keep the first n_rows
+        for (int64_t i = 0; i < ld; ++i) {
+            const VT val = c.random_init_x == '1' ? (VT)dist(engine) : c.random_init_x == 'm' ? (VT)vmean : (VT)5.0;
+            if (i < n_rows) xo[(size_t)i] = val;
+        }
         ck(uspmv_apply_permutation(xp.data(), xo.data(), n2o, n_rows, dtype), "uspmv_apply_permutation");
         for (int64_t i = 0; i < n_rows; ++i) {
             if (c.layout == USPMV_ROWWISE) hx[(size_t)(i * b + v)] = xp[(size_t)i];
@@ -237,10 +244,24 @@ int run(const Config &c, uspmv_coo_t *coo) {
         hk(hipEventCreate(&e0), "hipEventCreate"); hk(hipEventCreate(&e1), "hipEventCreate");
         n_iter = 2;
         float ms = 0.f;
+        // launch-bound matrices: replay a captured graph of GRAPH_BATCH kernel launches instead of
+        // GRAPH_BATCH host launches (same kernels, same count; only the host-side launch cost changes)
+        constexpr int GRAPH_BATCH = 64;
+        hipStream_t gs = nullptr;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t gexec = nullptr;
+        if (c.use_graph) {
+            hk(hipStreamCreate(&gs), "hipStreamCreate");
+            hk(hipStreamBeginCapture(gs, hipStreamCaptureModeGlobal), "hipStreamBeginCapture");
+            for (int k = 0; k < GRAPH_BATCH; ++k) r.exec_on(gs);
+            hk(hipStreamEndCapture(gs, &graph), "hipStreamEndCapture");
+            hk(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+        }
         do {  // code/main.cpp:483-518
-            hk(hipEventRecord(e0, nullptr), "hipEventRecord");
-            for (int k = 0; k < n_iter; ++k) r.exec();
-            hk(hipEventRecord(e1, nullptr), "hipEventRecord");
+            hk(hipEventRecord(e0, gs), "hipEventRecord");
+            if (gexec && n_iter >= GRAPH_BATCH) for (int k = 0; k < n_iter / GRAPH_BATCH; ++k) hk(hipGraphLaunch(gexec, gs), "hipGraphLaunch");
+            else for (int k = 0; k < n_iter; ++k) r.exec_on(gs);
+            hk(hipEventRecord(e1, gs), "hipEventRecord");
             hk(hipEventSynchronize(e1), "hipEventSynchronize");
             hk(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
             n_iter *= 2;
@@ -309,7 +330,9 @@ int run(const Config &c, uspmv_coo_t *coo) {
     f << std::left << std::setw(w) << "Achieved GB/s:" << std::left << std::setw(w) << "Fraction of 8.0 TB/s:" << std::endl;
     f << std::left << std::setw(w) << "-------------" << std::left << std::setw(w) << "-------------" << std::endl;
     f << std::left << std::setprecision(6) << std::setw(w) << gbs << std::left << std::setw(w) << gbs / HBM_PEAK_GBS << std::endl << std::endl;
-    printf("n_rows = %ld, nnz = %ld, n_elements = %ld, beta = %.8f\n", (long)n_rows, (long)nnz, (long)n_el, beta);
+    if (ap) printf("n_rows = %ld, nnz = %ld, dp: %ld nnz in %ld elements, sp: %ld nnz in %ld elements\n", (long)n_rows, (long)nnz,
+                   (long)meta[7], (long)n_el, (long)meta_sp[7], (long)meta_sp[6]);
+    else printf("n_rows = %ld, nnz = %ld, n_elements = %ld, beta = %.8f\n", (long)n_rows, (long)nnz, (long)n_el, beta);
     printf("Total Gflops: %.4f   (%d iterations in %.4f s, %.6f ms per SpMV)\n", perf, n_iter, runtime, t_iter * 1e3);
     printf("Achieved GB/s: %.1f   (%.1f %% of the %.0f GB/s HBM3E roofline; algorithmic bytes %.0f per SpMV)\n", gbs,
            100.0 * gbs / HBM_PEAK_GBS, HBM_PEAK_GBS, bytes);
