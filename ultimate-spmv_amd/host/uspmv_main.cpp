@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "uspmv.h"
+#include "uspmv_dist.hpp"
 
 #define WARM_UP_REPS 100  // code/main.cpp:22
 #define HBM_PEAK_GBS 8000.0
@@ -122,8 +123,8 @@ Config parse(int argc, char **argv) {
     if (ap && c.ap_threshold_1 == 0.0) fprintf(stderr, "WARNING: Two-way adaptive precision used, but the first threshold is not entered.\n");
     if (c.dropout && c.dropout_threshold == 0.0) fprintf(stderr, "WARNING: Dropout selected, but dropout_threshold is 0.\n");
     if (c.kernel_format != "crs" && c.kernel_format != "csr" && c.kernel_format != "scs") die("kernel format not recognized.");
-    if (c.comm_halos) {
-        printf("single-process run, forcing comm_halos = 0 (multi-GPU runs: bench.py / DistSpmv over RCCL).\n");
+    if (c.comm_halos && !uspmv_dist_requested()) {
+        printf("single rank (WORLD_SIZE not set), forcing comm_halos = 0.\n");  // reference: "USE_MPI not defined, forcing comm_halos = 0."
         c.comm_halos = 0;
     }
     if (c.equilibrate || c.dropout) die("-equilibrate / -dropout are not implemented in this harness yet.");
@@ -343,6 +344,19 @@ int run(const Config &c, uspmv_coo_t *coo) {
 
 int main(int argc, char **argv) {
     Config c = parse(argc, argv);
+    if (uspmv_dist_requested()) {  // one process per GPU, halo exchange on RCCL (uspmv_dist.cpp)
+        if (c.mode != 'b' || c.kernel_format != "scs" || c.value_type != "dp" || c.block_vec_size != 1)
+            die("multi-rank runs support `scs -dp -mode b` with a single vector in this round "
+                "(the reference also refuses ap with MPI, code/utilities.hpp:1443-1450)");
+        DistConfig d;
+        d.C = c.chunk_size; d.sigma = c.sigma; d.seg_nnz = c.seg_method == "seg-nnz"; d.comm_halos = c.comm_halos != 0;
+        d.ba_synch = c.ba_synch != 0; d.tlc = c.tlc != 0; d.verbose = c.verbose != 0; d.bench_time = c.bench_time;
+        d.matrix_name = c.matrix_file_name;
+        uspmv_coo_t *coo = load_matrix(c);
+        int rc = uspmv_run_distributed(d, coo);
+        uspmv_coo_free(coo);
+        return rc;
+    }
     int ndev = 0;
     ck(uspmv_device_count(&ndev), "uspmv_device_count");
     if (ndev < 1) die("no HIP device visible: uspmv has no CPU path");
