@@ -150,9 +150,19 @@ def test_crs(pkg, orc, torch_cuda, name):
         pkg.uspmv_csr_gpu(s.n_rows, A.chunk_ptrs, A.col_idxs, A.values, x, y)
         assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= TOL[dt] * bound + 1e-300)
         # the generic SELL kernel at C = 1 is the sequential chain: bit-exact with the oracle
+        y_seq = orc.spmv_csr(s.n_rows, a["chunk_ptrs"], a["col_idxs"], a["values"], xp)
         A1 = pkg.DeviceMatrix(s)
         pkg.spmv(A1, x, y)
-        assert np.array_equal(y.cpu().numpy(), orc.spmv_csr(s.n_rows, a["chunk_ptrs"], a["col_idxs"], a["values"], xp))
+        assert np.array_equal(y.cpu().numpy(), y_seq)
+        # optimised crs handle: internally SELL-32-1 (+ tile-local columns), still the sequential chain
+        A2 = pkg.DeviceMatrix(s, crs=True, tlc=True)
+        y2 = t.full((s.n_rows,), 4.0, dtype=A.torch_dtype, device="cuda")      # exactly n_rows elements: no overrun allowed
+        pkg.spmv(A2, x, y2)
+        # (bit-exact when the re-chunked struct is used; ragged matrices whose padding would grow > 25 % keep the
+        #  multi-lane CRS kernel, which is held to the CRS tolerance)
+        assert np.all(np.abs(y2.cpu().numpy().astype(np.float64) - y_seq.astype(np.float64)) <= TOL[dt] * bound + 1e-300)
+        if name in ("FDM-2d-16",):
+            assert np.array_equal(y2.cpu().numpy(), y_seq)
 
 
 @pytest.mark.parametrize("name", ["FDM-2d-16", "impcol_e", "bcsstk13"])
@@ -306,7 +316,11 @@ def test_tile_local_column_kernel_bitexact(pkg, orc, torch_cuda, name):
                 pkg.set_tuning(tlc_tile_rows=tile_rows)
                 A = pkg.DeviceMatrix(s, tlc=True, tlc_max_lines=max_lines)
                 pkg.set_tuning(tlc_tile_rows=256)
-                assert A.tlc_tiles == (s.n_chunks + tile_rows // Cc - 1) // (tile_rows // Cc)
+                if Cc < 32:      # narrow chunks are re-chunked to C = 32 internally (same row order)
+                    nc32 = (s.n_chunks * Cc + 31) // 32
+                    assert A.tlc_tiles in (0, (nc32 + tile_rows // 32 - 1) // (tile_rows // 32))
+                else:
+                    assert A.tlc_tiles == (s.n_chunks + tile_rows // Cc - 1) // (tile_rows // Cc)
                 for nt in (0, 1):
                     pkg.set_tuning(nontemporal=nt)
                     y = t.full((s.n_rows_padded,), 9.0, dtype=A.torch_dtype, device="cuda")

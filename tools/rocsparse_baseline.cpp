@@ -1,0 +1,98 @@
+// Vendor baseline on the same matrix (measurement tool, not product code): rocSPARSE CSR (default,
+// adaptive) and sliced-ELL SpMV -- the ROCm twin of the reference's optional cuSPARSE path
+// (USE_CUSPARSE: cusparseCreateCsr / cusparseCreateSlicedEll + cusparseSpMV, code/utilities.hpp:3380-3550,
+// code/classes_structs.hpp:998-1011).  Matrix and SELL-C-sigma arrays come from libuspmv's host layer.
+//   hipcc -O2 -std=c++17 -Iinclude tools/rocsparse_baseline.cpp -o tools/rocsparse_baseline \
+//         -Lultimate-spmv_amd -luspmv -lrocsparse -Wl,-rpath,$PWD/ultimate-spmv_amd
+#include <hip/hip_runtime.h>
+#include <rocsparse/rocsparse.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "uspmv.h"
+#pragma clang diagnostic ignored "-Wdeprecated-declarations"
+#define HK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+#define RK(x) do { rocsparse_status s = (x); if (s != rocsparse_status_success) { printf("%s: status %d\n", #x, (int)s); return 1; } } while (0)
+#define UK(x) do { int r = (x); if (r) { printf("%s: %s\n", #x, uspmv_last_error()); return 1; } } while (0)
+
+template <typename T> T *to_dev(const void *h, size_t n) {
+    void *d = nullptr;
+    if (hipMalloc(&d, n * sizeof(T) + 16) != hipSuccess) return nullptr;
+    hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice);
+    return (T *)d;
+}
+
+int main(int argc, char **argv) {
+    const long g = argc > 1 ? atol(argv[1]) : 253;
+    const int dof = argc > 2 ? atoi(argv[2]) : 1;
+    uspmv_coo_t *coo;
+    UK(uspmv_gen_stencil27(g, g, g, dof, 0x5EED, 0.0, 0, g * g * g * dof, &coo));
+    int64_t n, nc, nnz;
+    uspmv_coo_dims(coo, &n, &nc, &nnz);
+    rocsparse_handle h;
+    RK(rocsparse_create_handle(&h));
+    std::vector<double> hx((size_t)n + 512, 5.0);
+    double *dx = to_dev<double>(hx.data(), hx.size()), *dy = to_dev<double>(hx.data(), hx.size());
+    rocsparse_dnvec_descr vx, vy;
+    const double alpha = 1.0, beta = 0.0;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto run = [&](const char *name, rocsparse_spmat_descr A, rocsparse_spmv_alg alg, long rows) -> int {
+        RK(rocsparse_create_dnvec_descr(&vx, n, dx, rocsparse_datatype_f64_r));
+        RK(rocsparse_create_dnvec_descr(&vy, rows, dy, rocsparse_datatype_f64_r));
+        size_t bs = 0;
+        rocsparse_status st = rocsparse_spmv(h, rocsparse_operation_none, &alpha, A, vx, &beta, vy, rocsparse_datatype_f64_r, alg,
+                                             rocsparse_spmv_stage_buffer_size, &bs, nullptr);
+        if (st != rocsparse_status_success) { printf("%-28s not supported (status %d)\n", name, (int)st); return 0; }
+        void *buf = nullptr;
+        HK(hipMalloc(&buf, bs + 16));
+        RK(rocsparse_spmv(h, rocsparse_operation_none, &alpha, A, vx, &beta, vy, rocsparse_datatype_f64_r, alg, rocsparse_spmv_stage_preprocess, &bs, buf));
+        for (int k = 0; k < 5; ++k)
+            RK(rocsparse_spmv(h, rocsparse_operation_none, &alpha, A, vx, &beta, vy, rocsparse_datatype_f64_r, alg, rocsparse_spmv_stage_compute, &bs, buf));
+        hipEventRecord(e0);
+        const int reps = 50;
+        for (int k = 0; k < reps; ++k)
+            RK(rocsparse_spmv(h, rocsparse_operation_none, &alpha, A, vx, &beta, vy, rocsparse_datatype_f64_r, alg, rocsparse_spmv_stage_compute, &bs, buf));
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+        printf("%-28s %8.4f ms  %8.1f GF/s  %7.0f GB/s (12 B/nnz + vectors)\n", name, ms, 2.0 * nnz / ms / 1e6, (12.0 * nnz + 16.0 * n) / ms / 1e6);
+        fflush(stdout);
+        hipFree(buf);
+        return 0;
+    };
+    {   // CSR = SELL-1-1
+        uspmv_scs_t *s;
+        UK(uspmv_convert_to_scs(coo, 1, 1, USPMV_F64, nullptr, &s));
+        const int32_t *rp, *ci; const void *va;
+        uspmv_scs_arrays(s, &rp, nullptr, &ci, &va, nullptr, nullptr);
+        int32_t *drp = to_dev<int32_t>(rp, (size_t)n + 1), *dci = to_dev<int32_t>(ci, (size_t)nnz);
+        double *dva = to_dev<double>(va, (size_t)nnz);
+        rocsparse_spmat_descr A;
+        RK(rocsparse_create_csr_descr(&A, n, n, nnz, drp, dci, dva, rocsparse_indextype_i32, rocsparse_indextype_i32, rocsparse_index_base_zero, rocsparse_datatype_f64_r));
+        if (run("rocsparse csr default", A, rocsparse_spmv_alg_default, n)) return 1;
+        if (run("rocsparse csr adaptive", A, rocsparse_spmv_alg_csr_adaptive, n)) return 1;
+        if (run("rocsparse csr rowsplit", A, rocsparse_spmv_alg_csr_rowsplit, n)) return 1;
+        if (run("rocsparse csr lrb", A, rocsparse_spmv_alg_csr_lrb, n)) return 1;
+        rocsparse_destroy_spmat_descr(A);
+        hipFree(drp); hipFree(dci); hipFree(dva); uspmv_scs_free(s);
+    }
+    {   // sliced ELL, slice = 32, from the SELL-32-512 struct (rows in sigma-sorted order; x is constant)
+        uspmv_scs_t *s;
+        UK(uspmv_convert_to_scs(coo, 32, 512, USPMV_F64, nullptr, &s));
+        int64_t meta[8]; uspmv_scs_meta(s, meta);
+        const int32_t *cp, *ci, *o2n; const void *va;
+        uspmv_scs_arrays(s, &cp, nullptr, &ci, &va, &o2n, nullptr);
+        uspmv_permute_scs_cols(s, o2n);
+        uspmv_scs_arrays(s, &cp, nullptr, &ci, &va, nullptr, nullptr);
+        int32_t *dcp = to_dev<int32_t>(cp, (size_t)meta[5] + 1), *dci = to_dev<int32_t>(ci, (size_t)meta[6]);
+        double *dva = to_dev<double>(va, (size_t)meta[6]);
+        rocsparse_spmat_descr A;
+        rocsparse_status st = rocsparse_create_sell_descr(&A, meta[4], meta[4], nnz, 32, meta[6], dcp, dci, dva, rocsparse_indextype_i32,
+                                                          rocsparse_indextype_i32, rocsparse_index_base_zero, rocsparse_datatype_f64_r);
+        if (st != rocsparse_status_success) printf("rocsparse sliced-ELL descriptor: status %d\n", (int)st);
+        else if (run("rocsparse sliced-ELL (32)", A, rocsparse_spmv_alg_sell, meta[4])) return 1;
+    }
+    return 0;
+}

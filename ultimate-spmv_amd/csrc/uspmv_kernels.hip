@@ -40,6 +40,8 @@ struct uspmv_dmat {
     const void *values = nullptr;
     bool owns = false;
     bool crs = false;
+    long n_store = 0;              // rows of y the kernels may write (= n_chunks*C unless re-chunked)
+    uspmv_dmat *alt = nullptr;     // internal C = 32 re-chunking of a C in {1,2,4,8,16} struct (same row order)
     // scratch for the internal row-major copies of column-major block vectors (uspmv_spmmv); grown
     // on demand, released with the handle.  Not thread-safe per handle, like the reference's kernel object.
     mutable void *ws = nullptr;
@@ -66,6 +68,7 @@ struct Tuning {
     int csr_lanes = 0;  // 0 = choose from average row length
     int ablate = 0;     // measurement only
     int tlc = 1;            // use the tile-local-column kernel when the handle carries a plan
+    int rechunk = 1;        // uspmv_dmat_optimize may re-chunk C < 32 structs to C = 32 internally
     int tlc_tile_rows = 256;  // rows (= threads) per tile used by the NEXT uspmv_dmat_optimize
     int tail_batch = 0;     // ragged tail of a chunk as one predicated batch
     int spmmv_unroll = 0;   // 0 = auto (2 for 64-byte rows, else 4)
@@ -138,7 +141,7 @@ template <typename VT, int CT, int U, bool NT, bool IDS, int ABL = 0, bool TAILB
 __global__ void scs_spmv_rows(const long n_work_chunks, const int C_rt, const int *__restrict__ chunk_ptrs,
                               const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                               const VT *__restrict__ values, const VT *__restrict__ x, VT *__restrict__ y,
-                              const int *__restrict__ chunk_ids, const int xcd_remap) {
+                              const int *__restrict__ chunk_ids, const int xcd_remap, const long n_store) {
     const int C = CT > 0 ? CT : C_rt;
     const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
     const long vrow = (long)lb * blockDim.x + threadIdx.x;
@@ -194,7 +197,7 @@ __global__ void scs_spmv_rows(const long n_work_chunks, const int C_rt, const in
             acc = fma_t(v, ABL == 0 ? x[ci] : ABL == 1 ? x[ci & 63] : (VT)ci, acc);
         }
     }
-    st_y<NT>(y + (c * C + i), acc);
+    if (c * C + i < n_store) st_y<NT>(y + (c * C + i), acc);   // n_store < n_rows_padded only for re-chunked structs
 }
 
 // Software-pipelined form of scs_spmv_rows (same lane <-> row mapping, same FMA chain, bit-exact):
@@ -212,7 +215,7 @@ template <typename VT, int CT, int U, bool NT, bool IDS>
 __global__ void scs_spmv_rows_pipe(const long n_work_chunks, const int C_rt, const int *__restrict__ chunk_ptrs,
                                    const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                                    const VT *__restrict__ values, const VT *__restrict__ x, VT *__restrict__ y,
-                                   const int *__restrict__ chunk_ids, const int xcd_remap) {
+                                   const int *__restrict__ chunk_ids, const int xcd_remap, const long n_store) {
     const int C = CT > 0 ? CT : C_rt;
     const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
     const long vrow = (long)lb * blockDim.x + threadIdx.x;
@@ -278,7 +281,7 @@ __global__ void scs_spmv_rows_pipe(const long n_work_chunks, const int C_rt, con
             acc = (j + u < L) ? t : acc;
         }
     }
-    if (valid) st_y<NT>(y + (c * C + i), acc);
+    if (valid && c * C + i < n_store) st_y<NT>(y + (c * C + i), acc);
 }
 
 // SpMV over a tile-local-column plan (host/tlc_plan.cpp).  One 256-thread workgroup = one tile of
@@ -293,7 +296,7 @@ __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const 
         const VT *__restrict__ x, VT *__restrict__ y, const int *__restrict__ tile_line_ptr,
         const int *__restrict__ tile_lines, const unsigned *__restrict__ c16_ptrs,
         const unsigned short *__restrict__ col16, const long x_len, const int *__restrict__ tile_ids,
-        const int xcd_remap) {
+        const int xcd_remap, const long n_store) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tlc_smem[];
     VT *xs = (VT *)tlc_smem;
     constexpr int EPL = 16 / (int)sizeof(VT);   // elements per 16-byte load
@@ -370,7 +373,7 @@ __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const 
         }
         for (; j < L; ++j) acc = fma_t(ld_stream<NT>(vp + (long)j * C), x[ld_stream<NT>(cp + (long)j * C)], acc);
     }
-    if (valid) st_y<NT>(y + row, acc);
+    if (valid && row < n_store) st_y<NT>(y + row, acc);
 }
 
 // Adaptive precision dp+sp over a tile-local-column plan shared by the two structs (one line list
@@ -803,27 +806,27 @@ void launch_rows_ids(bool ids, unsigned grid, int block, hipStream_t st, long nw
     if (g_tune.spmv_variant == 2) {
         if (ids)
             hipLaunchKernelGGL((scs_spmv_rows_pipe<VT, CT, U, NT, true>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
-                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap, A->n_store);
         else
             hipLaunchKernelGGL((scs_spmv_rows_pipe<VT, CT, U, NT, false>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
-                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap, A->n_store);
         return;
     }
     if (g_tune.tail_batch && U > 1) {
         if (ids)
             hipLaunchKernelGGL((scs_spmv_rows<VT, CT, U, NT, true, 0, true>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
-                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap, A->n_store);
         else
             hipLaunchKernelGGL((scs_spmv_rows<VT, CT, U, NT, false, 0, true>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
-                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+                               A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap, A->n_store);
         return;
     }
     if (ids)
         hipLaunchKernelGGL((scs_spmv_rows<VT, CT, U, NT, true>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
-                           A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+                           A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap, A->n_store);
     else
         hipLaunchKernelGGL((scs_spmv_rows<VT, CT, U, NT, false>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
-                           A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+                           A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap, A->n_store);
 }
 
 template <typename VT, int CT, int U>
@@ -856,7 +859,7 @@ int launch_spmv_tlc(const uspmv_dmat *A, const int *tile_ids, long n_tiles, cons
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(A->tlc_tile_rows), lds, st, (long)A->n_chunks, C, A->chunk_ptrs,        \
                            A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, A->tlc_line_ptr, A->tlc_lines,   \
-                           A->tlc_c16_ptrs, A->tlc_col16, (long)A->tlc_x_len, tile_ids, g_tune.xcd_remap);              \
+                           A->tlc_c16_ptrs, A->tlc_col16, (long)A->tlc_x_len, tile_ids, g_tune.xcd_remap, A->n_store);              \
     } while (0)
 #define TLC_LAUNCH_C(NTV, IDSV) do { if (C == 32) TLC_LAUNCH(32, NTV, IDSV); else TLC_LAUNCH(0, NTV, IDSV); } while (0)
     if (tile_ids) { if (g_tune.nontemporal) TLC_LAUNCH_C(true, true); else TLC_LAUNCH_C(false, true); }
@@ -889,10 +892,10 @@ int launch_spmv_scs(const uspmv_dmat *A, const int *chunk_ids, long n_ids, const
         if (g_tune.ablate && C == 32 && !ids) {  // measurement-only (results are wrong by construction)
             if (g_tune.ablate == 1)
                 hipLaunchKernelGGL((scs_spmv_rows<VT, 32, 8, true, false, 1>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
-                                   A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+                                   A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap, A->n_store);
             else
                 hipLaunchKernelGGL((scs_spmv_rows<VT, 32, 8, true, false, 2>), dim3(grid), dim3(block), 0, st, nwc, C, A->chunk_ptrs,
-                                   A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap);
+                                   A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, chunk_ids, g_tune.xcd_remap, A->n_store);
             HIP_TRY(hipGetLastError());
             return USPMV_OK;
         }
@@ -1074,6 +1077,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "tail_batch")) g_tune.tail_batch = value != 0;
     else if (!strcmp(key, "spmmv_unroll")) g_tune.spmmv_unroll = value;
     else if (!strcmp(key, "tlc")) g_tune.tlc = value != 0;
+    else if (!strcmp(key, "rechunk")) g_tune.rechunk = value != 0;
     else if (!strcmp(key, "tlc_tile_rows")) {
         if (value != 256 && value != 512 && value != 1024) return uspmv::fail(USPMV_ERR_INVALID, "tlc_tile_rows must be 256|512|1024");
         g_tune.tlc_tile_rows = value;
@@ -1105,6 +1109,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "tail_batch")) *value = g_tune.tail_batch;
     else if (!strcmp(key, "spmmv_unroll")) *value = g_tune.spmmv_unroll;
     else if (!strcmp(key, "tlc")) *value = g_tune.tlc;
+    else if (!strcmp(key, "rechunk")) *value = g_tune.rechunk;
     else if (!strcmp(key, "tlc_tile_rows")) *value = g_tune.tlc_tile_rows;
     else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_get_tuning: unknown key '%s'", key);
     return USPMV_OK;
@@ -1115,6 +1120,7 @@ int uspmv_dmat_upload(const uspmv_scs_t *s, uspmv_dmat_t **out) {
     if (int rc = require_device()) return rc;
     auto *A = new uspmv_dmat;
     A->C = s->C; A->n_chunks = s->n_chunks; A->n_elements = s->n_elements; A->dtype = s->dtype; A->owns = true;
+    A->n_store = (long)(s->n_chunks * s->C);
     const size_t vsz = s->dtype == USPMV_F64 ? 8 : 4;
     void *cp = nullptr, *cl = nullptr, *ci = nullptr, *va = nullptr;
     const size_t ne = (size_t)std::max<int64_t>(s->n_elements, 1);
@@ -1147,7 +1153,7 @@ int uspmv_dmat_wrap(int64_t C, int64_t n_chunks, int64_t n_elements, int dtype, 
         !d_chunk_ptrs || (n_chunks > 0 && !d_chunk_lengths) || (n_elements > 0 && (!d_col_idxs || !d_values)))
         return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_wrap: bad argument");
     auto *A = new uspmv_dmat;
-    A->C = C; A->n_chunks = n_chunks; A->n_elements = n_elements; A->dtype = dtype;
+    A->C = C; A->n_chunks = n_chunks; A->n_elements = n_elements; A->dtype = dtype; A->n_store = (long)(n_chunks * C);
     A->chunk_ptrs = d_chunk_ptrs; A->chunk_lengths = d_chunk_lengths; A->col_idxs = d_col_idxs; A->values = d_values;
     A->owns = false;
     *out = A;
@@ -1166,6 +1172,23 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
         return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: handle and host struct do not describe the same matrix");
     if (int rc = require_device()) return rc;
     if (A->tlc) tlc_release(A);
+    if (A->alt) { uspmv_dmat_free(A->alt); A->alt = nullptr; }
+    if (s->C < 32 && 32 % s->C == 0 && g_tune.rechunk) {
+        // narrow chunks (incl. crs = C 1): run on an internal C = 32 re-chunking with the same row order
+        uspmv_scs r;
+        int rc = uspmv_scs_rechunk32(s, &r);
+        if (rc == USPMV_OK && (double)r.n_elements <= 1.25 * (double)std::max<int64_t>(s->n_elements, 1) + 4096) {
+            uspmv_dmat_t *alt = nullptr;
+            if (int rc2 = uspmv_dmat_upload(&r, &alt)) return rc2;
+            alt->n_store = (long)(s->n_chunks * s->C);      // y of the caller has only the original padded rows
+            g_tune.rechunk = 0;                             // (no recursion)
+            rc = uspmv_dmat_optimize(alt, &r, max_lines, n_tiles, n_staged);
+            g_tune.rechunk = 1;
+            if (rc) { uspmv_dmat_free(alt); return rc; }
+            A->alt = alt;
+            return USPMV_OK;
+        }
+    }
     if (max_lines <= 0) max_lines = 512;                       // 64 KiB of doubles: 2 workgroups per CU at worst
     const int cap = (int)(160 * 1024 / (16 * (s->dtype == USPMV_F64 ? 8 : 4)));
     if (max_lines > cap) max_lines = cap;
@@ -1237,6 +1260,7 @@ int uspmv_dmat_optimize_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t
 
 void uspmv_dmat_free(uspmv_dmat_t *A) {
     if (!A) return;
+    if (A->alt) { uspmv_dmat_free(A->alt); A->alt = nullptr; }
     if (A->tlc) tlc_release(A);
     if (A->ws) (void)hipFree(A->ws);
     if (A->owns) {
@@ -1257,6 +1281,10 @@ int uspmv_spmv(const uspmv_dmat_t *A, const void *d_x, void *d_y, void *stream) 
     if (int rc = check_dmat(A, "uspmv_spmv")) return rc;
     if (!d_x || !d_y) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv: NULL vector");
     if (int rc = require_device()) return rc;
+    if (A->alt && g_tune.tlc && g_tune.rechunk && g_tune.spmv_variant == 0 && !g_tune.ablate) {
+        if (A->dtype == USPMV_F64) return launch_spmv_scs<double>(A->alt, nullptr, 0, (const double *)d_x, (double *)d_y, (hipStream_t)stream);
+        return launch_spmv_scs<float>(A->alt, nullptr, 0, (const float *)d_x, (float *)d_y, (hipStream_t)stream);
+    }
     if (A->crs) {
         if (A->dtype == USPMV_F64)
             return launch_csr<double>((long)A->n_chunks, (long)A->n_elements, A->chunk_ptrs, A->col_idxs,
@@ -1376,6 +1404,7 @@ int uspmv_spmv_ap_generic(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const 
         if (int rc = require_device()) return rc;                                                                   \
         uspmv_dmat A;                                                                                               \
         A.C = C; A.n_chunks = n_chunks; A.dtype = DT; A.chunk_ptrs = cp; A.chunk_lengths = cl; A.col_idxs = ci;     \
+        A.n_store = (long)(C * n_chunks);                                                                           \
         A.values = va;                                                                                              \
         if (int rc = check_dmat(&A, "uspmv_scs_gpu_" #SUF)) return rc;                                              \
         return launch_spmv_scs<VT>(&A, nullptr, 0, x, y, (hipStream_t)stream);                                      \

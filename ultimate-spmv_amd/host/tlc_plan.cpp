@@ -136,3 +136,50 @@ int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines,
     p->valid = n_staged > 0;
     return USPMV_OK;
 }
+
+
+// Re-chunk a SELL-C-sigma struct with C in {1,2,4,8,16} into chunks of 32 rows WITHOUT touching the row
+// order: new chunk k = old chunks [k*32/C, (k+1)*32/C), its length the longest of theirs.  Row r keeps
+// its position r and its slot order, so y and the per-row FMA chain are unchanged; the matrix stream
+// becomes 256/128-byte coalesced segments (a CRS struct, C = 1, turns into SELL-32-1).  Used internally
+// by uspmv_dmat_optimize when the extra padding stays small.
+int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *o) {
+    const int64_t C = s->C;
+    if (C < 1 || C >= 32 || 32 % C != 0) return USPMV_ERR_UNSUPPORTED;
+    const int64_t per = 32 / C, n_pad_old = s->n_chunks * C;
+    const int64_t nc = (s->n_chunks + per - 1) / per;
+    o->C = 32; o->sigma = s->sigma; o->n_rows = s->n_rows; o->n_cols = s->n_cols; o->nnz = s->nnz; o->dtype = s->dtype;
+    o->n_chunks = nc; o->n_rows_padded = nc * 32;
+    o->chunk_lengths.assign((size_t)nc, 0);
+    o->chunk_ptrs.assign((size_t)nc + 1, 0);
+    int64_t cur = 0;
+    for (int64_t k = 0; k < nc; ++k) {
+        int32_t L = 0;
+        for (int64_t c = k * per; c < std::min((k + 1) * per, s->n_chunks); ++c) L = std::max(L, s->chunk_lengths[(size_t)c]);
+        o->chunk_lengths[(size_t)k] = L;
+        o->chunk_ptrs[(size_t)k] = (int32_t)cur;
+        cur += (int64_t)L * 32;
+        if (cur > INT32_MAX) return USPMV_ERR_OVERFLOW;
+    }
+    o->chunk_ptrs[(size_t)nc] = (int32_t)cur;
+    o->n_elements = cur;
+    o->col_idxs.assign((size_t)cur, 0);
+    if (s->dtype == USPMV_F64) o->values_f64.assign((size_t)cur, 0.0); else o->values_f32.assign((size_t)cur, 0.0f);
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < nc; ++k) {
+        const int64_t base = o->chunk_ptrs[(size_t)k];
+        for (int64_t i = 0; i < 32; ++i) {
+            const int64_t row = k * 32 + i;
+            if (row >= n_pad_old) break;
+            const int64_t co = row / C, io = row % C;
+            const int64_t cs = s->chunk_ptrs[(size_t)co], L = s->chunk_lengths[(size_t)co];
+            for (int64_t j = 0; j < L; ++j) {
+                const int64_t src = cs + j * C + io, dst = base + j * 32 + i;
+                o->col_idxs[(size_t)dst] = s->col_idxs[(size_t)src];
+                if (s->dtype == USPMV_F64) o->values_f64[(size_t)dst] = s->values_f64[(size_t)src];
+                else o->values_f32[(size_t)dst] = s->values_f32[(size_t)src];
+            }
+        }
+    }
+    return USPMV_OK;
+}

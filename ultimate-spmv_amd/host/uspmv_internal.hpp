@@ -53,6 +53,8 @@ struct uspmv_tlc_plan {
 };
 int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines, int tile_rows, uspmv_tlc_plan *plan);
 
+int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *out);   // host/tlc_plan.cpp
+
 namespace uspmv {
 int fail(int status, const char *fmt, ...);  // records the thread-local error text, returns status
 }
