@@ -183,7 +183,9 @@ int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_
  *   of G consecutive workgroups per XCD), "spmv_variant" 0 (lane per row, bit-exact) | 1 (two lanes
  *   per row, C=32 only), "csr_lanes" 0 (auto) | 1..64 lanes per row of the CRS kernel,
  *   "tlc" 1|0 use the tile-local-column kernel when the handle has a plan, "tail_batch" 0|1,
- *   "spmmv_variant" 0 (row-major panel kernel) | 1 (generic),
+ *   "spmmv_variant" 0 (auto) | 1 (generic) | 2 (row-major, transposing X phase) | 3 (row-major, lane per row),
+ *   "spmmv_prefetch" 1|0 (lane-per-row kernel: next batch of matrix entries requested behind the X rows),
+ *   "spmmv_unroll" 0 (auto) | 1|2|4|8 slots per batch,
  *   "ablate" 0 | 1 | 2 (measurement only: gathers collapsed / removed, results are wrong). */
 int uspmv_set_tuning(const char *key, int value);
 int uspmv_get_tuning(const char *key, int *value);

@@ -175,15 +175,15 @@ def test_spmmv_golden_bitexact(pkg, orc, torch_cuda, name):
         s, a, xp = _prep(pkg, m, int(g["C"]), int(g["sigma"]), code, g["x"])
         A = pkg.DeviceMatrix(s)
         ld = s.n_rows_padded
-        for variant in (0, 1):       # 0: row-major panel kernel (+ re-layout for colwise), 1: generic kernel
-            pkg.set_tuning(spmmv_variant=variant)
+        for variant, pf in ((0, 0), (1, 0), (2, 0), (3, 0), (3, 1)): # 0: auto, 1: generic kernel, 2: row-major + transposing X phase, 3: row-major lane per row (pf: with prefetch)
+            pkg.set_tuning(spmmv_variant=variant, spmmv_prefetch=pf)
             for b in (2, 8):
                 for rowwise in (0, 1):
                     X = block_x(xp, ld, b, ld, rowwise)
                     Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
                     pkg.spmmv(A, _dev(t, X), Y, b, ld, pkg.ROWWISE if rowwise else pkg.COLWISE)
                     assert np.array_equal(Y.cpu().numpy(), sp[f"{name}_{dt}_b{b}_{'row' if rowwise else 'col'}_Y"]), (dt, b, rowwise, variant)
-        pkg.set_tuning(spmmv_variant=0)
+        pkg.set_tuning(spmmv_variant=0, spmmv_prefetch=0)
         for b in (1, 3, 4, 5, 13, 16):     # widths without a golden: vs the oracle, colwise ld > n_rows_padded too
             for rowwise in (0, 1):
                 ld2 = ld + 7

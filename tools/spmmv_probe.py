@@ -19,12 +19,17 @@ for dt, tdt, vs in ((pkg.F64, torch.float64, 8), (pkg.F32, torch.float32, 4)):
     X = torch.rand(b * ld, dtype=tdt, device="cuda"); Y = torch.zeros_like(X)
     byts = s.n_elements * (vs + 4) + 8 * s.n_chunks + 2 * b * vs * ld
     for lay, nm in ((pkg.ROWWISE, "rowwise"), (pkg.COLWISE, "colwise")):
-        for u, blk, xr in itertools.product((1, 2, 4), (256, 512), (256, 0)):
-            pkg.set_tuning(spmmv_unroll=u, block=blk, xcd_remap=xr)
+        for var, u, pf, blk in ((0, 2, 0, 256), (3, 4, 1, 256), (3, 8, 1, 256), (3, 4, 1, 128), (3, 4, 1, 512), (3, 8, 1, 128), (3, 8, 0, 256), (3, 4, 0, 256)):
+            pkg.set_tuning(spmmv_variant=var, spmmv_unroll=u, spmmv_prefetch=pf, block=blk)
+            Yr = torch.zeros_like(X)
+            pkg.spmmv(A, X, Yr, b, ld, lay)
+            if var == 0 and u == 2 and pf == 0:
+                Yref = Yr.clone()
             B.time_launches(5, 3, A=A, x=X, y=Y, b=b, ld=ld, layout=lay)
             ms = B.time_launches(5, 30, A=A, x=X, y=Y, b=b, ld=ld, layout=lay)
-            print(json.dumps(dict(dtype=vs, sigma=sig, layout=nm, unroll=u, block=blk, xcd=xr, ms=round(ms, 4), GF=round(2 * s.nnz * b / ms / 1e6), GBs=round(byts / ms / 1e6))), flush=True)
-    pkg.set_tuning(spmmv_unroll=0, block=256, xcd_remap=256)
+            print(json.dumps(dict(dtype=vs, sigma=sig, layout=nm, variant=var, unroll=u, prefetch=pf, block=blk, same=bool(torch.equal(Yr, Yref)), ms=round(ms, 4), GF=round(2 * s.nnz * b / ms / 1e6), GBs=round(byts / ms / 1e6))), flush=True)
+    pkg.set_tuning(spmmv_prefetch=0)
+    pkg.set_tuning(spmmv_variant=0, spmmv_unroll=0, block=256, xcd_remap=256)
     # single-vector SpMV in this dtype for reference (TLC)
     A.optimize(s)
     x = torch.rand(ld, dtype=tdt, device="cuda"); y = torch.zeros_like(x)

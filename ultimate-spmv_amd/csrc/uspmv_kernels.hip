@@ -71,8 +71,9 @@ struct Tuning {
     int rechunk = 1;        // uspmv_dmat_optimize may re-chunk C < 32 structs to C = 32 internally
     int tlc_tile_rows = 256;  // rows (= threads) per tile used by the NEXT uspmv_dmat_optimize
     int tail_batch = 0;     // ragged tail of a chunk as one predicated batch
-    int spmmv_unroll = 0;   // 0 = auto (2 for 64-byte rows, else 4)
-    int spmmv_variant = 0;  // 0 = row-major panel kernel (+ re-layout for colwise), 1 = generic kernel
+    int spmmv_unroll = 0;   // 0 = auto (256 bytes of X rows per lane and batch)
+    int spmmv_prefetch = 1; // row-major lane-per-row kernel: request batch k+1's matrix entries behind batch k's X rows
+    int spmmv_variant = 0;  // 0 = auto (= 3 where a B-specialised kernel exists); 1 = generic kernel; 2 = row-major with transposing X phase; 3 = row-major, lane per row
 };
 Tuning g_tune;
 
@@ -594,7 +595,7 @@ __global__ void scs_spmmv_rows(const long n_chunks, const int C, const int *__re
 // Every (row, v) accumulator is still the slot-ordered FMA chain of block_spmv_omp_scs_general.
 // YCOL: write Y column-major (Y[row + v*ld]) straight from the accumulators -- per vector one
 // coalesced 64-lane store -- so that column-major callers only pay the X re-layout.
-template <typename VT, int B, int U, bool NT, bool YCOL>
+template <typename VT, int B, int U, bool NT, bool YCOL, bool PF>
 __global__ void scs_spmmv_rowmajor(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
                                    const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                                    const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
@@ -615,24 +616,63 @@ __global__ void scs_spmmv_rowmajor(const long n_chunks, const int C, const int *
 #pragma unroll
     for (int v = 0; v < B; ++v) acc[v] = VT(0);
     int j = 0;
-    for (; j + U <= L; j += U) {
-        VT a[U];
-        int ci[U];
+    if (PF) {
+        // PF: the (value, column) pairs of batch k+1 are requested right after the X rows of batch k, so a
+        // wave has both round trips in flight instead of one after the other (the kernel is latency-bound:
+        // 8 waves per SIMD x 2 dependent misses per batch).  Loads retire in order, so waiting for the X
+        // rows does not wait for the prefetch.  Past the end the prefetch re-reads slot L-1 and is ignored.
+        if (L >= U) {
+            VT a[U];
+            int ci[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { a[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
-        vec_t xr[U][NV];
+            for (int u = 0; u < U; ++u) { a[u] = ld_stream<NT>(vp + (long)u * C); ci[u] = ld_stream<NT>(cp + (long)u * C); }
+            for (; j + U <= L; j += U) {
+                vec_t xr[U][NV];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const vec_t *xp = (const vec_t *)(X + (long)ci[u] * B);
+                for (int u = 0; u < U; ++u) {
+                    const vec_t *xp = (const vec_t *)(X + (long)ci[u] * B);
 #pragma unroll
-            for (int k = 0; k < NV; ++k) xr[u][k] = xp[k];
+                    for (int k = 0; k < NV; ++k) xr[u][k] = xp[k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                VT an[U];
+                int cn[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int jj = min(j + U + u, L - 1);
+                    an[u] = ld_stream<NT>(vp + (long)jj * C); cn[u] = ld_stream<NT>(cp + (long)jj * C);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int k = 0; k < NV; ++k)
+#pragma unroll
+                        for (int w = 0; w < VW; ++w) acc[k * VW + w] = fma_t(a[u], xr[u][k][w], acc[k * VW + w]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) { a[u] = an[u]; ci[u] = cn[u]; }
+            }
         }
+    } else {
+        for (; j + U <= L; j += U) {
+            VT a[U];
+            int ci[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+            for (int u = 0; u < U; ++u) { a[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
+            vec_t xr[U][NV];
 #pragma unroll
-            for (int k = 0; k < NV; ++k)
+            for (int u = 0; u < U; ++u) {
+                const vec_t *xp = (const vec_t *)(X + (long)ci[u] * B);
 #pragma unroll
-                for (int w = 0; w < VW; ++w) acc[k * VW + w] = fma_t(a[u], xr[u][k][w], acc[k * VW + w]);
+                for (int k = 0; k < NV; ++k) xr[u][k] = xp[k];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+#pragma unroll
+                    for (int w = 0; w < VW; ++w) acc[k * VW + w] = fma_t(a[u], xr[u][k][w], acc[k * VW + w]);
+        }
     }
     for (; j < L; ++j) {
         const VT a = ld_stream<NT>(vp + (long)j * C);
@@ -655,6 +695,89 @@ __global__ void scs_spmmv_rowmajor(const long n_chunks, const int C, const int *
 #pragma unroll
             for (int w = 0; w < VW; ++w) t[w] = acc[k * VW + w];
             yp[k] = t;
+        }
+    }
+}
+
+// Row-major SpMMV, "transposing" form.  rocprofv3 counters on scs_spmmv_rowmajor (profiles/r01/spmmv_pmc.txt)
+// show the vector L1 saturated (846 M 64-byte accesses = 54 GB per launch for 25 GB of useful bytes):
+// a lane that owns a whole 64-byte X row fetches it as four 16-byte pieces in four instructions, and
+// every piece costs a full 64-byte L1 access.  Here the matrix stream keeps its lane <-> row mapping
+// (one coalesced 512-byte / 256-byte load per slot and wave), but the X phase runs in P = B*sizeof(VT)/16
+// rounds over 64/P rows each with P adjacent lanes per row: a round's loads fetch whole contiguous X
+// rows (one L1 access per row), the (value, column) pairs reaching the gathering lanes through
+// ds_bpermute.  Lane (r, g) accumulates piece g of rows r, r + 64/P, ...; every (row, v) chain is still
+// slot-ordered -> bit-exact.
+template <typename VT, int B, int U, bool NT, bool YCOL>
+__global__ void scs_spmmv_xpose(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
+                                const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
+                                const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
+                                const long ld, const int xcd_remap) {
+    constexpr int VW = 16 / (int)sizeof(VT);
+    constexpr int P = B / VW;          // 16-byte pieces per X row = rounds
+    constexpr int RPR = 64 / P;        // rows per round
+    typedef VT vec_t __attribute__((ext_vector_type(VW)));
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+    const int lane = threadIdx.x & 63;
+    const long row = (long)lb * blockDim.x + threadIdx.x;      // streaming role: this lane's row
+    const long wrow0 = row - lane;
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    int L = 0;
+    long cs = 0;
+    if (c < n_chunks) { cs = chunk_ptrs[c]; L = chunk_lengths[c]; }
+    int Lmax = L;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, o, 64));
+    Lmax = __builtin_amdgcn_readfirstlane(Lmax);
+    const VT *vp = values + cs + i;
+    const int *cp = col_idxs + cs + i;
+    const int rl = lane / P, g = lane % P;                      // gathering role: row-in-round, piece
+    const vec_t *Xg = (const vec_t *)X + g;
+    vec_t acc[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+        for (int w = 0; w < VW; ++w) acc[q][w] = VT(0);
+    for (int j = 0; j < Lmax; j += U) {
+        VT a[U];
+        int ci[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a[u] = VT(0); ci[u] = -1;
+            if (j + u < L) { a[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            vec_t xv[P];
+            VT aa[P];
+            int cc[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                cc[q] = __shfl(ci[u], q * RPR + rl, 64);
+                aa[q] = __shfl(a[u], q * RPR + rl, 64);
+                xv[q] = Xg[(long)(cc[q] < 0 ? 0 : cc[q]) * P];
+            }
+#pragma unroll
+            for (int q = 0; q < P; ++q)
+#pragma unroll
+                for (int w = 0; w < VW; ++w) {
+                    const VT t = fma_t(aa[q], xv[q][w], acc[q][w]);
+                    acc[q][w] = cc[q] >= 0 ? t : acc[q][w];
+                }
+        }
+    }
+    const long n_pad = n_chunks * (long)C;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const long r = wrow0 + q * RPR + rl;
+        if (r < n_pad) {
+            if (YCOL) {
+#pragma unroll
+                for (int w = 0; w < VW; ++w) st_y<NT>(Y + (r + (long)(g * VW + w) * ld), acc[q][w]);
+            } else {
+                ((vec_t *)Y)[r * P + g] = acc[q];
+            }
         }
     }
 }
@@ -966,20 +1089,53 @@ void launch_spmmv_rowmajor_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, b
     const int block = g_tune.block;
     const unsigned grid = grid_for(A->n_chunks * A->C, block);
 #define RM_LAUNCH(NTV, YC)                                                                                          \
-    hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, NTV, YC>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks,  \
-                       (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld,    \
-                       g_tune.xcd_remap)
+    do {                                                                                                            \
+        if (g_tune.spmmv_prefetch)                                                                                  \
+            hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, NTV, YC, true>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
+                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
+                               g_tune.xcd_remap);                                                                   \
+        else                                                                                                        \
+            hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, NTV, YC, false>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
+                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
+                               g_tune.xcd_remap);                                                                   \
+    } while (0)
     if (g_tune.nontemporal) { if (ycol) RM_LAUNCH(true, true); else RM_LAUNCH(true, false); }
     else { if (ycol) RM_LAUNCH(false, true); else RM_LAUNCH(false, false); }
 #undef RM_LAUNCH
 }
 
+template <typename VT, int B, int U>
+void launch_spmmv_xpose_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    const int block = g_tune.block;
+    const unsigned grid = grid_for(A->n_chunks * A->C, block);
+#define XP_LAUNCH(NTV, YC)                                                                                          \
+    hipLaunchKernelGGL((scs_spmmv_xpose<VT, B, U, NTV, YC>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks,     \
+                       (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld,    \
+                       g_tune.xcd_remap)
+    if (g_tune.nontemporal) { if (ycol) XP_LAUNCH(true, true); else XP_LAUNCH(true, false); }
+    else { if (ycol) XP_LAUNCH(false, true); else XP_LAUNCH(false, false); }
+#undef XP_LAUNCH
+}
+
 template <typename VT, int B>
 void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
-    int U = g_tune.spmmv_unroll;
-    if (U == 0) U = (B * (int)sizeof(VT) >= 64) ? 2 : 4;
-    if (U >= 4) launch_spmmv_rowmajor_u<VT, B, 4>(A, X, Y, ld, ycol, st);
-    else if (U >= 2) launch_spmmv_rowmajor_u<VT, B, 2>(A, X, Y, ld, ycol, st);
+    constexpr int RB = B * (int)sizeof(VT);          // bytes per X row
+    if constexpr (RB >= 32) {                        // at least two 16-byte pieces per X row
+        if (g_tune.spmmv_variant == 2) {             // transposing X phase: 2-7 % over the plain lane-per-row loop,
+            const int Up = g_tune.spmmv_unroll ? g_tune.spmmv_unroll : 4;   // but behind its prefetching form (spmmv_probe6.txt)
+            if (Up >= 4) launch_spmmv_xpose_u<VT, B, 4>(A, X, Y, ld, ycol, st);
+            else if (Up >= 2) launch_spmmv_xpose_u<VT, B, 2>(A, X, Y, ld, ycol, st);
+            else launch_spmmv_xpose_u<VT, B, 1>(A, X, Y, ld, ycol, st);
+            return;
+        }
+    }
+    // auto: 256 bytes of X rows per lane and batch (more spills the prefetching form at 128 VGPRs)
+    constexpr int UMAX = RB >= 128 ? 2 : RB >= 64 ? 4 : 8;
+    int U = g_tune.spmmv_unroll ? g_tune.spmmv_unroll : UMAX;
+    if (U > UMAX) U = UMAX;
+    if constexpr (UMAX >= 8) { if (U >= 8) { launch_spmmv_rowmajor_u<VT, B, 8>(A, X, Y, ld, ycol, st); return; } }
+    if constexpr (UMAX >= 4) { if (U >= 4) { launch_spmmv_rowmajor_u<VT, B, 4>(A, X, Y, ld, ycol, st); return; } }
+    if (U >= 2) launch_spmmv_rowmajor_u<VT, B, 2>(A, X, Y, ld, ycol, st);
     else launch_spmmv_rowmajor_u<VT, B, 1>(A, X, Y, ld, ycol, st);
 }
 
@@ -1009,7 +1165,7 @@ template <typename VT>
 int launch_spmmv(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int layout, hipStream_t st) {
     if (A->n_chunks == 0) return USPMV_OK;
     int rc = -1;
-    if (g_tune.spmmv_variant == 0 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0)) {
+    if (g_tune.spmmv_variant != 1 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0)) {
         constexpr int VW = 16 / (int)sizeof(VT);
         switch (b) {
             case 2: if (VW <= 2) rc = spmmv_fast<VT, 2>(A, X, Y, ld, layout, st); break;
@@ -1073,7 +1229,11 @@ int uspmv_set_tuning(const char *key, int value) {
         if (value < 0 || value > 65536) return uspmv::fail(USPMV_ERR_INVALID, "xcd_remap must be 0, 1 or a group size <= 65536");
         g_tune.xcd_remap = value;
     } else if (!strcmp(key, "ablate")) g_tune.ablate = value;
-    else if (!strcmp(key, "spmmv_variant")) g_tune.spmmv_variant = value != 0;
+    else if (!strcmp(key, "spmmv_prefetch")) g_tune.spmmv_prefetch = value != 0;
+    else if (!strcmp(key, "spmmv_variant")) {
+        if (value < 0 || value > 3) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0|1|2|3");
+        g_tune.spmmv_variant = value;
+    }
     else if (!strcmp(key, "tail_batch")) g_tune.tail_batch = value != 0;
     else if (!strcmp(key, "spmmv_unroll")) g_tune.spmmv_unroll = value;
     else if (!strcmp(key, "tlc")) g_tune.tlc = value != 0;
@@ -1105,6 +1265,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmv_variant")) *value = g_tune.spmv_variant;
     else if (!strcmp(key, "csr_lanes")) *value = g_tune.csr_lanes;
     else if (!strcmp(key, "ablate")) *value = g_tune.ablate;
+    else if (!strcmp(key, "spmmv_prefetch")) *value = g_tune.spmmv_prefetch;
     else if (!strcmp(key, "spmmv_variant")) *value = g_tune.spmmv_variant;
     else if (!strcmp(key, "tail_batch")) *value = g_tune.tail_batch;
     else if (!strcmp(key, "spmmv_unroll")) *value = g_tune.spmmv_unroll;
