@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink grids for quick runs")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--tune", default="", help="key=value,... passed to uspmv_set_tuning")
     args = ap.parse_args()
     import torch
     import __graft_entry__ as ge
@@ -27,6 +28,8 @@ def main():
     from oracle import oracle as orc
     torch.cuda.set_device(0)
     t = torch
+    if args.tune:
+        pkg.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
 
     def prep(coo, dtype, fixed=None):
         s = pkg.convert_to_scs(coo, 32, 512, dtype, fixed_permutation=fixed)
