@@ -708,7 +708,7 @@ __global__ void scs_spmmv_rowmajor(const long n_chunks, const int C, const int *
 // rows (one L1 access per row), the (value, column) pairs reaching the gathering lanes through
 // ds_bpermute.  Lane (r, g) accumulates piece g of rows r, r + 64/P, ...; every (row, v) chain is still
 // slot-ordered -> bit-exact.
-template <typename VT, int B, int U, bool NT, bool YCOL>
+template <typename VT, int B, int U, bool NT, bool YCOL, bool PF>
 __global__ void scs_spmmv_xpose(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
                                 const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                                 const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
@@ -739,33 +739,44 @@ __global__ void scs_spmmv_xpose(const long n_chunks, const int C, const int *__r
     for (int q = 0; q < P; ++q)
 #pragma unroll
         for (int w = 0; w < VW; ++w) acc[q][w] = VT(0);
-    for (int j = 0; j < Lmax; j += U) {
-        VT a[U];
-        int ci[U];
+    // one batch of U slots of this lane's row: value 0 / column -1 past the end of the chunk
+    auto load_batch = [&](int j, VT (&a)[U], int (&ci)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             a[u] = VT(0); ci[u] = -1;
             if (j + u < L) { a[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
         }
+    };
+    VT a[U];
+    int ci[U];
+    if (PF) load_batch(0, a, ci);
+    for (int j = 0; j < Lmax; j += U) {
+        if (!PF) load_batch(j, a, ci);
+        vec_t xv[U][P];
+        VT aa[U][P];
+        int cc[U][P];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            vec_t xv[P];
-            VT aa[P];
-            int cc[P];
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int q = 0; q < P; ++q) {
-                cc[q] = __shfl(ci[u], q * RPR + rl, 64);
-                aa[q] = __shfl(a[u], q * RPR + rl, 64);
-                xv[q] = Xg[(long)(cc[q] < 0 ? 0 : cc[q]) * P];
+                cc[u][q] = __shfl(ci[u], q * RPR + rl, 64);
+                aa[u][q] = __shfl(a[u], q * RPR + rl, 64);
+                xv[u][q] = Xg[(long)(cc[u][q] < 0 ? 0 : cc[u][q]) * P];
             }
+        if (PF) {   // next batch's matrix entries requested behind this batch's X rows (see scs_spmmv_rowmajor)
+            __builtin_amdgcn_sched_barrier(0);
+            load_batch(j + U, a, ci);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int q = 0; q < P; ++q)
 #pragma unroll
                 for (int w = 0; w < VW; ++w) {
-                    const VT t = fma_t(aa[q], xv[q][w], acc[q][w]);
-                    acc[q][w] = cc[q] >= 0 ? t : acc[q][w];
+                    const VT t = fma_t(aa[u][q], xv[u][q][w], acc[q][w]);
+                    acc[q][w] = cc[u][q] >= 0 ? t : acc[q][w];
                 }
-        }
     }
     const long n_pad = n_chunks * (long)C;
 #pragma unroll
@@ -1109,9 +1120,16 @@ void launch_spmmv_xpose_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool
     const int block = g_tune.block;
     const unsigned grid = grid_for(A->n_chunks * A->C, block);
 #define XP_LAUNCH(NTV, YC)                                                                                          \
-    hipLaunchKernelGGL((scs_spmmv_xpose<VT, B, U, NTV, YC>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks,     \
-                       (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld,    \
-                       g_tune.xcd_remap)
+    do {                                                                                                            \
+        if (g_tune.spmmv_prefetch)                                                                                  \
+            hipLaunchKernelGGL((scs_spmmv_xpose<VT, B, U, NTV, YC, true>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
+                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
+                               g_tune.xcd_remap);                                                                   \
+        else                                                                                                        \
+            hipLaunchKernelGGL((scs_spmmv_xpose<VT, B, U, NTV, YC, false>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
+                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
+                               g_tune.xcd_remap);                                                                   \
+    } while (0)
     if (g_tune.nontemporal) { if (ycol) XP_LAUNCH(true, true); else XP_LAUNCH(true, false); }
     else { if (ycol) XP_LAUNCH(false, true); else XP_LAUNCH(false, false); }
 #undef XP_LAUNCH
@@ -1122,7 +1140,8 @@ void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
     constexpr int RB = B * (int)sizeof(VT);          // bytes per X row
     if constexpr (RB >= 32) {                        // at least two 16-byte pieces per X row
         if (g_tune.spmmv_variant == 2) {             // transposing X phase: 2-7 % over the plain lane-per-row loop,
-            const int Up = g_tune.spmmv_unroll ? g_tune.spmmv_unroll : 4;   // but behind its prefetching form (spmmv_probe6.txt)
+            int Up = g_tune.spmmv_unroll ? g_tune.spmmv_unroll : 4;         // level with its prefetching form (spmmv_probe7.txt)
+            if (g_tune.spmmv_prefetch && RB >= 64 && Up > 2) Up = 2;        // 4 prefetching slots of 64-byte rows spill
             if (Up >= 4) launch_spmmv_xpose_u<VT, B, 4>(A, X, Y, ld, ycol, st);
             else if (Up >= 2) launch_spmmv_xpose_u<VT, B, 2>(A, X, Y, ld, ycol, st);
             else launch_spmmv_xpose_u<VT, B, 1>(A, X, Y, ld, ycol, st);
