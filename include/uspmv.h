@@ -107,6 +107,13 @@ int uspmv_device_count(int *count);
 int uspmv_set_device(int device);
 int uspmv_stream_synchronize(void *stream);
 
+/* SpMMV counterpart of uspmv_dmat_optimize (no reference counterpart): plan for block vectors of
+ * block_vec_size columns -- per 64-row tile the X rows it touches are staged in LDS once and the
+ * kernel reads them with 2-byte local indices.  Used by uspmv_spmmv for b*sizeof(VT) in {16,32,64,128}
+ * whose tiles fit, C = 32 or 64; other widths and chunk heights keep the gather kernels
+ * (*n_staged = 0).  Results are bit-identical with and without the plan. */
+int uspmv_dmat_optimize_block(uspmv_dmat_t *m, const uspmv_scs_t *s, int block_vec_size, int64_t *n_tiles, int64_t *n_staged);
+
 /* H2D staging of one SCS struct (assign_spmv_kernel_gpu_data, code/utilities.hpp:3721-3811). */
 int uspmv_dmat_upload(const uspmv_scs_t *s, uspmv_dmat_t **out);
 /* Wrap arrays that already live in HBM (owned by the caller, e.g. a framework allocator). */
@@ -183,7 +190,10 @@ int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_
  *   of G consecutive workgroups per XCD), "spmv_variant" 0 (lane per row, bit-exact) | 1 (two lanes
  *   per row, C=32 only), "csr_lanes" 0 (auto) | 1..64 lanes per row of the CRS kernel,
  *   "tlc" 1|0 use the tile-local-column kernel when the handle has a plan, "tail_batch" 0|1,
- *   "spmmv_variant" 0 (auto) | 1 (generic) | 2 (row-major, transposing X phase) | 3 (row-major, lane per row),
+ *   "spmmv_variant" 0 (auto) | 1 (generic) | 2 (row-major, transposing X phase) | 3 (row-major, lane per row)
+ *                   | 4 (block plan where present; 0 prefers it too, 2 and 3 ignore it),
+ *   "spmmv_tile_rows" 0 (auto) | 64 rows per tile and "spmmv_lds_kb" 0 (= 80) | LDS KiB per tile of the NEXT
+ *   uspmv_dmat_optimize_block,
  *   "spmmv_prefetch" 1|0 (lane-per-row kernel: next batch of matrix entries requested behind the X rows),
  *   "spmmv_unroll" 0 (auto) | 1|2|4|8 slots per batch,
  *   "ablate" 0 | 1 | 2 (measurement only: gathers collapsed / removed, results are wrong). */

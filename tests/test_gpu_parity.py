@@ -198,6 +198,59 @@ def test_spmmv_golden_bitexact(pkg, orc, torch_cuda, name):
                     assert np.array_equal(got, Yo)
 
 
+def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
+    """uspmv_dmat_optimize_block: LDS-staged X rows + 16-bit local indices give the same bits as the gather
+    kernels and the oracle (block_spmv_omp_scs_general, code/kernels.hpp:306-398); staged and unstaged tiles,
+    ragged chunk lengths inside a wave."""
+    t = torch_cuda
+    seen_partial = seen_full = False
+    for name, C, sigma, lds_kb, tile64 in (("FDM-2d-16", 16, 512, 0, 0), ("bcsstk13", 32, 512, 0, 0), ("bcsstk13", 4, 1, 0, 0),
+                                           ("impcol_e", 64, 64, 0, 0), ("matrix1", 1, 1, 0, 0), ("bcsstk13", 128, 128, 0, 0),
+                                           ("bcsstk13", 32, 1, 8, 0), ("bcsstk13", 64, 512, 12, 0), ("bcsstk13", 32, 512, 0, 64),
+                                           ("impcol_e", 32, 1, 0, 0)):
+        pkg.set_tuning(spmmv_lds_kb=lds_kb, spmmv_tile_rows=tile64)     # (apply to the plans built below)
+        m = pkg.read_mtx(mtx_path(name))
+        for code in (pkg.F64, pkg.F32):
+            s, a, xp = _prep(pkg, m, C, sigma, code, make_x(m.n_rows))
+            ld = s.n_rows_padded + 5
+            A0 = pkg.DeviceMatrix(s)
+            for b in (2, 4, 8, 16, 3):
+                A = pkg.DeviceMatrix(s, block_tlc=b)
+                row_bytes = b * (8 if code == pkg.F64 else 4)
+                if C not in (32, 64) or row_bytes not in (16, 32, 64, 128):
+                    assert A.block_staged == 0
+                else:
+                    tr = 32 if (C == 32 and row_bytes >= 64 and not tile64) else 64
+                    assert A.block_tiles == (s.n_rows_padded + tr - 1) // tr and 0 <= A.block_staged <= A.block_tiles
+                    seen_partial |= 0 < A.block_staged < A.block_tiles
+                    seen_full |= A.block_staged == A.block_tiles
+                for rowwise in (0, 1):
+                    X = block_x(xp, s.n_rows_padded, b, ld, rowwise)
+                    lay = pkg.ROWWISE if rowwise else pkg.COLWISE
+                    Y0 = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
+                    pkg.set_tuning(spmmv_variant=3)
+                    pkg.spmmv(A0, _dev(t, X), Y0, b, ld, lay)
+                    pkg.set_tuning(spmmv_variant=0)
+                    pkg.set_tuning(spmmv_variant=4)        # plan kernel for every width it supports
+                    Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
+                    pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
+                    pkg.set_tuning(spmmv_variant=0)
+                    assert t.equal(Y, Y0), (name, C, code, b, rowwise)
+                    Y.fill_(-3.0)                          # and whatever auto picks
+                    pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
+                    assert t.equal(Y, Y0), (name, C, code, b, rowwise, "auto")
+                    if b == 8:
+                        Yo = orc.spmmv_scs(s.C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, b, ld, rowwise)
+                        got = Y.cpu().numpy()
+                        n = s.n_rows_padded
+                        if rowwise:
+                            assert np.array_equal(got[:n * b], Yo[:n * b])
+                        else:
+                            assert np.array_equal(got.reshape(b, ld)[:, :n], Yo.reshape(b, ld)[:, :n])
+    pkg.set_tuning(spmmv_lds_kb=0, spmmv_tile_rows=0)
+    assert seen_partial and seen_full
+
+
 def test_crs_spmmv_golden(pkg, torch_cuda):
     """block_spmv_omp_csr (code/kernels.hpp:68-154): C = 1 structs through uspmv_spmmv, b = 4, both layouts."""
     t = torch_cuda

@@ -75,6 +75,7 @@ _SIGS = {
     "uspmv_spmv_chunks": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "uspmv_spmv_tiles": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "uspmv_dmat_tile_rows": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "uspmv_dmat_optimize_block": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_optimize_ap": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp]),
     "uspmv_spmv_ap": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -340,7 +341,7 @@ class DeviceMatrix:
     """SELL-C-sigma matrix resident in HBM (what assign_spmv_kernel_gpu_data stages,
     code/utilities.hpp:3721-3811).  Arrays are torch tensors owned by this object."""
 
-    def __init__(self, scs, device="cuda", crs=False, tlc=False, tlc_max_lines=0):
+    def __init__(self, scs, device="cuda", crs=False, tlc=False, tlc_max_lines=0, block_tlc=0):
         import torch
         a = scs.arrays()
         self.C, self.n_chunks, self.n_elements, self.dtype = scs.C, scs.n_chunks, scs.n_elements, scs.dtype
@@ -360,6 +361,16 @@ class DeviceMatrix:
             _ck(lib().uspmv_dmat_set_crs(h, 1))
         if tlc:
             self.optimize(scs, tlc_max_lines)
+        self.block_tiles = self.block_staged = 0
+        if block_tlc:
+            self.optimize_block(scs, block_tlc)
+
+    def optimize_block(self, scs, block_vec_size):
+        """Build the LDS-staged SpMMV plan for block vectors of this width (uspmv_dmat_optimize_block)."""
+        a, b = _i64(), _i64()
+        _ck(lib().uspmv_dmat_optimize_block(self.h, scs.h, int(block_vec_size), C.byref(a), C.byref(b)))
+        self.block_tiles, self.block_staged = a.value, b.value
+        return a.value, b.value
 
     def optimize(self, scs, max_lines=0):
         """Build the tile-local-column plan (uspmv_dmat_optimize); returns (n_tiles, n_staged_tiles)."""

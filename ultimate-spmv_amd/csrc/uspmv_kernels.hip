@@ -54,6 +54,13 @@ struct uspmv_dmat {
     int32_t *tlc_line_ptr = nullptr, *tlc_lines = nullptr;
     uint32_t *tlc_c16_ptrs = nullptr;
     uint16_t *tlc_col16 = nullptr;
+    // block (SpMMV) plan: 64-row tiles, per tile the list of X rows it touches (uspmv_dmat_optimize_block)
+    bool bt = false;
+    int bt_max_rows = 0, bt_tile_rows = 64;
+    int64_t bt_n_tiles = 0, bt_staged = 0;
+    int32_t *bt_line_ptr = nullptr, *bt_xrows = nullptr;
+    uint32_t *bt_c16_ptrs = nullptr;
+    uint16_t *bt_col16 = nullptr;
 };
 
 namespace {
@@ -72,6 +79,8 @@ struct Tuning {
     int tlc_tile_rows = 256;  // rows (= threads) per tile used by the NEXT uspmv_dmat_optimize
     int tail_batch = 0;     // ragged tail of a chunk as one predicated batch
     int spmmv_unroll = 0;   // 0 = auto (256 bytes of X rows per lane and batch)
+    int spmmv_lds_kb = 0;    // block plan: LDS budget per tile in KiB for the NEXT uspmv_dmat_optimize_block (0 = 80)
+    int spmmv_tile_rows = 0; // block plan: 0 = auto (32-row tiles for >= 64-byte rows on C = 32), 64 = always 64
     int spmmv_prefetch = 1; // row-major lane-per-row kernel: request batch k+1's matrix entries behind batch k's X rows
     int spmmv_variant = 0;  // 0 = auto (= 3 where a B-specialised kernel exists); 1 = generic kernel; 2 = row-major with transposing X phase; 3 = row-major, lane per row
 };
@@ -587,6 +596,8 @@ __global__ void scs_spmmv_rows(const long n_chunks, const int C, const int *__re
     }
 }
 
+constexpr size_t BT_LDS_CAP = 80 * 1024;  // LDS per single-wave SpMMV tile (block plan): two tiles per CU at worst
+
 // SpMMV with ROW-MAJOR block vectors of compile-time width B (X[col*B + v]): one lane per row, B
 // accumulators per lane.  Per slot a lane reads its whole X row -- B*sizeof(VT) contiguous bytes --
 // with 16-byte loads, so one wave-instruction moves 1 KiB of X instead of 512 B of eight-byte
@@ -789,6 +800,176 @@ __global__ void scs_spmmv_xpose(const long n_chunks, const int C, const int *__r
             } else {
                 ((vec_t *)Y)[r * P + g] = acc[q];
             }
+        }
+    }
+}
+
+// Row-major SpMMV over a block plan (uspmv_dmat_optimize_block): one 64-row tile per single-wave
+// workgroup.  The gather kernels above stop at the L2 -> CU path (every non-zero pulls its 16*NV-byte X
+// row through L1: 16.6 GB per launch on config 3); here a tile's distinct X rows (listed
+// by the plan, 6-8x fewer than its non-zeros) cross that path once, by LDS-DMA (global_load_lds_dwordx4:
+// per-lane source address, lane-linear destination, no VGPRs), and every non-zero reads its operand with
+// ds_read_b128 through the 2-byte local index stream.  LDS holds 2-3 tiles per CU, so latency is hidden
+// by depth instead of occupancy: the row list first (a 4-byte DMA into LDS), then up to NB register
+// batches of 4*G slots of matrix entries and the whole X DMA are in flight together.  X rows sit piece-swizzled in LDS (physical
+// piece = piece ^ f(row), applied to the DMA's source address and to the reads) so that the 16 lanes
+// of a ds_read_b128 group spread over all 64 banks.  C is a template parameter (32 | 64) so that a
+// batch addresses its slots with immediate offsets.  Same slot-ordered FMA chain per (row, v):
+// bit-exact.  Tiles without a row list (footprint too large for LDS) gather from global memory.
+// HS = 2 (C = 32, rows of >= 64 bytes): 32-row tiles, two lanes per row with half of the B columns each --
+// half the LDS per tile, so twice the tiles per CU to overlap one tile's staging with another's arithmetic.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_cvoid_t;
+
+template <typename VT, int B, bool NT, bool YCOL, int G, int C, int HS>
+__global__ void __launch_bounds__(64) scs_spmmv_tlc(const long n_chunks, const int *__restrict__ chunk_ptrs,
+        const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const VT *__restrict__ values,
+        const VT *__restrict__ X, VT *__restrict__ Y, const long ld, const int *__restrict__ tile_line_ptr,
+        const int *__restrict__ tile_xrows, const unsigned *__restrict__ c16_ptrs,
+        const unsigned short *__restrict__ col16, const long x_rows, const int xcd_remap, const long n_store, const int x_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tlc_smem[];
+    constexpr int VW = 16 / (int)sizeof(VT);  // elements per 16-byte piece
+    constexpr int NV = B / VW;                // pieces per X row (1, 2, 4, 8)
+    constexpr int NVS = NV == 1 ? 0 : NV == 2 ? 1 : NV == 4 ? 2 : 3;
+    constexpr int SWS = 4 - NVS;              // rows 2^SWS apart start on the same bank
+    constexpr int NB = 4;                     // register batches in flight
+    typedef VT vec_t __attribute__((ext_vector_type(VW)));
+    typedef unsigned long long u64;
+    const vec_t *xs = (const vec_t *)tlc_smem;
+    const unsigned tile = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+    const int lp0 = tile_line_ptr[tile];
+    const int nl = tile_line_ptr[tile + 1] - lp0;
+    const int lane = threadIdx.x;
+    // HS = 2: two lanes per row (lane and lane + 32), each owning half of the row's B columns; a tile is 32 rows
+    constexpr int NVH = NV / HS;              // 16-byte pieces of an X row per lane
+    constexpr int BH = B / HS;                // accumulators per lane
+    const int h = HS == 2 ? lane >> 5 : 0;
+    const long row = (long)tile * (64 / HS) + (HS == 2 ? lane & 31 : lane);
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    const bool valid = c < n_chunks;
+    int cs = 0, L = 0;
+    unsigned q0 = 0;
+    if (valid) { cs = chunk_ptrs[c]; L = chunk_lengths[c]; q0 = c16_ptrs[c]; }
+    VT acc[BH];
+#pragma unroll
+    for (int v = 0; v < BH; ++v) acc[v] = VT(0);
+    const VT *vp = values + (long)cs + i;
+    auto fma_row = [&](const VT a, const vec_t *xp, const unsigned sw) {
+#pragma unroll
+        for (int k = 0; k < NVH; ++k) {
+            const vec_t xv = xp[(unsigned)(k + h * NVH) ^ sw];
+#pragma unroll
+            for (int w = 0; w < VW; ++w) acc[k * VW + w] = fma_t(a, xv[w], acc[k * VW + w]);
+        }
+    };
+    auto fma_local = [&](const VT a, const unsigned local) {
+        fma_row(a, xs + local * NV, NV > 1 ? (local >> SWS) & (NV - 1) : 0u);
+    };
+    if (nl > 0) {
+        const u64 *cq = (const u64 *)(col16 + q0) + i;
+        int Lmin = L, Lmax = L;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { Lmin = min(Lmin, __shfl_xor(Lmin, o, 64)); Lmax = max(Lmax, __shfl_xor(Lmax, o, 64)); }
+        Lmin = __builtin_amdgcn_readfirstlane(Lmin);
+        Lmax = __builtin_amdgcn_readfirstlane(Lmax);
+        const int ngf = Lmin >> 2;            // groups of four slots every lane of the wave has in full
+        const int nbt = ngf / G;              // register batches
+        // ---- 1. the tile's row list -> LDS (behind the X rows), by DMA as well: one latency, no registers
+        const int np = nl << NVS;
+        int *rl = (int *)(tlc_smem + x_bytes);
+#pragma unroll 1
+        for (int r0 = 0; r0 < nl; r0 += 64)
+            if (r0 + lane < nl)
+                __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(tile_xrows + lp0 + r0 + lane), (lds_void_t *)(rl + r0), 4, 0, 0);
+        __syncthreads();                      // (drains the DMA: vmcnt(0) + barrier)
+        // ---- 2. matrix entries: up to NB batches requested before anything is waited for
+        auto load_batch = [&](const int bi, VT (&a)[4 * G], u64 (&q)[G]) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const long gg = (long)bi * G + g;
+                q[g] = ld_stream<NT>(cq + gg * C);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[4 * g + u] = ld_stream<NT>(vp + (4 * gg + u) * C);
+            }
+        };
+        auto compute_batch = [&](const VT (&a)[4 * G], const u64 (&q)[G]) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    fma_local(a[4 * g + u], (unsigned)(q[g] >> (16 * u)) & 0xFFFFu);
+                    if (NV >= 8 || u == 3) __builtin_amdgcn_sched_barrier(0);   // at most 64 VGPRs of LDS reads ahead of their FMAs
+                }
+            }
+        };
+        VT a0[4 * G], a1[4 * G], a2[NB > 2 ? 4 * G : 1], a3[NB > 2 ? 4 * G : 1];
+        u64 qa[G], qb[G], qc[NB > 2 ? G : 1], qd[NB > 2 ? G : 1];
+        if (nbt > 0) load_batch(0, a0, qa);
+        if (nbt > 1) load_batch(1, a1, qb);
+        if constexpr (NB > 2) {
+            if (nbt > 2) load_batch(2, a2, qc);
+            if (nbt > 3) load_batch(3, a3, qd);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 3. X rows -> LDS by DMA: LDS position p = (row k, physical piece pp) takes logical piece pp ^ f(k)
+#pragma unroll 1
+        for (int t0 = 0; t0 * 64 < np; t0 += 8) {
+            int xr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = (t0 + u) * 64 + lane;
+                xr[u] = p < np ? rl[p >> NVS] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = (t0 + u) * 64 + lane;
+                if (p < np) {
+                    const unsigned k = (unsigned)p >> NVS;
+                    const unsigned piece = ((unsigned)p & (NV - 1)) ^ (NV > 1 ? (k >> SWS) & (NV - 1) : 0u);
+                    const VT *src = X + (long)xr[u] * B + piece * VW;
+                    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)src, (lds_void_t *)(tlc_smem + (t0 + u) * 1024), 16, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                      // drains the DMA (vmcnt) and the batches requested before it
+        for (int bi = 0; bi < nbt; bi += NB) {
+            compute_batch(a0, qa);
+            if (bi + NB < nbt) load_batch(bi + NB, a0, qa);
+            if (bi + 1 < nbt) { compute_batch(a1, qb); if (bi + 1 + NB < nbt) load_batch(bi + 1 + NB, a1, qb); }
+            if constexpr (NB > 2) {
+                if (bi + 2 < nbt) { compute_batch(a2, qc); if (bi + 2 + NB < nbt) load_batch(bi + 2 + NB, a2, qc); }
+                if (bi + 3 < nbt) { compute_batch(a3, qd); if (bi + 3 + NB < nbt) load_batch(bi + 3 + NB, a3, qd); }
+            }
+        }
+        for (int g = nbt * G; g < ngf; ++g) {  // full groups that do not fill a batch
+            const u64 q = ld_stream<NT>(cq + (long)g * C);
+            VT a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = ld_stream<NT>(vp + (long)(4 * g + u) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fma_local(a[u], (unsigned)(q >> (16 * u)) & 0xFFFFu);
+        }
+        const unsigned short *c16 = col16 + q0;
+        for (int j = 4 * ngf; j < Lmax; ++j)   // ragged rest: lanes past their chunk's length sit out
+            if (j < L) fma_local(ld_stream<NT>(vp + (long)j * C), c16[(long)(j >> 2) * 4 * C + i * 4 + (j & 3)]);
+    } else if (L > 0) {  // wide-footprint tile: 32-bit columns, X rows gathered from global memory
+        const int *cp = col_idxs + (long)cs + i;
+        for (int j = 0; j < L; ++j)
+            fma_row(ld_stream<NT>(vp + (long)j * C), (const vec_t *)(X + (long)ld_stream<NT>(cp + (long)j * C) * B), 0u);
+    }
+    if (!valid || row >= n_store) return;
+    if (YCOL) {
+#pragma unroll
+        for (int v = 0; v < BH; ++v) st_y<NT>(Y + (row + (long)(h * BH + v) * ld), acc[v]);
+    } else {
+        vec_t *yp = (vec_t *)(Y + row * B) + h * NVH;
+#pragma unroll
+        for (int k = 0; k < NVH; ++k) {
+            vec_t t;
+#pragma unroll
+            for (int w = 0; w < VW; ++w) t[w] = acc[k * VW + w];
+            yp[k] = t;
         }
     }
 }
@@ -1135,9 +1316,41 @@ void launch_spmmv_xpose_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool
 #undef XP_LAUNCH
 }
 
+template <typename VT, int B, int G, int CT, int HS>
+void launch_spmmv_tlc_g(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    const size_t x_bytes = (size_t)A->bt_max_rows * B * sizeof(VT);
+    const size_t lds = x_bytes + (((size_t)A->bt_max_rows * 4 + 15) & ~(size_t)15);   // X rows + the tile's row list
+#define BT_LAUNCH(NTV, YC)                                                                                              \
+    do {                                                                                                                \
+        auto kfn = scs_spmmv_tlc<VT, B, NTV, YC, G, CT, HS>;                                                                \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)A->bt_n_tiles), dim3(64), lds, st, (long)A->n_chunks,                    \
+                           A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, A->bt_line_ptr, \
+                           A->bt_xrows, A->bt_c16_ptrs, A->bt_col16, ld, g_tune.xcd_remap, (long)A->n_store, (int)x_bytes); \
+    } while (0)
+    if (g_tune.nontemporal) { if (ycol) BT_LAUNCH(true, true); else BT_LAUNCH(true, false); }
+    else { if (ycol) BT_LAUNCH(false, true); else BT_LAUNCH(false, false); }
+#undef BT_LAUNCH
+}
+
 template <typename VT, int B>
 void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
     constexpr int RB = B * (int)sizeof(VT);          // bytes per X row
+    if constexpr (RB >= 16 && RB <= 128) {
+        // block plan staged in LDS, if the handle carries one whose tiles fit this row width
+        // auto takes the plan for rows of <= 32 bytes only: there 4+ tiles fit a CU and the kernel is 12-15 % ahead of
+        // the gather form; with 64-byte rows (2-3 tiles per CU) each tile's chain of dependent fetches is exposed and
+        // it is 20 % behind (profiles/r01/spmmv_probe13.txt).  Variant 4 forces it.
+        if (A->bt && ((g_tune.spmmv_variant == 0 && RB <= 32) || g_tune.spmmv_variant == 4) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
+            if (A->bt_tile_rows == 32) {
+                if constexpr (RB >= 64) { launch_spmmv_tlc_g<VT, B, 4, 32, 2>(A, X, Y, ld, ycol, st); return; }
+            } else {
+                if (A->C == 32) launch_spmmv_tlc_g<VT, B, 4, 32, 1>(A, X, Y, ld, ycol, st);
+                else launch_spmmv_tlc_g<VT, B, 4, 64, 1>(A, X, Y, ld, ycol, st);
+                return;
+            }
+        }
+    }
     if constexpr (RB >= 32) {                        // at least two 16-byte pieces per X row
         if (g_tune.spmmv_variant == 2) {             // transposing X phase: 2-7 % over the plain lane-per-row loop,
             int Up = g_tune.spmmv_unroll ? g_tune.spmmv_unroll : 4;         // level with its prefetching form (spmmv_probe7.txt)
@@ -1249,8 +1462,10 @@ int uspmv_set_tuning(const char *key, int value) {
         g_tune.xcd_remap = value;
     } else if (!strcmp(key, "ablate")) g_tune.ablate = value;
     else if (!strcmp(key, "spmmv_prefetch")) g_tune.spmmv_prefetch = value != 0;
+    else if (!strcmp(key, "spmmv_tile_rows")) g_tune.spmmv_tile_rows = value == 64 ? 64 : 0;
+    else if (!strcmp(key, "spmmv_lds_kb")) g_tune.spmmv_lds_kb = value < 0 ? 0 : value;
     else if (!strcmp(key, "spmmv_variant")) {
-        if (value < 0 || value > 3) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0|1|2|3");
+        if (value < 0 || value > 4) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0|1|2|3|4");
         g_tune.spmmv_variant = value;
     }
     else if (!strcmp(key, "tail_batch")) g_tune.tail_batch = value != 0;
@@ -1285,6 +1500,8 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "csr_lanes")) *value = g_tune.csr_lanes;
     else if (!strcmp(key, "ablate")) *value = g_tune.ablate;
     else if (!strcmp(key, "spmmv_prefetch")) *value = g_tune.spmmv_prefetch;
+    else if (!strcmp(key, "spmmv_tile_rows")) *value = g_tune.spmmv_tile_rows;
+    else if (!strcmp(key, "spmmv_lds_kb")) *value = g_tune.spmmv_lds_kb;
     else if (!strcmp(key, "spmmv_variant")) *value = g_tune.spmmv_variant;
     else if (!strcmp(key, "tail_batch")) *value = g_tune.tail_batch;
     else if (!strcmp(key, "spmmv_unroll")) *value = g_tune.spmmv_unroll;
@@ -1397,6 +1614,52 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     return USPMV_OK;
 }
 
+static void bt_release(uspmv_dmat_t *A) {
+    (void)hipFree(A->bt_line_ptr); (void)hipFree(A->bt_xrows); (void)hipFree(A->bt_c16_ptrs); (void)hipFree(A->bt_col16);
+    A->bt_line_ptr = A->bt_xrows = nullptr; A->bt_c16_ptrs = nullptr; A->bt_col16 = nullptr;
+    A->bt = false;
+}
+
+int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_vec_size, int64_t *n_tiles, int64_t *n_staged) {
+    if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: NULL argument");
+    if (A->C != s->C || A->n_chunks != s->n_chunks || A->dtype != s->dtype)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: handle and host struct do not describe the same matrix");
+    if (block_vec_size < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: block_vec_size must be >= 1");
+    if (int rc = require_device()) return rc;
+    if (A->bt) bt_release(A);
+    if (n_tiles) *n_tiles = 0;
+    if (n_staged) *n_staged = 0;
+    const size_t row_bytes = (size_t)block_vec_size * (s->dtype == USPMV_F64 ? 8 : 4);
+    // only the 16-byte-piece kernels (b*sizeof(VT) in {16,32,64,128}) read the plan, compiled for C = 32 and 64
+    if (row_bytes % 16 != 0 || (row_bytes & (row_bytes - 1)) != 0 || row_bytes > 128 || (s->C != 32 && s->C != 64)) return USPMV_OK;
+    const size_t cap = g_tune.spmmv_lds_kb > 0 ? std::min<size_t>((size_t)g_tune.spmmv_lds_kb * 1024, BT_LDS_CAP) : BT_LDS_CAP;
+    const int max_rows = (int)(cap / row_bytes);
+    // rows of >= 64 bytes on C = 32: 32-row tiles, two lanes per row (half the LDS per tile, twice the tiles per CU)
+    const int tile_rows = (s->C == 32 && row_bytes >= 64 && g_tune.spmmv_tile_rows != 64) ? 32 : 64;
+    uspmv_tlc_plan p;
+    if (int rc = uspmv_build_tlc_plan(s, nullptr, max_rows, tile_rows, &p, /*line_shift=*/0)) return rc;
+    if (n_tiles) *n_tiles = p.n_tiles;
+    if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
+    if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] block plan: b=%d tile_rows=%d tiles=%lld staged=%lld max_rows=%d (cap %d) rows_total=%zu\n",
+                                         block_vec_size, p.tile_rows, (long long)p.n_tiles, (long long)p.n_staged_tiles, p.max_lines_used, max_rows, p.tile_lines.size());
+    if (!p.valid) return USPMV_OK;
+    auto up = [&](const void *h, size_t bytes, void **d) -> hipError_t {
+        hipError_t e = hipMalloc(d, bytes ? bytes : 4);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(p.tile_line_ptr.data(), p.tile_line_ptr.size() * 4, (void **)&A->bt_line_ptr);
+    if (e == hipSuccess) e = up(p.tile_lines.data(), p.tile_lines.size() * 4, (void **)&A->bt_xrows);
+    if (e == hipSuccess) e = up(p.c16_ptrs.data(), p.c16_ptrs.size() * 4, (void **)&A->bt_c16_ptrs);
+    if (e == hipSuccess) e = up(p.col16.data(), p.col16.size() * 2, (void **)&A->bt_col16);
+    if (e != hipSuccess) {
+        bt_release(A);
+        return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_block: device copy failed: %s", hipGetErrorString(e));
+    }
+    A->bt = true; A->bt_tile_rows = p.tile_rows; A->bt_max_rows = p.max_lines_used; A->bt_n_tiles = p.n_tiles; A->bt_staged = p.n_staged_tiles;
+    return USPMV_OK;
+}
+
 int uspmv_dmat_optimize_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t *s_dp, const uspmv_scs_t *s_sp,
                            int max_lines, int64_t *n_tiles, int64_t *n_staged) {
     if (!dp || !sp || !s_dp || !s_sp) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_ap: NULL argument");
@@ -1442,6 +1705,7 @@ void uspmv_dmat_free(uspmv_dmat_t *A) {
     if (!A) return;
     if (A->alt) { uspmv_dmat_free(A->alt); A->alt = nullptr; }
     if (A->tlc) tlc_release(A);
+    if (A->bt) bt_release(A);
     if (A->ws) (void)hipFree(A->ws);
     if (A->owns) {
         (void)hipFree((void *)A->chunk_ptrs); (void)hipFree((void *)A->chunk_lengths);

@@ -19,16 +19,22 @@
 
 #include "uspmv_internal.hpp"
 
-int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines, int tile_rows, uspmv_tlc_plan *p) {
+int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines, int tile_rows, uspmv_tlc_plan *p, int line_shift) {
     // s2 (optional): a second struct with the same row layout (the sp part of an ap[dp_sp] pair);
     // the line list of a tile then covers the columns of both, each struct gets its own col16.
     p->valid = false;
     const int64_t C = s->C;
-    if (tile_rows != 256 && tile_rows != 512 && tile_rows != 1024) tile_rows = 256;
+    // line_shift: log2 of the elements per line -- 4 (16-element lines) for SpMV; 0 for the block-vector
+    // plan, where an "element" is a whole X row of b values and a tile is one wave (64 rows) tall.
+    if (line_shift < 0 || line_shift > 4) line_shift = 4;
+    const int LS = line_shift;
+    const int32_t LM = (1 << LS) - 1;
+    if (tile_rows != 32 && tile_rows != 64 && tile_rows != 128 && tile_rows != 256 && tile_rows != 512 && tile_rows != 1024) tile_rows = 256;
     if (C < 1 || C > tile_rows || tile_rows % C != 0 || s->n_chunks < 1) return USPMV_OK;  // unsupported shape: no plan
     if (s2 && (s2->C != C || s2->n_chunks != s->n_chunks)) return USPMV_OK;
     if (max_lines < 1) return USPMV_OK;
-    if (max_lines > 4096) max_lines = 4096;  // 16-bit local indices
+    if (max_lines > (65536 >> LS)) max_lines = 65536 >> LS;  // 16-bit local indices
+    p->line_shift = LS;
     const int64_t T = tile_rows / C;
     p->tile_rows = tile_rows;
     const int64_t n_tiles = (s->n_chunks + T - 1) / T;
@@ -66,7 +72,7 @@ int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines,
                 const int64_t e0 = ss[w]->chunk_ptrs[(size_t)c0], e1 = ss[w]->chunk_ptrs[(size_t)c1];
                 n_el += e1 - e0;
                 for (int64_t k = e0; k < e1; ++k) {
-                    const int32_t l = ci[k] >> 4;
+                    const int32_t l = ci[k] >> LS;
                     lo = std::min(lo, l); hi = std::max(hi, l);
                     my_max = std::max(my_max, ci[k]);
                 }
@@ -79,7 +85,7 @@ int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines,
                 pos.assign((size_t)range, -1);
                 for (int w = 0; w < ns; ++w) {
                     const int32_t *ci = ss[w]->col_idxs.data();
-                    for (int64_t k = ss[w]->chunk_ptrs[(size_t)c0]; k < ss[w]->chunk_ptrs[(size_t)c1]; ++k) pos[(size_t)((ci[k] >> 4) - lo)] = 0;
+                    for (int64_t k = ss[w]->chunk_ptrs[(size_t)c0]; k < ss[w]->chunk_ptrs[(size_t)c1]; ++k) pos[(size_t)((ci[k] >> LS) - lo)] = 0;
                 }
                 for (int64_t r = 0; r < range && n <= max_lines; ++r)
                     if (pos[(size_t)r] == 0) { pos[(size_t)r] = n++; lines.push_back((int32_t)(lo + r)); }
@@ -87,7 +93,7 @@ int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines,
                 lines.reserve((size_t)n_el);
                 for (int w = 0; w < ns; ++w) {
                     const int32_t *ci = ss[w]->col_idxs.data();
-                    for (int64_t k = ss[w]->chunk_ptrs[(size_t)c0]; k < ss[w]->chunk_ptrs[(size_t)c1]; ++k) lines.push_back(ci[k] >> 4);
+                    for (int64_t k = ss[w]->chunk_ptrs[(size_t)c0]; k < ss[w]->chunk_ptrs[(size_t)c1]; ++k) lines.push_back(ci[k] >> LS);
                 }
                 std::sort(lines.begin(), lines.end());
                 lines.erase(std::unique(lines.begin(), lines.end()), lines.end());
@@ -95,10 +101,10 @@ int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines,
             }
             if (n > max_lines) continue;                // gather path for this tile
             auto local_of = [&](int32_t col) -> uint16_t {
-                const int32_t l = col >> 4;
+                const int32_t l = col >> LS;
                 const int32_t pl = dense ? pos[(size_t)(l - lo)]
                                          : (int32_t)(std::lower_bound(lines.begin(), lines.end(), l) - lines.begin());
-                return (uint16_t)((pl << 4) | (col & 15));
+                return (uint16_t)((pl << LS) | (col & LM));
             };
             for (int w = 0; w < ns; ++w) {
                 const int32_t *ci = ss[w]->col_idxs.data();

@@ -42,7 +42,7 @@ struct uspmv_halo {
 // Tile-local-column plan (host copy), see host/tlc_plan.cpp
 struct uspmv_tlc_plan {
     bool valid = false;
-    int chunks_per_tile = 0, max_lines_used = 0, tile_rows = 256;
+    int chunks_per_tile = 0, max_lines_used = 0, tile_rows = 256, line_shift = 4;
     int64_t n_tiles = 0, n_staged_tiles = 0, x_len_min = 0;
     std::vector<int32_t> tile_line_ptr;   // n_tiles+1
     std::vector<int32_t> tile_lines;      // line ids (col >> 4), sorted per tile; empty tile list = gather path
@@ -51,7 +51,7 @@ struct uspmv_tlc_plan {
     std::vector<uint32_t> c16_ptrs_b;     // same for the optional second struct (sp part of an ap pair)
     std::vector<uint16_t> col16_b;
 };
-int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines, int tile_rows, uspmv_tlc_plan *plan);
+int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines, int tile_rows, uspmv_tlc_plan *plan, int line_shift = 4);
 
 int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *out);   // host/tlc_plan.cpp
 

@@ -229,6 +229,10 @@ int run(const Config &c, uspmv_coo_t *coo) {
         if (ap) ck(uspmv_dmat_optimize_ap(r.A, r.A_sp, scs, scs_sp, 0, &nt, &ns), "uspmv_dmat_optimize_ap");
         else ck(uspmv_dmat_optimize(r.A, scs, 0, &nt, &ns), "uspmv_dmat_optimize");
         printf("tile-local-column plan: %ld of %ld tiles staged in LDS\n", (long)ns, (long)nt);
+    } else if (c.tlc && b > 1 && !ap && (size_t)b * sizeof(VT) <= 32) {   // block plan pays for rows of <= 32 bytes
+        int64_t nt = 0, ns = 0;
+        ck(uspmv_dmat_optimize_block(r.A, scs, b, &nt, &ns), "uspmv_dmat_optimize_block");
+        if (nt) printf("block plan: %ld of %ld tiles staged in LDS\n", (long)ns, (long)nt);
     }
     r.x = dev_alloc<VT>((size_t)b * ld);
     r.y = dev_alloc<VT>((size_t)b * ld);
