@@ -116,6 +116,18 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *m, const uspmv_scs_t *s, int block_v
 
 /* H2D staging of one SCS struct (assign_spmv_kernel_gpu_data, code/utilities.hpp:3721-3811). */
 int uspmv_dmat_upload(const uspmv_scs_t *s, uspmv_dmat_t **out);
+/* GPU-side conversion: the result of uspmv_convert_to_scs [+ uspmv_permute_scs_cols with the
+ * struct's own old_to_new_idx when permute_cols != 0] + uspmv_dmat_upload, bit for bit, but only the
+ * O(n_rows) layout (row lengths, sigma-window std::sort, chunk lengths / pointers, permutations) is
+ * computed on the host; the O(nnz) scatter of code/utilities.hpp:2013-2036 runs on the device straight
+ * from the uploaded COO arrays.  *layout is a host struct WITHOUT entries: meta data, chunk arrays and
+ * the permutations are there, uspmv_scs_arrays returns NULL for col_idxs / values, and the functions that
+ * need host entries (uspmv_dmat_upload / _optimize*, uspmv_halo_discover, ...) refuse it.  The COO entries
+ * must be sorted by row (uspmv_read_mtx and the generators produce that order). */
+int uspmv_convert_to_scs_device(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dtype, const int32_t *fixed_permutation,
+                                int permute_cols, uspmv_scs_t **layout, uspmv_dmat_t **out);
+/* copies of the device arrays of a handle (any pointer may be NULL): n_chunks+1, n_chunks, n_elements, n_elements */
+int uspmv_dmat_download(const uspmv_dmat_t *m, int32_t *chunk_ptrs, int32_t *chunk_lengths, int32_t *col_idxs, void *values);
 /* Wrap arrays that already live in HBM (owned by the caller, e.g. a framework allocator). */
 int uspmv_dmat_wrap(int64_t C, int64_t n_chunks, int64_t n_elements, int dtype, const int32_t *d_chunk_ptrs,
                     const int32_t *d_chunk_lengths, const int32_t *d_col_idxs, const void *d_values,

@@ -198,6 +198,59 @@ def test_spmmv_golden_bitexact(pkg, orc, torch_cuda, name):
                     assert np.array_equal(got, Yo)
 
 
+def test_convert_to_scs_device_bitexact(pkg, torch_cuda):
+    """uspmv_convert_to_scs_device = uspmv_convert_to_scs (+ permute_scs_cols) + upload, bit for bit: C x sigma grid,
+    dp / sp, fixed permutation, empty rows; and the SpMV on the device-built struct matches the host-built one."""
+    t = torch_cuda
+    rng = np.random.default_rng(3)
+    n = 300                                               # rows 0, 7, 14, ... and the last 40 rows are empty
+    I = np.sort(rng.integers(0, n - 40, 3000)); I = I[I % 7 != 0]
+    ragged = pkg.Coo.from_arrays(n, n, I, rng.integers(0, n, I.size), rng.standard_normal(I.size))
+    for name in ("FDM-2d-16", "impcol_e", "bcsstk13", "matrix1", "matrix_band_klein", ragged):
+        m = pkg.read_mtx(mtx_path(name)) if isinstance(name, str) else name
+        for C, sigma in ((1, 1), (4, 4), (16, 512), (32, 512), (32, 1), (64, 128), (128, 256), (5, 7)):
+            for code in (pkg.F64, pkg.F32):
+                for permute in (True, False):
+                    s = pkg.convert_to_scs(m, C, sigma, code)
+                    if permute:
+                        pkg.permute_scs_cols(s, s.arrays()["old_to_new_idx"])
+                    a = s.arrays()
+                    lay, A = pkg.convert_to_scs_device(m, C, sigma, code, permute_cols=permute)
+                    assert (lay.n_chunks, lay.n_elements, lay.n_rows_padded, lay.nnz) == (s.n_chunks, s.n_elements, s.n_rows_padded, s.nnz)
+                    la = lay.arrays()
+                    assert la["col_idxs"] is None and la["values"] is None
+                    for k in ("chunk_ptrs", "chunk_lengths", "old_to_new_idx", "new_to_old_idx"):
+                        assert np.array_equal(la[k], a[k]), (name, C, sigma, k)
+                    d = pkg.dmat_download(A)
+                    for k in ("chunk_ptrs", "chunk_lengths", "col_idxs", "values"):
+                        assert np.array_equal(d[k], a[k]), (name, C, sigma, code, permute, k)
+        # fixed permutation (a valid one: the struct's own sort order), quirk included
+        s0 = pkg.convert_to_scs(m, 8, 32, pkg.F64)
+        fp = s0.arrays()["old_to_new_idx"].copy()
+        s1 = pkg.convert_to_scs(m, 8, 32, pkg.F64, fixed_permutation=fp)
+        lay, A = pkg.convert_to_scs_device(m, 8, 32, pkg.F64, fixed_permutation=fp, permute_cols=False)
+        d = pkg.dmat_download(A)
+        for k in ("chunk_ptrs", "chunk_lengths", "col_idxs", "values"):
+            assert np.array_equal(d[k], s1.arrays()[k]), (name, "fixed", k)
+        assert np.array_equal(lay.arrays()["old_to_new_idx"], s1.arrays()["old_to_new_idx"])
+    # SpMV on the device-built struct; layout-only structs are refused where host entries are needed
+    m = pkg.read_mtx(mtx_path("bcsstk13"))
+    lay, A = pkg.convert_to_scs_device(m, 32, 512, pkg.F64)
+    s, a, xp = _prep(pkg, m, 32, 512, pkg.F64, make_x(m.n_rows))
+    A0 = pkg.DeviceMatrix(s)
+    x = _dev(t, xp)
+    y = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda"); y0 = t.zeros_like(y)
+    pkg.spmv(A, x, y); pkg.spmv(A0, x, y0)
+    assert t.equal(y, y0)
+    with pytest.raises(pkg.UspmvError):
+        A.optimize(lay)
+    with pytest.raises(pkg.UspmvError):
+        pkg.permute_scs_cols(lay, la["old_to_new_idx"])
+    unsorted = pkg.Coo.from_arrays(3, 3, [2, 0, 1], [0, 1, 2], [1.0, 2.0, 3.0])
+    with pytest.raises(pkg.UspmvError):
+        pkg.convert_to_scs_device(unsorted, 2, 2)
+
+
 def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
     """uspmv_dmat_optimize_block: LDS-staged X rows + 16-bit local indices give the same bits as the gather
     kernels and the oracle (block_spmv_omp_scs_general, code/kernels.hpp:306-398); staged and unstaged tiles,

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Set-up time of the host path (convert_to_scs + permute_scs_cols + upload) against uspmv_convert_to_scs_device
+on the nlpkkt200-class matrix; also checks that both produce the same device arrays."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import __graft_entry__ as ge
+pkg = ge.load_package()
+torch.cuda.set_device(0)
+g = int(sys.argv[1]) if len(sys.argv) > 1 else 253
+t0 = time.time(); coo = pkg.gen_stencil27(g, g, g); t_gen = time.time() - t0
+for rep in range(2):
+    t0 = time.time()
+    s = pkg.convert_to_scs(coo, 32, 512, pkg.F64); t1 = time.time()
+    pkg.permute_scs_cols(s, s.arrays()["old_to_new_idx"]); t2 = time.time()
+    A = pkg.DeviceMatrix(s); torch.cuda.synchronize(); t3 = time.time()
+    lay, Ad = pkg.convert_to_scs_device(coo, 32, 512, pkg.F64); t4 = time.time()
+    same = None
+    if rep == 1:
+        d = pkg.dmat_download(Ad); a = s.arrays()
+        same = bool(np.array_equal(d["col_idxs"], a["col_idxs"]) and np.array_equal(d["values"], a["values"]) and np.array_equal(d["chunk_ptrs"], a["chunk_ptrs"]))
+    print(json.dumps(dict(grid=g, nnz=coo.nnz, gen_s=round(t_gen, 2), host_convert_s=round(t1 - t0, 2), host_permute_cols_s=round(t2 - t1, 2),
+                          upload_s=round(t3 - t2, 2), host_path_total_s=round(t3 - t0, 2), device_path_total_s=round(t4 - t3, 2), identical=same)), flush=True)
+    del A, Ad, s, lay

@@ -67,6 +67,8 @@ _SIGS = {
     "uspmv_set_device": (C.c_int, [C.c_int]),
     "uspmv_stream_synchronize": (C.c_int, [_vp]),
     "uspmv_dmat_upload": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "uspmv_convert_to_scs_device": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
+    "uspmv_dmat_download": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "uspmv_dmat_wrap": (C.c_int, [_i64, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "uspmv_dmat_free": (None, [_vp]),
     "uspmv_dmat_set_crs": (C.c_int, [_vp, C.c_int]),
@@ -216,10 +218,11 @@ class Scs:
         _ck(lib().uspmv_scs_arrays(self.h, C.byref(cp), C.byref(cl), C.byref(ci), C.byref(va), C.byref(o2n),
                                    C.byref(n2o)))
         vp = C.cast(va, C.POINTER(C.c_double if self.dtype == F64 else C.c_float))
+        full = bool(ci) or self.n_elements == 0        # layout-only structs (convert_to_scs_device) carry no host entries
         return dict(chunk_ptrs=_view(cp, self.n_chunks + 1, np.int32, self),
                     chunk_lengths=_view(cl, self.n_chunks, np.int32, self),
-                    col_idxs=_view(ci, self.n_elements, np.int32, self),
-                    values=_view(vp, self.n_elements, self.np_dtype, self),
+                    col_idxs=_view(ci, self.n_elements, np.int32, self) if full else None,
+                    values=_view(vp, self.n_elements, self.np_dtype, self) if full else None,
                     old_to_new_idx=_view(o2n, self.n_rows, np.int32, self),
                     new_to_old_idx=_view(n2o, self.n_rows, np.int32, self))
 
@@ -341,8 +344,15 @@ class DeviceMatrix:
     """SELL-C-sigma matrix resident in HBM (what assign_spmv_kernel_gpu_data stages,
     code/utilities.hpp:3721-3811).  Arrays are torch tensors owned by this object."""
 
-    def __init__(self, scs, device="cuda", crs=False, tlc=False, tlc_max_lines=0, block_tlc=0):
+    def __init__(self, scs, device="cuda", crs=False, tlc=False, tlc_max_lines=0, block_tlc=0, _handle=None):
         import torch
+        if _handle is not None:          # arrays owned by the library (convert_to_scs_device)
+            self.C, self.n_chunks, self.n_elements, self.dtype = scs.C, scs.n_chunks, scs.n_elements, scs.dtype
+            self.n_rows, self.n_rows_padded, self.nnz = scs.n_rows, scs.n_rows_padded, scs.nnz
+            self.torch_dtype = torch.float64 if scs.dtype == F64 else torch.float32
+            self.h = _handle
+            self.tlc_tiles = self.tlc_staged = self.tile_rows = self.block_tiles = self.block_staged = 0
+            return
         a = scs.arrays()
         self.C, self.n_chunks, self.n_elements, self.dtype = scs.C, scs.n_chunks, scs.n_elements, scs.dtype
         self.n_rows, self.n_rows_padded, self.nnz = scs.n_rows, scs.n_rows_padded, scs.nnz
@@ -386,6 +396,27 @@ class DeviceMatrix:
         if getattr(self, "h", None) and _LIB is not None:
             _LIB.uspmv_dmat_free(self.h)
             self.h = None
+
+
+def convert_to_scs_device(coo, C_, sigma, dtype=F64, fixed_permutation=None, permute_cols=True, device="cuda"):
+    """GPU-side convert_to_scs (+ permute_scs_cols): returns (layout-only Scs, DeviceMatrix)."""
+    import torch
+    dev = torch.device(device)
+    if dev.index is not None:
+        torch.cuda.set_device(dev)
+    fp = None if fixed_permutation is None else np.ascontiguousarray(fixed_permutation, np.int32)
+    hs, hA = _vp(), _vp()
+    _ck(lib().uspmv_convert_to_scs_device(coo.h, C_, sigma, dtype, _np_ptr(fp), int(bool(permute_cols)), C.byref(hs), C.byref(hA)))
+    s = Scs(hs)
+    return s, DeviceMatrix(s, device, _handle=hA)
+
+
+def dmat_download(A):
+    """Host copies of a DeviceMatrix's arrays (tests / debugging)."""
+    cp = np.empty(A.n_chunks + 1, np.int32); cl = np.empty(A.n_chunks, np.int32)
+    ci = np.empty(A.n_elements, np.int32); va = np.empty(A.n_elements, np.float64 if A.dtype == F64 else np.float32)
+    _ck(lib().uspmv_dmat_download(A.h, _np_ptr(cp), _np_ptr(cl), _np_ptr(ci), _np_ptr(va)))
+    return dict(chunk_ptrs=cp, chunk_lengths=cl, col_idxs=ci, values=va)
 
 
 def optimize_ap(A_dp, A_sp, scs_dp, scs_sp, max_lines=0):

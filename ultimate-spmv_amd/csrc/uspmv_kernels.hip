@@ -1082,6 +1082,28 @@ __global__ void scs_spmv_ap_rows(const long n_chunks, const int C, const int *__
     st_y<NT>(y + row, dt + st);
 }
 
+// COO -> SELL-C-sigma scatter of uspmv_convert_to_scs_device: one thread per COO entry k (entries sorted by
+// row, order inside a row preserved): slot = k - row_start[row], destination as convert_to_scs
+// (code/utilities.hpp:2013-2036).  perm != nullptr folds permute_scs_cols (:1802-1831) into the same pass.
+template <typename VT>
+__global__ void scs_fill_kernel(const long nnz, const int C, const int n_rows, const int *__restrict__ I,
+                                const int *__restrict__ J, const double *__restrict__ V,
+                                const int *__restrict__ row_start, const int *__restrict__ row_map,
+                                const int *__restrict__ perm, const int *__restrict__ chunk_ptrs,
+                                int *__restrict__ col_idxs, VT *__restrict__ values) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const int r = I[k];
+    const int slot = (int)(k - row_start[r]);
+    const int row = row_map[r];
+    const int c = row / C;
+    const long dst = (long)chunk_ptrs[c] + (long)slot * C + (row - c * C);
+    int col = J[k];
+    if (perm && col < n_rows) col = perm[col];
+    col_idxs[dst] = col;
+    values[dst] = (VT)V[k];
+}
+
 // out[i] = in[perm[idx ? idx[i] : i] + offset]   (pack_send_buf with idx, apply_permutation without)
 template <typename VT>
 __global__ void gather_kernel(VT *__restrict__ out, const VT *__restrict__ in, const int *__restrict__ perm,
@@ -1514,6 +1536,7 @@ int uspmv_get_tuning(const char *key, int *value) {
 
 int uspmv_dmat_upload(const uspmv_scs_t *s, uspmv_dmat_t **out) {
     if (!s || !out) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_upload: NULL argument");
+    if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_upload: layout-only struct (its entries already live on the device)");
     if (int rc = require_device()) return rc;
     auto *A = new uspmv_dmat;
     A->C = s->C; A->n_chunks = s->n_chunks; A->n_elements = s->n_elements; A->dtype = s->dtype; A->owns = true;
@@ -1557,6 +1580,84 @@ int uspmv_dmat_wrap(int64_t C, int64_t n_chunks, int64_t n_elements, int dtype, 
     return USPMV_OK;
 }
 
+int uspmv_convert_to_scs_device(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dtype, const int32_t *fixed_permutation,
+                                int permute_cols, uspmv_scs_t **layout, uspmv_dmat_t **out) {
+    if (!m || !layout || !out) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_convert_to_scs_device: NULL argument");
+    if (int rc = require_device()) return rc;
+    auto *s = new uspmv_scs;
+    std::vector<int64_t> row_start;
+    if (int rc = uspmv_scs_layout(m, C, sigma, dtype, fixed_permutation, s, &row_start, "uspmv_convert_to_scs_device")) { delete s; return rc; }
+    if (row_start.empty() && m->nnz > 0) {
+        delete s;
+        return uspmv::fail(USPMV_ERR_UNSUPPORTED, "uspmv_convert_to_scs_device: COO entries must be sorted by row "
+                                                  "(uspmv_read_mtx and the generators produce that order)");
+    }
+    if (m->nnz > INT32_MAX) { delete s; return uspmv::fail(USPMV_ERR_OVERFLOW, "uspmv_convert_to_scs_device: nnz exceeds int32"); }
+    std::vector<int32_t> rs32(row_start.begin(), row_start.end());
+    const int32_t *row_map = fixed_permutation ? fixed_permutation : s->old_to_new_idx.data();
+    auto *A = new uspmv_dmat;
+    A->C = s->C; A->n_chunks = s->n_chunks; A->n_elements = s->n_elements; A->dtype = dtype; A->owns = true;
+    A->n_store = (long)(s->n_chunks * s->C);
+    const size_t vsz = dtype == USPMV_F64 ? 8 : 4;
+    const size_t ne = (size_t)std::max<int64_t>(s->n_elements, 1), nz = (size_t)std::max<int64_t>(m->nnz, 1);
+    void *cp = nullptr, *cl = nullptr, *ci = nullptr, *va = nullptr;
+    int32_t *dI = nullptr, *dJ = nullptr, *drs = nullptr, *dmap = nullptr, *dperm = nullptr;
+    double *dV = nullptr;
+    hipError_t e = hipSuccess;
+    auto up = [&](const void *h, size_t bytes, void **d) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(d, bytes ? bytes : 4);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+    };
+    up(s->chunk_ptrs.data(), 4 * s->chunk_ptrs.size(), &cp);
+    up(s->chunk_lengths.data(), 4 * s->chunk_lengths.size(), &cl);
+    if (e == hipSuccess) e = hipMalloc(&ci, 4 * ne);
+    if (e == hipSuccess) e = hipMalloc(&va, vsz * ne);
+    // padding: value 0, column 0 -- which permute_scs_cols maps like any other local column (code/utilities.hpp:1820-1826)
+    const int pad_col = (permute_cols && m->n_rows > 0) ? s->old_to_new_idx[0] : 0;
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)ci, pad_col, ne, nullptr);
+    if (e == hipSuccess) e = hipMemsetAsync(va, 0, vsz * ne, nullptr);
+    up(m->I.data(), 4 * (size_t)m->nnz, (void **)&dI);
+    up(m->J.data(), 4 * (size_t)m->nnz, (void **)&dJ);
+    up(m->values.data(), 8 * (size_t)m->nnz, (void **)&dV);
+    up(rs32.data(), 4 * rs32.size(), (void **)&drs);
+    up(row_map, 4 * (size_t)m->n_rows, (void **)&dmap);
+    if (permute_cols) up(s->old_to_new_idx.data(), 4 * (size_t)m->n_rows, (void **)&dperm);
+    A->chunk_ptrs = (const int32_t *)cp; A->chunk_lengths = (const int32_t *)cl; A->col_idxs = (const int32_t *)ci; A->values = va;
+    if (e == hipSuccess && m->nnz > 0) {
+        const unsigned grid = (unsigned)((nz + 255) / 256);
+        if (dtype == USPMV_F64)
+            hipLaunchKernelGGL(scs_fill_kernel<double>, dim3(grid), dim3(256), 0, nullptr, (long)m->nnz, (int)C, (int)m->n_rows, dI, dJ, dV,
+                               drs, dmap, dperm, (const int *)cp, (int *)ci, (double *)va);
+        else
+            hipLaunchKernelGGL(scs_fill_kernel<float>, dim3(grid), dim3(256), 0, nullptr, (long)m->nnz, (int)C, (int)m->n_rows, dI, dJ, dV,
+                               drs, dmap, dperm, (const int *)cp, (int *)ci, (float *)va);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    (void)hipFree(dI); (void)hipFree(dJ); (void)hipFree(dV); (void)hipFree(drs); (void)hipFree(dmap); (void)hipFree(dperm);
+    if (e != hipSuccess) {
+        uspmv_dmat_free(A); delete s;
+        return uspmv::fail(USPMV_ERR_HIP, "uspmv_convert_to_scs_device: %s", hipGetErrorString(e));
+    }
+    *layout = s;
+    *out = A;
+    return USPMV_OK;
+}
+
+int uspmv_dmat_download(const uspmv_dmat_t *A, int32_t *chunk_ptrs, int32_t *chunk_lengths, int32_t *col_idxs, void *values) {
+    if (int rc = check_dmat(A, "uspmv_dmat_download")) return rc;
+    if (int rc = require_device()) return rc;
+    const size_t vsz = A->dtype == USPMV_F64 ? 8 : 4;
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && chunk_ptrs) e = hipMemcpy(chunk_ptrs, A->chunk_ptrs, 4 * (size_t)(A->n_chunks + 1), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && chunk_lengths) e = hipMemcpy(chunk_lengths, A->chunk_lengths, 4 * (size_t)A->n_chunks, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && col_idxs) e = hipMemcpy(col_idxs, A->col_idxs, 4 * (size_t)A->n_elements, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && values) e = hipMemcpy(values, A->values, vsz * (size_t)A->n_elements, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return uspmv::fail(USPMV_ERR_HIP, "uspmv_dmat_download: %s", hipGetErrorString(e));
+    return USPMV_OK;
+}
+
 static void tlc_release(uspmv_dmat_t *A) {
     (void)hipFree(A->tlc_line_ptr); (void)hipFree(A->tlc_lines); (void)hipFree(A->tlc_c16_ptrs); (void)hipFree(A->tlc_col16);
     A->tlc_line_ptr = A->tlc_lines = nullptr; A->tlc_c16_ptrs = nullptr; A->tlc_col16 = nullptr;
@@ -1565,6 +1666,7 @@ static void tlc_release(uspmv_dmat_t *A) {
 
 int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
     if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: NULL argument");
+    if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: layout-only struct; the plan builder needs the host column indices");
     if (A->C != s->C || A->n_chunks != s->n_chunks || A->dtype != s->dtype)
         return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: handle and host struct do not describe the same matrix");
     if (int rc = require_device()) return rc;
@@ -1622,6 +1724,7 @@ static void bt_release(uspmv_dmat_t *A) {
 
 int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_vec_size, int64_t *n_tiles, int64_t *n_staged) {
     if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: NULL argument");
+    if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: layout-only struct; the plan builder needs the host column indices");
     if (A->C != s->C || A->n_chunks != s->n_chunks || A->dtype != s->dtype)
         return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: handle and host struct do not describe the same matrix");
     if (block_vec_size < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: block_vec_size must be >= 1");
@@ -1663,6 +1766,8 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
 int uspmv_dmat_optimize_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t *s_dp, const uspmv_scs_t *s_sp,
                            int max_lines, int64_t *n_tiles, int64_t *n_staged) {
     if (!dp || !sp || !s_dp || !s_sp) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_ap: NULL argument");
+    if (!uspmv::scs_has_entries(s_dp) || !uspmv::scs_has_entries(s_sp))
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_ap: layout-only struct; the plan builder needs the host column indices");
     if (dp->C != s_dp->C || dp->n_chunks != s_dp->n_chunks || dp->dtype != USPMV_F64 || s_dp->dtype != USPMV_F64 ||
         sp->C != s_sp->C || sp->n_chunks != s_sp->n_chunks || sp->dtype != USPMV_F32 || s_sp->dtype != USPMV_F32 ||
         dp->C != sp->C || dp->n_chunks != sp->n_chunks)

@@ -79,6 +79,7 @@ int uspmv_seg_local_coo(const uspmv_coo_t *t, const int32_t *wsa, int rank, uspm
 int uspmv_halo_discover(uspmv_scs_t *s, const int32_t *wsa, int rank, int P, uspmv_halo_t **out) {
     if (!s || !wsa || !out || P < 1 || rank < 0 || rank >= P)
         return uspmv::fail(USPMV_ERR_INVALID, "uspmv_halo_discover: bad argument");
+    if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_halo_discover: layout-only struct (uspmv_convert_to_scs_device)");
     const int32_t lo = wsa[rank], hi = wsa[rank + 1];
     const int64_t n_cols = std::max<int64_t>(s->n_cols, wsa[P]);
     const int64_t n_el = s->n_elements;
@@ -154,6 +155,7 @@ int uspmv_scs_split_chunks(const uspmv_scs_t *s, int64_t n_local, int32_t **inte
                            int32_t **boundary, int64_t *n_boundary) {
     if (!s || !interior || !boundary || !n_interior || !n_boundary)
         return uspmv::fail(USPMV_ERR_INVALID, "uspmv_scs_split_chunks: NULL argument");
+    if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_scs_split_chunks: layout-only struct (uspmv_convert_to_scs_device)");
     const int64_t nc = s->n_chunks, C = s->C;
     std::vector<uint8_t> is_bnd((size_t)nc, 0);
     const int32_t *ci = s->col_idxs.data();

@@ -22,31 +22,40 @@
 
 #include "uspmv_internal.hpp"
 
-extern "C" {
-
-int uspmv_convert_to_scs(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dtype,
-                         const int32_t *fixed_permutation, uspmv_scs_t **out) {
-    if (!m || !out) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_convert_to_scs: NULL argument");
-    if (C < 1 || sigma < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_convert_to_scs: C and sigma must be >= 1");
-    if (dtype != USPMV_F64 && dtype != USPMV_F32)
-        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_convert_to_scs: unknown dtype %d", dtype);
-    if (m->n_rows < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_convert_to_scs: matrix has no rows");
+// Everything of convert_to_scs except the O(nnz) scatter: row lengths, sigma-window sort (or the
+// fixed permutation), chunk lengths / pointers, both permutations.  `s` comes back with empty
+// col_idxs / values ("layout-only").  row_start (n_rows + 1 offsets into the COO arrays) is filled
+// when the COO entries are sorted by row, left empty otherwise.
+int uspmv_scs_layout(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dtype, const int32_t *fixed_permutation,
+                     uspmv_scs *s, std::vector<int64_t> *row_start, const char *who) {
+    if (C < 1 || sigma < 1) return uspmv::fail(USPMV_ERR_INVALID, "%s: C and sigma must be >= 1", who);
+    if (dtype != USPMV_F64 && dtype != USPMV_F32) return uspmv::fail(USPMV_ERR_INVALID, "%s: unknown dtype %d", who, dtype);
+    if (m->n_rows < 1) return uspmv::fail(USPMV_ERR_INVALID, "%s: matrix has no rows", who);
 
     const int64_t n_rows = m->n_rows, nnz = m->nnz;
     const int64_t n_chunks = (n_rows + C - 1) / C;
     const int64_t n_pad = n_chunks * C;
-    if (n_pad > INT32_MAX) return uspmv::fail(USPMV_ERR_OVERFLOW, "uspmv_convert_to_scs: padded rows exceed int32");
+    if (n_pad > INT32_MAX) return uspmv::fail(USPMV_ERR_OVERFLOW, "%s: padded rows exceed int32", who);
 
     using row_len = std::pair<long, long>;  // {original row, population count}
     std::vector<row_len> rl((size_t)(n_pad + sigma));
     for (int64_t i = 0; i < n_pad; ++i) rl[(size_t)i].first = i;
-    for (int64_t k = 0; k < nnz; ++k) ++rl[(size_t)m->I[(size_t)k]].second;
+    bool sorted = true;
+    for (int64_t k = 0; k < nnz; ++k) {
+        ++rl[(size_t)m->I[(size_t)k]].second;
+        if (k && m->I[(size_t)k - 1] > m->I[(size_t)k]) sorted = false;
+    }
+    row_start->clear();
+    if (sorted) {
+        row_start->assign((size_t)n_rows + 1, 0);
+        for (int64_t r = 0; r < n_rows; ++r) (*row_start)[(size_t)r + 1] = (*row_start)[(size_t)r] + rl[(size_t)r].second;
+    }
 
     if (fixed_permutation) {
         for (int64_t i = 0; i < n_rows; ++i)
             if (fixed_permutation[i] < 0 || fixed_permutation[i] >= n_pad)
-                return uspmv::fail(USPMV_ERR_INVALID, "uspmv_convert_to_scs: fixed_permutation[%lld]=%d out of range",
-                                   (long long)i, fixed_permutation[i]);
+                return uspmv::fail(USPMV_ERR_INVALID, "%s: fixed_permutation[%lld]=%d out of range", who, (long long)i,
+                                   fixed_permutation[i]);
         std::vector<row_len> tmp((size_t)n_pad);
         for (int64_t i = 0; i < n_pad; ++i) {
             tmp[(size_t)i].first = rl[(size_t)i].first;
@@ -64,7 +73,6 @@ int uspmv_convert_to_scs(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dty
         }
     }
 
-    auto *s = new uspmv_scs;
     s->C = C; s->sigma = sigma; s->n_rows = n_rows; s->n_cols = m->n_cols; s->nnz = nnz;
     s->n_chunks = n_chunks; s->n_rows_padded = n_pad; s->dtype = dtype;
     s->chunk_lengths.assign((size_t)n_chunks, 0);
@@ -77,10 +85,7 @@ int uspmv_convert_to_scs(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dty
         s->chunk_lengths[(size_t)c] = (int32_t)mx;
         s->chunk_ptrs[(size_t)c] = (int32_t)cur;
         cur += mx * C;
-        if (cur > INT32_MAX) {
-            delete s;
-            return uspmv::fail(USPMV_ERR_OVERFLOW, "uspmv_convert_to_scs: chunk_ptrs exceed the 32-bit index type");
-        }
+        if (cur > INT32_MAX) return uspmv::fail(USPMV_ERR_OVERFLOW, "%s: chunk_ptrs exceed the 32-bit index type", who);
     }
     s->chunk_ptrs[(size_t)n_chunks] = (int32_t)cur;
     s->n_elements = cur;
@@ -95,6 +100,26 @@ int uspmv_convert_to_scs(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dty
         int32_t p = s->old_to_new_idx[(size_t)i];
         if (p < n_rows) s->new_to_old_idx[(size_t)p] = (int32_t)i;  // (reference writes out of bounds otherwise)
     }
+    if (fixed_permutation && sorted) {
+        // a non-empty row mapped onto a slot of a shorter chunk would overrun it (the reference does, code/utilities.hpp:1919-1922)
+        for (int64_t r = 0; r < n_rows; ++r)
+            if ((*row_start)[(size_t)r + 1] - (*row_start)[(size_t)r] > s->chunk_lengths[(size_t)(fixed_permutation[r] / C)])
+                return uspmv::fail(USPMV_ERR_INVALID,
+                                   "%s: fixed_permutation maps a non-empty row onto a padded slot "
+                                   "(the reference overruns its chunk here, code/utilities.hpp:1919-1922)", who);
+    }
+    return USPMV_OK;
+}
+
+extern "C" {
+
+int uspmv_convert_to_scs(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dtype,
+                         const int32_t *fixed_permutation, uspmv_scs_t **out) {
+    if (!m || !out) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_convert_to_scs: NULL argument");
+    auto *s = new uspmv_scs;
+    std::vector<int64_t> row_start;
+    if (int rc = uspmv_scs_layout(m, C, sigma, dtype, fixed_permutation, s, &row_start, "uspmv_convert_to_scs")) { delete s; return rc; }
+    const int64_t n_rows = m->n_rows, nnz = m->nnz, n_pad = s->n_rows_padded, cur = s->n_elements;
 
     // ---- fill, preserving the COO order inside every row
     s->col_idxs.assign((size_t)cur, 0);  // padding: column 0 (code/utilities.hpp:1991-2002)
@@ -102,9 +127,6 @@ int uspmv_convert_to_scs(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dty
     else s->values_f32.assign((size_t)cur, 0.0f);
 
     const int32_t *row_map = fixed_permutation ? fixed_permutation : s->old_to_new_idx.data();
-    bool sorted = true;
-    for (int64_t k = 1; k < nnz && sorted; ++k) sorted = m->I[(size_t)k - 1] <= m->I[(size_t)k];
-
     int bad = 0;
     auto place = [&](int64_t k, int64_t slot) {
         int64_t row = row_map[m->I[(size_t)k]];
@@ -115,10 +137,7 @@ int uspmv_convert_to_scs(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dty
         if (dtype == USPMV_F64) s->values_f64[(size_t)idx] = m->values[(size_t)k];
         else s->values_f32[(size_t)idx] = (float)m->values[(size_t)k];
     };
-    if (sorted) {
-        std::vector<int64_t> row_start((size_t)n_rows + 1, 0);
-        for (int64_t k = 0; k < nnz; ++k) row_start[(size_t)m->I[(size_t)k] + 1]++;
-        for (int64_t r = 0; r < n_rows; ++r) row_start[(size_t)r + 1] += row_start[(size_t)r];
+    if (!row_start.empty()) {
 #pragma omp parallel for schedule(static)
         for (int64_t r = 0; r < n_rows; ++r)
             for (int64_t k = row_start[(size_t)r]; k < row_start[(size_t)r + 1]; ++k) place(k, k - row_start[(size_t)r]);
@@ -158,8 +177,9 @@ int uspmv_scs_arrays(const uspmv_scs_t *s, const int32_t **chunk_ptrs, const int
     if (!s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_scs_arrays: NULL matrix");
     if (chunk_ptrs) *chunk_ptrs = s->chunk_ptrs.data();
     if (chunk_lengths) *chunk_lengths = s->chunk_lengths.data();
-    if (col_idxs) *col_idxs = s->col_idxs.data();
-    if (values) *values = s->values_ptr();
+    const bool full = uspmv::scs_has_entries(s);      // layout-only structs (uspmv_convert_to_scs_device): NULL
+    if (col_idxs) *col_idxs = full ? s->col_idxs.data() : nullptr;
+    if (values) *values = full ? s->values_ptr() : nullptr;
     if (old_to_new_idx) *old_to_new_idx = s->old_to_new_idx.data();
     if (new_to_old_idx) *new_to_old_idx = s->new_to_old_idx.data();
     return USPMV_OK;
@@ -173,6 +193,7 @@ int uspmv_scs_col_idxs_mut(uspmv_scs_t *s, int32_t **col_idxs) {
 
 int uspmv_permute_scs_cols(uspmv_scs_t *s, const int32_t *perm) {
     if (!s || !perm) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_permute_scs_cols: NULL argument");
+    if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_permute_scs_cols: layout-only struct (uspmv_convert_to_scs_device)");
     const int64_t n = s->n_elements, n_rows = s->n_rows;
     int32_t *ci = s->col_idxs.data();
 #pragma omp parallel for schedule(static)

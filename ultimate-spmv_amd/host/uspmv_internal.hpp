@@ -55,6 +55,11 @@ int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines,
 
 int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *out);   // host/tlc_plan.cpp
 
+int uspmv_scs_layout(const uspmv_coo *m, int64_t C, int64_t sigma, int dtype, const int32_t *fixed_permutation,
+                     uspmv_scs *s, std::vector<int64_t> *row_start, const char *who);   // host/scs_convert.cpp
+
 namespace uspmv {
 int fail(int status, const char *fmt, ...);  // records the thread-local error text, returns status
+// false for the layout-only structs uspmv_convert_to_scs_device hands back (entries live on the device only)
+inline bool scs_has_entries(const uspmv_scs *s) { return (int64_t)s->col_idxs.size() == s->n_elements; }
 }
