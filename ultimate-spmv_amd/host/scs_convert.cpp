@@ -40,10 +40,33 @@ int uspmv_scs_layout(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dtype, 
     using row_len = std::pair<long, long>;  // {original row, population count}
     std::vector<row_len> rl((size_t)(n_pad + sigma));
     for (int64_t i = 0; i < n_pad; ++i) rl[(size_t)i].first = i;
+    // row populations and the sortedness test in one parallel sweep: every thread walks a contiguous piece of
+    // the entry list and adds one count per run of equal row indices (one atomic per run, not per entry)
     bool sorted = true;
-    for (int64_t k = 0; k < nnz; ++k) {
-        ++rl[(size_t)m->I[(size_t)k]].second;
-        if (k && m->I[(size_t)k - 1] > m->I[(size_t)k]) sorted = false;
+    const int32_t *I = m->I.data();
+#pragma omp parallel
+    {
+        bool my_sorted = true;
+#pragma omp for schedule(static) nowait
+        for (int64_t blk = 0; blk < (nnz + 65535) / 65536; ++blk) {
+            const int64_t k0 = blk * 65536, k1 = std::min(k0 + 65536, nnz);
+            if (k0 > 0 && I[k0 - 1] > I[k0]) my_sorted = false;
+            int64_t run_start = k0;
+            for (int64_t k = k0 + 1; k <= k1; ++k) {
+                if (k == k1 || I[k] != I[k - 1]) {
+                    long &cnt = rl[(size_t)I[k - 1]].second;
+                    const long add = (long)(k - run_start);
+#pragma omp atomic
+                    cnt += add;
+                    run_start = k;
+                }
+                if (k < k1 && I[k - 1] > I[k]) my_sorted = false;
+            }
+        }
+        if (!my_sorted) {
+#pragma omp atomic write
+            sorted = false;
+        }
     }
     row_start->clear();
     if (sorted) {
