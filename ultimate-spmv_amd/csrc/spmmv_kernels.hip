@@ -1,0 +1,609 @@
+// SpMMV kernels (block vectors) and their dispatch: reference twin block_spmv_omp_scs_general
+// (code/kernels.hpp:306-398) and block_spmv_omp_csr (:68-154).  See uspmv_device.hpp / DESIGN.md 5.
+#include "uspmv_device.hpp"
+
+using namespace uspmv_dev;
+
+namespace {
+
+// SELL-C-sigma SpMMV (block of b vectors), one lane per row, VB vectors per pass held in registers.
+// colwise: X[col + v*ld], Y[row + v*ld];  rowwise: X[col*b + v], Y[row*b + v].
+template <typename VT, int VB, bool ROWWISE, bool NT>
+__global__ void scs_spmmv_rows(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
+                               const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
+                               const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
+                               const int b, const long ld, const int xcd_remap) {
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+    const long row = (long)lb * blockDim.x + threadIdx.x;
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    if (c >= n_chunks) return;
+    const long cs = chunk_ptrs[c];
+    const int L = chunk_lengths[c];
+    const VT *vp = values + cs + i;
+    const int *cp = col_idxs + cs + i;
+    for (int v0 = 0; v0 < b; v0 += VB) {
+        VT acc[VB];
+#pragma unroll
+        for (int v = 0; v < VB; ++v) acc[v] = VT(0);
+        for (int j = 0; j < L; ++j) {
+            const VT a = ld_stream<NT>(vp + (long)j * C);
+            const long col = ld_stream<NT>(cp + (long)j * C);
+#pragma unroll
+            for (int v = 0; v < VB; ++v) {
+                if (v0 + v < b) {
+                    const VT xv = ROWWISE ? X[col * b + v0 + v] : X[col + (long)(v0 + v) * ld];
+                    acc[v] = fma_t(a, xv, acc[v]);
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {
+            if (v0 + v < b) {
+                if (ROWWISE) st_y<NT>(Y + (row * b + v0 + v), acc[v]);
+                else st_y<NT>(Y + (row + (long)(v0 + v) * ld), acc[v]);
+            }
+        }
+    }
+}
+
+// SpMMV with ROW-MAJOR block vectors of compile-time width B (X[col*B + v]): one lane per row, B
+// accumulators per lane.  Per slot a lane reads its whole X row -- B*sizeof(VT) contiguous bytes --
+// with 16-byte loads, so one wave-instruction moves 1 KiB of X instead of 512 B of eight-byte
+// column gathers: 1 + 1 + B*sizeof(VT)/16 vector-memory instructions per 64 non-zeros (the
+// column-major form needs 2 + B, each fetching a whole 64-byte sector per lane for 8 useful bytes).
+// Every (row, v) accumulator is still the slot-ordered FMA chain of block_spmv_omp_scs_general.
+// YCOL: write Y column-major (Y[row + v*ld]) straight from the accumulators -- per vector one
+// coalesced 64-lane store -- so that column-major callers only pay the X re-layout.
+template <typename VT, int B, int U, bool NT, bool YCOL, bool PF>
+__global__ void scs_spmmv_rowmajor(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
+                                   const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
+                                   const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
+                                   const long ld, const int xcd_remap) {
+    constexpr int VW = 16 / (int)sizeof(VT);  // elements per 16-byte load
+    constexpr int NV = B / VW;
+    typedef VT vec_t __attribute__((ext_vector_type(VW)));
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+    const long row = (long)lb * blockDim.x + threadIdx.x;
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    if (c >= n_chunks) return;
+    const long cs = chunk_ptrs[c];
+    const int L = chunk_lengths[c];
+    const VT *vp = values + cs + i;
+    const int *cp = col_idxs + cs + i;
+    VT acc[B];
+#pragma unroll
+    for (int v = 0; v < B; ++v) acc[v] = VT(0);
+    int j = 0;
+    if (PF) {
+        // PF: the (value, column) pairs of batch k+1 are requested right after the X rows of batch k, so a
+        // wave has both round trips in flight instead of one after the other (the kernel is latency-bound:
+        // 8 waves per SIMD x 2 dependent misses per batch).  Loads retire in order, so waiting for the X
+        // rows does not wait for the prefetch.  Past the end the prefetch re-reads slot L-1 and is ignored.
+        if (L >= U) {
+            VT a[U];
+            int ci[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a[u] = ld_stream<NT>(vp + (long)u * C); ci[u] = ld_stream<NT>(cp + (long)u * C); }
+            for (; j + U <= L; j += U) {
+                vec_t xr[U][NV];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const vec_t *xp = (const vec_t *)(X + (long)ci[u] * B);
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) xr[u][k] = xp[k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                VT an[U];
+                int cn[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int jj = min(j + U + u, L - 1);
+                    an[u] = ld_stream<NT>(vp + (long)jj * C); cn[u] = ld_stream<NT>(cp + (long)jj * C);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int k = 0; k < NV; ++k)
+#pragma unroll
+                        for (int w = 0; w < VW; ++w) acc[k * VW + w] = fma_t(a[u], xr[u][k][w], acc[k * VW + w]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) { a[u] = an[u]; ci[u] = cn[u]; }
+            }
+        }
+    } else {
+        for (; j + U <= L; j += U) {
+            VT a[U];
+            int ci[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
+            vec_t xr[U][NV];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const vec_t *xp = (const vec_t *)(X + (long)ci[u] * B);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) xr[u][k] = xp[k];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+#pragma unroll
+                    for (int w = 0; w < VW; ++w) acc[k * VW + w] = fma_t(a[u], xr[u][k][w], acc[k * VW + w]);
+        }
+    }
+    for (; j < L; ++j) {
+        const VT a = ld_stream<NT>(vp + (long)j * C);
+        const vec_t *xp = (const vec_t *)(X + (long)ld_stream<NT>(cp + (long)j * C) * B);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const vec_t xv = xp[k];
+#pragma unroll
+            for (int w = 0; w < VW; ++w) acc[k * VW + w] = fma_t(a, xv[w], acc[k * VW + w]);
+        }
+    }
+    if (YCOL) {
+#pragma unroll
+        for (int v = 0; v < B; ++v) st_y<NT>(Y + (row + (long)v * ld), acc[v]);
+    } else {
+        vec_t *yp = (vec_t *)(Y + row * B);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            vec_t t;
+#pragma unroll
+            for (int w = 0; w < VW; ++w) t[w] = acc[k * VW + w];
+            yp[k] = t;
+        }
+    }
+}
+
+// Row-major SpMMV, "transposing" form.  rocprofv3 counters on scs_spmmv_rowmajor (profiles/r01/spmmv_pmc.txt)
+// show the vector L1 saturated (846 M 64-byte accesses = 54 GB per launch for 25 GB of useful bytes):
+// a lane that owns a whole 64-byte X row fetches it as four 16-byte pieces in four instructions, and
+// every piece costs a full 64-byte L1 access.  Here the matrix stream keeps its lane <-> row mapping
+// (one coalesced 512-byte / 256-byte load per slot and wave), but the X phase runs in P = B*sizeof(VT)/16
+// rounds over 64/P rows each with P adjacent lanes per row: a round's loads fetch whole contiguous X
+// rows (one L1 access per row), the (value, column) pairs reaching the gathering lanes through
+// ds_bpermute.  Lane (r, g) accumulates piece g of rows r, r + 64/P, ...; every (row, v) chain is still
+// slot-ordered -> bit-exact.
+template <typename VT, int B, int U, bool NT, bool YCOL, bool PF>
+__global__ void scs_spmmv_xpose(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
+                                const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
+                                const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
+                                const long ld, const int xcd_remap) {
+    constexpr int VW = 16 / (int)sizeof(VT);
+    constexpr int P = B / VW;          // 16-byte pieces per X row = rounds
+    constexpr int RPR = 64 / P;        // rows per round
+    typedef VT vec_t __attribute__((ext_vector_type(VW)));
+    const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+    const int lane = threadIdx.x & 63;
+    const long row = (long)lb * blockDim.x + threadIdx.x;      // streaming role: this lane's row
+    const long wrow0 = row - lane;
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    int L = 0;
+    long cs = 0;
+    if (c < n_chunks) { cs = chunk_ptrs[c]; L = chunk_lengths[c]; }
+    int Lmax = L;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, o, 64));
+    Lmax = __builtin_amdgcn_readfirstlane(Lmax);
+    const VT *vp = values + cs + i;
+    const int *cp = col_idxs + cs + i;
+    const int rl = lane / P, g = lane % P;                      // gathering role: row-in-round, piece
+    const vec_t *Xg = (const vec_t *)X + g;
+    vec_t acc[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+        for (int w = 0; w < VW; ++w) acc[q][w] = VT(0);
+    // one batch of U slots of this lane's row: value 0 / column -1 past the end of the chunk
+    auto load_batch = [&](int j, VT (&a)[U], int (&ci)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a[u] = VT(0); ci[u] = -1;
+            if (j + u < L) { a[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
+        }
+    };
+    VT a[U];
+    int ci[U];
+    if (PF) load_batch(0, a, ci);
+    for (int j = 0; j < Lmax; j += U) {
+        if (!PF) load_batch(j, a, ci);
+        vec_t xv[U][P];
+        VT aa[U][P];
+        int cc[U][P];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                cc[u][q] = __shfl(ci[u], q * RPR + rl, 64);
+                aa[u][q] = __shfl(a[u], q * RPR + rl, 64);
+                xv[u][q] = Xg[(long)(cc[u][q] < 0 ? 0 : cc[u][q]) * P];
+            }
+        if (PF) {   // next batch's matrix entries requested behind this batch's X rows (see scs_spmmv_rowmajor)
+            __builtin_amdgcn_sched_barrier(0);
+            load_batch(j + U, a, ci);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < P; ++q)
+#pragma unroll
+                for (int w = 0; w < VW; ++w) {
+                    const VT t = fma_t(aa[u][q], xv[u][q][w], acc[q][w]);
+                    acc[q][w] = cc[u][q] >= 0 ? t : acc[q][w];
+                }
+    }
+    const long n_pad = n_chunks * (long)C;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const long r = wrow0 + q * RPR + rl;
+        if (r < n_pad) {
+            if (YCOL) {
+#pragma unroll
+                for (int w = 0; w < VW; ++w) st_y<NT>(Y + (r + (long)(g * VW + w) * ld), acc[q][w]);
+            } else {
+                ((vec_t *)Y)[r * P + g] = acc[q];
+            }
+        }
+    }
+}
+
+// Row-major SpMMV over a block plan (uspmv_dmat_optimize_block): one 64-row tile per single-wave
+// workgroup.  The gather kernels above stop at the L2 -> CU path (every non-zero pulls its 16*NV-byte X
+// row through L1: 16.6 GB per launch on config 3); here a tile's distinct X rows (listed
+// by the plan, 6-8x fewer than its non-zeros) cross that path once, by LDS-DMA (global_load_lds_dwordx4:
+// per-lane source address, lane-linear destination, no VGPRs), and every non-zero reads its operand with
+// ds_read_b128 through the 2-byte local index stream.  LDS holds 2-3 tiles per CU, so latency is hidden
+// by depth instead of occupancy: the row list first (a 4-byte DMA into LDS), then up to NB register
+// batches of 4*G slots of matrix entries and the whole X DMA are in flight together.  X rows sit piece-swizzled in LDS (physical
+// piece = piece ^ f(row), applied to the DMA's source address and to the reads) so that the 16 lanes
+// of a ds_read_b128 group spread over all 64 banks.  C is a template parameter (32 | 64) so that a
+// batch addresses its slots with immediate offsets.  Same slot-ordered FMA chain per (row, v):
+// bit-exact.  Tiles without a row list (footprint too large for LDS) gather from global memory.
+// HS = 2 (C = 32, rows of >= 64 bytes): 32-row tiles, two lanes per row with half of the B columns each --
+// half the LDS per tile, so twice the tiles per CU to overlap one tile's staging with another's arithmetic.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_cvoid_t;
+
+template <typename VT, int B, bool NT, bool YCOL, int G, int C, int HS>
+__global__ void __launch_bounds__(64) scs_spmmv_tlc(const long n_chunks, const int *__restrict__ chunk_ptrs,
+        const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const VT *__restrict__ values,
+        const VT *__restrict__ X, VT *__restrict__ Y, const long ld, const int *__restrict__ tile_line_ptr,
+        const int *__restrict__ tile_xrows, const unsigned *__restrict__ c16_ptrs,
+        const unsigned short *__restrict__ col16, const long x_rows, const int xcd_remap, const long n_store, const int x_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tlc_smem[];
+    constexpr int VW = 16 / (int)sizeof(VT);  // elements per 16-byte piece
+    constexpr int NV = B / VW;                // pieces per X row (1, 2, 4, 8)
+    constexpr int NVS = NV == 1 ? 0 : NV == 2 ? 1 : NV == 4 ? 2 : 3;
+    constexpr int SWS = 4 - NVS;              // rows 2^SWS apart start on the same bank
+    constexpr int NB = 4;                     // register batches in flight
+    typedef VT vec_t __attribute__((ext_vector_type(VW)));
+    typedef unsigned long long u64;
+    const vec_t *xs = (const vec_t *)tlc_smem;
+    const unsigned tile = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+    const int lp0 = tile_line_ptr[tile];
+    const int nl = tile_line_ptr[tile + 1] - lp0;
+    const int lane = threadIdx.x;
+    // HS = 2: two lanes per row (lane and lane + 32), each owning half of the row's B columns; a tile is 32 rows
+    constexpr int NVH = NV / HS;              // 16-byte pieces of an X row per lane
+    constexpr int BH = B / HS;                // accumulators per lane
+    const int h = HS == 2 ? lane >> 5 : 0;
+    const long row = (long)tile * (64 / HS) + (HS == 2 ? lane & 31 : lane);
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    const bool valid = c < n_chunks;
+    int cs = 0, L = 0;
+    unsigned q0 = 0;
+    if (valid) { cs = chunk_ptrs[c]; L = chunk_lengths[c]; q0 = c16_ptrs[c]; }
+    VT acc[BH];
+#pragma unroll
+    for (int v = 0; v < BH; ++v) acc[v] = VT(0);
+    const VT *vp = values + (long)cs + i;
+    auto fma_row = [&](const VT a, const vec_t *xp, const unsigned sw) {
+#pragma unroll
+        for (int k = 0; k < NVH; ++k) {
+            const vec_t xv = xp[(unsigned)(k + h * NVH) ^ sw];
+#pragma unroll
+            for (int w = 0; w < VW; ++w) acc[k * VW + w] = fma_t(a, xv[w], acc[k * VW + w]);
+        }
+    };
+    auto fma_local = [&](const VT a, const unsigned local) {
+        fma_row(a, xs + local * NV, NV > 1 ? (local >> SWS) & (NV - 1) : 0u);
+    };
+    if (nl > 0) {
+        const u64 *cq = (const u64 *)(col16 + q0) + i;
+        int Lmin = L, Lmax = L;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { Lmin = min(Lmin, __shfl_xor(Lmin, o, 64)); Lmax = max(Lmax, __shfl_xor(Lmax, o, 64)); }
+        Lmin = __builtin_amdgcn_readfirstlane(Lmin);
+        Lmax = __builtin_amdgcn_readfirstlane(Lmax);
+        const int ngf = Lmin >> 2;            // groups of four slots every lane of the wave has in full
+        const int nbt = ngf / G;              // register batches
+        // ---- 1. the tile's row list -> LDS (behind the X rows), by DMA as well: one latency, no registers
+        const int np = nl << NVS;
+        int *rl = (int *)(tlc_smem + x_bytes);
+#pragma unroll 1
+        for (int r0 = 0; r0 < nl; r0 += 64)
+            if (r0 + lane < nl)
+                __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(tile_xrows + lp0 + r0 + lane), (lds_void_t *)(rl + r0), 4, 0, 0);
+        __syncthreads();                      // (drains the DMA: vmcnt(0) + barrier)
+        // ---- 2. matrix entries: up to NB batches requested before anything is waited for
+        auto load_batch = [&](const int bi, VT (&a)[4 * G], u64 (&q)[G]) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const long gg = (long)bi * G + g;
+                q[g] = ld_stream<NT>(cq + gg * C);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[4 * g + u] = ld_stream<NT>(vp + (4 * gg + u) * C);
+            }
+        };
+        auto compute_batch = [&](const VT (&a)[4 * G], const u64 (&q)[G]) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    fma_local(a[4 * g + u], (unsigned)(q[g] >> (16 * u)) & 0xFFFFu);
+                    if (NV >= 8 || u == 3) __builtin_amdgcn_sched_barrier(0);   // at most 64 VGPRs of LDS reads ahead of their FMAs
+                }
+            }
+        };
+        VT a0[4 * G], a1[4 * G], a2[NB > 2 ? 4 * G : 1], a3[NB > 2 ? 4 * G : 1];
+        u64 qa[G], qb[G], qc[NB > 2 ? G : 1], qd[NB > 2 ? G : 1];
+        if (nbt > 0) load_batch(0, a0, qa);
+        if (nbt > 1) load_batch(1, a1, qb);
+        if constexpr (NB > 2) {
+            if (nbt > 2) load_batch(2, a2, qc);
+            if (nbt > 3) load_batch(3, a3, qd);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 3. X rows -> LDS by DMA: LDS position p = (row k, physical piece pp) takes logical piece pp ^ f(k)
+#pragma unroll 1
+        for (int t0 = 0; t0 * 64 < np; t0 += 8) {
+            int xr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = (t0 + u) * 64 + lane;
+                xr[u] = p < np ? rl[p >> NVS] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = (t0 + u) * 64 + lane;
+                if (p < np) {
+                    const unsigned k = (unsigned)p >> NVS;
+                    const unsigned piece = ((unsigned)p & (NV - 1)) ^ (NV > 1 ? (k >> SWS) & (NV - 1) : 0u);
+                    const VT *src = X + (long)xr[u] * B + piece * VW;
+                    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)src, (lds_void_t *)(tlc_smem + (t0 + u) * 1024), 16, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                      // drains the DMA (vmcnt) and the batches requested before it
+        for (int bi = 0; bi < nbt; bi += NB) {
+            compute_batch(a0, qa);
+            if (bi + NB < nbt) load_batch(bi + NB, a0, qa);
+            if (bi + 1 < nbt) { compute_batch(a1, qb); if (bi + 1 + NB < nbt) load_batch(bi + 1 + NB, a1, qb); }
+            if constexpr (NB > 2) {
+                if (bi + 2 < nbt) { compute_batch(a2, qc); if (bi + 2 + NB < nbt) load_batch(bi + 2 + NB, a2, qc); }
+                if (bi + 3 < nbt) { compute_batch(a3, qd); if (bi + 3 + NB < nbt) load_batch(bi + 3 + NB, a3, qd); }
+            }
+        }
+        for (int g = nbt * G; g < ngf; ++g) {  // full groups that do not fill a batch
+            const u64 q = ld_stream<NT>(cq + (long)g * C);
+            VT a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = ld_stream<NT>(vp + (long)(4 * g + u) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fma_local(a[u], (unsigned)(q >> (16 * u)) & 0xFFFFu);
+        }
+        const unsigned short *c16 = col16 + q0;
+        for (int j = 4 * ngf; j < Lmax; ++j)   // ragged rest: lanes past their chunk's length sit out
+            if (j < L) fma_local(ld_stream<NT>(vp + (long)j * C), c16[(long)(j >> 2) * 4 * C + i * 4 + (j & 3)]);
+    } else if (L > 0) {  // wide-footprint tile: 32-bit columns, X rows gathered from global memory
+        const int *cp = col_idxs + (long)cs + i;
+        for (int j = 0; j < L; ++j)
+            fma_row(ld_stream<NT>(vp + (long)j * C), (const vec_t *)(X + (long)ld_stream<NT>(cp + (long)j * C) * B), 0u);
+    }
+    if (!valid || row >= n_store) return;
+    if (YCOL) {
+#pragma unroll
+        for (int v = 0; v < BH; ++v) st_y<NT>(Y + (row + (long)(h * BH + v) * ld), acc[v]);
+    } else {
+        vec_t *yp = (vec_t *)(Y + row * B) + h * NVH;
+#pragma unroll
+        for (int k = 0; k < NVH; ++k) {
+            vec_t t;
+#pragma unroll
+            for (int w = 0; w < VW; ++w) t[w] = acc[k * VW + w];
+            yp[k] = t;
+        }
+    }
+}
+
+// colwise (b vectors of leading dimension ld) <-> row-major (n rows of B) re-layout, one lane per row
+template <typename VT, int B, bool TO_ROWMAJOR>
+__global__ void block_vector_relayout(const VT *__restrict__ in, VT *__restrict__ out, const long n, const long ld) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    if (TO_ROWMAJOR) {
+        VT t[B];
+#pragma unroll
+        for (int v = 0; v < B; ++v) t[v] = in[r + (long)v * ld];
+#pragma unroll
+        for (int v = 0; v < B; ++v) out[r * B + v] = t[v];
+    } else {
+        VT t[B];
+#pragma unroll
+        for (int v = 0; v < B; ++v) t[v] = in[r * B + v];
+#pragma unroll
+        for (int v = 0; v < B; ++v) out[r + (long)v * ld] = t[v];
+    }
+}
+
+template <typename VT, int VB>
+void launch_spmmv_vb(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int layout, hipStream_t st) {
+    const int block = g_tune.block;
+    const unsigned grid = grid_for(A->n_chunks * A->C, block);
+    const bool nt = g_tune.nontemporal != 0;
+#define SPMMV_LAUNCH(RW, NTV)                                                                                     \
+    hipLaunchKernelGGL((scs_spmmv_rows<VT, VB, RW, NTV>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks,      \
+                       (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, b, ld, \
+                       g_tune.xcd_remap)
+    if (layout == USPMV_ROWWISE) { if (nt) SPMMV_LAUNCH(true, true); else SPMMV_LAUNCH(true, false); }
+    else { if (nt) SPMMV_LAUNCH(false, true); else SPMMV_LAUNCH(false, false); }
+#undef SPMMV_LAUNCH
+}
+
+template <typename VT, int B, int U>
+void launch_spmmv_rowmajor_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    const int block = g_tune.block;
+    const unsigned grid = grid_for(A->n_chunks * A->C, block);
+#define RM_LAUNCH(NTV, YC)                                                                                          \
+    do {                                                                                                            \
+        if (g_tune.spmmv_prefetch)                                                                                  \
+            hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, NTV, YC, true>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
+                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
+                               g_tune.xcd_remap);                                                                   \
+        else                                                                                                        \
+            hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, NTV, YC, false>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
+                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
+                               g_tune.xcd_remap);                                                                   \
+    } while (0)
+    if (g_tune.nontemporal) { if (ycol) RM_LAUNCH(true, true); else RM_LAUNCH(true, false); }
+    else { if (ycol) RM_LAUNCH(false, true); else RM_LAUNCH(false, false); }
+#undef RM_LAUNCH
+}
+
+template <typename VT, int B, int U>
+void launch_spmmv_xpose_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    const int block = g_tune.block;
+    const unsigned grid = grid_for(A->n_chunks * A->C, block);
+#define XP_LAUNCH(NTV, YC)                                                                                          \
+    do {                                                                                                            \
+        if (g_tune.spmmv_prefetch)                                                                                  \
+            hipLaunchKernelGGL((scs_spmmv_xpose<VT, B, U, NTV, YC, true>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
+                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
+                               g_tune.xcd_remap);                                                                   \
+        else                                                                                                        \
+            hipLaunchKernelGGL((scs_spmmv_xpose<VT, B, U, NTV, YC, false>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
+                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
+                               g_tune.xcd_remap);                                                                   \
+    } while (0)
+    if (g_tune.nontemporal) { if (ycol) XP_LAUNCH(true, true); else XP_LAUNCH(true, false); }
+    else { if (ycol) XP_LAUNCH(false, true); else XP_LAUNCH(false, false); }
+#undef XP_LAUNCH
+}
+
+template <typename VT, int B, int G, int CT, int HS>
+void launch_spmmv_tlc_g(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    const size_t x_bytes = (size_t)A->bt_max_rows * B * sizeof(VT);
+    const size_t lds = x_bytes + (((size_t)A->bt_max_rows * 4 + 15) & ~(size_t)15);   // X rows + the tile's row list
+#define BT_LAUNCH(NTV, YC)                                                                                              \
+    do {                                                                                                                \
+        auto kfn = scs_spmmv_tlc<VT, B, NTV, YC, G, CT, HS>;                                                                \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)A->bt_n_tiles), dim3(64), lds, st, (long)A->n_chunks,                    \
+                           A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, A->bt_line_ptr, \
+                           A->bt_xrows, A->bt_c16_ptrs, A->bt_col16, ld, g_tune.xcd_remap, (long)A->n_store, (int)x_bytes); \
+    } while (0)
+    if (g_tune.nontemporal) { if (ycol) BT_LAUNCH(true, true); else BT_LAUNCH(true, false); }
+    else { if (ycol) BT_LAUNCH(false, true); else BT_LAUNCH(false, false); }
+#undef BT_LAUNCH
+}
+
+template <typename VT, int B>
+void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    constexpr int RB = B * (int)sizeof(VT);          // bytes per X row
+    if constexpr (RB >= 16 && RB <= 128) {
+        // block plan staged in LDS, if the handle carries one whose tiles fit this row width
+        // auto takes the plan for rows of <= 32 bytes only: there 4+ tiles fit a CU and the kernel is 12-15 % ahead of
+        // the gather form; with 64-byte rows (2-3 tiles per CU) each tile's chain of dependent fetches is exposed and
+        // it is 20 % behind (profiles/r01/spmmv_probe13.txt).  Variant 4 forces it.
+        if (A->bt && ((g_tune.spmmv_variant == 0 && RB <= 32) || g_tune.spmmv_variant == 4) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
+            if (A->bt_tile_rows == 32) {
+                if constexpr (RB >= 64) { launch_spmmv_tlc_g<VT, B, 4, 32, 2>(A, X, Y, ld, ycol, st); return; }
+            } else {
+                if (A->C == 32) launch_spmmv_tlc_g<VT, B, 4, 32, 1>(A, X, Y, ld, ycol, st);
+                else launch_spmmv_tlc_g<VT, B, 4, 64, 1>(A, X, Y, ld, ycol, st);
+                return;
+            }
+        }
+    }
+    if constexpr (RB >= 32) {                        // at least two 16-byte pieces per X row
+        if (g_tune.spmmv_variant == 2) {             // transposing X phase: 2-7 % over the plain lane-per-row loop,
+            int Up = g_tune.spmmv_unroll ? g_tune.spmmv_unroll : 4;         // level with its prefetching form (spmmv_probe7.txt)
+            if (g_tune.spmmv_prefetch && RB >= 64 && Up > 2) Up = 2;        // 4 prefetching slots of 64-byte rows spill
+            if (Up >= 4) launch_spmmv_xpose_u<VT, B, 4>(A, X, Y, ld, ycol, st);
+            else if (Up >= 2) launch_spmmv_xpose_u<VT, B, 2>(A, X, Y, ld, ycol, st);
+            else launch_spmmv_xpose_u<VT, B, 1>(A, X, Y, ld, ycol, st);
+            return;
+        }
+    }
+    // auto: 256 bytes of X rows per lane and batch (more spills the prefetching form at 128 VGPRs)
+    constexpr int UMAX = RB >= 128 ? 2 : RB >= 64 ? 4 : 8;
+    int U = g_tune.spmmv_unroll ? g_tune.spmmv_unroll : UMAX;
+    if (U > UMAX) U = UMAX;
+    if constexpr (UMAX >= 8) { if (U >= 8) { launch_spmmv_rowmajor_u<VT, B, 8>(A, X, Y, ld, ycol, st); return; } }
+    if constexpr (UMAX >= 4) { if (U >= 4) { launch_spmmv_rowmajor_u<VT, B, 4>(A, X, Y, ld, ycol, st); return; } }
+    if (U >= 2) launch_spmmv_rowmajor_u<VT, B, 2>(A, X, Y, ld, ycol, st);
+    else launch_spmmv_rowmajor_u<VT, B, 1>(A, X, Y, ld, ycol, st);
+}
+
+// B-specialised path: row-major kernel; column-major callers get X re-laid out once into the handle's
+// scratch and Y written column-major directly by the kernel.
+template <typename VT, int B>
+int spmmv_fast(const uspmv_dmat *A, const VT *X, VT *Y, long ld, int layout, hipStream_t st) {
+    if (layout == USPMV_ROWWISE) {
+        launch_spmmv_rowmajor<VT, B>(A, X, Y, ld, false, st);
+        return USPMV_OK;
+    }
+    const size_t need = sizeof(VT) * (size_t)B * (size_t)ld;
+    if (A->ws_bytes < need) {
+        if (A->ws) (void)hipFree(A->ws);
+        A->ws = nullptr; A->ws_bytes = 0;
+        hipError_t e = hipMalloc(&A->ws, need);
+        if (e != hipSuccess) return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_spmmv: workspace of %zu bytes: %s", need, hipGetErrorString(e));
+        A->ws_bytes = need;
+    }
+    VT *Xr = (VT *)A->ws;
+    hipLaunchKernelGGL((block_vector_relayout<VT, B, true>), dim3(grid_for(ld, 256)), dim3(256), 0, st, X, Xr, ld, ld);
+    launch_spmmv_rowmajor<VT, B>(A, Xr, Y, ld, true, st);
+    return USPMV_OK;
+}
+
+}  // namespace
+
+namespace uspmv_dev {
+
+template <typename VT>
+int launch_spmmv(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int layout, hipStream_t st) {
+    if (A->n_chunks == 0) return USPMV_OK;
+    int rc = -1;
+    if (g_tune.spmmv_variant != 1 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0)) {
+        constexpr int VW = 16 / (int)sizeof(VT);
+        switch (b) {
+            case 2: if (VW <= 2) rc = spmmv_fast<VT, 2>(A, X, Y, ld, layout, st); break;
+            case 4: rc = spmmv_fast<VT, 4>(A, X, Y, ld, layout, st); break;
+            case 8: rc = spmmv_fast<VT, 8>(A, X, Y, ld, layout, st); break;
+            case 16: rc = spmmv_fast<VT, 16>(A, X, Y, ld, layout, st); break;
+            default: break;
+        }
+    }
+    if (rc > 0) return rc;
+    if (rc < 0) {  // generic width / layout
+        if (b <= 1) launch_spmmv_vb<VT, 1>(A, X, Y, b, ld, layout, st);
+        else if (b <= 2) launch_spmmv_vb<VT, 2>(A, X, Y, b, ld, layout, st);
+        else if (b <= 4) launch_spmmv_vb<VT, 4>(A, X, Y, b, ld, layout, st);
+        else launch_spmmv_vb<VT, 8>(A, X, Y, b, ld, layout, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+template int launch_spmmv<double>(const uspmv_dmat *, const double *, double *, int, long, int, hipStream_t);
+template int launch_spmmv<float>(const uspmv_dmat *, const float *, float *, int, long, int, hipStream_t);
+
+}  // namespace uspmv_dev

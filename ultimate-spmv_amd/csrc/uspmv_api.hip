@@ -1,0 +1,666 @@
+// Device half of the C ABI (include/uspmv.h): handles, tuning, plans, GPU-side conversion, the small gather /
+// stream kernels and the entry points that dispatch into spmv_kernels.hip, spmmv_kernels.hip and ap_kernels.hip.
+#include "uspmv_device.hpp"
+
+using namespace uspmv_dev;
+
+namespace uspmv_dev {
+
+Tuning g_tune;
+
+int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        return uspmv::fail(USPMV_ERR_NO_DEVICE, "no HIP device is visible (hipGetDeviceCount: %s); "
+                           "libuspmv has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    }
+    return USPMV_OK;
+}
+
+int check_dmat(const uspmv_dmat *A, const char *who) {
+    if (!A) return uspmv::fail(USPMV_ERR_INVALID, "%s: NULL matrix", who);
+    if (A->C < 1 || A->n_chunks < 0) return uspmv::fail(USPMV_ERR_INVALID, "%s: corrupt matrix handle", who);
+    if (A->n_chunks * A->C > INT32_MAX) return uspmv::fail(USPMV_ERR_OVERFLOW, "%s: padded rows exceed int32", who);
+    return USPMV_OK;
+}
+
+
+}  // namespace uspmv_dev
+
+namespace {
+
+
+// COO -> SELL-C-sigma scatter of uspmv_convert_to_scs_device: one thread per COO entry k (entries sorted by
+// row, order inside a row preserved): slot = k - row_start[row], destination as convert_to_scs
+// (code/utilities.hpp:2013-2036).  perm != nullptr folds permute_scs_cols (:1802-1831) into the same pass.
+template <typename VT>
+__global__ void scs_fill_kernel(const long nnz, const int C, const int n_rows, const int *__restrict__ I,
+                                const int *__restrict__ J, const double *__restrict__ V,
+                                const int *__restrict__ row_start, const int *__restrict__ row_map,
+                                const int *__restrict__ perm, const int *__restrict__ chunk_ptrs,
+                                int *__restrict__ col_idxs, VT *__restrict__ values) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const int r = I[k];
+    const int slot = (int)(k - row_start[r]);
+    const int row = row_map[r];
+    const int c = row / C;
+    const long dst = (long)chunk_ptrs[c] + (long)slot * C + (row - c * C);
+    int col = J[k];
+    if (perm && col < n_rows) col = perm[col];
+    col_idxs[dst] = col;
+    values[dst] = (VT)V[k];
+}
+
+// out[i] = in[perm[idx ? idx[i] : i] + offset]   (pack_send_buf with idx, apply_permutation without)
+template <typename VT>
+__global__ void gather_kernel(VT *__restrict__ out, const VT *__restrict__ in, const int *__restrict__ perm,
+                              const int *__restrict__ idx, const long n, const long offset) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[(long)perm[idx ? idx[i] : (int)i] + offset];
+}
+
+// STREAM-style calibrators: 16 bytes per lane, grid-stride.
+__global__ void stream_copy_kernel(double2 *__restrict__ a, const double2 *__restrict__ b, const long n2) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) a[i] = b[i];
+}
+__global__ void stream_triad_kernel(double2 *__restrict__ a, const double2 *__restrict__ b,
+                                    const double2 *__restrict__ c, const double s, const long n2) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+        double2 bb = b[i], cc = c[i];
+        a[i] = make_double2(bb.x + s * cc.x, bb.y + s * cc.y);
+    }
+}
+__global__ void stream_read_kernel(const double2 *__restrict__ b, const long n2, double *__restrict__ partial) {
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+        const double *pb = (const double *)(b + i);
+        acc += __builtin_nontemporal_load(pb) + __builtin_nontemporal_load(pb + 1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) partial[((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6] = acc;
+}
+
+
+}  // namespace
+
+// ============================================================================================ C ABI
+extern "C" {
+
+int uspmv_device_count(int *count) {
+    if (!count) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_device_count: NULL argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return USPMV_OK;
+}
+
+int uspmv_set_device(int device) {
+    if (int rc = require_device()) return rc;
+    HIP_TRY(hipSetDevice(device));
+    return USPMV_OK;
+}
+
+int uspmv_stream_synchronize(void *stream) {
+    if (int rc = require_device()) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return USPMV_OK;
+}
+
+int uspmv_set_tuning(const char *key, int value) {
+    if (!key) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_set_tuning: NULL key");
+    if (!strcmp(key, "unroll")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8) return uspmv::fail(USPMV_ERR_INVALID, "unroll must be 1|2|4|8");
+        g_tune.unroll = value;
+    } else if (!strcmp(key, "nontemporal")) g_tune.nontemporal = value != 0;
+    else if (!strcmp(key, "xcd_remap")) {
+        if (value < 0 || value > 65536) return uspmv::fail(USPMV_ERR_INVALID, "xcd_remap must be 0, 1 or a group size <= 65536");
+        g_tune.xcd_remap = value;
+    } else if (!strcmp(key, "ablate")) g_tune.ablate = value;
+    else if (!strcmp(key, "spmmv_prefetch")) g_tune.spmmv_prefetch = value != 0;
+    else if (!strcmp(key, "spmmv_tile_rows")) g_tune.spmmv_tile_rows = value == 64 ? 64 : 0;
+    else if (!strcmp(key, "spmmv_lds_kb")) g_tune.spmmv_lds_kb = value < 0 ? 0 : value;
+    else if (!strcmp(key, "spmmv_variant")) {
+        if (value < 0 || value > 4) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0|1|2|3|4");
+        g_tune.spmmv_variant = value;
+    }
+    else if (!strcmp(key, "tail_batch")) g_tune.tail_batch = value != 0;
+    else if (!strcmp(key, "spmmv_unroll")) g_tune.spmmv_unroll = value;
+    else if (!strcmp(key, "tlc")) g_tune.tlc = value != 0;
+    else if (!strcmp(key, "rechunk")) g_tune.rechunk = value != 0;
+    else if (!strcmp(key, "tlc_tile_rows")) {
+        if (value != 256 && value != 512 && value != 1024) return uspmv::fail(USPMV_ERR_INVALID, "tlc_tile_rows must be 256|512|1024");
+        g_tune.tlc_tile_rows = value;
+    }
+    else if (!strcmp(key, "block")) {
+        if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
+            return uspmv::fail(USPMV_ERR_INVALID, "block must be 64|128|256|512|1024");
+        g_tune.block = value;
+    } else if (!strcmp(key, "spmv_variant")) {
+        if (value < 0 || value > 2) return uspmv::fail(USPMV_ERR_INVALID, "spmv_variant must be 0|1|2");
+        g_tune.spmv_variant = value;
+    } else if (!strcmp(key, "csr_lanes")) {
+        if (value < 0 || value > 64 || (value & (value - 1))) return uspmv::fail(USPMV_ERR_INVALID, "csr_lanes must be 0 or a power of two <= 64");
+        g_tune.csr_lanes = value;
+    } else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_set_tuning: unknown key '%s'", key);
+    return USPMV_OK;
+}
+
+int uspmv_get_tuning(const char *key, int *value) {
+    if (!key || !value) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_get_tuning: NULL argument");
+    if (!strcmp(key, "unroll")) *value = g_tune.unroll;
+    else if (!strcmp(key, "nontemporal")) *value = g_tune.nontemporal;
+    else if (!strcmp(key, "xcd_remap")) *value = g_tune.xcd_remap;
+    else if (!strcmp(key, "block")) *value = g_tune.block;
+    else if (!strcmp(key, "spmv_variant")) *value = g_tune.spmv_variant;
+    else if (!strcmp(key, "csr_lanes")) *value = g_tune.csr_lanes;
+    else if (!strcmp(key, "ablate")) *value = g_tune.ablate;
+    else if (!strcmp(key, "spmmv_prefetch")) *value = g_tune.spmmv_prefetch;
+    else if (!strcmp(key, "spmmv_tile_rows")) *value = g_tune.spmmv_tile_rows;
+    else if (!strcmp(key, "spmmv_lds_kb")) *value = g_tune.spmmv_lds_kb;
+    else if (!strcmp(key, "spmmv_variant")) *value = g_tune.spmmv_variant;
+    else if (!strcmp(key, "tail_batch")) *value = g_tune.tail_batch;
+    else if (!strcmp(key, "spmmv_unroll")) *value = g_tune.spmmv_unroll;
+    else if (!strcmp(key, "tlc")) *value = g_tune.tlc;
+    else if (!strcmp(key, "rechunk")) *value = g_tune.rechunk;
+    else if (!strcmp(key, "tlc_tile_rows")) *value = g_tune.tlc_tile_rows;
+    else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_get_tuning: unknown key '%s'", key);
+    return USPMV_OK;
+}
+
+int uspmv_dmat_upload(const uspmv_scs_t *s, uspmv_dmat_t **out) {
+    if (!s || !out) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_upload: NULL argument");
+    if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_upload: layout-only struct (its entries already live on the device)");
+    if (int rc = require_device()) return rc;
+    auto *A = new uspmv_dmat;
+    A->C = s->C; A->n_chunks = s->n_chunks; A->n_elements = s->n_elements; A->dtype = s->dtype; A->owns = true;
+    A->n_store = (long)(s->n_chunks * s->C);
+    const size_t vsz = s->dtype == USPMV_F64 ? 8 : 4;
+    void *cp = nullptr, *cl = nullptr, *ci = nullptr, *va = nullptr;
+    const size_t ne = (size_t)std::max<int64_t>(s->n_elements, 1);
+    hipError_t e;
+    if ((e = hipMalloc(&cp, sizeof(int32_t) * (size_t)(s->n_chunks + 1))) != hipSuccess ||
+        (e = hipMalloc(&cl, sizeof(int32_t) * (size_t)std::max<int64_t>(s->n_chunks, 1))) != hipSuccess ||
+        (e = hipMalloc(&ci, sizeof(int32_t) * ne)) != hipSuccess || (e = hipMalloc(&va, vsz * ne)) != hipSuccess) {
+        (void)hipFree(cp); (void)hipFree(cl); (void)hipFree(ci); (void)hipFree(va);
+        delete A;
+        return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_upload: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    A->chunk_ptrs = (const int32_t *)cp; A->chunk_lengths = (const int32_t *)cl;
+    A->col_idxs = (const int32_t *)ci; A->values = va;
+    e = hipMemcpy(cp, s->chunk_ptrs.data(), sizeof(int32_t) * (size_t)(s->n_chunks + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(cl, s->chunk_lengths.data(), sizeof(int32_t) * (size_t)s->n_chunks, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ci, s->col_idxs.data(), sizeof(int32_t) * (size_t)s->n_elements, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(va, s->values_ptr(), vsz * (size_t)s->n_elements, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        uspmv_dmat_free(A);
+        return uspmv::fail(USPMV_ERR_HIP, "uspmv_dmat_upload: hipMemcpy failed: %s", hipGetErrorString(e));
+    }
+    *out = A;
+    return USPMV_OK;
+}
+
+int uspmv_dmat_wrap(int64_t C, int64_t n_chunks, int64_t n_elements, int dtype, const int32_t *d_chunk_ptrs,
+                    const int32_t *d_chunk_lengths, const int32_t *d_col_idxs, const void *d_values,
+                    uspmv_dmat_t **out) {
+    if (!out || C < 1 || n_chunks < 0 || n_elements < 0 || (dtype != USPMV_F64 && dtype != USPMV_F32) ||
+        !d_chunk_ptrs || (n_chunks > 0 && !d_chunk_lengths) || (n_elements > 0 && (!d_col_idxs || !d_values)))
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_wrap: bad argument");
+    auto *A = new uspmv_dmat;
+    A->C = C; A->n_chunks = n_chunks; A->n_elements = n_elements; A->dtype = dtype; A->n_store = (long)(n_chunks * C);
+    A->chunk_ptrs = d_chunk_ptrs; A->chunk_lengths = d_chunk_lengths; A->col_idxs = d_col_idxs; A->values = d_values;
+    A->owns = false;
+    *out = A;
+    return USPMV_OK;
+}
+
+int uspmv_convert_to_scs_device(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dtype, const int32_t *fixed_permutation,
+                                int permute_cols, uspmv_scs_t **layout, uspmv_dmat_t **out) {
+    if (!m || !layout || !out) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_convert_to_scs_device: NULL argument");
+    if (int rc = require_device()) return rc;
+    auto *s = new uspmv_scs;
+    std::vector<int64_t> row_start;
+    if (int rc = uspmv_scs_layout(m, C, sigma, dtype, fixed_permutation, s, &row_start, "uspmv_convert_to_scs_device")) { delete s; return rc; }
+    if (row_start.empty() && m->nnz > 0) {
+        delete s;
+        return uspmv::fail(USPMV_ERR_UNSUPPORTED, "uspmv_convert_to_scs_device: COO entries must be sorted by row "
+                                                  "(uspmv_read_mtx and the generators produce that order)");
+    }
+    if (m->nnz > INT32_MAX) { delete s; return uspmv::fail(USPMV_ERR_OVERFLOW, "uspmv_convert_to_scs_device: nnz exceeds int32"); }
+    std::vector<int32_t> rs32(row_start.begin(), row_start.end());
+    const int32_t *row_map = fixed_permutation ? fixed_permutation : s->old_to_new_idx.data();
+    auto *A = new uspmv_dmat;
+    A->C = s->C; A->n_chunks = s->n_chunks; A->n_elements = s->n_elements; A->dtype = dtype; A->owns = true;
+    A->n_store = (long)(s->n_chunks * s->C);
+    const size_t vsz = dtype == USPMV_F64 ? 8 : 4;
+    const size_t ne = (size_t)std::max<int64_t>(s->n_elements, 1), nz = (size_t)std::max<int64_t>(m->nnz, 1);
+    void *cp = nullptr, *cl = nullptr, *ci = nullptr, *va = nullptr;
+    int32_t *dI = nullptr, *dJ = nullptr, *drs = nullptr, *dmap = nullptr, *dperm = nullptr;
+    double *dV = nullptr;
+    hipError_t e = hipSuccess;
+    auto up = [&](const void *h, size_t bytes, void **d) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(d, bytes ? bytes : 4);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+    };
+    up(s->chunk_ptrs.data(), 4 * s->chunk_ptrs.size(), &cp);
+    up(s->chunk_lengths.data(), 4 * s->chunk_lengths.size(), &cl);
+    if (e == hipSuccess) e = hipMalloc(&ci, 4 * ne);
+    if (e == hipSuccess) e = hipMalloc(&va, vsz * ne);
+    // padding: value 0, column 0 -- which permute_scs_cols maps like any other local column (code/utilities.hpp:1820-1826)
+    const int pad_col = (permute_cols && m->n_rows > 0) ? s->old_to_new_idx[0] : 0;
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)ci, pad_col, ne, nullptr);
+    if (e == hipSuccess) e = hipMemsetAsync(va, 0, vsz * ne, nullptr);
+    up(m->I.data(), 4 * (size_t)m->nnz, (void **)&dI);
+    up(m->J.data(), 4 * (size_t)m->nnz, (void **)&dJ);
+    up(m->values.data(), 8 * (size_t)m->nnz, (void **)&dV);
+    up(rs32.data(), 4 * rs32.size(), (void **)&drs);
+    up(row_map, 4 * (size_t)m->n_rows, (void **)&dmap);
+    if (permute_cols) up(s->old_to_new_idx.data(), 4 * (size_t)m->n_rows, (void **)&dperm);
+    A->chunk_ptrs = (const int32_t *)cp; A->chunk_lengths = (const int32_t *)cl; A->col_idxs = (const int32_t *)ci; A->values = va;
+    if (e == hipSuccess && m->nnz > 0) {
+        const unsigned grid = (unsigned)((nz + 255) / 256);
+        if (dtype == USPMV_F64)
+            hipLaunchKernelGGL(scs_fill_kernel<double>, dim3(grid), dim3(256), 0, nullptr, (long)m->nnz, (int)C, (int)m->n_rows, dI, dJ, dV,
+                               drs, dmap, dperm, (const int *)cp, (int *)ci, (double *)va);
+        else
+            hipLaunchKernelGGL(scs_fill_kernel<float>, dim3(grid), dim3(256), 0, nullptr, (long)m->nnz, (int)C, (int)m->n_rows, dI, dJ, dV,
+                               drs, dmap, dperm, (const int *)cp, (int *)ci, (float *)va);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    (void)hipFree(dI); (void)hipFree(dJ); (void)hipFree(dV); (void)hipFree(drs); (void)hipFree(dmap); (void)hipFree(dperm);
+    if (e != hipSuccess) {
+        uspmv_dmat_free(A); delete s;
+        return uspmv::fail(USPMV_ERR_HIP, "uspmv_convert_to_scs_device: %s", hipGetErrorString(e));
+    }
+    *layout = s;
+    *out = A;
+    return USPMV_OK;
+}
+
+int uspmv_dmat_download(const uspmv_dmat_t *A, int32_t *chunk_ptrs, int32_t *chunk_lengths, int32_t *col_idxs, void *values) {
+    if (int rc = check_dmat(A, "uspmv_dmat_download")) return rc;
+    if (int rc = require_device()) return rc;
+    const size_t vsz = A->dtype == USPMV_F64 ? 8 : 4;
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && chunk_ptrs) e = hipMemcpy(chunk_ptrs, A->chunk_ptrs, 4 * (size_t)(A->n_chunks + 1), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && chunk_lengths) e = hipMemcpy(chunk_lengths, A->chunk_lengths, 4 * (size_t)A->n_chunks, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && col_idxs) e = hipMemcpy(col_idxs, A->col_idxs, 4 * (size_t)A->n_elements, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && values) e = hipMemcpy(values, A->values, vsz * (size_t)A->n_elements, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return uspmv::fail(USPMV_ERR_HIP, "uspmv_dmat_download: %s", hipGetErrorString(e));
+    return USPMV_OK;
+}
+
+static void tlc_release(uspmv_dmat_t *A) {
+    (void)hipFree(A->tlc_line_ptr); (void)hipFree(A->tlc_lines); (void)hipFree(A->tlc_c16_ptrs); (void)hipFree(A->tlc_col16);
+    A->tlc_line_ptr = A->tlc_lines = nullptr; A->tlc_c16_ptrs = nullptr; A->tlc_col16 = nullptr;
+    A->tlc = false; A->tlc_plan_id = 0;
+}
+
+int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
+    if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: NULL argument");
+    if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: layout-only struct; the plan builder needs the host column indices");
+    if (A->C != s->C || A->n_chunks != s->n_chunks || A->dtype != s->dtype)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: handle and host struct do not describe the same matrix");
+    if (int rc = require_device()) return rc;
+    if (A->tlc) tlc_release(A);
+    if (A->alt) { uspmv_dmat_free(A->alt); A->alt = nullptr; }
+    if (s->C < 32 && 32 % s->C == 0 && g_tune.rechunk) {
+        // narrow chunks (incl. crs = C 1): run on an internal C = 32 re-chunking with the same row order
+        uspmv_scs r;
+        int rc = uspmv_scs_rechunk32(s, &r);
+        if (rc == USPMV_OK && (double)r.n_elements <= 1.25 * (double)std::max<int64_t>(s->n_elements, 1) + 4096) {
+            uspmv_dmat_t *alt = nullptr;
+            if (int rc2 = uspmv_dmat_upload(&r, &alt)) return rc2;
+            alt->n_store = (long)(s->n_chunks * s->C);      // y of the caller has only the original padded rows
+            g_tune.rechunk = 0;                             // (no recursion)
+            rc = uspmv_dmat_optimize(alt, &r, max_lines, n_tiles, n_staged);
+            g_tune.rechunk = 1;
+            if (rc) { uspmv_dmat_free(alt); return rc; }
+            A->alt = alt;
+            return USPMV_OK;
+        }
+    }
+    if (max_lines <= 0) max_lines = 512;                       // 64 KiB of doubles: 2 workgroups per CU at worst
+    const int cap = (int)(160 * 1024 / (16 * (s->dtype == USPMV_F64 ? 8 : 4)));
+    if (max_lines > cap) max_lines = cap;
+    uspmv_tlc_plan p;
+    if (int rc = uspmv_build_tlc_plan(s, nullptr, max_lines, g_tune.tlc_tile_rows, &p)) return rc;
+    if (n_tiles) *n_tiles = p.n_tiles;
+    if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
+    if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] tlc plan: tile_rows=%d tiles=%lld staged=%lld max_lines=%d lines_total=%zu col16=%zu\n",
+                                         p.tile_rows, (long long)p.n_tiles, (long long)p.n_staged_tiles, p.max_lines_used, p.tile_lines.size(), p.col16.size());
+    if (!p.valid) return USPMV_OK;                              // nothing worth staging: plain kernel stays
+    auto up = [&](const void *h, size_t bytes, void **d) -> hipError_t {
+        hipError_t e = hipMalloc(d, bytes ? bytes : 4);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(p.tile_line_ptr.data(), p.tile_line_ptr.size() * 4, (void **)&A->tlc_line_ptr);
+    if (e == hipSuccess) e = up(p.tile_lines.data(), p.tile_lines.size() * 4, (void **)&A->tlc_lines);
+    if (e == hipSuccess) e = up(p.c16_ptrs.data(), p.c16_ptrs.size() * 4, (void **)&A->tlc_c16_ptrs);
+    if (e == hipSuccess) e = up(p.col16.data(), p.col16.size() * 2, (void **)&A->tlc_col16);
+    if (e != hipSuccess) {
+        tlc_release(A);
+        return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize: device copy failed: %s", hipGetErrorString(e));
+    }
+    A->tlc = true; A->tlc_tile_rows = p.tile_rows; A->tlc_max_lines = p.max_lines_used; A->tlc_x_len = p.x_len_min; A->tlc_n_tiles = p.n_tiles;
+    A->tlc_staged = p.n_staged_tiles;
+    return USPMV_OK;
+}
+
+static void bt_release(uspmv_dmat_t *A) {
+    (void)hipFree(A->bt_line_ptr); (void)hipFree(A->bt_xrows); (void)hipFree(A->bt_c16_ptrs); (void)hipFree(A->bt_col16);
+    A->bt_line_ptr = A->bt_xrows = nullptr; A->bt_c16_ptrs = nullptr; A->bt_col16 = nullptr;
+    A->bt = false;
+}
+
+int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_vec_size, int64_t *n_tiles, int64_t *n_staged) {
+    if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: NULL argument");
+    if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: layout-only struct; the plan builder needs the host column indices");
+    if (A->C != s->C || A->n_chunks != s->n_chunks || A->dtype != s->dtype)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: handle and host struct do not describe the same matrix");
+    if (block_vec_size < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: block_vec_size must be >= 1");
+    if (int rc = require_device()) return rc;
+    if (A->bt) bt_release(A);
+    if (n_tiles) *n_tiles = 0;
+    if (n_staged) *n_staged = 0;
+    const size_t row_bytes = (size_t)block_vec_size * (s->dtype == USPMV_F64 ? 8 : 4);
+    // only the 16-byte-piece kernels (b*sizeof(VT) in {16,32,64,128}) read the plan, compiled for C = 32 and 64
+    if (row_bytes % 16 != 0 || (row_bytes & (row_bytes - 1)) != 0 || row_bytes > 128 || (s->C != 32 && s->C != 64)) return USPMV_OK;
+    const size_t cap = g_tune.spmmv_lds_kb > 0 ? std::min<size_t>((size_t)g_tune.spmmv_lds_kb * 1024, BT_LDS_CAP) : BT_LDS_CAP;
+    const int max_rows = (int)(cap / row_bytes);
+    // rows of >= 64 bytes on C = 32: 32-row tiles, two lanes per row (half the LDS per tile, twice the tiles per CU)
+    const int tile_rows = (s->C == 32 && row_bytes >= 64 && g_tune.spmmv_tile_rows != 64) ? 32 : 64;
+    uspmv_tlc_plan p;
+    if (int rc = uspmv_build_tlc_plan(s, nullptr, max_rows, tile_rows, &p, /*line_shift=*/0)) return rc;
+    if (n_tiles) *n_tiles = p.n_tiles;
+    if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
+    if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] block plan: b=%d tile_rows=%d tiles=%lld staged=%lld max_rows=%d (cap %d) rows_total=%zu\n",
+                                         block_vec_size, p.tile_rows, (long long)p.n_tiles, (long long)p.n_staged_tiles, p.max_lines_used, max_rows, p.tile_lines.size());
+    if (!p.valid) return USPMV_OK;
+    auto up = [&](const void *h, size_t bytes, void **d) -> hipError_t {
+        hipError_t e = hipMalloc(d, bytes ? bytes : 4);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(p.tile_line_ptr.data(), p.tile_line_ptr.size() * 4, (void **)&A->bt_line_ptr);
+    if (e == hipSuccess) e = up(p.tile_lines.data(), p.tile_lines.size() * 4, (void **)&A->bt_xrows);
+    if (e == hipSuccess) e = up(p.c16_ptrs.data(), p.c16_ptrs.size() * 4, (void **)&A->bt_c16_ptrs);
+    if (e == hipSuccess) e = up(p.col16.data(), p.col16.size() * 2, (void **)&A->bt_col16);
+    if (e != hipSuccess) {
+        bt_release(A);
+        return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_block: device copy failed: %s", hipGetErrorString(e));
+    }
+    A->bt = true; A->bt_tile_rows = p.tile_rows; A->bt_max_rows = p.max_lines_used; A->bt_n_tiles = p.n_tiles; A->bt_staged = p.n_staged_tiles;
+    return USPMV_OK;
+}
+
+int uspmv_dmat_optimize_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t *s_dp, const uspmv_scs_t *s_sp,
+                           int max_lines, int64_t *n_tiles, int64_t *n_staged) {
+    if (!dp || !sp || !s_dp || !s_sp) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_ap: NULL argument");
+    if (!uspmv::scs_has_entries(s_dp) || !uspmv::scs_has_entries(s_sp))
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_ap: layout-only struct; the plan builder needs the host column indices");
+    if (dp->C != s_dp->C || dp->n_chunks != s_dp->n_chunks || dp->dtype != USPMV_F64 || s_dp->dtype != USPMV_F64 ||
+        sp->C != s_sp->C || sp->n_chunks != s_sp->n_chunks || sp->dtype != USPMV_F32 || s_sp->dtype != USPMV_F32 ||
+        dp->C != sp->C || dp->n_chunks != sp->n_chunks)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_ap: handles / host structs do not form a dp+sp pair");
+    if (int rc = require_device()) return rc;
+    if (dp->tlc) tlc_release(dp);
+    if (sp->tlc) tlc_release(sp);
+    if (max_lines <= 0) max_lines = 512;
+    if (max_lines > 1280) max_lines = 1280;
+    uspmv_tlc_plan p;
+    if (int rc = uspmv_build_tlc_plan(s_dp, s_sp, max_lines, g_tune.tlc_tile_rows, &p)) return rc;
+    if (n_tiles) *n_tiles = p.n_tiles;
+    if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
+    if (!p.valid) return USPMV_OK;
+    auto up = [&](const void *h, size_t bytes, void **d) -> hipError_t {
+        hipError_t e = hipMalloc(d, bytes ? bytes : 4);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(p.tile_line_ptr.data(), p.tile_line_ptr.size() * 4, (void **)&dp->tlc_line_ptr);
+    if (e == hipSuccess) e = up(p.tile_lines.data(), p.tile_lines.size() * 4, (void **)&dp->tlc_lines);
+    if (e == hipSuccess) e = up(p.c16_ptrs.data(), p.c16_ptrs.size() * 4, (void **)&dp->tlc_c16_ptrs);
+    if (e == hipSuccess) e = up(p.col16.data(), p.col16.size() * 2, (void **)&dp->tlc_col16);
+    if (e == hipSuccess) e = up(p.c16_ptrs_b.data(), p.c16_ptrs_b.size() * 4, (void **)&sp->tlc_c16_ptrs);
+    if (e == hipSuccess) e = up(p.col16_b.data(), p.col16_b.size() * 2, (void **)&sp->tlc_col16);
+    if (e != hipSuccess) {
+        tlc_release(dp); tlc_release(sp);
+        return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_ap: device copy failed: %s", hipGetErrorString(e));
+    }
+    static uint64_t next_plan_id = 1;
+    const uint64_t id = next_plan_id++;
+    for (uspmv_dmat_t *A : {dp, sp}) {
+        A->tlc = true; A->tlc_tile_rows = p.tile_rows; A->tlc_max_lines = p.max_lines_used; A->tlc_x_len = p.x_len_min;
+        A->tlc_n_tiles = p.n_tiles; A->tlc_staged = p.n_staged_tiles; A->tlc_plan_id = id;
+    }
+    return USPMV_OK;
+}
+
+void uspmv_dmat_free(uspmv_dmat_t *A) {
+    if (!A) return;
+    if (A->alt) { uspmv_dmat_free(A->alt); A->alt = nullptr; }
+    if (A->tlc) tlc_release(A);
+    if (A->bt) bt_release(A);
+    if (A->ws) (void)hipFree(A->ws);
+    if (A->owns) {
+        (void)hipFree((void *)A->chunk_ptrs); (void)hipFree((void *)A->chunk_lengths);
+        (void)hipFree((void *)A->col_idxs); (void)hipFree((void *)A->values);
+    }
+    delete A;
+}
+
+int uspmv_dmat_set_crs(uspmv_dmat_t *A, int on) {
+    if (!A) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_set_crs: NULL matrix");
+    if (on && A->C != 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_set_crs: crs needs C = 1 (got %lld)", (long long)A->C);
+    A->crs = on != 0;
+    return USPMV_OK;
+}
+
+int uspmv_spmv(const uspmv_dmat_t *A, const void *d_x, void *d_y, void *stream) {
+    if (int rc = check_dmat(A, "uspmv_spmv")) return rc;
+    if (!d_x || !d_y) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv: NULL vector");
+    if (int rc = require_device()) return rc;
+    if (A->alt && g_tune.tlc && g_tune.rechunk && g_tune.spmv_variant == 0 && !g_tune.ablate) {
+        if (A->dtype == USPMV_F64) return launch_spmv_scs<double>(A->alt, nullptr, 0, (const double *)d_x, (double *)d_y, (hipStream_t)stream);
+        return launch_spmv_scs<float>(A->alt, nullptr, 0, (const float *)d_x, (float *)d_y, (hipStream_t)stream);
+    }
+    if (A->crs) {
+        if (A->dtype == USPMV_F64)
+            return launch_csr<double>((long)A->n_chunks, (long)A->n_elements, A->chunk_ptrs, A->col_idxs,
+                                      (const double *)A->values, (const double *)d_x, (double *)d_y, (hipStream_t)stream);
+        return launch_csr<float>((long)A->n_chunks, (long)A->n_elements, A->chunk_ptrs, A->col_idxs,
+                                 (const float *)A->values, (const float *)d_x, (float *)d_y, (hipStream_t)stream);
+    }
+    if (A->dtype == USPMV_F64) return launch_spmv_scs<double>(A, nullptr, 0, (const double *)d_x, (double *)d_y, (hipStream_t)stream);
+    return launch_spmv_scs<float>(A, nullptr, 0, (const float *)d_x, (float *)d_y, (hipStream_t)stream);
+}
+
+int uspmv_spmv_chunks(const uspmv_dmat_t *A, const int32_t *d_chunk_ids, int64_t n_ids, const void *d_x, void *d_y,
+                      void *stream) {
+    if (int rc = check_dmat(A, "uspmv_spmv_chunks")) return rc;
+    if (n_ids < 0 || n_ids > A->n_chunks || (n_ids > 0 && !d_chunk_ids) || !d_x || !d_y)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_chunks: bad argument");
+    if (int rc = require_device()) return rc;
+    if (n_ids == 0) return USPMV_OK;
+    if (A->dtype == USPMV_F64) return launch_spmv_scs<double>(A, d_chunk_ids, n_ids, (const double *)d_x, (double *)d_y, (hipStream_t)stream);
+    return launch_spmv_scs<float>(A, d_chunk_ids, n_ids, (const float *)d_x, (float *)d_y, (hipStream_t)stream);
+}
+
+int uspmv_spmv_tiles(const uspmv_dmat_t *A, const int32_t *d_tile_ids, int64_t n_ids, const void *d_x, void *d_y,
+                     void *stream) {
+    if (int rc = check_dmat(A, "uspmv_spmv_tiles")) return rc;
+    if (!A->tlc || A->tlc_plan_id != 0) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_tiles: handle has no tile-local-column plan (uspmv_dmat_optimize)");
+    if (n_ids < 0 || n_ids > A->tlc_n_tiles || (n_ids > 0 && !d_tile_ids) || !d_x || !d_y)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_tiles: bad argument");
+    if ((uintptr_t)d_x % 16) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_tiles: x must be 16-byte aligned");
+    if (int rc = require_device()) return rc;
+    if (A->dtype == USPMV_F64) return launch_spmv_tlc<double>(A, d_tile_ids, (long)n_ids, (const double *)d_x, (double *)d_y, (hipStream_t)stream);
+    return launch_spmv_tlc<float>(A, d_tile_ids, (long)n_ids, (const float *)d_x, (float *)d_y, (hipStream_t)stream);
+}
+
+int uspmv_dmat_tile_rows(const uspmv_dmat_t *A, int *tile_rows) {
+    if (!A || !tile_rows) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_tile_rows: NULL argument");
+    *tile_rows = A->tlc ? A->tlc_tile_rows : 0;
+    return USPMV_OK;
+}
+
+int uspmv_spmmv(const uspmv_dmat_t *A, const void *d_X, void *d_Y, int b, int64_t ld, int layout, void *stream) {
+    if (int rc = check_dmat(A, "uspmv_spmmv")) return rc;
+    if (!d_X || !d_Y || b < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmmv: bad argument");
+    if (layout != USPMV_COLWISE && layout != USPMV_ROWWISE) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmmv: unknown layout %d", layout);
+    if (layout == USPMV_COLWISE && ld < A->n_chunks * A->C)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmmv: ld=%lld smaller than n_rows_padded=%lld", (long long)ld,
+                           (long long)(A->n_chunks * A->C));
+    if (int rc = require_device()) return rc;
+    if (A->dtype == USPMV_F64) return launch_spmmv<double>(A, (const double *)d_X, (double *)d_Y, b, (long)ld, layout, (hipStream_t)stream);
+    return launch_spmmv<float>(A, (const float *)d_X, (float *)d_Y, b, (long)ld, layout, (hipStream_t)stream);
+}
+
+static int spmv_ap_impl(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const double *d_x, const float *d_x_sp,
+                        double *d_y, void *stream, const char *who) {
+    if (int rc = check_dmat(dp, who)) return rc;
+    if (int rc = check_dmat(sp, who)) return rc;
+    if (dp->dtype != USPMV_F64 || sp->dtype != USPMV_F32)
+        return uspmv::fail(USPMV_ERR_INVALID, "%s: expects a double and a float struct", who);
+    if (dp->C != sp->C || dp->n_chunks != sp->n_chunks)
+        return uspmv::fail(USPMV_ERR_INVALID, "%s: dp and sp structs must share C and n_chunks", who);
+    if (!d_x || !d_y) return uspmv::fail(USPMV_ERR_INVALID, "%s: NULL vector", who);
+    if (int rc = require_device()) return rc;
+    if (dp->n_chunks == 0) return USPMV_OK;
+    return launch_spmv_ap(dp, sp, d_x, d_x_sp, d_y, (hipStream_t)stream);
+}
+
+int uspmv_spmv_ap(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const double *d_x, double *d_y, void *stream) {
+    return spmv_ap_impl(dp, sp, d_x, nullptr, d_y, stream, "uspmv_spmv_ap");
+}
+
+int uspmv_spmv_ap_generic(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const double *d_x, const float *d_x_sp,
+                          double *d_y, void *stream) {
+    if (!d_x_sp) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmv_ap_generic: NULL float x");
+    return spmv_ap_impl(dp, sp, d_x, d_x_sp, d_y, stream, "uspmv_spmv_ap_generic");
+}
+
+#define RAW_SCS(SUF, VT, DT)                                                                                        \
+    int uspmv_scs_gpu_##SUF(int64_t C, int64_t n_chunks, const int32_t *cp, const int32_t *cl, const int32_t *ci,   \
+                            const VT *va, const VT *x, VT *y, void *stream) {                                       \
+        if (C < 1 || n_chunks < 0 || !cp || (n_chunks > 0 && (!cl || !ci || !va || !x || !y)))                      \
+            return uspmv::fail(USPMV_ERR_INVALID, "uspmv_scs_gpu_" #SUF ": bad argument");                          \
+        if (int rc = require_device()) return rc;                                                                   \
+        uspmv_dmat A;                                                                                               \
+        A.C = C; A.n_chunks = n_chunks; A.dtype = DT; A.chunk_ptrs = cp; A.chunk_lengths = cl; A.col_idxs = ci;     \
+        A.n_store = (long)(C * n_chunks);                                                                           \
+        A.values = va;                                                                                              \
+        if (int rc = check_dmat(&A, "uspmv_scs_gpu_" #SUF)) return rc;                                              \
+        return launch_spmv_scs<VT>(&A, nullptr, 0, x, y, (hipStream_t)stream);                                      \
+    }                                                                                                               \
+    int uspmv_csr_gpu_##SUF(int64_t n_rows, const int32_t *rp, const int32_t *ci, const VT *va, const VT *x, VT *y, \
+                            void *stream) {                                                                         \
+        if (n_rows < 0 || !rp || (n_rows > 0 && (!x || !y)))                                                        \
+            return uspmv::fail(USPMV_ERR_INVALID, "uspmv_csr_gpu_" #SUF ": bad argument");                          \
+        if (int rc = require_device()) return rc;                                                                   \
+        return launch_csr<VT>((long)n_rows, 0, rp, ci, va, x, y, (hipStream_t)stream);                              \
+    }
+RAW_SCS(f64, double, USPMV_F64)
+RAW_SCS(f32, float, USPMV_F32)
+#undef RAW_SCS
+
+int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_perm, int64_t n, int dtype,
+                                void *stream) {
+    if (!d_out || !d_in || !d_perm || n < 0) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_apply_permutation_dev: bad argument");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return USPMV_OK;
+    const unsigned grid = grid_for(n, 256);
+    if (dtype == USPMV_F64)
+        hipLaunchKernelGGL((gather_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (double *)d_out,
+                           (const double *)d_in, d_perm, (const int *)nullptr, (long)n, 0L);
+    else if (dtype == USPMV_F32)
+        hipLaunchKernelGGL((gather_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (float *)d_out,
+                           (const float *)d_in, d_perm, (const int *)nullptr, (long)n, 0L);
+    else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_apply_permutation_dev: unknown dtype %d", dtype);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int uspmv_pack_send_buf(const void *d_x, const int32_t *d_perm, const int32_t *d_send_idxs, int64_t n,
+                        int64_t block_offset, void *d_send, int dtype, void *stream) {
+    if (n < 0 || (n > 0 && (!d_x || !d_perm || !d_send_idxs || !d_send)))
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_pack_send_buf: bad argument");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return USPMV_OK;
+    const unsigned grid = grid_for(n, 256);
+    if (dtype == USPMV_F64)
+        hipLaunchKernelGGL((gather_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (double *)d_send,
+                           (const double *)d_x, d_perm, d_send_idxs, (long)n, (long)block_offset);
+    else if (dtype == USPMV_F32)
+        hipLaunchKernelGGL((gather_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (float *)d_send,
+                           (const float *)d_x, d_perm, d_send_idxs, (long)n, (long)block_offset);
+    else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_pack_send_buf: unknown dtype %d", dtype);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int uspmv_stream_copy(double *a, const double *b, int64_t n, void *stream) {
+    if (!a || !b || n < 0 || (n & 1)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_stream_copy: bad argument (n must be even)");
+    if (int rc = require_device()) return rc;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (double2 *)a, (const double2 *)b, (long)(n / 2));
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int uspmv_stream_triad(double *a, const double *b, const double *c, double s, int64_t n, void *stream) {
+    if (!a || !b || !c || n < 0 || (n & 1)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_stream_triad: bad argument (n must be even)");
+    if (int rc = require_device()) return rc;
+    hipLaunchKernelGGL(stream_triad_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (double2 *)a, (const double2 *)b, (const double2 *)c, s, (long)(n / 2));
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int uspmv_stream_read(const double *b, int64_t n, double *partial, void *stream) {
+    if (!b || !partial || n < 0 || (n & 1)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_stream_read: bad argument (n must be even; partial needs 8192 doubles)");
+    if (int rc = require_device()) return rc;
+    hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const double2 *)b, (long)(n / 2), partial);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int uspmv_time_launches(int what, int reps, const uspmv_dmat_t *A, const uspmv_dmat_t *B, const void *d_x, void *d_y,
+                        int64_t n, int b, int64_t ld, int layout, void *stream, double *avg_ms) {
+    if (reps < 1 || !avg_ms) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_time_launches: bad argument");
+    if (int rc = require_device()) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = USPMV_OK;
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int r = 0; r < reps && rc == USPMV_OK; ++r) {
+        switch (what) {
+            case 0: rc = uspmv_spmv(A, d_x, d_y, stream); break;
+            case 1: rc = uspmv_stream_copy((double *)d_y, (const double *)d_x, n, stream); break;
+            case 2: rc = uspmv_stream_triad((double *)d_y, (const double *)d_x, (const double *)d_x + n, 3.0, n, stream); break;
+            case 3: rc = uspmv_stream_read((const double *)d_x, n, (double *)d_y, stream); break;
+            case 4: rc = uspmv_spmv_ap(A, B, (const double *)d_x, (double *)d_y, stream); break;
+            case 5: rc = uspmv_spmmv(A, d_x, d_y, b, ld, layout, stream); break;
+            default: rc = uspmv::fail(USPMV_ERR_INVALID, "uspmv_time_launches: unknown kind %d", what);
+        }
+    }
+    hipError_t e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc != USPMV_OK) return rc;
+    if (e != hipSuccess) return uspmv::fail(USPMV_ERR_HIP, "uspmv_time_launches: %s", hipGetErrorString(e));
+    *avg_ms = (double)ms / reps;
+    return USPMV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+// Shared declarations of the device half of libuspmv: the matrix handle, the tuning knobs, the
+// device helpers every kernel file uses and the launch entry points the C ABI (uspmv_api.hip) calls.
+// Kernels live in spmv_kernels.hip, spmmv_kernels.hip and ap_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../host/uspmv_internal.hpp"
+
+struct uspmv_dmat {
+    int64_t C = 0, n_chunks = 0, n_elements = 0;
+    int dtype = USPMV_F64;
+    const int32_t *chunk_ptrs = nullptr, *chunk_lengths = nullptr, *col_idxs = nullptr;
+    const void *values = nullptr;
+    bool owns = false;
+    bool crs = false;
+    long n_store = 0;              // rows of y the kernels may write (= n_chunks*C unless re-chunked)
+    uspmv_dmat *alt = nullptr;     // internal C = 32 re-chunking of a C in {1,2,4,8,16} struct (same row order)
+    // scratch for the internal row-major copies of column-major block vectors (uspmv_spmmv); grown
+    // on demand, released with the handle.  Not thread-safe per handle, like the reference's kernel object.
+    mutable void *ws = nullptr;
+    mutable size_t ws_bytes = 0;
+    // tile-local-column plan (host/tlc_plan.cpp), device copies owned by the handle
+    bool tlc = false;
+    int tlc_max_lines = 0, tlc_tile_rows = 256;
+    int64_t tlc_x_len = 0, tlc_n_tiles = 0, tlc_staged = 0;
+    uint64_t tlc_plan_id = 0;   // structs planned together (ap pair) carry the same non-zero id
+    int32_t *tlc_line_ptr = nullptr, *tlc_lines = nullptr;
+    uint32_t *tlc_c16_ptrs = nullptr;
+    uint16_t *tlc_col16 = nullptr;
+    // block (SpMMV) plan: 64-row tiles, per tile the list of X rows it touches (uspmv_dmat_optimize_block)
+    bool bt = false;
+    int bt_max_rows = 0, bt_tile_rows = 64;
+    int64_t bt_n_tiles = 0, bt_staged = 0;
+    int32_t *bt_line_ptr = nullptr, *bt_xrows = nullptr;
+    uint32_t *bt_c16_ptrs = nullptr;
+    uint16_t *bt_col16 = nullptr;
+};
+
+namespace uspmv_dev {
+
+struct Tuning {
+    // defaults = fastest of the interleaved sweep on the nlpkkt200-class matrix (profiles/r01_sweep253.txt)
+    int unroll = 8;
+    int nontemporal = 1;
+    int xcd_remap = 256;  // groups of 256 consecutive workgroups per XCD (profiles/r01/sweepH.txt)
+    int block = 256;
+    int spmv_variant = 0;
+    int csr_lanes = 0;  // 0 = choose from average row length
+    int ablate = 0;     // measurement only
+    int tlc = 1;            // use the tile-local-column kernel when the handle carries a plan
+    int rechunk = 1;        // uspmv_dmat_optimize may re-chunk C < 32 structs to C = 32 internally
+    int tlc_tile_rows = 256;  // rows (= threads) per tile used by the NEXT uspmv_dmat_optimize
+    int tail_batch = 0;     // ragged tail of a chunk as one predicated batch
+    int spmmv_unroll = 0;   // 0 = auto (256 bytes of X rows per lane and batch)
+    int spmmv_lds_kb = 0;    // block plan: LDS budget per tile in KiB for the NEXT uspmv_dmat_optimize_block (0 = 80)
+    int spmmv_tile_rows = 0; // block plan: 0 = auto (32-row tiles for >= 64-byte rows on C = 32), 64 = always 64
+    int spmmv_prefetch = 1; // row-major lane-per-row kernel: request batch k+1's matrix entries behind batch k's X rows
+    int spmmv_variant = 0;  // 0 = auto (= 3 where a B-specialised kernel exists); 1 = generic kernel; 2 = row-major with transposing X phase; 3 = row-major, lane per row
+};
+extern Tuning g_tune;   // uspmv_api.hip
+
+int require_device();                                    // uspmv_api.hip
+int check_dmat(const uspmv_dmat *A, const char *who);    // uspmv_api.hip
+inline unsigned grid_for(long work_items, int block) { return (unsigned)((work_items + block - 1) / block); }
+
+constexpr size_t BT_LDS_CAP = 80 * 1024;  // LDS per single-wave SpMMV tile (block plan): two tiles per CU at worst
+
+// launch entry points (explicitly instantiated for double and float in their kernel files)
+template <typename VT>
+int launch_spmv_scs(const uspmv_dmat *A, const int *chunk_ids, long n_ids, const VT *x, VT *y, hipStream_t st);   // spmv_kernels.hip
+template <typename VT>
+int launch_spmv_tlc(const uspmv_dmat *A, const int *tile_ids, long n_tiles, const VT *x, VT *y, hipStream_t st);  // spmv_kernels.hip
+template <typename VT>
+int launch_csr(long n_rows, long nnz_hint, const int *rp, const int *ci, const VT *va, const VT *x, VT *y, hipStream_t st);  // spmv_kernels.hip
+template <typename VT>
+int launch_spmmv(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int layout, hipStream_t st);            // spmmv_kernels.hip
+int launch_spmv_ap(const uspmv_dmat *dp, const uspmv_dmat *sp, const double *d_x, const float *d_x_sp, double *d_y,
+                   hipStream_t stream);                                                                           // ap_kernels.hip
+
+}  // namespace uspmv_dev
+
+#define HIP_TRY(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return uspmv::fail(USPMV_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                               __FILE__, __LINE__);                                                \
+    } while (0)
+
+
+// ------------------------------------------------------------------------------------------
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_stream(const T *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+// y store.  A y vector is ~2 % of the bytes of an SpMV, but its HBM write stream costs 15-18 % of the
+// kernel when it goes through the write-back L2 (profiles/r01_microbench.txt: 0.74 ms without the
+// store, 0.88 ms with plain stores, 0.83 ms write-through).  Relaxed agent-scope atomic stores
+// compile to `global_store_dword[x2] ... sc1` (write-through, line not kept in L2).
+template <bool WT, typename T>
+__device__ __forceinline__ void st_y(T *p, T v) {
+    if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// logical block id.  Hardware deals blocks round-robin over the 8 XCDs (b, b+8, b+16, ... share
+// one).  mode 0: identity.  mode 1: every XCD walks one contiguous eighth of the grid.
+// mode G >= 2: groups of G consecutive logical blocks per XCD, the 8 groups of a super-block
+// of 8*G blocks being processed concurrently (keeps all XCDs inside one moving DRAM window while
+// neighbouring blocks -- which share x lines -- share an L2).
+__device__ __forceinline__ unsigned remap_block(unsigned b, unsigned nb, int mode) {
+    if (mode == 0 || nb < 16) return b;
+    if (mode == 1) {
+        const unsigned xcd = b & 7u, q = nb >> 3, r = nb & 7u;
+        const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        return base + (b >> 3);
+    }
+    const unsigned G = (unsigned)mode, SG = 8u * G;
+    const unsigned full = (nb / SG) * SG;
+    if (b >= full) return b;
+    const unsigned sup = b / SG, rem = b - sup * SG;
+    return sup * SG + (rem & 7u) * G + (rem >> 3);
+}
+
