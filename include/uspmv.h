@@ -204,6 +204,7 @@ int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_
  *   "tlc" 1|0 use the tile-local-column kernel when the handle has a plan, "tail_batch" 0|1,
  *   "spmmv_variant" 0 (auto) | 1 (generic) | 2 (row-major, transposing X phase) | 3 (row-major, lane per row)
  *                   | 4 (block plan where present; 0 prefers it too, 2 and 3 ignore it),
+ *   "spmmv_swizzle" 0|1 bank-swizzled LDS rows in the block-plan kernel,
  *   "spmmv_tile_rows" 0 (auto) | 64 rows per tile and "spmmv_lds_kb" 0 (= 80) | LDS KiB per tile of the NEXT
  *   uspmv_dmat_optimize_block,
  *   "spmmv_prefetch" 1|0 (lane-per-row kernel: next batch of matrix entries requested behind the X rows),

@@ -284,11 +284,12 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                     pkg.set_tuning(spmmv_variant=3)
                     pkg.spmmv(A0, _dev(t, X), Y0, b, ld, lay)
                     pkg.set_tuning(spmmv_variant=0)
-                    pkg.set_tuning(spmmv_variant=4)        # plan kernel for every width it supports
-                    Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
-                    pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
-                    pkg.set_tuning(spmmv_variant=0)
-                    assert t.equal(Y, Y0), (name, C, code, b, rowwise)
+                    for swz in (0, 1):                     # plan kernel for every width it supports, both LDS layouts
+                        pkg.set_tuning(spmmv_variant=4, spmmv_swizzle=swz)
+                        Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
+                        pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
+                        assert t.equal(Y, Y0), (name, C, code, b, rowwise, swz)
+                    pkg.set_tuning(spmmv_variant=0, spmmv_swizzle=0)
                     Y.fill_(-3.0)                          # and whatever auto picks
                     pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
                     assert t.equal(Y, Y0), (name, C, code, b, rowwise, "auto")

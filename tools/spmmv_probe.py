@@ -36,16 +36,16 @@ for dt, tdt, vs in ((pkg.F64, torch.float64, 8), (pkg.F32, torch.float32, 4)):
     Ab = pkg.DeviceMatrix(s, block_tlc=b)
     print(json.dumps(dict(dtype=vs, block_plan_tiles=Ab.block_tiles, staged=Ab.block_staged, plan_s=round(time.time() - t0, 2))), flush=True)
     for lay, nm in ((pkg.ROWWISE, "rowwise"), (pkg.COLWISE, "colwise")):
-        for batch, xr in ((5, 256),):
-            pkg.set_tuning(xcd_remap=xr)
+        for batch, xr in ((1, 256), (0, 256), (0, 1024)):
+            pkg.set_tuning(spmmv_swizzle=batch, xcd_remap=xr)
             Y2 = torch.zeros_like(X)
             pkg.set_tuning(spmmv_variant=4); pkg.spmmv(Ab, X, Y2, b, ld, lay); pkg.set_tuning(spmmv_variant=3); pkg.spmmv(A, X, Y, b, ld, lay); pkg.set_tuning(spmmv_variant=0)
             same = bool(torch.equal(Y, Y2))
             pkg.set_tuning(spmmv_variant=4)
             B.time_launches(5, 3, A=Ab, x=X, y=Y, b=b, ld=ld, layout=lay)
             ms = B.time_launches(5, 30, A=Ab, x=X, y=Y, b=b, ld=ld, layout=lay)
-            print(json.dumps(dict(dtype=vs, layout=nm, variant="block_plan", batch=batch, xcd=xr, bitexact_vs_gather=same, ms=round(ms, 4), GF=round(2 * s.nnz * b / ms / 1e6), GBs=round(byts / ms / 1e6))), flush=True)
-    pkg.set_tuning(xcd_remap=256, spmmv_variant=0)
+            print(json.dumps(dict(dtype=vs, layout=nm, variant="block_plan", swizzle=batch, xcd=xr, bitexact_vs_gather=same, ms=round(ms, 4), GF=round(2 * s.nnz * b / ms / 1e6), GBs=round(byts / ms / 1e6))), flush=True)
+    pkg.set_tuning(spmmv_swizzle=1, xcd_remap=256, spmmv_variant=0)
     del Ab
     # single-vector SpMV in this dtype for reference (TLC)
     A.optimize(s)

@@ -270,7 +270,7 @@ __global__ void scs_spmmv_xpose(const long n_chunks, const int C, const int *__r
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_cvoid_t;
 
-template <typename VT, int B, bool NT, bool YCOL, int G, int C, int HS>
+template <typename VT, int B, bool NT, bool YCOL, int G, int C, int HS, bool SWZ>
 __global__ void __launch_bounds__(64) scs_spmmv_tlc(const long n_chunks, const int *__restrict__ chunk_ptrs,
         const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const VT *__restrict__ values,
         const VT *__restrict__ X, VT *__restrict__ Y, const long ld, const int *__restrict__ tile_line_ptr,
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(64) scs_spmmv_tlc(const long n_chunks, const i
         }
     };
     auto fma_local = [&](const VT a, const unsigned local) {
-        fma_row(a, xs + local * NV, NV > 1 ? (local >> SWS) & (NV - 1) : 0u);
+        fma_row(a, xs + local * NV, (SWZ && NV > 1) ? (local >> SWS) & (NV - 1) : 0u);
     };
     if (nl > 0) {
         const u64 *cq = (const u64 *)(col16 + q0) + i;
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(64) scs_spmmv_tlc(const long n_chunks, const i
                 const int p = (t0 + u) * 64 + lane;
                 if (p < np) {
                     const unsigned k = (unsigned)p >> NVS;
-                    const unsigned piece = ((unsigned)p & (NV - 1)) ^ (NV > 1 ? (k >> SWS) & (NV - 1) : 0u);
+                    const unsigned piece = ((unsigned)p & (NV - 1)) ^ ((SWZ && NV > 1) ? (k >> SWS) & (NV - 1) : 0u);
                     const VT *src = X + (long)xr[u] * B + piece * VW;
                     __builtin_amdgcn_global_load_lds((glb_cvoid_t *)src, (lds_void_t *)(tlc_smem + (t0 + u) * 1024), 16, 0, 0);
                 }
@@ -497,13 +497,13 @@ void launch_spmmv_xpose_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool
 #undef XP_LAUNCH
 }
 
-template <typename VT, int B, int G, int CT, int HS>
+template <typename VT, int B, int G, int CT, int HS, bool SWZ>
 void launch_spmmv_tlc_g(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
     const size_t x_bytes = (size_t)A->bt_max_rows * B * sizeof(VT);
     const size_t lds = x_bytes + (((size_t)A->bt_max_rows * 4 + 15) & ~(size_t)15);   // X rows + the tile's row list
 #define BT_LAUNCH(NTV, YC)                                                                                              \
     do {                                                                                                                \
-        auto kfn = scs_spmmv_tlc<VT, B, NTV, YC, G, CT, HS>;                                                                \
+        auto kfn = scs_spmmv_tlc<VT, B, NTV, YC, G, CT, HS, SWZ>;                                                                \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)A->bt_n_tiles), dim3(64), lds, st, (long)A->n_chunks,                    \
                            A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, A->bt_line_ptr, \
@@ -523,11 +523,16 @@ void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
         // the gather form; with 64-byte rows (2-3 tiles per CU) each tile's chain of dependent fetches is exposed and
         // it is 20 % behind (profiles/r01/spmmv_probe13.txt).  Variant 4 forces it.
         if (A->bt && ((g_tune.spmmv_variant == 0 && RB <= 32) || g_tune.spmmv_variant == 4) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
+            const bool swz = g_tune.spmmv_swizzle != 0;
             if (A->bt_tile_rows == 32) {
-                if constexpr (RB >= 64) { launch_spmmv_tlc_g<VT, B, 4, 32, 2>(A, X, Y, ld, ycol, st); return; }
+                if constexpr (RB >= 64) {
+                    if (swz) launch_spmmv_tlc_g<VT, B, 4, 32, 2, true>(A, X, Y, ld, ycol, st);
+                    else launch_spmmv_tlc_g<VT, B, 4, 32, 2, false>(A, X, Y, ld, ycol, st);
+                    return;
+                }
             } else {
-                if (A->C == 32) launch_spmmv_tlc_g<VT, B, 4, 32, 1>(A, X, Y, ld, ycol, st);
-                else launch_spmmv_tlc_g<VT, B, 4, 64, 1>(A, X, Y, ld, ycol, st);
+                if (A->C == 32) { if (swz) launch_spmmv_tlc_g<VT, B, 4, 32, 1, true>(A, X, Y, ld, ycol, st); else launch_spmmv_tlc_g<VT, B, 4, 32, 1, false>(A, X, Y, ld, ycol, st); }
+                else { if (swz) launch_spmmv_tlc_g<VT, B, 4, 64, 1, true>(A, X, Y, ld, ycol, st); else launch_spmmv_tlc_g<VT, B, 4, 64, 1, false>(A, X, Y, ld, ycol, st); }
                 return;
             }
         }

@@ -122,6 +122,7 @@ int uspmv_set_tuning(const char *key, int value) {
         g_tune.xcd_remap = value;
     } else if (!strcmp(key, "ablate")) g_tune.ablate = value;
     else if (!strcmp(key, "spmmv_prefetch")) g_tune.spmmv_prefetch = value != 0;
+    else if (!strcmp(key, "spmmv_swizzle")) g_tune.spmmv_swizzle = value != 0;
     else if (!strcmp(key, "spmmv_tile_rows")) g_tune.spmmv_tile_rows = value == 64 ? 64 : 0;
     else if (!strcmp(key, "spmmv_lds_kb")) g_tune.spmmv_lds_kb = value < 0 ? 0 : value;
     else if (!strcmp(key, "spmmv_variant")) {
@@ -160,6 +161,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "csr_lanes")) *value = g_tune.csr_lanes;
     else if (!strcmp(key, "ablate")) *value = g_tune.ablate;
     else if (!strcmp(key, "spmmv_prefetch")) *value = g_tune.spmmv_prefetch;
+    else if (!strcmp(key, "spmmv_swizzle")) *value = g_tune.spmmv_swizzle;
     else if (!strcmp(key, "spmmv_tile_rows")) *value = g_tune.spmmv_tile_rows;
     else if (!strcmp(key, "spmmv_lds_kb")) *value = g_tune.spmmv_lds_kb;
     else if (!strcmp(key, "spmmv_variant")) *value = g_tune.spmmv_variant;
