@@ -1,0 +1,95 @@
+"""Randomised cross-checks against the genuine reference (oracle/_ref, built from /root/reference by oracle/Makefile):
+random COO matrices with heavy length ties, empty rows and ragged shapes through convert_to_scs
+(code/utilities.hpp:1842-2104, incl. the std::sort tie order), the dp+sp split (:2899-2911) and -- on the GPU --
+the kernels.  Seeds are fixed; the CPU part needs no GPU."""
+import numpy as np
+import pytest
+
+from oracle import refshim
+
+@pytest.fixture(scope="module")
+def torch_cuda(pkg):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    torch.cuda.set_device(0)
+    return torch
+
+
+pytestmark = pytest.mark.skipif(not refshim.available("colwise"), reason="oracle/_ref not built (reference sources absent)")
+
+
+def random_coo(rng, n_rows, n_cols, density, tie_heavy):
+    if tie_heavy:                      # few distinct row lengths -> many ties inside every sigma window
+        lens = rng.choice([0, 1, 2, 2, 3, 3, 3, 7], n_rows)
+    else:
+        lens = rng.poisson(density * n_cols, n_rows)
+    lens = np.minimum(lens, n_cols)
+    I = np.repeat(np.arange(n_rows), lens)
+    J = np.concatenate([rng.choice(n_cols, k, replace=False) for k in lens]) if I.size else np.zeros(0, np.int64)
+    V = rng.standard_normal(I.size) * 10.0 ** rng.integers(-6, 3, I.size)
+    return I.astype(np.int32), J.astype(np.int32), V
+
+
+CASES = [(seed, n, C, sigma) for seed, (n, C, sigma) in enumerate([
+    (1, 1, 1), (2, 4, 4), (17, 4, 8), (33, 32, 64), (64, 32, 512), (97, 16, 48), (130, 64, 128), (257, 128, 256),
+    (300, 8, 8), (301, 5, 15), (511, 32, 32), (777, 2, 1000), (1000, 32, 512), (1025, 64, 64)])]
+
+
+@pytest.mark.parametrize("seed,n,C,sigma", CASES)
+def test_convert_and_split_match_reference(pkg, seed, n, C, sigma):
+    rng = np.random.default_rng(1000 + seed)
+    n_cols = n if seed % 3 else n + 7
+    I, J, V = random_coo(rng, n, n_cols, 0.05, tie_heavy=bool(seed % 2))
+    if I.size == 0:
+        I, J, V = np.array([0], np.int32), np.array([0], np.int32), np.array([1.5])
+    m = pkg.Coo.from_arrays(n, n_cols, I, J, V)
+    rm = refshim.RefMtx.from_coo(n, n_cols, I, J, V)
+    for dt, code in (("f64", pkg.F64), ("f32", pkg.F32)):
+        s = pkg.convert_to_scs(m, C, sigma, code)
+        r = refshim.convert_to_scs(rm, C, sigma, dt)
+        a, ra = s.arrays(), r.arrays()
+        assert (s.n_chunks, s.n_elements, s.n_rows_padded) == (r.n_chunks, r.n_elements, r.n_rows_padded)
+        for k in ("chunk_ptrs", "chunk_lengths", "col_idxs", "values", "old_to_new_idx"):
+            assert np.array_equal(a[k], ra[k]), (seed, dt, k)
+        # new_to_old_idx: the reference leaves the slots that received a padding row uninitialised (raw new[],
+        # code/utilities.hpp:2060-2069), so only the written ones are comparable
+        written = a["old_to_new_idx"][a["old_to_new_idx"] < n]
+        assert np.array_equal(a["new_to_old_idx"][written], ra["new_to_old_idx"][written]), (seed, dt, "new_to_old_idx")
+    th = float(np.median(np.abs(V)))
+    dp, sp = pkg.partition_precisions(m, th)
+    rdp, _, (sI, sJ, sV) = refshim.partition_precisions_dpsp(rm, th)
+    rI, rJ, rV = rdp.arrays()
+    I2, J2, V2 = dp.arrays()
+    assert np.array_equal(I2, rI) and np.array_equal(J2, rJ) and np.array_equal(V2, rV)
+    I2, J2, V2 = sp.arrays()
+    assert np.array_equal(I2, sI) and np.array_equal(J2, sJ) and np.array_equal(V2.astype(np.float32), sV)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,C,sigma", CASES[3:])
+def test_kernels_match_reference_on_random_matrices(pkg, torch_cuda, seed, n, C, sigma):
+    t = torch_cuda
+    rng = np.random.default_rng(2000 + seed)
+    I, J, V = random_coo(rng, n, n, 0.05, tie_heavy=bool(seed % 2))
+    m = pkg.Coo.from_arrays(n, n, I, J, V)
+    x0 = rng.standard_normal(n)
+    for dt, code, kind in (("f64", pkg.F64, "adv" if C in (2, 4, 8, 16, 32, 64, 128) else "gen"), ("f32", pkg.F32, "gen")):
+        s = pkg.convert_to_scs(m, C, sigma, code)
+        pkg.permute_scs_cols(s, s.arrays()["old_to_new_idx"])
+        a = s.arrays()
+        xp = np.zeros(max(s.n_rows_padded, n), s.np_dtype)
+        xp[:n] = pkg.apply_permutation(x0.astype(s.np_dtype), a["new_to_old_idx"])
+        yr = refshim.spmv_scs(kind, C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+        for tlc in (False, True):
+            A = pkg.DeviceMatrix(s, tlc=tlc)
+            y = t.full((s.n_rows_padded,), 7.0, dtype=A.torch_dtype, device="cuda")
+            pkg.spmv(A, t.from_numpy(xp).cuda(), y)
+            assert np.array_equal(y.cpu().numpy(), yr), (seed, dt, tlc)
+        b, ld = 4, s.n_rows_padded + 3
+        X = np.zeros(b * ld, s.np_dtype)
+        for v in range(b):
+            X[v * ld: v * ld + len(xp[:s.n_rows_padded])] = xp[:s.n_rows_padded] * (1 + v)
+        Yr = refshim.spmmv_scs_general(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, b, ld, 0)
+        Y = t.zeros(b * ld, dtype=A.torch_dtype, device="cuda")
+        pkg.spmmv(A, t.from_numpy(X).cuda(), Y, b, ld, pkg.COLWISE)
+        assert np.array_equal(Y.cpu().numpy().reshape(b, ld)[:, :s.n_rows_padded], Yr.reshape(b, ld)[:, :s.n_rows_padded]), (seed, dt, "spmmv")
