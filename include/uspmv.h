@@ -60,6 +60,10 @@ const char *uspmv_version(void);
  * real / integer / pattern (= 0.01) coordinate files, general or symmetric (expanded), entries
  * stable-sorted by row. */
 int uspmv_read_mtx(const char *path, uspmv_coo_t **out);
+/* Binary cache of a COO handle (no reference counterpart): what uspmv_read_mtx returned --
+ * expanded, row-sorted -- written / read back verbatim, so that later runs skip the text parse. */
+int uspmv_coo_save(const uspmv_coo_t *m, const char *path);
+int uspmv_coo_load(const char *path, uspmv_coo_t **out);
 /* MtxData filled by a host application (API_doc.md:7-9).  Arrays are copied. */
 int uspmv_coo_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *I, const int32_t *J,
                      const double *values, uspmv_coo_t **out);

@@ -103,6 +103,26 @@ def test_convert_to_scs_grid_hashes(pkg):
                 assert sha(arr) == e[f], (key, dt, f)
 
 
+def test_coo_binary_cache_roundtrip(pkg, tmp_path):
+    """uspmv_coo_save / uspmv_coo_load: verbatim round trip, corrupt files refused."""
+    m = pkg.read_mtx(mtx_path("bcsstk13"))
+    f = str(tmp_path / "m.uspmvcoo")
+    m.save(f)
+    r = pkg.Coo.load(f)
+    assert (r.n_rows, r.n_cols, r.nnz) == (m.n_rows, m.n_cols, m.nnz)
+    for x, y in zip(m.arrays(), r.arrays()):
+        assert np.array_equal(x, y)
+    raw = open(f, "rb").read()
+    open(f, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(pkg.UspmvError):
+        pkg.Coo.load(f)
+    open(f, "wb").write(b"not a cache")
+    with pytest.raises(pkg.UspmvError):
+        pkg.Coo.load(f)
+    with pytest.raises(pkg.UspmvError):
+        pkg.Coo.load(str(tmp_path / "missing"))
+
+
 def test_convert_errors(pkg):
     m = pkg.Coo.from_arrays(3, 3, [0, 1, 2], [0, 1, 2], [1.0, 2.0, 3.0])
     for C_, s_ in ((0, 1), (1, 0), (-4, 2)):

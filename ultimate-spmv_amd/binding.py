@@ -48,6 +48,8 @@ _SIGS = {
     "uspmv_last_error": (C.c_char_p, []),
     "uspmv_version": (C.c_char_p, []),
     "uspmv_read_mtx": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "uspmv_coo_save": (C.c_int, [_vp, C.c_char_p]),
+    "uspmv_coo_load": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "uspmv_coo_create": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
     "uspmv_coo_dims": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_coo_arrays": (C.c_int, [_vp, C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_f64p)]),
@@ -164,6 +166,16 @@ class Coo:
         v = np.ascontiguousarray(values, np.float64)
         h = _vp()
         _ck(lib().uspmv_coo_create(n_rows, n_cols, len(I), _np_ptr(I), _np_ptr(J), _np_ptr(v), C.byref(h)))
+        return cls(h)
+
+    def save(self, path):
+        """Binary cache of this matrix (uspmv_coo_save)."""
+        _ck(lib().uspmv_coo_save(self.h, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, path):
+        h = _vp()
+        _ck(lib().uspmv_coo_load(os.fsencode(path), C.byref(h)))
         return cls(h)
 
     def arrays(self):

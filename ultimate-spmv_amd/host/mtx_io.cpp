@@ -121,6 +121,48 @@ int uspmv_coo_arrays(const uspmv_coo_t *m, const int32_t **I, const int32_t **J,
 
 void uspmv_coo_free(uspmv_coo_t *m) { delete m; }
 
+// Binary COO cache: header {magic, version, n_rows, n_cols, nnz} + I, J, values as stored in
+// the handle (already expanded and row-sorted), so that a second run skips the text parse.
+namespace {
+constexpr uint64_t COO_MAGIC = 0x4f4f43564d505355ull;   // "USPMVCOO"
+struct CooHeader { uint64_t magic, version; int64_t n_rows, n_cols, nnz; };
+}
+
+int uspmv_coo_save(const uspmv_coo_t *m, const char *path) {
+    if (!m || !path) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_coo_save: NULL argument");
+    FILE *f = fopen(path, "wb");
+    if (!f) return uspmv::fail(USPMV_ERR_IO, "uspmv_coo_save: cannot create '%s'", path);
+    const CooHeader h{COO_MAGIC, 1, m->n_rows, m->n_cols, m->nnz};
+    const size_t nz = (size_t)m->nnz;
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(m->I.data(), 4, nz, f) == nz && fwrite(m->J.data(), 4, nz, f) == nz &&
+              fwrite(m->values.data(), 8, nz, f) == nz;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { remove(path); return uspmv::fail(USPMV_ERR_IO, "uspmv_coo_save: short write to '%s'", path); }
+    return USPMV_OK;
+}
+
+int uspmv_coo_load(const char *path, uspmv_coo_t **out) {
+    if (!path || !out) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_coo_load: NULL argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return uspmv::fail(USPMV_ERR_IO, "uspmv_coo_load: cannot open '%s'", path);
+    CooHeader h{};
+    if (fread(&h, sizeof h, 1, f) != 1 || h.magic != COO_MAGIC || h.version != 1 || h.n_rows < 0 || h.n_cols < 0 || h.nnz < 0 ||
+        h.n_rows > INT32_MAX || h.n_cols > INT32_MAX) {
+        fclose(f);
+        return uspmv::fail(USPMV_ERR_IO, "uspmv_coo_load: '%s' is not a uspmv COO cache", path);
+    }
+    auto *m = new uspmv_coo;
+    m->n_rows = h.n_rows; m->n_cols = h.n_cols; m->nnz = h.nnz;
+    const size_t nz = (size_t)h.nnz;
+    m->I.resize(nz); m->J.resize(nz); m->values.resize(nz);
+    bool ok = fread(m->I.data(), 4, nz, f) == nz && fread(m->J.data(), 4, nz, f) == nz && fread(m->values.data(), 8, nz, f) == nz;
+    fclose(f);
+    for (size_t k = 0; ok && k < nz; ++k) ok = m->I[k] >= 0 && m->I[k] < h.n_rows && m->J[k] >= 0 && m->J[k] < h.n_cols;
+    if (!ok) { delete m; return uspmv::fail(USPMV_ERR_IO, "uspmv_coo_load: '%s' is truncated or corrupt", path); }
+    *out = m;
+    return USPMV_OK;
+}
+
 int uspmv_read_mtx(const char *path, uspmv_coo_t **out) {
     if (!path || !out) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_read_mtx: NULL argument");
     Slurp s;

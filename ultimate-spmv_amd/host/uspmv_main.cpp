@@ -14,6 +14,7 @@
 // achieved HBM GB/s and the roofline fraction are reported next to GF/s.  `<matrix>` may also be
 // `gen:NXxNYxNZ[:dof[:decades]]` to use the built-in 27-point-stencil generator.
 #include <hip/hip_runtime_api.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <cmath>
@@ -140,7 +141,16 @@ uspmv_coo_t *load_matrix(const Config &c) {
         if (n < 3) die("generator syntax: gen:NXxNYxNZ[:dof[:decades]]");
         ck(uspmv_gen_stencil27(nx, ny, nz, dof, 0x5EED, dec, 0, nx * ny * nz * dof, &m), "uspmv_gen_stencil27");
     } else {
+        // USPMV_MTX_CACHE=1: keep / reuse a binary copy next to the .mtx file (<file>.uspmvcoo), newer than the text
+        const char *use_cache = getenv("USPMV_MTX_CACHE");
+        const std::string cache = c.matrix_file_name + ".uspmvcoo";
+        struct stat st_m{}, st_c{};
+        if (use_cache && atoi(use_cache) && stat(c.matrix_file_name.c_str(), &st_m) == 0 && stat(cache.c_str(), &st_c) == 0 &&
+            st_c.st_mtime >= st_m.st_mtime && uspmv_coo_load(cache.c_str(), &m) == USPMV_OK)
+            return m;
         ck(uspmv_read_mtx(c.matrix_file_name.c_str(), &m), "uspmv_read_mtx");
+        if (use_cache && atoi(use_cache) && uspmv_coo_save(m, cache.c_str()) != USPMV_OK)
+            fprintf(stderr, "warning: %s\n", uspmv_last_error());
     }
     return m;
 }
