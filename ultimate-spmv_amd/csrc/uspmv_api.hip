@@ -320,9 +320,7 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
             uspmv_dmat_t *alt = nullptr;
             if (int rc2 = uspmv_dmat_upload(&r, &alt)) return rc2;
             alt->n_store = (long)(s->n_chunks * s->C);      // y of the caller has only the original padded rows
-            g_tune.rechunk = 0;                             // (no recursion)
-            rc = uspmv_dmat_optimize(alt, &r, max_lines, n_tiles, n_staged);
-            g_tune.rechunk = 1;
+            rc = uspmv_dmat_optimize(alt, &r, max_lines, n_tiles, n_staged);   // (C = 32: does not re-enter this branch)
             if (rc) { uspmv_dmat_free(alt); return rc; }
             A->alt = alt;
             return USPMV_OK;
