@@ -64,6 +64,9 @@ int uspmv_read_mtx(const char *path, uspmv_coo_t **out);
  * expanded, row-sorted -- written / read back verbatim, so that later runs skip the text parse. */
 int uspmv_coo_save(const uspmv_coo_t *m, const char *path);
 int uspmv_coo_load(const char *path, uspmv_coo_t **out);
+/* -equilibrate 1 of a one-precision run: equilibrate_matrix (code/utilities.hpp:2667-2685), in place.  (With
+ * ap[dp_sp] the reference indexes two empty vectors here, code/main.cpp:1143-1153 -- undefined behaviour, not offered.) */
+int uspmv_coo_equilibrate(uspmv_coo_t *m);
 /* MtxData filled by a host application (API_doc.md:7-9).  Arrays are copied. */
 int uspmv_coo_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *I, const int32_t *J,
                      const double *values, uspmv_coo_t **out);

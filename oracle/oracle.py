@@ -54,6 +54,7 @@ def lib():
         L.orc_convert_to_scs.restype = C.c_long
         L.orc_partition_precisions_dpsp.argtypes = [C.c_long, _f64p, C.c_double, _u8p]
         L.orc_partition_precisions_dpsp.restype = C.c_long
+        L.orc_equilibrate_matrix.argtypes = [C.c_long, C.c_long, C.c_long, _i32p, _i32p, _f64p]
         L.orc_seg_work_sharing_arr.argtypes = [C.c_int, C.c_long, C.c_long, _i32p, C.c_int, _i32p]
         L.orc_collect_local_needed_heri.argtypes = [C.c_long, _i32p, _i32p, C.c_int, C.c_int, C.c_long, _i32p,
                                                     _i32p, _i32p]
@@ -179,6 +180,14 @@ def partition_precisions_dpsp(vals, threshold):
     m = np.zeros(len(vals), np.uint8)
     lib().orc_partition_precisions_dpsp(len(vals), vals, float(threshold), m)
     return m.astype(bool)
+
+
+def equilibrate_matrix(n_rows, n_cols, I, J, vals):
+    """equilibrate_matrix (code/utilities.hpp:2667-2685): returns the scaled values."""
+    v = _c(vals, np.float64).copy()
+    I = _c(I, np.int32); J = _c(J, np.int32)
+    lib().orc_equilibrate_matrix(n_rows, n_cols, len(v), I, J, v)
+    return v
 
 
 def seg_work_sharing_arr(method, n_rows, I, P):

@@ -81,6 +81,9 @@ void ref_mtx_arrays(void *h, int *I, int *J, double *vals) {
 
 void ref_mtx_free(void *h) { delete (MtxData<double, int> *)h; }
 
+// -equilibrate 1 for a one-precision run: equilibrate_matrix (code/utilities.hpp:2667-2685), in place
+void ref_equilibrate_matrix(void *h) { equilibrate_matrix<double, int>((MtxData<double, int> *)h); }
+
 // float copy of a double COO exactly as compute_result<float,int> sees it
 // (MtxData<VT,IT>::copy, code/classes_structs.hpp:1277-1299)
 void *ref_mtx_to_f32(void *h) {

@@ -41,6 +41,8 @@ def lib(variant="colwise"):
     L.ref_mtx_f32_free.argtypes = [_vp]
     L.ref_mtx_f32_dims.argtypes = [_vp, C.POINTER(C.c_long)]
     L.ref_mtx_f32_arrays.argtypes = [_vp, _i32p, _i32p, _f32p]
+    if hasattr(L, "ref_equilibrate_matrix"):
+        L.ref_equilibrate_matrix.argtypes = [_vp]
     L.ref_partition_precisions_dpsp.argtypes = [_vp, C.c_double, C.POINTER(_vp), C.POINTER(_vp)]
     for suf, fp in (("f64", _f64p), ("f32", _f32p)):
         f = getattr(L, f"ref_convert_to_scs_{suf}"); f.argtypes = [_vp, C.c_long, C.c_long, _vp]; f.restype = _vp
@@ -91,6 +93,10 @@ class RefMtx:
     def from_coo(cls, n_rows, n_cols, I, J, vals, variant="colwise"):
         I = _c(I, np.int32); J = _c(J, np.int32); v = _c(vals, np.float64)
         return cls(lib(variant).ref_mtx_from_coo(n_rows, n_cols, len(I), I, J, v), variant)
+
+    def equilibrate(self):
+        """equilibrate_matrix (code/utilities.hpp:2667-2685), in place."""
+        lib(self.variant).ref_equilibrate_matrix(self.h)
 
     def arrays(self):
         I = np.zeros(self.nnz, np.int32); J = np.zeros(self.nnz, np.int32); v = np.zeros(self.nnz, np.float64)

@@ -302,6 +302,20 @@ long orc_partition_precisions_dpsp(long nnz, const double *vals, double threshol
 
 /* 1-D row partition.  code/mpi_funcs.hpp:446-493 (+ the empty-last-rank fix-up :602-606).
  * method 0 = seg-rows, 1 = seg-nnz.  I = row index of every COO entry (sorted by row). */
+/* equilibrate_matrix (code/utilities.hpp:2667-2685): values /= largest |value| of their row (:2610-2626,
+ * :2646-2654), then /= largest |value| of their column in the row-scaled matrix (:2628-2644, :2656-2664).
+ * The reference sizes both scratch vectors with n_cols (:2670, :2678), so n_rows <= n_cols is assumed. */
+void orc_equilibrate_matrix(long n_rows, long n_cols, long nnz, const int *I, const int *J, double *vals) {
+    long n = n_rows > n_cols ? n_rows : n_cols;
+    double *mx = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+    for (long k = 0; k < nnz; ++k) { double a = fabs(vals[k]); if (a > mx[I[k]]) mx[I[k]] = a; }
+    for (long k = 0; k < nnz; ++k) vals[k] = vals[k] / mx[I[k]];
+    memset(mx, 0, (size_t)(n > 0 ? n : 1) * sizeof(double));
+    for (long k = 0; k < nnz; ++k) { double a = fabs(vals[k]); if (a > mx[J[k]]) mx[J[k]] = a; }
+    for (long k = 0; k < nnz; ++k) vals[k] = vals[k] / mx[J[k]];
+    free(mx);
+}
+
 void orc_seg_work_sharing_arr(int method, long n_rows, long nnz, const int *I, int P, int *wsa) {
     wsa[0] = 0;
     if (method == 0) {

@@ -27,6 +27,8 @@ def test_cli_argument_checks(pkg, tmp_path):
                       ([m, "scs", "-seg_metis"], "USE_METIS not defined"),
                       ([m, "scs", "-ap[dp_sp]", "-block_vec_size", "2"], "SpMMV is not yet implemented for AP kernels"),
                       ([m, "scs", "-mode", "x"], "Only bench (b) and solve (s) modes"),
+                      ([m, "scs", "-equilibrate", "2"], "You can only choose to equilibrate data"),
+                      ([m, "scs", "-ap[dp_sp]", "-equilibrate", "1"], "undefined behaviour in the reference"),
                       ([m, "scs", "-block_vec_layout", "rowwise"], "Row-wise block vector layout selected")):
         r = run(args, tmp_path)
         assert r.returncode == 1 and msg in r.stderr, (args, r.stderr)
@@ -48,5 +50,7 @@ def test_cli_bench_and_solve(pkg, tmp_path):
     assert r.returncode == 0 and "CRS SpMMV kernel selected" in r.stdout
     r = run([mtx_path("impcol_e"), "scs", "-c", "32", "-s", "512", "-ap[dp_sp]", "-ap_threshold_1", "1.0", "-bench_time", "0.1"], tmp_path)
     assert r.returncode == 0 and "ap[dp_sp]" in r.stdout and "data_type: ap[dp_sp], threshold: 1.00" in open(tmp_path / "spmv_bench.txt").read()
+    r = run([mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-mode", "s", "-equilibrate", "1", "-dropout", "1", "-dropout_threshold", "0.5"], tmp_path)
+    assert r.returncode == 0 and "-> OK" in r.stdout, r.stdout + r.stderr
     r = run([str(tmp_path / "nope.mtx"), "scs", "-c", "4", "-s", "4"], tmp_path)
     assert r.returncode == 1 and "cannot open" in r.stderr

@@ -65,6 +65,29 @@ def test_convert_and_split_match_reference(pkg, seed, n, C, sigma):
     assert np.array_equal(I2, sI) and np.array_equal(J2, sJ) and np.array_equal(V2.astype(np.float32), sV)
 
 
+@pytest.mark.parametrize("name", ["bcsstk13", "impcol_e", "FDM-2d-16", None])
+def test_equilibrate_matches_reference_and_oracle(pkg, orc, name):
+    """uspmv_coo_equilibrate and the oracle's restatement against equilibrate_matrix of the genuine reference
+    (code/utilities.hpp:2667-2685): bit-identical values."""
+    from conftest import mtx_path
+    if name is None:
+        rng = np.random.default_rng(77)
+        I, J, V = random_coo(rng, 200, 200, 0.05, tie_heavy=False)
+        m = pkg.Coo.from_arrays(200, 200, I, J, V)
+    else:
+        m = pkg.read_mtx(mtx_path(name))
+    I, J, V = [a.copy() for a in m.arrays()]
+    rm = refshim.RefMtx.from_coo(m.n_rows, m.n_cols, I, J, V)
+    if not hasattr(refshim.lib("colwise"), "ref_equilibrate_matrix"):
+        pytest.skip("oracle/_ref predates ref_equilibrate_matrix")
+    rm.equilibrate()
+    ref_vals = rm.arrays()[2]
+    assert np.array_equal(orc.equilibrate_matrix(m.n_rows, m.n_cols, I, J, V), ref_vals)
+    m.equilibrate()
+    assert np.array_equal(m.arrays()[2], ref_vals)
+    assert np.array_equal(m.arrays()[0], I) and np.array_equal(m.arrays()[1], J)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,n,C,sigma", CASES[3:])
 def test_kernels_match_reference_on_random_matrices(pkg, torch_cuda, seed, n, C, sigma):

@@ -50,6 +50,7 @@ _SIGS = {
     "uspmv_read_mtx": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "uspmv_coo_save": (C.c_int, [_vp, C.c_char_p]),
     "uspmv_coo_load": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "uspmv_coo_equilibrate": (C.c_int, [_vp]),
     "uspmv_coo_create": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
     "uspmv_coo_dims": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_coo_arrays": (C.c_int, [_vp, C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_f64p)]),
@@ -167,6 +168,10 @@ class Coo:
         h = _vp()
         _ck(lib().uspmv_coo_create(n_rows, n_cols, len(I), _np_ptr(I), _np_ptr(J), _np_ptr(v), C.byref(h)))
         return cls(h)
+
+    def equilibrate(self):
+        """equilibrate_matrix (-equilibrate 1, code/utilities.hpp:2667-2685), in place."""
+        _ck(lib().uspmv_coo_equilibrate(self.h))
 
     def save(self, path):
         """Binary cache of this matrix (uspmv_coo_save)."""

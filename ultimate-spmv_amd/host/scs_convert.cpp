@@ -227,6 +227,32 @@ int uspmv_permute_scs_cols(uspmv_scs_t *s, const int32_t *perm) {
 
 void uspmv_scs_free(uspmv_scs_t *s) { delete s; }
 
+int uspmv_coo_equilibrate(uspmv_coo_t *m) {
+    // equilibrate_matrix (code/utilities.hpp:2667-2685, -equilibrate 1 of a one-precision run): every value divided
+    // by the largest magnitude of its row, then by the largest magnitude of its column in the row-scaled matrix.
+    // max and division are order-independent, so the parallel sweeps give the reference's bits.
+    if (!m) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_coo_equilibrate: NULL matrix");
+    const int64_t nnz = m->nnz;
+    for (int pass = 0; pass < 2; ++pass) {
+        const std::vector<int32_t> &idx = pass == 0 ? m->I : m->J;
+        std::vector<double> mx((size_t)std::max<int64_t>(pass == 0 ? m->n_rows : m->n_cols, 1), 0.0);
+#pragma omp parallel
+        {
+            std::vector<double> local(mx.size(), 0.0);
+#pragma omp for schedule(static) nowait
+            for (int64_t k = 0; k < nnz; ++k) {
+                const double a = std::fabs(m->values[(size_t)k]);
+                if (a > local[(size_t)idx[(size_t)k]]) local[(size_t)idx[(size_t)k]] = a;
+            }
+#pragma omp critical
+            for (size_t r = 0; r < mx.size(); ++r) mx[r] = std::max(mx[r], local[r]);
+        }
+#pragma omp parallel for schedule(static)
+        for (int64_t k = 0; k < nnz; ++k) m->values[(size_t)k] = m->values[(size_t)k] / mx[(size_t)idx[(size_t)k]];
+    }
+    return USPMV_OK;
+}
+
 int uspmv_apply_permutation(void *out, const void *in, const int32_t *perm, int64_t n, int dtype) {
     if (!out || !in || !perm || n < 0) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_apply_permutation: bad argument");
     if (dtype == USPMV_F64) {

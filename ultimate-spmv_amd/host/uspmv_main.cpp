@@ -128,7 +128,9 @@ Config parse(int argc, char **argv) {
         printf("single rank (WORLD_SIZE not set), forcing comm_halos = 0.\n");  // reference: "USE_MPI not defined, forcing comm_halos = 0."
         c.comm_halos = 0;
     }
-    if (c.equilibrate || c.dropout) die("-equilibrate / -dropout are not implemented in this harness yet.");
+    if (c.equilibrate != 0 && c.equilibrate != 1) die("You can only choose to equilibrate data (1, i.e. yes) or not (0, i.e. no).");
+    if (c.equilibrate && ap) die("-equilibrate with ap[dp_sp] runs into undefined behaviour in the reference (empty scratch vectors, code/main.cpp:1143-1153); not offered.");
+    // (-dropout / -dropout_threshold are parsed and printed by the reference but never applied, code/utilities.hpp:1281-1301)
     if (c.kernel_format != "scs") { c.chunk_size = 1; c.sigma = 1; }
     return c;
 }
@@ -146,12 +148,15 @@ uspmv_coo_t *load_matrix(const Config &c) {
         const std::string cache = c.matrix_file_name + ".uspmvcoo";
         struct stat st_m{}, st_c{};
         if (use_cache && atoi(use_cache) && stat(c.matrix_file_name.c_str(), &st_m) == 0 && stat(cache.c_str(), &st_c) == 0 &&
-            st_c.st_mtime >= st_m.st_mtime && uspmv_coo_load(cache.c_str(), &m) == USPMV_OK)
-            return m;
-        ck(uspmv_read_mtx(c.matrix_file_name.c_str(), &m), "uspmv_read_mtx");
-        if (use_cache && atoi(use_cache) && uspmv_coo_save(m, cache.c_str()) != USPMV_OK)
-            fprintf(stderr, "warning: %s\n", uspmv_last_error());
+            st_c.st_mtime >= st_m.st_mtime && uspmv_coo_load(cache.c_str(), &m) == USPMV_OK) {
+            // (binary copy is current)
+        } else {
+            ck(uspmv_read_mtx(c.matrix_file_name.c_str(), &m), "uspmv_read_mtx");
+            if (use_cache && atoi(use_cache) && uspmv_coo_save(m, cache.c_str()) != USPMV_OK)
+                fprintf(stderr, "warning: %s\n", uspmv_last_error());
+        }
     }
+    if (c.equilibrate) ck(uspmv_coo_equilibrate(m), "uspmv_coo_equilibrate");   // code/main.cpp:1117-1125
     return m;
 }
 
