@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink grids for quick runs")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--tune", default="", help="key=value,... passed to uspmv_set_tuning")
+    ap.add_argument("--sp", action="store_true", help="config 3 in single precision (block plan kernel)")
+    ap.add_argument("--no-block-plan", action="store_true", help="config 3 --sp without uspmv_dmat_optimize_block")
     args = ap.parse_args()
     import torch
     import __graft_entry__ as ge
@@ -54,25 +56,27 @@ def main():
         elif cfg == "3":
             g = int(111 * args.scale)
             coo = pkg.gen_stencil27(g, g, g, dof=3)
-            s = prep(coo, pkg.F64)
+            vdt, ndt, tdt, vs = (pkg.F32, np.float32, t.float32, 4) if args.sp else (pkg.F64, np.float64, t.float64, 8)
+            s = prep(coo, vdt)
             a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
-            A = pkg.DeviceMatrix(s)
             b, ld = 8, s.n_rows_padded
-            xp = np.zeros(ld); xp[:s.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(s.n_rows) % 1000), a["new_to_old_idx"])
+            A = pkg.DeviceMatrix(s, block_tlc=b if (args.sp and not args.no_block_plan) else 0)
+            xp = np.zeros(ld, ndt); xp[:s.n_rows] = pkg.apply_permutation((1.0 + 1e-3 * (np.arange(s.n_rows) % 1000)).astype(ndt), a["new_to_old_idx"])
             res = {}
             for lay, nm in ((pkg.COLWISE, "colwise"), (pkg.ROWWISE, "rowwise")):
-                X = np.zeros(b * ld)
+                X = np.zeros(b * ld, ndt)
                 for v in range(b):
-                    col = xp * (1.0 + v / 8.0)
+                    col = (xp * ndt(1.0 + v / 8.0)).astype(ndt)
                     if lay == pkg.ROWWISE: X[np.arange(ld) * b + v] = col
                     else: X[v * ld:(v + 1) * ld] = col
-                dX = t.from_numpy(X).cuda(); dY = t.zeros(b * ld, dtype=t.float64, device="cuda")
+                dX = t.from_numpy(X).cuda(); dY = t.zeros(b * ld, dtype=tdt, device="cuda")
                 pkg.spmmv(A, dX, dY, b, ld, lay)
                 okl = None if args.no_check else bool(np.array_equal(dY.cpu().numpy(), orc.spmmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, b, ld, lay == pkg.ROWWISE)))
                 res[nm] = (B.time_launches(5, args.reps, A=A, x=dX, y=dY, b=b, ld=ld, layout=lay), okl)
             ms, ok = res["colwise"]
-            byts = s.n_elements * 12 + 8 * s.n_chunks + b * 8 * s.n_rows + b * 8 * s.n_rows_padded
-            out = dict(config=3, workload=f"Queen_4147-class stencil27 {g}^3 x 3 dof scs -c 32 -s 512 -dp -block_vec_size 8", n=s.n_rows, nnz=s.nnz, b=b,
+            byts = s.n_elements * (vs + 4) + 8 * s.n_chunks + b * vs * s.n_rows + b * vs * s.n_rows_padded
+            out = dict(config=3, workload=f"Queen_4147-class stencil27 {g}^3 x 3 dof scs -c 32 -s 512 {'-sp' if args.sp else '-dp'} -block_vec_size 8", n=s.n_rows, nnz=s.nnz, b=b,
+                       block_plan_tiles=[A.block_staged, A.block_tiles],
                        rowwise_ms=round(res["rowwise"][0], 5), rowwise_bitexact=res["rowwise"][1])
             flops = 2.0 * s.nnz * b
         else:
