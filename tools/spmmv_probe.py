@@ -19,7 +19,7 @@ for dt, tdt, vs in ((pkg.F64, torch.float64, 8), (pkg.F32, torch.float32, 4)):
     X = torch.rand(b * ld, dtype=tdt, device="cuda"); Y = torch.zeros_like(X)
     byts = s.n_elements * (vs + 4) + 8 * s.n_chunks + 2 * b * vs * ld
     for lay, nm in ((pkg.ROWWISE, "rowwise"), (pkg.COLWISE, "colwise")):
-        for var, u, pf, blk in ((0, 0, 1, 256),):
+        for var, u, pf, blk in ((0, 0, 1, 256), (3, 4, 1, 256), (3, 8, 1, 256), (3, 8, 1, 128), (3, 8, 1, 64)):
             pkg.set_tuning(spmmv_variant=var, spmmv_unroll=u, spmmv_prefetch=pf, block=blk)
             Yr = torch.zeros_like(X)
             pkg.spmmv(A, X, Yr, b, ld, lay)

@@ -56,7 +56,7 @@ __global__ void scs_spmmv_rows(const long n_chunks, const int C, const int *__re
 // YCOL: write Y column-major (Y[row + v*ld]) straight from the accumulators -- per vector one
 // coalesced 64-lane store -- so that column-major callers only pay the X re-layout.
 template <typename VT, int B, int U, bool NT, bool YCOL, bool PF>
-__global__ void scs_spmmv_rowmajor(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
+__global__ void __launch_bounds__(256) scs_spmmv_rowmajor(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
                                    const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                                    const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
                                    const long ld, const int xcd_remap) {
@@ -459,7 +459,7 @@ void launch_spmmv_vb(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, in
 
 template <typename VT, int B, int U>
 void launch_spmmv_rowmajor_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
-    const int block = g_tune.block;
+    const int block = std::min(g_tune.block, 256);      // (__launch_bounds__(256): deep batches may use > 128 VGPRs)
     const unsigned grid = grid_for(A->n_chunks * A->C, block);
 #define RM_LAUNCH(NTV, YC)                                                                                          \
     do {                                                                                                            \
@@ -548,8 +548,9 @@ void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
         }
     }
     // auto: 256 bytes of X rows per lane and batch (more spills the prefetching form at 128 VGPRs)
-    constexpr int UMAX = RB >= 128 ? 2 : RB >= 64 ? 4 : 8;
-    int U = g_tune.spmmv_unroll ? g_tune.spmmv_unroll : UMAX;
+    constexpr int UMAX = RB >= 128 ? 4 : 8;
+    constexpr int UDEF = RB >= 128 ? 2 : RB >= 64 ? 4 : 8;
+    int U = g_tune.spmmv_unroll ? g_tune.spmmv_unroll : UDEF;
     if (U > UMAX) U = UMAX;
     if constexpr (UMAX >= 8) { if (U >= 8) { launch_spmmv_rowmajor_u<VT, B, 8>(A, X, Y, ld, ycol, st); return; } }
     if constexpr (UMAX >= 4) { if (U >= 4) { launch_spmmv_rowmajor_u<VT, B, 4>(A, X, Y, ld, ycol, st); return; } }
