@@ -251,6 +251,42 @@ def test_convert_to_scs_device_bitexact(pkg, torch_cuda):
         pkg.convert_to_scs_device(unsorted, 2, 2)
 
 
+def test_device_plan_builder_matches_host_planner(pkg, orc, torch_cuda):
+    """uspmv_dmat_optimize_device: the plan built on the GPU from the handle's arrays equals the host planner's
+    (line lists, 16-bit indices) and the SpMV on it is bit-exact; also on handles made by convert_to_scs_device and
+    with a line budget that leaves some tiles unstaged."""
+    t = torch_cuda
+    for name, C, sigma, max_lines in (("bcsstk13", 32, 512, 0), ("bcsstk13", 32, 512, 40), ("FDM-2d-16", 16, 512, 0),
+                                      ("impcol_e", 64, 64, 0), ("bcsstk13", 128, 128, 0), ("matrix1", 256, 256, 0),
+                                      ("bcsstk13", 8, 1, 0)):
+        m = pkg.read_mtx(mtx_path(name))
+        for code in (pkg.F64, pkg.F32):
+            s, a, xp = _prep(pkg, m, C, sigma, code, make_x(m.n_rows))
+            pkg.set_tuning(rechunk=0)                         # compare like with like: no internal C = 32 re-chunking
+            Ah = pkg.DeviceMatrix(s); Ah.optimize(s, max_lines)
+            pkg.set_tuning(rechunk=1)
+            Ad = pkg.DeviceMatrix(s); Ad.optimize_device(max_lines)
+            assert (Ad.tlc_tiles, Ad.tlc_staged) == (Ah.tlc_tiles, Ah.tlc_staged), (name, C, code)
+            ph, pd = Ah.plan_download(), Ad.plan_download()
+            assert (ph is None) == (pd is None)
+            if ph is not None:
+                for k in ("tile_line_ptr", "tile_lines", "c16_ptrs", "col16"):
+                    assert np.array_equal(ph[k], pd[k]), (name, C, code, k)
+                assert ph["max_lines_used"] == pd["max_lines_used"]
+            yo = orc.spmv_scs(s.C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+            y = t.full((s.n_rows_padded,), 3.0, dtype=Ad.torch_dtype, device="cuda")
+            pkg.spmv(Ad, _dev(t, xp), y)
+            assert np.array_equal(y.cpu().numpy(), yo), (name, C, code)
+    m = pkg.read_mtx(mtx_path("bcsstk13"))                    # device-converted handle, no host entries at all
+    lay, A = pkg.convert_to_scs_device(m, 32, 512, pkg.F64)
+    nt, ns = A.optimize_device()
+    assert nt > 0 and ns == nt
+    s, a, xp = _prep(pkg, m, 32, 512, pkg.F64, make_x(m.n_rows))
+    y = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
+    pkg.spmv(A, _dev(t, xp), y)
+    assert np.array_equal(y.cpu().numpy(), orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp))
+
+
 def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
     """uspmv_dmat_optimize_block: LDS-staged X rows + 16-bit local indices give the same bits as the gather
     kernels and the oracle (block_spmv_omp_scs_general, code/kernels.hpp:306-398); staged and unstaged tiles,
@@ -594,6 +630,21 @@ def test_full_size_nlpkkt200_class(pkg, orc, torch_cuda):
     y2 = t.zeros_like(y)
     pkg.spmv(A, 2.0 * x, y2)
     assert t.equal(y2, 2.0 * y)
+    # GPU-side set-up path at this size: device conversion + device plan builder == host conversion + host planner
+    # (here every tile carries padding entries whose column lies far from the tile's own range: split bitmap)
+    t0 = time.time()
+    lay, Ad = pkg.convert_to_scs_device(m, 32, 512)
+    Ad.optimize_device()
+    print(f"[full] device convert + plan {time.time() - t0:.1f}s, {Ad.tlc_staged} of {Ad.tlc_tiles} tiles staged", flush=True)
+    assert (Ad.tlc_tiles, Ad.tlc_staged) == (A.tlc_tiles, A.tlc_staged)
+    ph, pd = A.plan_download(), Ad.plan_download()
+    for k in ("tile_line_ptr", "tile_lines", "c16_ptrs", "col16"):
+        assert np.array_equal(ph[k], pd[k]), k
+    del ph, pd
+    y2.zero_()
+    pkg.spmv(Ad, x, y2)
+    assert t.equal(y2, y)
+    del Ad, lay
     # sample of rows against the row-sorted COO (original numbering)
     I, J, V = m.arrays()
     yo = pkg.apply_permutation(yh, a["old_to_new_idx"])

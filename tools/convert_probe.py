@@ -17,10 +17,13 @@ for rep in range(2):
     pkg.permute_scs_cols(s, s.arrays()["old_to_new_idx"]); t2 = time.time()
     A = pkg.DeviceMatrix(s); torch.cuda.synchronize(); t3 = time.time()
     lay, Ad = pkg.convert_to_scs_device(coo, 32, 512, pkg.F64); t4 = time.time()
+    Ad.optimize_device(); torch.cuda.synchronize(); t5 = time.time()
+    A.optimize(s); torch.cuda.synchronize(); t6 = time.time()
     same = None
     if rep == 1:
         d = pkg.dmat_download(Ad); a = s.arrays()
         same = bool(np.array_equal(d["col_idxs"], a["col_idxs"]) and np.array_equal(d["values"], a["values"]) and np.array_equal(d["chunk_ptrs"], a["chunk_ptrs"]))
     print(json.dumps(dict(grid=g, nnz=coo.nnz, gen_s=round(t_gen, 2), host_convert_s=round(t1 - t0, 2), host_permute_cols_s=round(t2 - t1, 2),
-                          upload_s=round(t3 - t2, 2), host_path_total_s=round(t3 - t0, 2), device_path_total_s=round(t4 - t3, 2), identical=same)), flush=True)
+                          upload_s=round(t3 - t2, 2), host_path_total_s=round(t3 - t0, 2), device_path_total_s=round(t4 - t3, 2), device_plan_s=round(t5 - t4, 2), host_plan_s=round(t6 - t5, 2),
+                          plan_tiles=[Ad.tlc_staged, Ad.tlc_tiles, A.tlc_staged, A.tlc_tiles], identical=same)), flush=True)
     del A, Ad, s, lay

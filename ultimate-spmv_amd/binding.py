@@ -80,6 +80,8 @@ _SIGS = {
     "uspmv_spmv_chunks": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "uspmv_spmv_tiles": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "uspmv_dmat_tile_rows": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "uspmv_dmat_optimize_device": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
+    "uspmv_dmat_plan_download": (C.c_int, [_vp, C.POINTER(_i64), _vp, _vp, _vp, _vp]),
     "uspmv_dmat_optimize_block": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_optimize_ap": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp]),
@@ -391,6 +393,28 @@ class DeviceMatrix:
         self.block_tiles = self.block_staged = 0
         if block_tlc:
             self.optimize_block(scs, block_tlc)
+
+    def optimize_device(self, max_lines=0):
+        """Build the tile-local-column plan on the device from the handle's own arrays (uspmv_dmat_optimize_device)."""
+        a, b = _i64(), _i64()
+        _ck(lib().uspmv_dmat_optimize_device(self.h, max_lines, C.byref(a), C.byref(b)))
+        self.tlc_tiles, self.tlc_staged = a.value, b.value
+        tr = C.c_int()
+        _ck(lib().uspmv_dmat_tile_rows(self.h, C.byref(tr)))
+        self.tile_rows = tr.value
+        return a.value, b.value
+
+    def plan_download(self):
+        """Host copies of the tile-local-column plan (tests): dict or None when the handle has no plan."""
+        meta = (_i64 * 4)()
+        _ck(lib().uspmv_dmat_plan_download(self.h, meta, None, None, None, None))
+        nt, nl, n16, mx = [int(v) for v in meta]
+        if nt == 0:
+            return None
+        lp = np.empty(nt + 1, np.int32); tl = np.empty(nl, np.int32)
+        cp = np.empty(self.n_chunks + 1, np.uint32); c16 = np.empty(n16, np.uint16)
+        _ck(lib().uspmv_dmat_plan_download(self.h, meta, _np_ptr(lp), _np_ptr(tl), _np_ptr(cp), _np_ptr(c16)))
+        return dict(tile_line_ptr=lp, tile_lines=tl, c16_ptrs=cp, col16=c16, max_lines_used=mx)
 
     def optimize_block(self, scs, block_vec_size):
         """Build the LDS-staged SpMMV plan for block vectors of this width (uspmv_dmat_optimize_block)."""

@@ -1,0 +1,158 @@
+// Device-side builder of the tile-local-column plan (the structure host/tlc_plan.cpp derives on the CPU): for
+// handles whose SCS arrays exist only in HBM (uspmv_dmat_wrap, uspmv_convert_to_scs_device).  Two sweeps over
+// col_idxs, one 256-thread workgroup per tile (thread <-> row): the first counts a tile's distinct 16-element
+// x lines with a bitmap in LDS, the second -- after an exclusive scan of those counts on the host (n_tiles
+// integers) -- writes the sorted line list and the 16-bit local indices.  The bitmap covers 65 536 lines: the
+// tile's whole line range when it fits, else the 32 768 lines from its lowest and the 32 768 lines up to its
+// highest line (padding entries carry one far-away column, permute_scs_cols(0): the usual reason for a wide
+// range).  Tiles with lines in between are left unstaged (the host planner sorts those), which changes the plan,
+// never y; everywhere else the plan is identical to the host planner's.
+#include "uspmv_device.hpp"
+
+using namespace uspmv_dev;
+
+namespace {
+
+constexpr int PLAN_BITS = 65536;            // lines a tile's bitmap covers
+constexpr int PLAN_WORDS = PLAN_BITS / 32;
+constexpr int PLAN_HALF = PLAN_BITS / 2;
+
+// line -> bit (or -1: not representable) and back, for a tile with lowest / highest line lo / hi
+__device__ __forceinline__ int line_to_bit(int l, int lo, int hi) {
+    if (hi - lo < PLAN_BITS) return l - lo;
+    if (l - lo < PLAN_HALF) return l - lo;
+    if (hi - l < PLAN_HALF) return PLAN_BITS - 1 - (hi - l);
+    return -1;
+}
+__device__ __forceinline__ int bit_to_line(int b, int lo, int hi) {
+    if (hi - lo < PLAN_BITS || b < PLAN_HALF) return lo + b;
+    return hi - (PLAN_BITS - 1 - b);
+}
+
+// Marks the lines of the tile in bits[]; returns (lo line, line range) through LDS scalars.  range = 0: empty tile.
+__device__ void tile_bitmap(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
+                            const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const long tile,
+                            unsigned *bits, int *s_lo, int *s_hi, int *s_maxcol, int *s_bad) {
+    const long row = tile * 256 + threadIdx.x;
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    int cs = 0, L = 0;
+    if (c < n_chunks) { cs = chunk_ptrs[c]; L = chunk_lengths[c]; }
+    if (threadIdx.x == 0) { *s_lo = INT32_MAX; *s_hi = -1; *s_bad = 0; }
+    for (int w = threadIdx.x; w < PLAN_WORDS; w += 256) bits[w] = 0u;
+    __syncthreads();
+    int lo = INT32_MAX, hi = -1;
+    for (int j = 0; j < L; ++j) {
+        const int col = col_idxs[(long)cs + (long)j * C + i];
+        lo = min(lo, col); hi = max(hi, col);
+    }
+    if (hi >= 0) { atomicMin(s_lo, lo >> 4); atomicMax(s_hi, hi >> 4); atomicMax(s_maxcol, hi); }
+    __syncthreads();
+    const int tlo = *s_lo, thi = *s_hi;
+    if (thi < 0) return;
+    bool bad = false;
+    for (int j = 0; j < L; ++j) {
+        const int b = line_to_bit(col_idxs[(long)cs + (long)j * C + i] >> 4, tlo, thi);
+        if (b < 0) bad = true;
+        else atomicOr(&bits[b >> 5], 1u << (b & 31));
+    }
+    if (bad) *s_bad = 1;
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) plan_count_lines(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
+        const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const int max_lines,
+        int *__restrict__ n_lines, int *__restrict__ max_col) {
+    __shared__ unsigned bits[PLAN_WORDS];
+    __shared__ int s_lo, s_hi, s_cnt, s_maxcol, s_bad;
+    if (threadIdx.x == 0) { s_cnt = 0; s_maxcol = 0; }
+    const long tile = blockIdx.x;
+    tile_bitmap(n_chunks, C, chunk_ptrs, chunk_lengths, col_idxs, tile, bits, &s_lo, &s_hi, &s_maxcol, &s_bad);
+    int n = 0;
+    if (s_hi >= 0 && !s_bad) {
+        int cnt = 0;
+        for (int w = threadIdx.x; w < PLAN_WORDS; w += 256) cnt += __popc(bits[w]);
+        atomicAdd(&s_cnt, cnt);
+        __syncthreads();
+        n = s_cnt <= max_lines ? s_cnt : 0;
+    }
+    if (threadIdx.x == 0) {
+        n_lines[tile] = n;
+        atomicMax(max_col, s_maxcol);
+    }
+}
+
+__global__ void __launch_bounds__(256) plan_write(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
+        const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const int *__restrict__ tile_line_ptr,
+        const unsigned *__restrict__ c16_ptrs, int *__restrict__ tile_lines, unsigned short *__restrict__ col16) {
+    __shared__ unsigned bits[PLAN_WORDS];
+    __shared__ unsigned short rank0[PLAN_WORDS];   // set bits in the words before this one (< 4096)
+    __shared__ int s_lo, s_hi, s_dummy, s_bad;
+    __shared__ int wsum[256];
+    const long tile = blockIdx.x;
+    const int lp0 = tile_line_ptr[tile];
+    if (tile_line_ptr[tile + 1] == lp0) return;   // unstaged or empty tile: col16 stays zero, the kernel gathers
+    if (threadIdx.x == 0) s_dummy = 0;
+    tile_bitmap(n_chunks, C, chunk_ptrs, chunk_lengths, col_idxs, tile, bits, &s_lo, &s_hi, &s_dummy, &s_bad);
+    // exclusive prefix of the popcounts: 8 consecutive words per thread, then a block scan of the 256 partial sums
+    constexpr int WPT = PLAN_WORDS / 256;
+    int part = 0;
+    for (int k = 0; k < WPT; ++k) part += __popc(bits[threadIdx.x * WPT + k]);
+    wsum[threadIdx.x] = part;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = threadIdx.x >= o ? wsum[threadIdx.x - o] : 0;
+        __syncthreads();
+        wsum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = wsum[threadIdx.x] - part;
+    for (int k = 0; k < WPT; ++k) {
+        const int w = threadIdx.x * WPT + k;
+        rank0[w] = (unsigned short)run;
+        unsigned b = bits[w];
+        int r = run;
+        while (b) {                                 // the tile's sorted line list
+            const int bit = __ffs(b) - 1;
+            tile_lines[lp0 + r++] = bit_to_line(w * 32 + bit, s_lo, s_hi);
+            b &= b - 1;
+        }
+        run += __popc(bits[w]);
+    }
+    __syncthreads();
+    const long row = tile * 256 + threadIdx.x;
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    if (c >= n_chunks) return;
+    const int cs = chunk_ptrs[c], L = chunk_lengths[c];
+    unsigned short *q = col16 + c16_ptrs[c];
+    const int tlo = s_lo, thi = s_hi;
+    for (int j = 0; j < L; ++j) {
+        const int col = col_idxs[(long)cs + (long)j * C + i];
+        const int l = line_to_bit(col >> 4, tlo, thi);
+        const unsigned below = bits[l >> 5] & ((1u << (l & 31)) - 1u);
+        const int pos = rank0[l >> 5] + __popc(below);
+        q[(long)(j >> 2) * 4 * C + i * 4 + (j & 3)] = (unsigned short)((pos << 4) | (col & 15));
+    }
+}
+
+}  // namespace
+
+namespace uspmv_dev {
+
+int launch_plan_count(const uspmv_dmat *A, long n_tiles, int max_lines, int *d_n_lines, int *d_max_col, hipStream_t st) {
+    hipLaunchKernelGGL(plan_count_lines, dim3((unsigned)n_tiles), dim3(256), 0, st, (long)A->n_chunks, (int)A->C, A->chunk_ptrs,
+                       A->chunk_lengths, A->col_idxs, max_lines, d_n_lines, d_max_col);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int launch_plan_write(const uspmv_dmat *A, long n_tiles, const int *d_tile_line_ptr, const unsigned *d_c16_ptrs, int *d_tile_lines,
+                      unsigned short *d_col16, hipStream_t st) {
+    hipLaunchKernelGGL(plan_write, dim3((unsigned)n_tiles), dim3(256), 0, st, (long)A->n_chunks, (int)A->C, A->chunk_ptrs,
+                       A->chunk_lengths, A->col_idxs, d_tile_line_ptr, d_c16_ptrs, d_tile_lines, d_col16);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+}  // namespace uspmv_dev

@@ -354,6 +354,94 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     return USPMV_OK;
 }
 
+int uspmv_dmat_optimize_device(uspmv_dmat_t *A, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
+    if (int rc = check_dmat(A, "uspmv_dmat_optimize_device")) return rc;
+    if (int rc = require_device()) return rc;
+    if (A->tlc) tlc_release(A);
+    if (A->alt) { uspmv_dmat_free(A->alt); A->alt = nullptr; }
+    if (n_tiles) *n_tiles = 0;
+    if (n_staged) *n_staged = 0;
+    const int64_t C = A->C, nc = A->n_chunks;
+    if (C > 256 || 256 % C != 0 || nc < 1) return USPMV_OK;                    // shape without a plan
+    if (max_lines <= 0) max_lines = 512;
+    max_lines = std::min(max_lines, (int)(160 * 1024 / (16 * (A->dtype == USPMV_F64 ? 8 : 4))));
+    max_lines = std::min(max_lines, 4096);
+    const int64_t T = 256 / C, nt = (nc + T - 1) / T;
+    // 16-bit index offsets per chunk: O(n_chunks) on the host from the chunk lengths
+    std::vector<int32_t> cl((size_t)nc);
+    HIP_TRY(hipMemcpy(cl.data(), A->chunk_lengths, 4 * (size_t)nc, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> c16p((size_t)nc + 1, 0);
+    int64_t tot16 = 0;
+    for (int64_t c = 0; c < nc; ++c) {
+        c16p[(size_t)c] = (uint32_t)tot16;
+        tot16 += ((int64_t)(cl[(size_t)c] + 3) / 4) * 4 * C;
+        if (tot16 > (int64_t)UINT32_MAX) return USPMV_OK;                    // too large for 32-bit offsets: no plan
+    }
+    c16p[(size_t)nc] = (uint32_t)tot16;
+    int *d_n = nullptr, *d_max = nullptr;
+    hipError_t e = hipMalloc((void **)&d_n, 4 * (size_t)nt);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_max, 4);
+    if (e == hipSuccess) e = hipMemset(d_max, 0, 4);
+    if (e != hipSuccess) { (void)hipFree(d_n); (void)hipFree(d_max); return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_device: %s", hipGetErrorString(e)); }
+    int rc = launch_plan_count(A, (long)nt, max_lines, d_n, d_max, nullptr);
+    std::vector<int32_t> lp((size_t)nt + 1, 0);
+    int max_col = 0;
+    if (!rc) {
+        e = hipMemcpy(lp.data() + 1, d_n, 4 * (size_t)nt, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(&max_col, d_max, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = uspmv::fail(USPMV_ERR_HIP, "uspmv_dmat_optimize_device: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_n); (void)hipFree(d_max);
+    if (rc) return rc;
+    int64_t staged = 0, total = 0;
+    int used = 0;
+    for (int64_t t = 0; t < nt; ++t) {
+        const int n = lp[(size_t)t + 1];
+        staged += n > 0; used = std::max(used, n);
+        total += n;
+        if (total > INT32_MAX) return USPMV_OK;
+        lp[(size_t)t + 1] = (int32_t)total;
+    }
+    if (n_tiles) *n_tiles = nt;
+    if (n_staged) *n_staged = staged;
+    if (staged == 0) return USPMV_OK;
+    e = hipMalloc((void **)&A->tlc_line_ptr, 4 * ((size_t)nt + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&A->tlc_lines, 4 * (size_t)std::max<int64_t>(total, 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&A->tlc_c16_ptrs, 4 * ((size_t)nc + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&A->tlc_col16, 2 * (size_t)std::max<int64_t>(tot16, 1));
+    if (e == hipSuccess) e = hipMemset(A->tlc_col16, 0, 2 * (size_t)std::max<int64_t>(tot16, 1));   // padded slots: index 0
+    if (e == hipSuccess) e = hipMemcpy(A->tlc_line_ptr, lp.data(), 4 * ((size_t)nt + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(A->tlc_c16_ptrs, c16p.data(), 4 * ((size_t)nc + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess && launch_plan_write(A, (long)nt, A->tlc_line_ptr, A->tlc_c16_ptrs, A->tlc_lines, A->tlc_col16, nullptr) != USPMV_OK)
+        e = hipErrorUnknown;
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        tlc_release(A);
+        return uspmv::fail(USPMV_ERR_HIP, "uspmv_dmat_optimize_device: %s", hipGetErrorString(e));
+    }
+    A->tlc = true; A->tlc_tile_rows = 256; A->tlc_max_lines = used; A->tlc_x_len = (int64_t)max_col + 1; A->tlc_n_tiles = nt;
+    A->tlc_staged = staged;
+    return USPMV_OK;
+}
+
+int uspmv_dmat_plan_download(const uspmv_dmat_t *A, int64_t meta[4], int32_t *tile_line_ptr, int32_t *tile_lines, uint32_t *c16_ptrs,
+                             uint16_t *col16) {
+    if (int rc = check_dmat(A, "uspmv_dmat_plan_download")) return rc;
+    if (!meta) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_plan_download: NULL meta");
+    meta[0] = meta[1] = meta[2] = meta[3] = 0;
+    if (!A->tlc) return USPMV_OK;
+    if (int rc = require_device()) return rc;
+    int32_t last = 0; uint32_t last16 = 0;
+    HIP_TRY(hipMemcpy(&last, A->tlc_line_ptr + A->tlc_n_tiles, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&last16, A->tlc_c16_ptrs + A->n_chunks, 4, hipMemcpyDeviceToHost));
+    meta[0] = A->tlc_n_tiles; meta[1] = last; meta[2] = last16; meta[3] = A->tlc_max_lines;
+    if (tile_line_ptr) HIP_TRY(hipMemcpy(tile_line_ptr, A->tlc_line_ptr, 4 * ((size_t)A->tlc_n_tiles + 1), hipMemcpyDeviceToHost));
+    if (tile_lines && last) HIP_TRY(hipMemcpy(tile_lines, A->tlc_lines, 4 * (size_t)last, hipMemcpyDeviceToHost));
+    if (c16_ptrs) HIP_TRY(hipMemcpy(c16_ptrs, A->tlc_c16_ptrs, 4 * ((size_t)A->n_chunks + 1), hipMemcpyDeviceToHost));
+    if (col16 && last16) HIP_TRY(hipMemcpy(col16, A->tlc_col16, 2 * (size_t)last16, hipMemcpyDeviceToHost));
+    return USPMV_OK;
+}
+
 static void bt_release(uspmv_dmat_t *A) {
     (void)hipFree(A->bt_line_ptr); (void)hipFree(A->bt_xrows); (void)hipFree(A->bt_c16_ptrs); (void)hipFree(A->bt_col16);
     A->bt_line_ptr = A->bt_xrows = nullptr; A->bt_c16_ptrs = nullptr; A->bt_col16 = nullptr;

@@ -85,6 +85,10 @@ int launch_spmmv(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int la
 int launch_spmv_ap(const uspmv_dmat *dp, const uspmv_dmat *sp, const double *d_x, const float *d_x_sp, double *d_y,
                    hipStream_t stream);                                                                           // ap_kernels.hip
 
+int launch_plan_count(const uspmv_dmat *A, long n_tiles, int max_lines, int *d_n_lines, int *d_max_col, hipStream_t st);      // plan_kernels.hip
+int launch_plan_write(const uspmv_dmat *A, long n_tiles, const int *d_tile_line_ptr, const unsigned *d_c16_ptrs, int *d_tile_lines,
+                      unsigned short *d_col16, hipStream_t st);                                                            // plan_kernels.hip
+
 }  // namespace uspmv_dev
 
 #define HIP_TRY(call)                                                                              \
