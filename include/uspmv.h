@@ -222,11 +222,14 @@ int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_
  *   "spmmv_variant" 0 (auto) | 1 (generic) | 2 (row-major, transposing X phase) | 3 (row-major, lane per row)
  *                   | 4 (block plan where present; 0 prefers it too, 2 and 3 ignore it),
  *   "spmmv_swizzle" 0|1 bank-swizzled LDS rows in the block-plan kernel,
+ *   "raw_plan_cache" 0|1 uspmv_scs_gpu_f64/f32 keep a device-built plan per set of array addresses (the caller
+ *   promises not to put another matrix behind the same pointers; uspmv_raw_plan_cache_clear() otherwise),
  *   "spmmv_tile_rows" 0 (auto) | 64 rows per tile and "spmmv_lds_kb" 0 (= 80) | LDS KiB per tile of the NEXT
  *   uspmv_dmat_optimize_block,
  *   "spmmv_prefetch" 1|0 (lane-per-row kernel: next batch of matrix entries requested behind the X rows),
  *   "spmmv_unroll" 0 (auto) | 1|2|4|8 slots per batch,
  *   "ablate" 0 | 1 | 2 (measurement only: gathers collapsed / removed, results are wrong). */
+void uspmv_raw_plan_cache_clear(void);
 int uspmv_set_tuning(const char *key, int value);
 int uspmv_get_tuning(const char *key, int *value);
 

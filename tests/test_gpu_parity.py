@@ -287,6 +287,31 @@ def test_device_plan_builder_matches_host_planner(pkg, orc, torch_cuda):
     assert np.array_equal(y.cpu().numpy(), orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp))
 
 
+def test_raw_entry_point_plan_cache(pkg, orc, torch_cuda):
+    """uspmv_scs_gpu_f64/f32 with the opt-in plan cache ("raw_plan_cache"): same bits as without, for repeated calls,
+    several matrices behind different pointers, and after uspmv_raw_plan_cache_clear()."""
+    t = torch_cuda
+    mats = []
+    for name, C, sigma, code in (("bcsstk13", 32, 512, pkg.F64), ("impcol_e", 64, 64, pkg.F32), ("FDM-2d-16", 5, 7, pkg.F64)):
+        m = pkg.read_mtx(mtx_path(name))
+        s, a, xp = _prep(pkg, m, C, sigma, code, make_x(m.n_rows))
+        A = pkg.DeviceMatrix(s)          # torch-owned device arrays = what a host application would pass
+        yo = orc.spmv_scs(s.C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+        mats.append((s, A, _dev(t, xp), yo))
+    try:
+        for cache in (1, 0, 1):
+            pkg.set_tuning(raw_plan_cache=cache)
+            for rep in range(3):
+                for s, A, x, yo in mats:
+                    y = t.full((s.n_rows_padded,), -5.0, dtype=A.torch_dtype, device="cuda")
+                    pkg.uspmv_scs_gpu(s.C, s.n_chunks, A.chunk_ptrs, A.chunk_lengths, A.col_idxs, A.values, x, y)
+                    assert np.array_equal(y.cpu().numpy(), yo), (cache, rep, s.C)
+            pkg.lib().uspmv_raw_plan_cache_clear()
+    finally:
+        pkg.set_tuning(raw_plan_cache=0)
+        pkg.lib().uspmv_raw_plan_cache_clear()
+
+
 def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
     """uspmv_dmat_optimize_block: LDS-staged X rows + 16-bit local indices give the same bits as the gather
     kernels and the oracle (block_spmv_omp_scs_general, code/kernels.hpp:306-398); staged and unstaged tiles,

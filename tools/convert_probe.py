@@ -26,4 +26,18 @@ for rep in range(2):
     print(json.dumps(dict(grid=g, nnz=coo.nnz, gen_s=round(t_gen, 2), host_convert_s=round(t1 - t0, 2), host_permute_cols_s=round(t2 - t1, 2),
                           upload_s=round(t3 - t2, 2), host_path_total_s=round(t3 - t0, 2), device_path_total_s=round(t4 - t3, 2), device_plan_s=round(t5 - t4, 2), host_plan_s=round(t6 - t5, 2),
                           plan_tiles=[Ad.tlc_staged, Ad.tlc_tiles, A.tlc_staged, A.tlc_tiles], identical=same)), flush=True)
+    if rep == 1:      # the raw-array entry point (the reference's function-pointer seam) with and without the plan cache
+        from ultimate_spmv_amd import binding as B
+        x = torch.rand(s.n_rows_padded, dtype=torch.float64, device="cuda"); y = torch.zeros_like(x)
+        A0 = pkg.DeviceMatrix(s)
+        for cache in (0, 1):
+            pkg.set_tuning(raw_plan_cache=cache)
+            for _ in range(5):
+                pkg.uspmv_scs_gpu(32, s.n_chunks, A0.chunk_ptrs, A0.chunk_lengths, A0.col_idxs, A0.values, x, y)
+            torch.cuda.synchronize(); t7 = time.time()
+            for _ in range(50):
+                pkg.uspmv_scs_gpu(32, s.n_chunks, A0.chunk_ptrs, A0.chunk_lengths, A0.col_idxs, A0.values, x, y)
+            torch.cuda.synchronize()
+            print(json.dumps(dict(raw_entry_point_plan_cache=cache, ms_per_call=round((time.time() - t7) / 50 * 1e3, 4))), flush=True)
+        pkg.set_tuning(raw_plan_cache=0); pkg.lib().uspmv_raw_plan_cache_clear()
     del A, Ad, s, lay

@@ -92,6 +92,7 @@ _SIGS = {
     "uspmv_csr_gpu_f64": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "uspmv_csr_gpu_f32": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "uspmv_apply_permutation_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
+    "uspmv_raw_plan_cache_clear": (None, []),
     "uspmv_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "uspmv_get_tuning": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "uspmv_seg_work_sharing_arr": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),

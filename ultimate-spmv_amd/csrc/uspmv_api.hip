@@ -2,6 +2,8 @@
 // stream kernels and the entry points that dispatch into spmv_kernels.hip, spmmv_kernels.hip and ap_kernels.hip.
 #include "uspmv_device.hpp"
 
+#include <mutex>
+
 using namespace uspmv_dev;
 
 namespace uspmv_dev {
@@ -123,6 +125,7 @@ int uspmv_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "ablate")) g_tune.ablate = value;
     else if (!strcmp(key, "spmmv_prefetch")) g_tune.spmmv_prefetch = value != 0;
     else if (!strcmp(key, "spmmv_swizzle")) g_tune.spmmv_swizzle = value != 0;
+    else if (!strcmp(key, "raw_plan_cache")) g_tune.raw_plan_cache = value != 0;
     else if (!strcmp(key, "spmmv_tile_rows")) g_tune.spmmv_tile_rows = value == 64 ? 64 : 0;
     else if (!strcmp(key, "spmmv_lds_kb")) g_tune.spmmv_lds_kb = value < 0 ? 0 : value;
     else if (!strcmp(key, "spmmv_variant")) {
@@ -162,6 +165,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "ablate")) *value = g_tune.ablate;
     else if (!strcmp(key, "spmmv_prefetch")) *value = g_tune.spmmv_prefetch;
     else if (!strcmp(key, "spmmv_swizzle")) *value = g_tune.spmmv_swizzle;
+    else if (!strcmp(key, "raw_plan_cache")) *value = g_tune.raw_plan_cache;
     else if (!strcmp(key, "spmmv_tile_rows")) *value = g_tune.spmmv_tile_rows;
     else if (!strcmp(key, "spmmv_lds_kb")) *value = g_tune.spmmv_lds_kb;
     else if (!strcmp(key, "spmmv_variant")) *value = g_tune.spmmv_variant;
@@ -636,6 +640,39 @@ int uspmv_spmv_ap_generic(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const 
     return spmv_ap_impl(dp, sp, d_x, d_x_sp, d_y, stream, "uspmv_spmv_ap_generic");
 }
 
+// Opt-in plan cache of the raw-array entry points (tuning key "raw_plan_cache"): the reference's function-pointer
+// seam passes the same device arrays on every call (code/classes_structs.hpp:997-1034), so the first call wraps them,
+// builds the tile-local-column plan on the device and later calls run the plan kernel.  Keyed on the array
+// addresses and shape -- the caller promises not to put a different matrix behind the same pointers
+// (uspmv_raw_plan_cache_clear() after freeing or rewriting them).  Mutex-guarded; a handful of entries.
+namespace {
+struct RawKey { const void *cp, *cl, *ci, *va; int64_t C, n_chunks; int dtype; };
+struct RawEntry { RawKey k; uspmv_dmat_t *A; };
+std::vector<RawEntry> g_raw_cache;
+std::mutex g_raw_mutex;
+
+const uspmv_dmat *raw_cached(const RawKey &k) {
+    std::lock_guard<std::mutex> lock(g_raw_mutex);
+    for (const RawEntry &e : g_raw_cache)
+        if (e.k.cp == k.cp && e.k.cl == k.cl && e.k.ci == k.ci && e.k.va == k.va && e.k.C == k.C && e.k.n_chunks == k.n_chunks && e.k.dtype == k.dtype)
+            return e.A;
+    int32_t last = 0;
+    if (hipMemcpy(&last, (const int32_t *)k.cp + k.n_chunks, 4, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    uspmv_dmat_t *A = nullptr;
+    if (uspmv_dmat_wrap(k.C, k.n_chunks, last, k.dtype, (const int32_t *)k.cp, (const int32_t *)k.cl, (const int32_t *)k.ci, k.va, &A)) return nullptr;
+    if (uspmv_dmat_optimize_device(A, 0, nullptr, nullptr)) { uspmv_dmat_free(A); return nullptr; }
+    if (g_raw_cache.size() >= 16) { uspmv_dmat_free(g_raw_cache.front().A); g_raw_cache.erase(g_raw_cache.begin()); }
+    g_raw_cache.push_back(RawEntry{k, A});
+    return A;
+}
+}  // namespace
+
+void uspmv_raw_plan_cache_clear(void) {
+    std::lock_guard<std::mutex> lock(g_raw_mutex);
+    for (RawEntry &e : g_raw_cache) uspmv_dmat_free(e.A);
+    g_raw_cache.clear();
+}
+
 #define RAW_SCS(SUF, VT, DT)                                                                                        \
     int uspmv_scs_gpu_##SUF(int64_t C, int64_t n_chunks, const int32_t *cp, const int32_t *cl, const int32_t *ci,   \
                             const VT *va, const VT *x, VT *y, void *stream) {                                       \
@@ -647,6 +684,9 @@ int uspmv_spmv_ap_generic(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const 
         A.n_store = (long)(C * n_chunks);                                                                           \
         A.values = va;                                                                                              \
         if (int rc = check_dmat(&A, "uspmv_scs_gpu_" #SUF)) return rc;                                              \
+        if (g_tune.raw_plan_cache && n_chunks > 0)                                                                  \
+            if (const uspmv_dmat *P = raw_cached(RawKey{cp, cl, ci, va, C, n_chunks, DT}))                          \
+                return launch_spmv_scs<VT>(P, nullptr, 0, x, y, (hipStream_t)stream);                               \
         return launch_spmv_scs<VT>(&A, nullptr, 0, x, y, (hipStream_t)stream);                                      \
     }                                                                                                               \
     int uspmv_csr_gpu_##SUF(int64_t n_rows, const int32_t *rp, const int32_t *ci, const VT *va, const VT *x, VT *y, \

@@ -60,6 +60,7 @@ struct Tuning {
     int spmmv_unroll = 0;   // 0 = auto (256 bytes of X rows per lane and batch)
     int spmmv_lds_kb = 0;    // block plan: LDS budget per tile in KiB for the NEXT uspmv_dmat_optimize_block (0 = 80)
     int spmmv_tile_rows = 0; // block plan: 0 = auto (32-row tiles for >= 64-byte rows on C = 32), 64 = always 64
+    int raw_plan_cache = 0; // uspmv_scs_gpu_*: remember a device-built plan per set of array addresses (opt-in)
     int spmmv_swizzle = 0;  // block-plan kernel: 1 = piece-swizzled X rows in LDS (all 64 banks); 0 = plain layout, which
                             // needs ~10 fewer address instructions per non-zero and measures 5-7 % faster (spmmv_probe16.txt)
     int spmmv_prefetch = 1; // row-major lane-per-row kernel: request batch k+1's matrix entries behind batch k's X rows
