@@ -98,3 +98,73 @@ def test_gloo_halo_exchange(case, world, overlap, pkg, orc):
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _worker_block(rank, world, port, case, b, q):
+    """Distributed SpMMV (block-vector halo exchange in one message per neighbour), both layouts."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import __graft_entry__ as ge
+        pkg = ge.load_package()
+        from oracle import oracle as orc
+        from ultimate_spmv_amd import binding as B
+        from ultimate_spmv_amd.distributed import DistSpmv
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        name, Cc, sg, method = case
+        tot = pkg.read_mtx(mtx_path(name))
+        wsa = pkg.seg_work_sharing_arr(tot, method, world)
+        loc = B.seg_local_coo(tot, wsa, rank)
+
+        def gather(out, vec, idx):
+            out.copy_(vec[idx.long()])
+
+        def spmmv(d, X, Y, bb, ld, layout):
+            a = d.scs.arrays()
+            Y.copy_(torch.from_numpy(orc.spmmv_scs(d.scs.C, d.scs.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"],
+                                                   a["values"], X.numpy(), bb, ld, layout == B.ROWWISE)))
+            return Y
+
+        d = DistSpmv(loc, wsa, Cc, sg, device="cpu", gather_fn=gather, spmmv_fn=spmmv)
+        # single-rank truth, column by column, on the whole matrix (same per-row summation order)
+        st = pkg.convert_to_scs(tot, Cc, sg)
+        ta = st.arrays()
+        pkg.permute_scs_cols(st, ta["old_to_new_idx"]); ta = st.arrays()
+        cols = [(1.0 + 1e-3 * (np.arange(tot.n_rows) % 1000)) * (1.0 + v / 8.0) for v in range(b)]
+        truth = []
+        for xg in cols:
+            xp = np.zeros(max(st.n_rows_padded, tot.n_rows)); xp[:tot.n_rows] = pkg.apply_permutation(xg, ta["new_to_old_idx"])
+            yp = orc.spmv_scs(Cc, st.n_chunks, ta["chunk_ptrs"], ta["chunk_lengths"], ta["col_idxs"], ta["values"], xp)
+            truth.append(pkg.apply_permutation(yp, ta["old_to_new_idx"]))
+        ld = d.padded_vec_size
+        for layout in (B.COLWISE, B.ROWWISE):
+            X = d.new_X([xg[wsa[rank]:wsa[rank + 1]] for xg in cols], b, layout)
+            Y = torch.zeros(b * ld, dtype=torch.float64)
+            for _ in range(2):
+                d.spmmv(X, Y, b, layout)
+            for v in range(b):
+                yv = Y[v:d.scs.n_rows_padded * b:b] if layout == B.ROWWISE else Y[v * ld:v * ld + d.scs.n_rows_padded]
+                yo = pkg.apply_permutation(np.ascontiguousarray(yv.numpy()), d.old_to_new)
+                assert np.array_equal(yo, truth[v][wsa[rank]:wsa[rank + 1]]), (layout, v)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("case,world,b", [(("bcsstk13", 32, 512, "seg-nnz"), 2, 4), (("impcol_e", 8, 16, "seg-rows"), 3, 3),
+                                          (("bcsstk13", 32, 512, "seg-rows"), 4, 8)])
+def test_gloo_block_vector_halo_exchange(case, world, b, pkg, orc):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_block, args=(r, world, port, case, b, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

@@ -73,3 +73,66 @@ def test_ranks_sharing_one_gpu(case, world, overlap, tlc, pkg):
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _worker_block(rank, world, port, case, b, q):
+    """Distributed SpMMV with device block vectors (production gather + SpMMV kernels, gloo bounce for the collective):
+    every column equals the single-GPU SpMV of that column on the whole matrix, bit for bit, both layouts."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        sys.path.insert(0, ROOT)
+        import torch
+        import torch.distributed as dist
+        import __graft_entry__ as ge
+        pkg = ge.load_package()
+        from ultimate_spmv_amd import binding as B
+        from ultimate_spmv_amd.distributed import DistSpmv
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        name, Cc, sg, method = case
+        tot = pkg.read_mtx(mtx_path(name))
+        wsa = pkg.seg_work_sharing_arr(tot, method, world)
+        d = DistSpmv(B.seg_local_coo(tot, wsa, rank), wsa, Cc, sg, device="cuda:0")
+        st = pkg.convert_to_scs(tot, Cc, sg)
+        ta = st.arrays()
+        pkg.permute_scs_cols(st, ta["old_to_new_idx"]); ta = st.arrays()
+        At = pkg.DeviceMatrix(st, "cuda:0")
+        cols = [(1.0 + 1e-3 * (np.arange(tot.n_rows) % 1000)) * (1.0 + v / 8.0) for v in range(b)]
+        truth = []
+        for xg in cols:
+            xp = np.zeros(max(st.n_rows_padded, tot.n_rows)); xp[:tot.n_rows] = pkg.apply_permutation(xg, ta["new_to_old_idx"])
+            yt = torch.zeros(st.n_rows_padded, dtype=torch.float64, device="cuda:0")
+            pkg.spmv(At, torch.from_numpy(xp).cuda(), yt)
+            truth.append(pkg.apply_permutation(yt.cpu().numpy(), ta["old_to_new_idx"]))
+        ld = d.padded_vec_size
+        for layout in (B.COLWISE, B.ROWWISE):
+            X = d.new_X([xg[wsa[rank]:wsa[rank + 1]] for xg in cols], b, layout)
+            Y = torch.zeros(b * ld, dtype=torch.float64, device="cuda:0")
+            for _ in range(2):
+                d.spmmv(X, Y, b, layout)
+            torch.cuda.synchronize()
+            Yh = Y.cpu().numpy()
+            for v in range(b):
+                yv = Yh[v:d.scs.n_rows_padded * b:b] if layout == B.ROWWISE else Yh[v * ld:v * ld + d.scs.n_rows_padded]
+                assert np.array_equal(pkg.apply_permutation(np.ascontiguousarray(yv), d.old_to_new), truth[v][wsa[rank]:wsa[rank + 1]]), (layout, v)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("case,world,b", [(("bcsstk13", 32, 512, "seg-nnz"), 2, 8), (("bcsstk13", 32, 512, "seg-rows"), 4, 4)])
+def test_block_vectors_ranks_sharing_one_gpu(case, world, b, pkg):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_block, args=(r, world, port, case, b, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

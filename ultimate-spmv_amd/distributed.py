@@ -57,7 +57,7 @@ class DistSpmv:
     """
 
     def __init__(self, local_coo, wsa, C, sigma, dtype=B.F64, device=None, group=None, overlap=True,
-                 pack_fn=None, spmv_fn=None, spmv_chunks_fn=None, tlc=True):
+                 pack_fn=None, spmv_fn=None, spmv_chunks_fn=None, tlc=True, gather_fn=None, spmmv_fn=None):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -67,6 +67,8 @@ class DistSpmv:
         self.on_gpu = self.device.type == "cuda"
         self.overlap = bool(overlap)
         self._pack_fn, self._spmv_fn, self._spmv_chunks_fn = pack_fn, spmv_fn, spmv_chunks_fn
+        self._gather_fn, self._spmmv_fn = gather_fn, spmmv_fn
+        self._block_plans = {}
         self.tdtype = torch.float64 if dtype == B.F64 else torch.float32
 
         # ---- local SELL-C-sigma + halo discovery (order as code/main.cpp:1128, :1271-1308)
@@ -203,6 +205,83 @@ class DistSpmv:
         if self.use_tiles:
             return B.spmv_tiles(self.A, ids, x, y)
         return B.spmv_chunks(self.A, ids, x, y)
+
+    # ------------------------------------------------------------------ block vectors (SpMMV)
+    def _a2a(self, out, inp, out_splits, in_splits):
+        """Blocking all-to-all-v; device tensors go through the host when the group is not RCCL (rehearsal)."""
+        if self.on_gpu and not self._needs_device_comm():
+            h_out = torch.empty(out.numel(), dtype=out.dtype)
+            dist.all_to_all_single(h_out, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(h_out)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+    def _block_plan(self, b, layout):
+        """Index lists of the block-vector halo exchange (the reference's BULKVEC idea, code/classes_structs.hpp:
+        909-924: all b vectors in ONE message per neighbour).  Row-wise X: a neighbour's block is [element][v], which
+        is exactly the row-wise halo region, so the all-to-all-v lands in the tail of X directly.  Column-wise X: a
+        neighbour's block is [v][element]; it lands in a staging buffer and b small gathers move it into the
+        halo region of every column."""
+        key = (b, layout)
+        if key in self._block_plans:
+            return self._block_plans[key]
+        rows = self.old_to_new[self.send_idxs].astype(np.int64)          # permuted local row of every send element
+        scum = np.concatenate([[0], np.cumsum(self.send_counts)]).astype(np.int64)
+        rcum = np.concatenate([[0], np.cumsum(self.recv_counts)]).astype(np.int64)
+        ld = self.padded_vec_size
+        if layout == B.ROWWISE:
+            src = (rows[:, None] * b + np.arange(b)[None, :]).reshape(-1)
+            unpack = None
+        else:
+            src = np.concatenate([(rows[scum[p]:scum[p + 1]][None, :] + (np.arange(b) * ld)[:, None]).reshape(-1)
+                                  for p in range(self.P)]) if self.n_send else np.zeros(0, np.int64)
+            owner = np.repeat(np.arange(self.P), self.recv_counts)          # owner rank of every halo slot
+            h = np.arange(self.n_halo)
+            unpack = [(b * rcum[owner] + v * self.recv_counts[owner] + (h - rcum[owner])).astype(np.int32) for v in range(b)]
+        assert src.size == 0 or src.max() < 2**31
+        plan = dict(src=torch.from_numpy(src.astype(np.int32)).to(self.device),
+                    unpack=None if unpack is None else [torch.from_numpy(u).to(self.device) for u in unpack],
+                    send=torch.zeros(max(b * self.n_send, 1), dtype=self.tdtype, device=self.device),
+                    recv=torch.zeros(max(b * self.n_halo, 1), dtype=self.tdtype, device=self.device),
+                    send_splits=[b * v for v in self.send_splits], recv_splits=[b * v for v in self.recv_splits])
+        self._block_plans[key] = plan
+        return plan
+
+    def _gather(self, out, vec, idx):
+        if idx.numel() == 0:
+            return
+        if self._gather_fn is not None:
+            self._gather_fn(out, vec, idx)
+        else:
+            B.apply_permutation_dev(out, vec, idx)
+
+    def new_X(self, X_local_orig, b, layout=B.COLWISE):
+        """Device block vector (b * padded_vec_size elements) from the b local columns in original row order."""
+        ld = self.padded_vec_size
+        X = torch.zeros(b * ld, dtype=self.tdtype, device=self.device)
+        for v in range(b):
+            xp = torch.from_numpy(B.apply_permutation(np.ascontiguousarray(X_local_orig[v], self.scs.np_dtype), self.new_to_old)).to(self.device)
+            if layout == B.ROWWISE:
+                X[v:self.n_local * b:b] = xp
+            else:
+                X[v * ld:v * ld + self.n_local] = xp
+        return X
+
+    def spmmv(self, X, Y, b, layout=B.COLWISE, comm_halos=True):
+        """One distributed SpMMV step: block-vector halo exchange (one message per neighbour) + local kernel."""
+        ld = self.padded_vec_size
+        if self.P > 1 and comm_halos:
+            pl = self._block_plan(b, layout)
+            self._gather(pl["send"], X, pl["src"])
+            if layout == B.ROWWISE:
+                self._a2a(X[self.n_local * b:(self.n_local + self.n_halo) * b], pl["send"][:b * self.n_send], pl["recv_splits"], pl["send_splits"])
+            else:
+                self._a2a(pl["recv"][:b * self.n_halo], pl["send"][:b * self.n_send], pl["recv_splits"], pl["send_splits"])
+                for v in range(b):
+                    self._gather(X[v * ld + self.n_local:v * ld + self.n_local + self.n_halo], pl["recv"], pl["unpack"][v])
+        if self._spmmv_fn is not None:
+            return self._spmmv_fn(self, X, Y, b, ld, layout)
+        return B.spmmv(self.A, X, Y, b, ld, layout)
 
     def spmv(self, x, y, comm_halos=True):
         """One distributed SpMV step: halo exchange (optional, -comm_halos) + local kernel."""
