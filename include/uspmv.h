@@ -114,23 +114,6 @@ int uspmv_device_count(int *count);
 int uspmv_set_device(int device);
 int uspmv_stream_synchronize(void *stream);
 
-/* SpMMV counterpart of uspmv_dmat_optimize (no reference counterpart): plan for block vectors of
- * block_vec_size columns -- per 64-row tile the X rows it touches are staged in LDS once and the
- * kernel reads them with 2-byte local indices.  Used by uspmv_spmmv for b*sizeof(VT) in {16,32,64,128}
- * whose tiles fit, C = 32 or 64; other widths and chunk heights keep the gather kernels
- * (*n_staged = 0).  Results are bit-identical with and without the plan. */
-int uspmv_dmat_optimize_block(uspmv_dmat_t *m, const uspmv_scs_t *s, int block_vec_size, int64_t *n_tiles, int64_t *n_staged);
-
-/* The same plan built ON THE DEVICE from the handle's own arrays: for handles without a host struct
- * (uspmv_dmat_wrap around the reference's cudaMalloc'ed arrays, uspmv_convert_to_scs_device).  Chunk heights that
- * divide 256; tiles whose line range exceeds 65 536 lines stay on the gather path (the host planner may still
- * stage those); otherwise the plan is identical to uspmv_dmat_optimize's.  Narrow chunks are not re-chunked here. */
-int uspmv_dmat_optimize_device(uspmv_dmat_t *m, int max_lines, int64_t *n_tiles, int64_t *n_staged);
-/* host copies of a handle's plan (tests): meta = {n_tiles, n_lines_total, n_col16, max_lines_used}; call with NULL
- * arrays first to size them */
-int uspmv_dmat_plan_download(const uspmv_dmat_t *m, int64_t meta[4], int32_t *tile_line_ptr, int32_t *tile_lines,
-                             uint32_t *c16_ptrs, uint16_t *col16);
-
 /* H2D staging of one SCS struct (assign_spmv_kernel_gpu_data, code/utilities.hpp:3721-3811). */
 int uspmv_dmat_upload(const uspmv_scs_t *s, uspmv_dmat_t **out);
 /* GPU-side conversion: the result of uspmv_convert_to_scs [+ uspmv_permute_scs_cols with the
@@ -160,6 +143,23 @@ int uspmv_dmat_optimize(uspmv_dmat_t *m, const uspmv_scs_t *s, int max_lines, in
  * indices for both structs; uspmv_spmv_ap then streams 10 + 6 instead of 12 + 8 bytes per non-zero. */
 int uspmv_dmat_optimize_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t *s_dp, const uspmv_scs_t *s_sp,
                            int max_lines, int64_t *n_tiles, int64_t *n_staged);
+/* SpMMV counterpart of uspmv_dmat_optimize (no reference counterpart): plan for block vectors of
+ * block_vec_size columns -- per 64-row tile the X rows it touches are staged in LDS once and the
+ * kernel reads them with 2-byte local indices.  Used by uspmv_spmmv for b*sizeof(VT) in {16,32,64,128}
+ * whose tiles fit, C = 32 or 64; other widths and chunk heights keep the gather kernels
+ * (*n_staged = 0).  Results are bit-identical with and without the plan. */
+int uspmv_dmat_optimize_block(uspmv_dmat_t *m, const uspmv_scs_t *s, int block_vec_size, int64_t *n_tiles, int64_t *n_staged);
+
+/* The same plan built ON THE DEVICE from the handle's own arrays: for handles without a host struct
+ * (uspmv_dmat_wrap around the reference's cudaMalloc'ed arrays, uspmv_convert_to_scs_device).  Chunk heights that
+ * divide 256; tiles whose line range exceeds 65 536 lines stay on the gather path (the host planner may still
+ * stage those); otherwise the plan is identical to uspmv_dmat_optimize's.  Narrow chunks are not re-chunked here. */
+int uspmv_dmat_optimize_device(uspmv_dmat_t *m, int max_lines, int64_t *n_tiles, int64_t *n_staged);
+/* host copies of a handle's plan (tests): meta = {n_tiles, n_lines_total, n_col16, max_lines_used}; call with NULL
+ * arrays first to size them */
+int uspmv_dmat_plan_download(const uspmv_dmat_t *m, int64_t meta[4], int32_t *tile_line_ptr, int32_t *tile_lines,
+                             uint32_t *c16_ptrs, uint16_t *col16);
+
 /* Rows per tile of the plan (256 | 512 | 1024; 0 = no plan).  A tile covers tile_rows/C consecutive chunks. */
 int uspmv_dmat_tile_rows(const uspmv_dmat_t *m, int *tile_rows);
 /* uspmv_spmv over a subset of tiles (d_tile_ids[n_ids]) of a handle with a plan: the interior /
