@@ -374,12 +374,28 @@ def test_crs_spmmv_golden(pkg, torch_cuda):
         m = pkg.read_mtx(mtx_path(name))
         for dt, code in (("f64", pkg.F64), ("f32", pkg.F32)):
             s, a, xp = _prep(pkg, m, 1, 1, code, make_x(m.n_rows))
-            A = pkg.DeviceMatrix(s)
-            for rowwise in (0, 1):
-                X = block_x(xp, s.n_rows, 4, s.n_rows, rowwise)
-                Y = t.zeros(4 * s.n_rows, dtype=A.torch_dtype, device="cuda")
-                pkg.spmmv(A, _dev(t, X), Y, 4, s.n_rows, pkg.ROWWISE if rowwise else pkg.COLWISE)
-                assert np.array_equal(Y.cpu().numpy(), c[f"{name}_{dt}_Yb4_{'row' if rowwise else 'col'}"]), (name, dt, rowwise)
+            for tlc in (False, True):      # True: optimised handle = internal SELL-32-1 re-chunking where the padding allows
+                A = pkg.DeviceMatrix(s, tlc=tlc)
+                for rowwise in (0, 1):
+                    X = block_x(xp, s.n_rows, 4, s.n_rows, rowwise)
+                    Y = t.full((4 * s.n_rows + 64,), 9.0, dtype=A.torch_dtype, device="cuda")     # + guard zone behind Y
+                    pkg.spmmv(A, _dev(t, X), Y, 4, s.n_rows, pkg.ROWWISE if rowwise else pkg.COLWISE)
+                    got = Y.cpu().numpy()
+                    assert np.array_equal(got[:4 * s.n_rows], c[f"{name}_{dt}_Yb4_{'row' if rowwise else 'col'}"]), (name, dt, rowwise, tlc)
+                    assert np.all(got[4 * s.n_rows:] == 9.0), "stores past the caller's rows"
+    # narrow SELL chunks on an optimised handle (C = 4, 8, 16 re-chunked to 32): against the plain handle
+    m = pkg.read_mtx(mtx_path("FDM-2d-16"))
+    for C, sigma in ((4, 8), (8, 64), (16, 512)):
+        for code in (pkg.F64, pkg.F32):
+            s, a, xp = _prep(pkg, m, C, sigma, code, make_x(m.n_rows))
+            A0, A1 = pkg.DeviceMatrix(s), pkg.DeviceMatrix(s, tlc=True)
+            for b in (8, 3):
+                for lay in (pkg.COLWISE, pkg.ROWWISE):
+                    ld = s.n_rows_padded
+                    X = block_x(xp, ld, b, ld, lay == pkg.ROWWISE)
+                    Y0 = t.full((b * ld + 64,), 9.0, dtype=A0.torch_dtype, device="cuda"); Y1 = Y0.clone()
+                    pkg.spmmv(A0, _dev(t, X), Y0, b, ld, lay); pkg.spmmv(A1, _dev(t, X), Y1, b, ld, lay)
+                    assert t.equal(Y0, Y1), (C, code, b, lay)
 
 
 @pytest.mark.parametrize("name", ["bcsstk13", "impcol_e", "FDM-2d-16", "matrix1"])

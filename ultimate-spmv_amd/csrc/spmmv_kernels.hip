@@ -12,7 +12,7 @@ template <typename VT, int VB, bool ROWWISE, bool NT>
 __global__ void scs_spmmv_rows(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
                                const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                                const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
-                               const int b, const long ld, const int xcd_remap) {
+                               const int b, const long ld, const int xcd_remap, const long n_store) {
     const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
     const long row = (long)lb * blockDim.x + threadIdx.x;
     const long c = row / C;
@@ -39,7 +39,7 @@ __global__ void scs_spmmv_rows(const long n_chunks, const int C, const int *__re
         }
 #pragma unroll
         for (int v = 0; v < VB; ++v) {
-            if (v0 + v < b) {
+            if (v0 + v < b && row < n_store) {
                 if (ROWWISE) st_y<NT>(Y + (row * b + v0 + v), acc[v]);
                 else st_y<NT>(Y + (row + (long)(v0 + v) * ld), acc[v]);
             }
@@ -59,7 +59,7 @@ template <typename VT, int B, int U, bool NT, bool YCOL, bool PF>
 __global__ void __launch_bounds__(256) scs_spmmv_rowmajor(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
                                    const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                                    const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
-                                   const long ld, const int xcd_remap) {
+                                   const long ld, const int xcd_remap, const long n_store) {
     constexpr int VW = 16 / (int)sizeof(VT);  // elements per 16-byte load
     constexpr int NV = B / VW;
     typedef VT vec_t __attribute__((ext_vector_type(VW)));
@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(256) scs_spmmv_rowmajor(const long n_chunks, c
             for (int w = 0; w < VW; ++w) acc[k * VW + w] = fma_t(a, xv[w], acc[k * VW + w]);
         }
     }
+    if (row >= n_store) return;               // (re-chunked handles: rows past the caller's padded rows)
     if (YCOL) {
 #pragma unroll
         for (int v = 0; v < B; ++v) st_y<NT>(Y + (row + (long)v * ld), acc[v]);
@@ -172,7 +173,7 @@ template <typename VT, int B, int U, bool NT, bool YCOL, bool PF>
 __global__ void scs_spmmv_xpose(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
                                 const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                                 const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
-                                const long ld, const int xcd_remap) {
+                                const long ld, const int xcd_remap, const long n_store) {
     constexpr int VW = 16 / (int)sizeof(VT);
     constexpr int P = B / VW;          // 16-byte pieces per X row = rounds
     constexpr int RPR = 64 / P;        // rows per round
@@ -242,7 +243,7 @@ __global__ void scs_spmmv_xpose(const long n_chunks, const int C, const int *__r
 #pragma unroll
     for (int q = 0; q < P; ++q) {
         const long r = wrow0 + q * RPR + rl;
-        if (r < n_pad) {
+        if (r < n_pad && r < n_store) {
             if (YCOL) {
 #pragma unroll
                 for (int w = 0; w < VW; ++w) st_y<NT>(Y + (r + (long)(g * VW + w) * ld), acc[q][w]);
@@ -451,7 +452,7 @@ void launch_spmmv_vb(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, in
 #define SPMMV_LAUNCH(RW, NTV)                                                                                     \
     hipLaunchKernelGGL((scs_spmmv_rows<VT, VB, RW, NTV>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks,      \
                        (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, b, ld, \
-                       g_tune.xcd_remap)
+                       g_tune.xcd_remap, (long)A->n_store)
     if (layout == USPMV_ROWWISE) { if (nt) SPMMV_LAUNCH(true, true); else SPMMV_LAUNCH(true, false); }
     else { if (nt) SPMMV_LAUNCH(false, true); else SPMMV_LAUNCH(false, false); }
 #undef SPMMV_LAUNCH
@@ -466,11 +467,11 @@ void launch_spmmv_rowmajor_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, b
         if (g_tune.spmmv_prefetch)                                                                                  \
             hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, NTV, YC, true>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
                                (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
-                               g_tune.xcd_remap);                                                                   \
+                               g_tune.xcd_remap, (long)A->n_store);                                                                   \
         else                                                                                                        \
             hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, NTV, YC, false>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
                                (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
-                               g_tune.xcd_remap);                                                                   \
+                               g_tune.xcd_remap, (long)A->n_store);                                                                   \
     } while (0)
     if (g_tune.nontemporal) { if (ycol) RM_LAUNCH(true, true); else RM_LAUNCH(true, false); }
     else { if (ycol) RM_LAUNCH(false, true); else RM_LAUNCH(false, false); }
@@ -486,11 +487,11 @@ void launch_spmmv_xpose_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool
         if (g_tune.spmmv_prefetch)                                                                                  \
             hipLaunchKernelGGL((scs_spmmv_xpose<VT, B, U, NTV, YC, true>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
                                (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
-                               g_tune.xcd_remap);                                                                   \
+                               g_tune.xcd_remap, (long)A->n_store);                                                                   \
         else                                                                                                        \
             hipLaunchKernelGGL((scs_spmmv_xpose<VT, B, U, NTV, YC, false>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
                                (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
-                               g_tune.xcd_remap);                                                                   \
+                               g_tune.xcd_remap, (long)A->n_store);                                                                   \
     } while (0)
     if (g_tune.nontemporal) { if (ycol) XP_LAUNCH(true, true); else XP_LAUNCH(true, false); }
     else { if (ycol) XP_LAUNCH(false, true); else XP_LAUNCH(false, false); }

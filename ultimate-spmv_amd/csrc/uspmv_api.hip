@@ -612,6 +612,9 @@ int uspmv_spmmv(const uspmv_dmat_t *A, const void *d_X, void *d_Y, int b, int64_
         return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmmv: ld=%lld smaller than n_rows_padded=%lld", (long long)ld,
                            (long long)(A->n_chunks * A->C));
     if (int rc = require_device()) return rc;
+    // narrow-chunk handles optimised by uspmv_dmat_optimize carry an internal C = 32 re-chunking with the same row
+    // order (crs: SELL-32-1): coalesced matrix stream for the block kernels too; its stores stop at the caller's rows
+    if (A->alt && g_tune.rechunk) A = A->alt;
     if (A->dtype == USPMV_F64) return launch_spmmv<double>(A, (const double *)d_X, (double *)d_Y, b, (long)ld, layout, (hipStream_t)stream);
     return launch_spmmv<float>(A, (const float *)d_X, (float *)d_Y, b, (long)ld, layout, (hipStream_t)stream);
 }

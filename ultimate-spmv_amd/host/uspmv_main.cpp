@@ -239,7 +239,7 @@ int run(const Config &c, uspmv_coo_t *coo) {
     ck(uspmv_dmat_upload(scs, &r.A), "uspmv_dmat_upload");
     if (ap) ck(uspmv_dmat_upload(scs_sp, &r.A_sp), "uspmv_dmat_upload");
     if (c.kernel_format != "scs") ck(uspmv_dmat_set_crs(r.A, 1), "uspmv_dmat_set_crs");
-    if (c.tlc && b == 1) {
+    if (c.tlc && (b == 1 || (!ap && c.chunk_size < 32 && 32 % c.chunk_size == 0))) {   // b > 1: for the internal C = 32 re-chunking of narrow chunks / crs
         int64_t nt = 0, ns = 0;
         if (ap) ck(uspmv_dmat_optimize_ap(r.A, r.A_sp, scs, scs_sp, 0, &nt, &ns), "uspmv_dmat_optimize_ap");
         else ck(uspmv_dmat_optimize(r.A, scs, 0, &nt, &ns), "uspmv_dmat_optimize");
