@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink grids for quick runs")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--tune", default="", help="key=value,... passed to uspmv_set_tuning")
+    ap.add_argument("--cpu-seconds", type=float, default=0.0, help="> 0: also time the genuine reference CPU kernel (oracle/_ref) for about this long")
     ap.add_argument("--sp", action="store_true", help="config 3 in single precision (block plan kernel)")
     ap.add_argument("--no-block-plan", action="store_true", help="config 3 --sp without uspmv_dmat_optimize_block")
     args = ap.parse_args()
@@ -53,6 +54,9 @@ def main():
             byts = s.n_elements * 12 + 8 * s.n_chunks + 8 * s.n_rows + 8 * s.n_rows_padded
             out = dict(config=2, workload=f"nlpkkt200-class stencil27 {g}^3 scs -c 32 -s 512 -dp", n=s.n_rows, nnz=s.nnz, b=1)
             flops = 2.0 * s.nnz
+            ycpu = np.zeros(s.n_rows_padded)
+            cpu_fn = lambda R: R.lib("colwise").ref_spmv_omp_scs_adv_f64(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp, ycpu)
+            cpu_name = "spmv_omp_scs_adv<C=32,double>"
         elif cfg == "3":
             g = int(111 * args.scale)
             coo = pkg.gen_stencil27(g, g, g, dof=3)
@@ -79,6 +83,13 @@ def main():
                        block_plan_tiles=[A.block_staged, A.block_tiles],
                        rowwise_ms=round(res["rowwise"][0], 5), rowwise_bitexact=res["rowwise"][1])
             flops = 2.0 * s.nnz * b
+            Xc = np.zeros(b * ld, ndt)
+            for v in range(b):
+                Xc[v * ld:(v + 1) * ld] = (xp * ndt(1.0 + v / 8.0)).astype(ndt)
+            Ycpu = np.zeros(b * ld, ndt)
+            cpu_fn = lambda R: getattr(R.lib("colwise"), "ref_block_spmv_omp_scs_general_" + ("f32" if args.sp else "f64"))(
+                32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], Xc, Ycpu, b, ld)
+            cpu_name = "block_spmv_omp_scs_general (colwise)"
         else:
             g = int(74 * args.scale)
             coo = pkg.gen_stencil27(g, g, g, dof=5, magnitude_decades=10.0)
@@ -112,6 +123,22 @@ def main():
             A.optimize(s)
             out["plain_dp_tlc_ms"] = round(B.time_launches(0, args.reps, A=A, x=x, y=y), 5)
             flops = 2.0 * coo.nnz
+            ycpu = np.zeros(ds.n_rows_padded); yspc = np.zeros(ds.n_rows_padded, np.float32); xspc = xp.astype(np.float32)
+            cpu_fn = lambda R: R.lib("colwise").ref_spmv_omp_scs_ap_adv(32, ds.n_chunks, da["chunk_ptrs"], da["chunk_lengths"], da["col_idxs"], da["values"], xp, ycpu,
+                                                                        sa["chunk_ptrs"], sa["chunk_lengths"], sa["col_idxs"], sa["values"], xspc, yspc)
+            cpu_name = "spmv_omp_scs_ap_adv<C=32>"
+        if args.cpu_seconds > 0:
+            from oracle import refshim
+            import bench as _bench
+            if refshim.available("colwise"):
+                cores = _bench.usable_cores(); _bench.set_omp_threads(cores)
+                cpu_fn(refshim)
+                reps, tc = 0, time.perf_counter()
+                while reps < 2 or time.perf_counter() - tc < args.cpu_seconds:
+                    cpu_fn(refshim); reps += 1
+                el = time.perf_counter() - tc
+                out["cpu_baseline"] = dict(value=round(flops * reps / el / 1e9, 2), unit="GFLOP/s", cores=cores, kind="reference",
+                                           sample=f"whole matrix, {reps} calls of {cpu_name} in {el:.1f} s, OMP threads = {cores}")
         out.update(kernel_ms=round(ms, 5), gflops=round(flops / ms / 1e6, 1), algorithmic_GBs=round(byts / ms / 1e6, 1),
                    frac_of_8TBs=round(byts / ms / 1e6 / 8000, 4), bitexact_vs_oracle=ok, setup_s=round(time.time() - t0, 1))
         print(json.dumps(out), flush=True)
