@@ -83,6 +83,11 @@ void uspmv_coo_free(uspmv_coo_t *m);
  * off-diagonal magnitudes log-uniformly over that many decades (HV15R-class, for -ap splits). */
 int uspmv_gen_stencil27(int64_t nx, int64_t ny, int64_t nz, int dof, uint64_t seed, double magnitude_decades,
                         int64_t row_begin, int64_t row_end, uspmv_coo_t **out);
+/* Banded-random matrix of SURVEY.md 8(d) (HV15R-class: n = 2 017 169, 140 entries per row, band +-50 000, magnitudes
+ * over 10 decades): the diagonal plus nnz_per_row - 1 hashed distinct columns in [i - band, i + band], general
+ * pattern, columns ascending inside a row; the irregular counterpart of the stencil generator. */
+int uspmv_gen_banded_random(int64_t n, int nnz_per_row, int64_t band, uint64_t seed, double magnitude_decades,
+                            int64_t row_begin, int64_t row_end, uspmv_coo_t **out);
 
 /* ------------------------------------------------------------------ L2: format conversion */
 /* convert_to_scs (code/utilities.hpp:1842-2104; library twin code/interface.hpp:401-656).
@@ -268,7 +273,7 @@ int uspmv_stream_triad(double *d_a, const double *d_b, const double *d_c, double
 int uspmv_stream_read(const double *d_b, int64_t n, double *d_partial, void *stream);
 /* Time `reps` back-to-back launches of one entry point with HIP events on `stream`;
  * what: 0 spmv(A,x,y) 1 stream_copy 2 stream_triad 3 stream_read 4 spmv_ap(A,B,x,y)
- *       5 spmmv(A,X,Y,b,ld,layout).  Returns the average milliseconds per launch.
+ *       5 spmmv(A,X,Y,b,ld,layout).  Two untimed launches precede the timed ones; returns the average milliseconds per launch.
  * For the STREAM kinds d_x is the source (n doubles; 2n for the triad: b = d_x, c = d_x + n) and d_y
  * the destination (n doubles; 8192 for the read kernel's partial sums). */
 int uspmv_time_launches(int what, int reps, const uspmv_dmat_t *A, const uspmv_dmat_t *B, const void *d_x,

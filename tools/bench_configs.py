@@ -90,9 +90,13 @@ def main():
             cpu_fn = lambda R: getattr(R.lib("colwise"), "ref_block_spmv_omp_scs_general_" + ("f32" if args.sp else "f64"))(
                 32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], Xc, Ycpu, b, ld)
             cpu_name = "block_spmv_omp_scs_general (colwise)"
-        else:
+        else:   # "4": stencil stand-in; "4b": the banded-random HV15R-class matrix of SURVEY.md 8(d)
             g = int(74 * args.scale)
-            coo = pkg.gen_stencil27(g, g, g, dof=5, magnitude_decades=10.0)
+            if cfg == "4b":
+                nb = int(2017169 * args.scale ** 3)
+                coo = pkg.gen_banded_random(nb, 140, 50000, magnitude_decades=10.0)
+            else:
+                coo = pkg.gen_stencil27(g, g, g, dof=5, magnitude_decades=10.0)
             dp, sp = pkg.partition_precisions(coo, 1e-3)
             ds = prep(dp, pkg.F64)
             perm = ds.arrays()["old_to_new_idx"].copy()
@@ -113,7 +117,8 @@ def main():
             ok = ok and bool(t.equal(y, y2)) if ok is not None else None
             ms = B.time_launches(4, args.reps, A=Ad, B=As, x=x, y=y)
             byts = 12 * ds.n_elements + 8 * ss.n_elements + 16 * ds.n_chunks + 8 * (ds.n_rows + ds.n_rows_padded)
-            out = dict(config=4, workload=f"HV15R-class stencil27 {g}^3 x 5 dof, |a_ij| log-uniform over 10 decades, scs -c 32 -s 512 -ap[dp_sp] -ap_threshold_1 1e-3",
+            out = dict(config=cfg, workload=(f"HV15R-class banded-random n={coo.n_rows} 140/row band 50000" if cfg == "4b" else f"HV15R-class stencil27 {g}^3 x 5 dof") +
+                       ", |a_ij| log-uniform over 10 decades, scs -c 32 -s 512 -ap[dp_sp] -ap_threshold_1 1e-3",
                        n=ds.n_rows, nnz=coo.nnz, dp_nnz=dp.nnz, sp_nnz=sp.nnz, dp_elements=ds.n_elements, sp_elements=ss.n_elements, b=1)
             # same matrix in plain dp for comparison
             s = prep(coo, pkg.F64); a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"])

@@ -56,6 +56,7 @@ _SIGS = {
     "uspmv_coo_arrays": (C.c_int, [_vp, C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_f64p)]),
     "uspmv_coo_free": (None, [_vp]),
     "uspmv_gen_stencil27": (C.c_int, [_i64, _i64, _i64, C.c_int, C.c_uint64, C.c_double, _i64, _i64, C.POINTER(_vp)]),
+    "uspmv_gen_banded_random": (C.c_int, [_i64, C.c_int, _i64, C.c_uint64, C.c_double, _i64, _i64, C.POINTER(_vp)]),
     "uspmv_convert_to_scs": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, C.POINTER(_vp)]),
     "uspmv_scs_meta": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_scs_dtype": (C.c_int, [_vp, C.POINTER(C.c_int)]),
@@ -210,6 +211,12 @@ def gen_stencil27(nx, ny, nz, dof=1, seed=0x5EED, magnitude_decades=0.0, row_beg
     h = _vp()
     _ck(lib().uspmv_gen_stencil27(nx, ny, nz, dof, seed, magnitude_decades, row_begin,
                                   n if row_end is None else row_end, C.byref(h)))
+    return Coo(h)
+
+
+def gen_banded_random(n, nnz_per_row, band, seed=0x5EED, magnitude_decades=0.0, row_begin=0, row_end=None):
+    h = _vp()
+    _ck(lib().uspmv_gen_banded_random(n, nnz_per_row, band, seed, magnitude_decades, row_begin, n if row_end is None else row_end, C.byref(h)))
     return Coo(h)
 
 

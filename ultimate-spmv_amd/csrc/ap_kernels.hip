@@ -115,13 +115,14 @@ __global__ void __launch_bounds__(1024) scs_spmv_ap_tlc(const long n_chunks, con
 // times the DOUBLE x, accumulated in double), y = dp + sp  (code/ap_kernels.hpp:59-75).
 // SPX: the generic-C reference kernel spmv_omp_scs_ap multiplies the sp values with the FLOAT copy
 // of x (float product, rounded, then widened and added; code/ap_kernels.hpp:619-623).
-template <int U, bool NT, bool SPX>
-__global__ void scs_spmv_ap_rows(const long n_chunks, const int C, const int *__restrict__ dp_cp,
+template <int U, bool NT, bool SPX, int CT>
+__global__ void scs_spmv_ap_rows(const long n_chunks, const int C_rt, const int *__restrict__ dp_cp,
                                  const int *__restrict__ dp_cl, const int *__restrict__ dp_ci,
                                  const double *__restrict__ dp_va, const int *__restrict__ sp_cp,
                                  const int *__restrict__ sp_cl, const int *__restrict__ sp_ci,
                                  const float *__restrict__ sp_va, const double *__restrict__ x,
                                  const float *__restrict__ x_sp, double *__restrict__ y, const int xcd_remap) {
+    const int C = CT > 0 ? CT : C_rt;        // CT = 32: slot strides become immediate offsets
     const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
     const long row = (long)lb * blockDim.x + threadIdx.x;
     const long c = row / C;
@@ -227,17 +228,19 @@ int launch_spmv_ap(const uspmv_dmat *dp, const uspmv_dmat *sp, const double *d_x
     }
     const int block = g_tune.block;
     const unsigned grid = grid_for(dp->n_chunks * dp->C, block);
-#define AP_LAUNCH_U(UU, NTV, SPXV)                                                                                   \
-    hipLaunchKernelGGL((scs_spmv_ap_rows<UU, NTV, SPXV>), dim3(grid), dim3(block), 0, (hipStream_t)stream,           \
+#define AP_LAUNCH_UC(UU, NTV, SPXV, CTV)                                                                             \
+    hipLaunchKernelGGL((scs_spmv_ap_rows<UU, NTV, SPXV, CTV>), dim3(grid), dim3(block), 0, (hipStream_t)stream,      \
                        (long)dp->n_chunks, (int)dp->C, dp->chunk_ptrs, dp->chunk_lengths, dp->col_idxs,              \
                        (const double *)dp->values, sp->chunk_ptrs, sp->chunk_lengths, sp->col_idxs,                  \
                        (const float *)sp->values, d_x, d_x_sp, d_y, g_tune.xcd_remap)
+#define AP_LAUNCH_U(UU, NTV, SPXV) do { if (dp->C == 32) AP_LAUNCH_UC(UU, NTV, SPXV, 32); else AP_LAUNCH_UC(UU, NTV, SPXV, 0); } while (0)
 #define AP_LAUNCH(NTV, SPXV)                                                                                         \
     do { if (g_tune.unroll >= 8) AP_LAUNCH_U(8, NTV, SPXV); else if (g_tune.unroll == 4) AP_LAUNCH_U(4, NTV, SPXV);  \
          else AP_LAUNCH_U(2, NTV, SPXV); } while (0)
     if (d_x_sp) { if (g_tune.nontemporal) AP_LAUNCH(true, true); else AP_LAUNCH(false, true); }
     else { if (g_tune.nontemporal) AP_LAUNCH(true, false); else AP_LAUNCH(false, false); }
 #undef AP_LAUNCH_U
+#undef AP_LAUNCH_UC
 #undef AP_LAUNCH
     HIP_TRY(hipGetLastError());
     return USPMV_OK;

@@ -88,3 +88,56 @@ extern "C" int uspmv_gen_stencil27(int64_t nx, int64_t ny, int64_t nz, int dof, 
     *out = m;
     return USPMV_OK;
 }
+
+// Banded-random matrix (the HV15R-class stand-in of SURVEY.md 8(d)): row i holds the diagonal plus
+// nnz_per_row - 1 distinct columns drawn by hash from [i - band, i + band] (clipped), ascending inside the row;
+// general (non-symmetric) pattern; off-diagonal magnitudes 10^(2 - D*u) with hashed sign when
+// magnitude_decades D > 0, else uniform in [-1,1); diagonal = nnz_per_row + u.
+extern "C" int uspmv_gen_banded_random(int64_t n, int nnz_per_row, int64_t band, uint64_t seed, double magnitude_decades,
+                                       int64_t row_begin, int64_t row_end, uspmv_coo_t **out) {
+    if (!out || n < 1 || nnz_per_row < 1 || band < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_gen_banded_random: bad argument");
+    if (n > INT32_MAX) return uspmv::fail(USPMV_ERR_OVERFLOW, "uspmv_gen_banded_random: %lld rows exceed int32", (long long)n);
+    if (row_begin < 0 || row_end > n || row_begin >= row_end) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_gen_banded_random: bad row range");
+    const int64_t nloc = row_end - row_begin;
+    auto window = [&](int64_t row, int64_t &lo, int64_t &hi) { lo = std::max<int64_t>(0, row - band); hi = std::min<int64_t>(n - 1, row + band); };
+    std::vector<int64_t> start((size_t)nloc + 1, 0);
+    for (int64_t r = 0; r < nloc; ++r) {
+        int64_t lo, hi; window(row_begin + r, lo, hi);
+        start[(size_t)r + 1] = start[(size_t)r] + std::min<int64_t>(nnz_per_row, hi - lo + 1);
+    }
+    const int64_t nnz = start[(size_t)nloc];
+    if (nnz > INT32_MAX) return uspmv::fail(USPMV_ERR_OVERFLOW, "uspmv_gen_banded_random: %lld local nnz exceed int32", (long long)nnz);
+    auto *m = new uspmv_coo;
+    m->n_rows = nloc; m->n_cols = n; m->nnz = nnz;
+    m->I.resize((size_t)nnz); m->J.resize((size_t)nnz); m->values.resize((size_t)nnz);
+#pragma omp parallel
+    {
+        std::vector<int64_t> cols;
+#pragma omp for schedule(static)
+        for (int64_t r = 0; r < nloc; ++r) {
+            const int64_t row = row_begin + r;
+            int64_t lo, hi; window(row, lo, hi);
+            const int64_t k = start[(size_t)r + 1] - start[(size_t)r], w = hi - lo + 1;
+            cols.clear(); cols.push_back(row);
+            uint64_t h = pair_hash((uint64_t)row, 0x6a09e667f3bcc909ull, seed);
+            while ((int64_t)cols.size() < k) {              // rejection of duplicates: k << window width in practice
+                h = mix64(h);
+                const int64_t c = lo + (int64_t)(h % (uint64_t)w);
+                if (std::find(cols.begin(), cols.end(), c) == cols.end()) cols.push_back(c);
+            }
+            std::sort(cols.begin(), cols.end());
+            for (int64_t j = 0; j < k; ++j) {
+                const int64_t col = cols[(size_t)j];
+                const uint64_t hv = pair_hash((uint64_t)row, (uint64_t)col, seed ^ 0xbb67ae8584caa73bull);
+                double v;
+                if (col == row) v = (double)nnz_per_row + (2.0 * u01(hv) - 1.0);
+                else if (magnitude_decades > 0.0) { v = std::pow(10.0, 2.0 - magnitude_decades * u01(hv)); if (mix64(hv) & 1) v = -v; }
+                else v = 2.0 * u01(hv) - 1.0;
+                const size_t p = (size_t)(start[(size_t)r] + j);
+                m->I[p] = (int32_t)r; m->J[p] = (int32_t)col; m->values[p] = v;
+            }
+        }
+    }
+    *out = m;
+    return USPMV_OK;
+}
