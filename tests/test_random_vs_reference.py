@@ -116,3 +116,42 @@ def test_kernels_match_reference_on_random_matrices(pkg, torch_cuda, seed, n, C,
         Y = t.zeros(b * ld, dtype=A.torch_dtype, device="cuda")
         pkg.spmmv(A, t.from_numpy(X).cuda(), Y, b, ld, pkg.COLWISE)
         assert np.array_equal(Y.cpu().numpy().reshape(b, ld)[:, :s.n_rows_padded], Yr.reshape(b, ld)[:, :s.n_rows_padded]), (seed, dt, "spmmv")
+
+
+@pytest.mark.skipif(not refshim.available("mpi"), reason="oracle/_ref mpi variant not built")
+@pytest.mark.parametrize("seed,n,P,method,C,sigma", [(0, 300, 2, "seg-rows", 32, 512), (1, 301, 3, "seg-nnz", 16, 64), (2, 640, 5, "seg-nnz", 32, 32),
+                                                    (3, 97, 4, "seg-rows", 4, 8), (4, 1000, 8, "seg-nnz", 64, 128), (5, 513, 2, "seg-nnz", 1, 1)])
+def test_partition_and_halo_discovery_match_reference(pkg, seed, n, P, method, C, sigma):
+    """seg_work_sharing_arr (code/mpi_funcs.hpp:424-622), seg_mtx_struct / localize_row_idx (:636-674, :862-877) and
+    collect_local_needed_heri (:242-415) of the genuine reference (fake-rank driver, no MPI_Init) on random matrices:
+    work-sharing array, local COO blocks, rewritten col_idxs, per-owner receive lists and their cumulative sums."""
+    from ultimate_spmv_amd import binding as B
+    rng = np.random.default_rng(3000 + seed)
+    I, J, V = random_coo(rng, n, n, 0.04, tie_heavy=bool(seed % 2))
+    # every row gets its diagonal: with empty rows in a block the reference itself is inconsistent (local n_rows =
+    # number of DISTINCT NON-EMPTY rows, row ids shifted by the first non-empty row, code/mpi_funcs.hpp:770, :862-877,
+    # while the vectors are sized by work_sharing_arr, code/main.cpp:1299) -- the product uses the block height
+    has_diag = np.zeros(n, bool); has_diag[I[I == J]] = True
+    add = np.flatnonzero(~has_diag)
+    I = np.concatenate([I, add]); J = np.concatenate([J, add]); V = np.concatenate([V, np.full(add.size, 2.5)])
+    o = np.lexsort((J, I)); I, J, V = I[o].astype(np.int32), J[o].astype(np.int32), V[o]
+    m = pkg.Coo.from_arrays(n, n, I, J, V)
+    rm = refshim.RefMtx.from_coo(n, n, I, J, V, "mpi")
+    wsa_ref = refshim.seg_work_sharing_arr(rm, method, P)
+    wsa = pkg.seg_work_sharing_arr(m, method, P)
+    assert np.array_equal(wsa, wsa_ref)
+    for r in range(P):
+        if wsa[r + 1] == wsa[r]:
+            continue
+        loc_ref = refshim.seg_local_mtx(rm, wsa, r)
+        loc = B.seg_local_coo(m, wsa, r)
+        for a, b in zip(loc.arrays(), loc_ref.arrays()):
+            assert np.array_equal(a, b)
+        s = pkg.convert_to_scs(loc, C, sigma, pkg.F64)
+        rs = refshim.convert_to_scs(loc_ref, C, sigma, "f64")
+        nh, recv_ref, cum_ref = refshim.collect_local_needed_heri(rs, wsa, r, P)
+        plan = B.HaloPlan(s, wsa, r, P)
+        assert plan.n_halo == nh and np.array_equal(plan.recv_counts_cumsum, cum_ref)
+        for p in range(P):
+            assert np.array_equal(plan.recv_idxs_of(p), recv_ref[p]), (r, p)
+        assert np.array_equal(s.arrays()["col_idxs"], rs.arrays()["col_idxs"]), r
