@@ -57,12 +57,26 @@ def test_convert_and_split_match_reference(pkg, seed, n, C, sigma):
         assert np.array_equal(a["new_to_old_idx"][written], ra["new_to_old_idx"][written]), (seed, dt, "new_to_old_idx")
     th = float(np.median(np.abs(V)))
     dp, sp = pkg.partition_precisions(m, th)
-    rdp, _, (sI, sJ, sV) = refshim.partition_precisions_dpsp(rm, th)
+    rdp, _, (sI, sJ, sV) = refshim.partition_precisions_dpsp(rm, th)       # _ = raw MtxData<float,int>* of the sp part
     rI, rJ, rV = rdp.arrays()
     I2, J2, V2 = dp.arrays()
     assert np.array_equal(I2, rI) and np.array_equal(J2, rJ) and np.array_equal(V2, rV)
     I2, J2, V2 = sp.arrays()
     assert np.array_equal(I2, sI) and np.array_equal(J2, sJ) and np.array_equal(V2.astype(np.float32), sV)
+    # the ap[dp_sp] structs: dp sorted on its own, sp placed with the dp permutation (code/main.cpp:1156-1160),
+    # including the quirk that such a struct reports the identity as old_to_new_idx
+    if dp.nnz and sp.nnz and n >= C:
+        ds = pkg.convert_to_scs(dp, C, sigma, pkg.F64)
+        rds = refshim.convert_to_scs(rdp, C, sigma, "f64")
+        perm = ds.arrays()["old_to_new_idx"].copy()
+        if np.all(perm < n):          # (a permutation that moves a row into a padding slot overruns the reference's chunk)
+            try:
+                ss = pkg.convert_to_scs(sp, C, sigma, pkg.F32, fixed_permutation=perm)
+            except pkg.UspmvError:
+                return                # the product refuses what the reference would overrun (non-empty row on a shorter chunk)
+            rss = refshim.convert_to_scs(_, C, sigma, "f32", fixed_perm=rds.arrays()["old_to_new_idx"])
+            for k in ("chunk_ptrs", "chunk_lengths", "col_idxs", "values", "old_to_new_idx"):
+                assert np.array_equal(ss.arrays()[k], rss.arrays()[k]), (seed, "sp struct", k)
 
 
 @pytest.mark.parametrize("name", ["bcsstk13", "impcol_e", "FDM-2d-16", None])
