@@ -229,7 +229,7 @@ int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_
  *   "spmmv_swizzle" 0|1 bank-swizzled LDS rows in the block-plan kernel,
  *   "raw_plan_cache" 0|1 uspmv_scs_gpu_f64/f32 keep a device-built plan per set of array addresses (the caller
  *   promises not to put another matrix behind the same pointers; uspmv_raw_plan_cache_clear() otherwise),
- *   "spmmv_tile_rows" 0 (auto) | 64 rows per tile and "spmmv_lds_kb" 0 (= 80) | LDS KiB per tile of the NEXT
+ *   "spmmv_tile_rows" 0 (auto) | 32 | 64 rows per tile and "spmmv_lds_kb" 0 (= 80) | LDS KiB per tile of the NEXT
  *   uspmv_dmat_optimize_block,
  *   "spmmv_prefetch" 1|0 (lane-per-row kernel: next batch of matrix entries requested behind the X rows),
  *   "spmmv_unroll" 0 (auto) | 1|2|4|8 slots per batch,

@@ -526,7 +526,7 @@ void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
         if (A->bt && ((g_tune.spmmv_variant == 0 && RB <= 32) || g_tune.spmmv_variant == 4) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
             const bool swz = g_tune.spmmv_swizzle != 0;
             if (A->bt_tile_rows == 32) {
-                if constexpr (RB >= 64) {
+                if constexpr (RB >= 32) {
                     if (swz) launch_spmmv_tlc_g<VT, B, 4, 32, 2, true>(A, X, Y, ld, ycol, st);
                     else launch_spmmv_tlc_g<VT, B, 4, 32, 2, false>(A, X, Y, ld, ycol, st);
                     return;

@@ -126,7 +126,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_prefetch")) g_tune.spmmv_prefetch = value != 0;
     else if (!strcmp(key, "spmmv_swizzle")) g_tune.spmmv_swizzle = value != 0;
     else if (!strcmp(key, "raw_plan_cache")) g_tune.raw_plan_cache = value != 0;
-    else if (!strcmp(key, "spmmv_tile_rows")) g_tune.spmmv_tile_rows = value == 64 ? 64 : 0;
+    else if (!strcmp(key, "spmmv_tile_rows")) g_tune.spmmv_tile_rows = value == 64 ? 64 : value == 32 ? 32 : 0;
     else if (!strcmp(key, "spmmv_lds_kb")) g_tune.spmmv_lds_kb = value < 0 ? 0 : value;
     else if (!strcmp(key, "spmmv_variant")) {
         if (value < 0 || value > 4) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0|1|2|3|4");
@@ -468,7 +468,7 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
     const size_t cap = g_tune.spmmv_lds_kb > 0 ? std::min<size_t>((size_t)g_tune.spmmv_lds_kb * 1024, BT_LDS_CAP) : BT_LDS_CAP;
     const int max_rows = (int)(cap / row_bytes);
     // rows of >= 64 bytes on C = 32: 32-row tiles, two lanes per row (half the LDS per tile, twice the tiles per CU)
-    const int tile_rows = (s->C == 32 && row_bytes >= 64 && g_tune.spmmv_tile_rows != 64) ? 32 : 64;
+    const int tile_rows = (s->C == 32 && g_tune.spmmv_tile_rows != 64 && (row_bytes >= 64 || (row_bytes >= 32 && g_tune.spmmv_tile_rows == 32))) ? 32 : 64;
     uspmv_tlc_plan p;
     if (int rc = uspmv_build_tlc_plan(s, nullptr, max_rows, tile_rows, &p, /*line_shift=*/0)) return rc;
     if (n_tiles) *n_tiles = p.n_tiles;
