@@ -312,6 +312,45 @@ def test_raw_entry_point_plan_cache(pkg, orc, torch_cuda):
         pkg.lib().uspmv_raw_plan_cache_clear()
 
 
+def test_special_values_propagate_like_the_reference(pkg, orc, torch_cuda):
+    """Inf / NaN / signed zeros in x (also at the column the padding entries point to): the kernels multiply the very
+    same (value, x) pairs in the same order as the reference, so the non-finite results agree too: NaN in the same
+    places (its sign / payload is the hardware's: x86 makes 0*inf the negative "indefinite" NaN, gfx950 the positive
+    canonical one), everything else -- infinities, signed zeros -- bit for bit.  Gather kernel, tile-local-column
+    kernel, SpMMV with and without the block plan."""
+    t = torch_cuda
+
+    def same_bits(got, ref, it):
+        return np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got[~np.isnan(ref)].view(it), ref[~np.isnan(ref)].view(it))
+
+    m = pkg.read_mtx(mtx_path("bcsstk13"))
+    for code, it in ((pkg.F64, np.int64), (pkg.F32, np.int32)):
+        s, a, xp = _prep(pkg, m, 32, 512, code, make_x(m.n_rows))
+        xp = xp.copy()
+        pad_col = int(a["col_idxs"][a["values"] == 0][0]) if np.any(a["values"] == 0) else 0
+        xp[pad_col] = np.inf                      # 0 * inf = NaN wherever a padding entry sits
+        xp[5] = -np.inf; xp[17] = np.nan; xp[40:60] = -0.0; xp[100] = np.finfo(xp.dtype).max; xp[101] = np.finfo(xp.dtype).tiny
+        yo = orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+        assert np.isnan(yo).any() and np.isfinite(yo).any()
+        x = _dev(t, xp)
+        for tlc in (False, True):
+            A = pkg.DeviceMatrix(s, tlc=tlc)
+            y = t.zeros(s.n_rows_padded, dtype=A.torch_dtype, device="cuda")
+            pkg.spmv(A, x, y)
+            assert same_bits(y.cpu().numpy(), yo, it), (code, tlc)
+        b, ld = 4, s.n_rows_padded
+        with np.errstate(over="ignore"):
+            X = np.concatenate([xp * xp.dtype.type(1 + v) for v in range(b)])
+        Yo = orc.spmmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, b, ld, 0)
+        for plan in (0, b):
+            A = pkg.DeviceMatrix(s, block_tlc=plan)
+            pkg.set_tuning(spmmv_variant=4 if plan else 0)
+            Y = t.zeros(b * ld, dtype=A.torch_dtype, device="cuda")
+            pkg.spmmv(A, _dev(t, X), Y, b, ld, pkg.COLWISE)
+            pkg.set_tuning(spmmv_variant=0)
+            assert same_bits(Y.cpu().numpy(), Yo, it), (code, "spmmv", plan)
+
+
 def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
     """uspmv_dmat_optimize_block: LDS-staged X rows + 16-bit local indices give the same bits as the gather
     kernels and the oracle (block_spmv_omp_scs_general, code/kernels.hpp:306-398); staged and unstaged tiles,
