@@ -162,4 +162,57 @@ void execute_uspmv(const ST chunk_size, const ST sigma, const ST *C, const ST *n
     else uspmv_csr_gpu<VT, IT>(*n_chunks, chunk_ptrs, col_idxs, values, x, y, stream);
 }
 
+// ---- beyond interface.hpp: a device-resident matrix with the MI355X plan, for callers that keep the matrix across
+// many SpMVs (what the reference's SpmvKernel object does with its cudaMalloc'ed arrays).  RAII over uspmv_dmat_t.
+class DeviceScs {
+public:
+    DeviceScs() = default;
+    DeviceScs(const DeviceScs &) = delete;
+    DeviceScs &operator=(const DeviceScs &) = delete;
+    DeviceScs(DeviceScs &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    ~DeviceScs() { if (h_) uspmv_dmat_free(h_); }
+    // arrays that already live in HBM (owned by the caller); optimise = build the tile-local-column plan on the device
+    template <typename VT, typename IT>
+    static DeviceScs wrap(ST C, ST n_chunks, ST n_elements, const IT *chunk_ptrs, const IT *chunk_lengths, const IT *col_idxs,
+                          const VT *values, bool optimise = true) {
+        DeviceScs d;
+        uspmv_detail::check(uspmv_dmat_wrap(C, n_chunks, n_elements, uspmv_detail::dtype_of<VT>(), chunk_ptrs, chunk_lengths, col_idxs,
+                                            values, &d.h_), "uspmv_dmat_wrap");
+        if (optimise) uspmv_detail::check(uspmv_dmat_optimize_device(d.h_, 0, nullptr, nullptr), "uspmv_dmat_optimize_device");
+        return d;
+    }
+    // COO -> SELL-C-sigma with the O(nnz) part on the GPU (convert_to_scs + permute_scs_cols + staging in one call);
+    // *perm receives old_to_new_idx for apply_permutation on x and y
+    static DeviceScs from_mtx(const MtxData<double, int> &m, ST C, ST sigma, bool single_precision, std::vector<int> *perm,
+                              std::vector<int> *inv_perm, bool optimise = true) {
+        uspmv_coo_t *coo = nullptr;
+        uspmv_detail::check(uspmv_coo_create(m.n_rows, m.n_cols, m.nnz, m.I.data(), m.J.data(), m.values.data(), &coo), "uspmv_coo_create");
+        uspmv_scs_t *layout = nullptr;
+        DeviceScs d;
+        int rc = uspmv_convert_to_scs_device(coo, C, sigma, single_precision ? USPMV_F32 : USPMV_F64, nullptr, 1, &layout, &d.h_);
+        uspmv_coo_free(coo);
+        uspmv_detail::check(rc, "uspmv_convert_to_scs_device");
+        const int32_t *o2n = nullptr, *n2o = nullptr;
+        uspmv_scs_arrays(layout, nullptr, nullptr, nullptr, nullptr, &o2n, &n2o);
+        if (perm) perm->assign(o2n, o2n + m.n_rows);
+        if (inv_perm) inv_perm->assign(n2o, n2o + m.n_rows);
+        int64_t meta[8];
+        uspmv_scs_meta(layout, meta);
+        d.n_rows_padded_ = meta[4];
+        uspmv_scs_free(layout);
+        if (optimise) uspmv_detail::check(uspmv_dmat_optimize_device(d.h_, 0, nullptr, nullptr), "uspmv_dmat_optimize_device");
+        return d;
+    }
+    void spmv(const void *d_x, void *d_y, void *stream = nullptr) const { uspmv_detail::check(uspmv_spmv(h_, d_x, d_y, stream), "uspmv_spmv"); }
+    void spmmv(const void *d_X, void *d_Y, int b, ST ld, bool rowwise, void *stream = nullptr) const {
+        uspmv_detail::check(uspmv_spmmv(h_, d_X, d_Y, b, ld, rowwise ? USPMV_ROWWISE : USPMV_COLWISE, stream), "uspmv_spmmv");
+    }
+    ST n_rows_padded() const { return n_rows_padded_; }
+    uspmv_dmat_t *handle() const { return h_; }
+
+private:
+    uspmv_dmat_t *h_ = nullptr;
+    ST n_rows_padded_ = 0;
+};
+
 #endif  // USPMV_INTERFACE_HPP
