@@ -31,7 +31,8 @@ class UspmvError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libuspmv.so")
+    # USPMV_LIB: another build of the same library (A/B measurements of kernel variants); default = the in-tree build
+    return os.environ.get("USPMV_LIB") or os.path.join(_HERE, "libuspmv.so")
 
 
 def build_library(force=False):
