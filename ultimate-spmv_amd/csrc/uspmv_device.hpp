@@ -109,11 +109,12 @@ __device__ __forceinline__ T ld_stream(const T *p) {
 }
 // y store.  A y vector is ~2 % of the bytes of an SpMV, but its HBM write stream costs 15-18 % of the
 // kernel when it goes through the write-back L2 (profiles/r01_microbench.txt: 0.74 ms without the
-// store, 0.88 ms with plain stores, 0.83 ms write-through).  Relaxed agent-scope atomic stores
-// compile to `global_store_dword[x2] ... sc1` (write-through, line not kept in L2).
+// store, 0.88 ms with plain stores).  Non-temporal stores (`global_store ... nt`) are the cheapest form
+// measured: A/B of two builds on one box (tools/ab.sh, profiles/r01/ystore_ab.txt) 0.765 ms against 0.822 ms
+// for write-through agent-scope stores (`sc1`) and 0.840 ms for plain stores on the nlpkkt200-class matrix.
 template <bool WT, typename T>
 __device__ __forceinline__ void st_y(T *p, T v) {
-    if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (WT) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
