@@ -7,9 +7,14 @@ A "step" is one SpMV y = A x over the whole (distributed) matrix, inputs residen
 Workload at N = 1 (BASELINE.json configs[1]): nlpkkt200-class matrix -- the SuiteSparse file is not
 available offline, so the deterministic stand-in of SURVEY.md 8(d) is used: 27-point stencil on a
 253^3 grid (n = 16 194 277, nnz = 4.33e8), `uspmv <mtx> scs -c 32 -s 512 -dp`.  A real .mtx can be
-given with --mtx.  At N > 1 the global grid is 253 x 253 x (253*N) (weak scaling: every GPU owns an
-nlpkkt200-class row block), partitioned by the reference's -seg_nnz rule, with the halo x-vector
-exchange (-comm_halos 1) on RCCL every step.  --scaling strong keeps the N = 1 matrix instead.
+given with --mtx.
+Workload at N > 1 (BASELINE.json configs[4]): ONE nlpkkt240-class matrix (27-point stencil on 304^3,
+n = 28 094 464, nnz = 7.5e8) split over the N GPUs by the reference's -seg_nnz rule -- STRONG scaling --
+with the halo x-vector exchange (-comm_halos 1) on RCCL every step.  The step runs in C++ behind the C ABI
+(uspmv_dist_run: pack kernel, grouped ncclSend/ncclRecv on a side stream, interior tiles, boundary tiles)
+and is replayed from one captured hipGraph.  A weak-scaling run (every GPU owns an nlpkkt200-class block,
+grid 253 x 253 x 253*N) is measured after it and reported inside the same JSON line under "weak_scaling";
+--scaling weak makes that the headline instead.
 
 GF/s = 2 * nnz_total / t_step / 1e9 (code/main.cpp:521-526).  Algorithmic bytes per SpMV per GPU
 = n_elements*(8+4) + 8*n_chunks + 8*(n_local + n_halo) + 8*n_rows_padded (code/main.cpp:655-663).
@@ -33,17 +38,22 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--grid", type=int, default=253, help="stencil grid edge (253 = nlpkkt200-class)")
+    ap.add_argument("--grid", type=int, default=0, help="stencil grid edge (default: 253 = nlpkkt200-class at N = 1 and for weak scaling, 304 = nlpkkt240-class for strong scaling at N > 1)")
     ap.add_argument("--mtx", default=None, help="MatrixMarket file instead of the synthetic matrix (N = 1)")
     ap.add_argument("-c", "--chunk", type=int, default=32)
     ap.add_argument("-s", "--sigma", type=int, default=512)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="N > 1: strong (default; BASELINE config 5) or weak")
+    ap.add_argument("--no-graph", action="store_true", help="N > 1: eager steps instead of hipGraph replay")
+    ap.add_argument("--no-second-line", action="store_true", help="N > 1: skip the other scaling mode's measurement")
+    ap.add_argument("--python-step", action="store_true", help="N > 1: round-1 path (torch.distributed all_to_all per step) instead of the C++ step")
     ap.add_argument("--seg", choices=["seg-nnz", "seg-rows"], default="seg-nnz")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--tune", default="", help="key=value,... forwarded to uspmv_set_tuning")
     ap.add_argument("--no-tlc", action="store_true", help="skip the tile-local-column plan (plain gather kernel)")
+    ap.add_argument("--no-traffic", action="store_true", help="N = 1: do not run the two rocprofv3 PMC child passes (roofline.traffic then comes from profiles/traffic.json)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -108,19 +118,187 @@ def cpu_baseline(scs_arrays, C, n_chunks, nnz, x, seconds):
                       f"OMP threads = {cores}"}
 
 
+def pmc_child(args):
+    """Child of measure_traffic(): the N = 1 workload, a few SpMV launches and a 1-GiB read for the FETCH_SIZE calibration."""
+    import torch
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    from ultimate_spmv_amd import binding as B
+    torch.cuda.set_device(0)
+    g = args.grid or 253
+    coo = pkg.gen_stencil27(g, g, g)
+    s = pkg.convert_to_scs(coo, args.chunk, args.sigma, B.F64)
+    a = s.arrays()
+    pkg.permute_scs_cols(s, a["old_to_new_idx"])
+    A = pkg.DeviceMatrix(s, tlc=not args.no_tlc)
+    x = torch.full((s.n_rows_padded,), 5.0, dtype=torch.float64, device="cuda")
+    y = torch.zeros(s.n_rows_padded, dtype=torch.float64, device="cuda")
+    B.time_launches(0, 4, A=A, x=x, y=y)
+    n = 1 << 27
+    sb = torch.ones(n, dtype=torch.float64, device="cuda")
+    part = torch.empty(8192, dtype=torch.float64, device="cuda")
+    B.time_launches(3, 4, x=sb, y=part, n=n)
+    torch.cuda.synchronize()
+
+
+def measure_traffic(args):
+    """HBM bytes per launch of the dominant kernel, measured in THIS run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+    kernel trace only) over a child process that repeats the workload, started before this process touches the GPU.
+    FETCH_SIZE is calibrated on a 1-GiB streaming read inside the same pass (gfx950 tallies 128-byte requests as 64 bytes,
+    /opt/skills/guides/MI355X_MICROARCH.md "HBM").  Returns (bytes, note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", td, "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--grid", str(args.grid or 253), "-c", str(args.chunk), "-s", str(args.sigma)] + (["--no-tlc"] if args.no_tlc else [])
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                return None, f"rocprofv3 pass {counter} failed: {e}"
+            vals = {}
+            for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    k = row["Kernel_Name"]
+                    key = "spmv" if "scs_spmv_" in k else "read" if "stream_read" in k else None
+                    if key:
+                        vals.setdefault(key, []).append(float(row["Counter_Value"]))
+            if "spmv" not in vals:
+                return None, f"rocprofv3 pass {counter}: no SpMV dispatch in the counter file (rc={r.returncode})"
+            out[counter] = {k: sum(v) / len(v) for k, v in vals.items()}
+    fetch_kib, write_kib = out["FETCH_SIZE"]["spmv"], out["WRITE_SIZE"]["spmv"]
+    cal = (1 << 20) / out["FETCH_SIZE"]["read"] if out["FETCH_SIZE"].get("read") else 2.0     # 1 GiB read / KiB reported
+    traffic = int(fetch_kib * 1024 * cal + write_kib * 1024)
+    return traffic, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE {fetch_kib:.0f} KiB x {cal:.3f} (calibrated on a 1-GiB read in the same pass) "
+                     f"+ --pmc WRITE_SIZE {write_kib:.0f} KiB, separate passes, kernel trace only")
+
+
+def stream_rates(B, torch, dev):
+    n = 1 << 27  # 1 GiB per array
+    sa = torch.empty(n, dtype=torch.float64, device=dev)
+    sb = torch.ones(2 * n, dtype=torch.float64, device=dev)
+    part = torch.empty(8192, dtype=torch.float64, device=dev)
+    B.time_launches(1, 3, x=sb, y=sa, n=n)
+    copy = 16.0 * n / (B.time_launches(1, 20, x=sb, y=sa, n=n) * 1e-3) / 1e9
+    triad = 24.0 * n / (B.time_launches(2, 20, x=sb, y=sa, n=n) * 1e-3) / 1e9
+    read = 8.0 * n / (B.time_launches(3, 20, x=sb, y=part, n=n) * 1e-3) / 1e9
+    return {"copy": round(copy, 1), "triad": round(triad, 1), "read": round(read, 1)}
+
+
+def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
+    """One N > 1 measurement: the C++ step (uspmv_dist_run) on one RCCL communicator, K timed steps between barriers."""
+    from ultimate_spmv_amd.distributed import DistSpmv
+    g = grid
+    nz = g * world if scaling == "weak" else g
+    t_setup = time.time()
+    counts = pkg.gen_stencil27_row_counts(g, g, nz)
+    n_global, total_nnz = int(counts.size), int(counts.sum(dtype=np.int64))
+    wsa = pkg.seg_from_row_counts(counts, args.seg, world)
+    del counts
+    loc = pkg.gen_stencil27(g, g, nz, row_begin=int(wsa[rank]), row_end=int(wsa[rank + 1]))
+    native = not args.python_step and not os.environ.get("USPMV_BENCH_ONE_DEVICE")
+    if native:
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        d = pkg.DistNative(loc, wsa, args.chunk, args.sigma, rank, world, bytes(idt.cpu().numpy().tobytes()), tlc=not args.no_tlc)
+        if args.no_overlap:
+            d.set_overlap(False)
+    else:
+        d = DistSpmv(loc, wsa, args.chunk, args.sigma, B.F64, device=dev, overlap=not args.no_overlap, tlc=not args.no_tlc)
+    del loc
+    x = d.new_x(np.full(d.n_local, 5.0))          # DefaultValues::x (code/classes_structs.hpp:1799-1800)
+    y = d.new_y()
+    s = d.scs
+    bytes_local = s.n_elements * 12 + 8 * s.n_chunks + 8 * (d.n_local + d.n_halo) + 8 * s.n_rows_padded
+    t_setup = time.time() - t_setup
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def steps(n):
+        if native:
+            d.run(x, y, n, use_graph=not args.no_graph)
+        else:
+            for _ in range(n):
+                d.spmv(x, y)
+
+    steps(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    steps(args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    ms = elapsed / args.steps * 1e3
+    if native:
+        d._refresh()
+        # the local kernel alone (interior + boundary tiles without the exchange), HIP events on the object's stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(d.stream):
+            d.spmv(x, y, comm_halos=False)
+            e0.record(d.stream)
+            for _ in range(20):
+                d.spmv(x, y, comm_halos=False)
+            e1.record(d.stream)
+        d.synchronize()
+        k_ms = e0.elapsed_time(e1) / 20
+        kind = d.plan_info()[0]
+    else:
+        k_ms = B.time_launches(0, 20, A=d.A, x=x, y=y)
+        kind = 1 if d.use_tiles else 0
+    klass = "nlpkkt240-class" if g == 304 else "nlpkkt200-class" if g == 253 else "stencil"
+    res = {
+        "value": round(2.0 * total_nnz / (ms * 1e-3) / 1e9, 2), "ms_per_step": round(ms, 5), "scaling": scaling,
+        "workload": (f"{klass} synthetic (27-pt stencil {g}x{g}x{nz}, n={n_global}, nnz={total_nnz}) scs -c {args.chunk} -s {args.sigma} -dp "
+                     f"-{args.seg.replace('-', '_')} -comm_halos 1"),
+        "n_rows": n_global, "nnz": total_nnz, "beta": round(s.nnz / s.n_elements, 6),
+        "step": ("C++ uspmv_dist_run, " + ("hipGraph replay" if d.graph_captured else "eager (graph capture refused)" if not args.no_graph else "eager")) if native
+                else "python: torch.distributed all_to_all_single per step",
+        "rank0": {"n_local": d.n_local, "n_halo": d.n_halo, "n_send": d.n_send, "interior": int(d.n_interior) if native else int(len(d.interior_ids)),
+                  "boundary": int(d.n_boundary) if native else int(len(d.boundary_ids)), "tiles": bool(d.use_tiles), "plan_kind": kind,
+                  "local_kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(bytes_local),
+                  "local_kernel_GBs": round(bytes_local / (k_ms * 1e-3) / 1e9, 1)},
+        "setup_s": round(t_setup, 1),
+    }
+    if native:
+        d.close()
+    del d, x, y
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.pmc_child:
+        return pmc_child(args)
+    traffic, traffic_note = None, "not measured"
+    if world == 1 and not args.mtx and not args.no_traffic:
+        traffic, traffic_note = measure_traffic(args)      # child processes under rocprofv3, BEFORE this process touches the GPU
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
 
     pkg = ge.load_package()
     from ultimate_spmv_amd import binding as B
-    from ultimate_spmv_amd.distributed import DistSpmv, seg_from_row_counts
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
@@ -141,104 +319,117 @@ def main():
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         pkg.set_tuning(**{k: int(v)})
+    tuning = {k: pkg.get_tuning(k) for k in ("unroll", "nontemporal", "xcd_remap", "block", "spmv_variant", "tlc")}
 
-    # ------------------------------------------------------------------ matrix (per-rank row block)
+    # ================================================================== N > 1: BASELINE config 5 (strong) + the weak line
+    if world > 1:
+        first = args.scaling or "strong"
+        grid1 = args.grid or (304 if first == "strong" else 253)
+        res = run_distributed(args, pkg, B, torch, dist, dev, world, rank, first, grid1)
+        other = None
+        if not args.no_second_line:
+            second = "weak" if first == "strong" else "strong"
+            other = run_distributed(args, pkg, B, torch, dist, dev, world, rank, second, 253 if second == "weak" else 304)
+        r0 = res["rank0"]
+        out = {
+            "metric": "SpMV GFLOP/s (SELL-32-512 dp; achieved HBM GB/s in roofline)",
+            "value": res["value"], "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": first, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": res["workload"], "C": args.chunk, "sigma": args.sigma, "n_rows": res["n_rows"], "nnz": res["nnz"], "beta": res["beta"],
+                       "x": "5.0 (DefaultValues)", "partition": args.seg, "halo_overlap": not args.no_overlap, "step": res["step"],
+                       "rank0": r0, "tuning": tuning},
+            "roofline": {"bound": "hbm", "achieved": r0["local_kernel_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(r0["local_kernel_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "rank 0's local SpMV (interior + boundary tiles, no exchange): " + ("scs_spmv_tlc<double,32>" if r0["plan_kind"] == 1 else "scs_spmv_rows<double,32,8>"),
+                         "kernel_ms": r0["local_kernel_ms"], "algorithmic_bytes_per_launch": r0["algorithmic_bytes"],
+                         "step_frac_of_n_gpu_roofline": round(sum([r0["algorithmic_bytes"]]) / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "setup_s": res["setup_s"],
+        }
+        if other is not None:
+            out[("weak" if first == "strong" else "strong") + "_scaling"] = {k: other[k] for k in ("value", "ms_per_step", "scaling", "workload", "step", "rank0", "setup_s")}
+            out[("weak" if first == "strong" else "strong") + "_scaling"]["unit"] = "GFLOP/s"
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    # ================================================================== N = 1: BASELINE config 2
     t_setup = time.time()
     if args.mtx:
-        assert world == 1, "--mtx is single-GPU in this round"
         loc = pkg.read_mtx(args.mtx)
-        wsa = np.array([0, loc.n_rows], np.int32)
         workload = f"{os.path.basename(args.mtx)} scs -c {args.chunk} -s {args.sigma} -dp"
-        total_nnz, n_global = loc.nnz, loc.n_rows
     else:
-        g = args.grid
-        nz = g * world if args.scaling == "weak" else g
-        counts = stencil_row_counts(g, g, nz)
-        n_global, total_nnz = int(counts.size), int(counts.sum())
-        wsa = seg_from_row_counts(counts, args.seg, world) if world > 1 else np.array([0, n_global], np.int32)
-        del counts
-        loc = pkg.gen_stencil27(g, g, nz, row_begin=int(wsa[rank]), row_end=int(wsa[rank + 1]))
-        workload = (f"nlpkkt200-class synthetic (27-pt stencil {g}x{g}x{nz}, n={n_global}, nnz={total_nnz}) "
-                    f"scs -c {args.chunk} -s {args.sigma} -dp" + (f" -{args.seg.replace('-', '_')} -comm_halos 1" if world > 1 else ""))
-    d = DistSpmv(loc, wsa, args.chunk, args.sigma, B.F64, device=dev, overlap=not args.no_overlap, tlc=not args.no_tlc)
+        g = args.grid or 253
+        loc = pkg.gen_stencil27(g, g, g)
+        workload = (f"nlpkkt200-class synthetic (27-pt stencil {g}x{g}x{g}, n={loc.n_rows}, nnz={loc.nnz}) "
+                    f"scs -c {args.chunk} -s {args.sigma} -dp")
+    total_nnz, n_global = loc.nnz, loc.n_rows
+    s = pkg.convert_to_scs(loc, args.chunk, args.sigma, B.F64)
+    a = s.arrays()
+    pkg.permute_scs_cols(s, a["old_to_new_idx"])
     del loc
-    x = d.new_x(np.full(d.n_local, 5.0))          # DefaultValues::x (code/classes_structs.hpp:1799-1800)
-    y = d.new_y()
-    s = d.scs
-    bytes_local = s.n_elements * 12 + 8 * s.n_chunks + 8 * (d.n_local + d.n_halo) + 8 * s.n_rows_padded
+    A = pkg.DeviceMatrix(s, dev, tlc=not args.no_tlc)
+    x = torch.full((s.n_rows_padded,), 0.0, dtype=torch.float64, device=dev)
+    x[:s.n_rows] = 5.0                            # DefaultValues::x (code/classes_structs.hpp:1799-1800); a constant is its own permutation
+    y = torch.zeros(s.n_rows_padded, dtype=torch.float64, device=dev)
+    bytes_local = s.n_elements * 12 + 8 * s.n_chunks + 8 * s.n_rows + 8 * s.n_rows_padded
     t_setup = time.time() - t_setup
-
-    def sync():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
 
     # ------------------------------------------------------------------ timed region
     for _ in range(args.warmup):
-        d.spmv(x, y)
-    sync()
+        B.spmv(A, x, y)
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        d.spmv(x, y)
-    sync()
+        B.spmv(A, x, y)
+    torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * total_nnz / (ms_per_step * 1e-3) / 1e9
 
     # ------------------------------------------------------------------ dominant kernel, HIP events on its stream
     reps = max(10, min(args.steps, 100))
-    k_ms = B.time_launches(0, reps, A=d.A, x=x, y=y)
+    k_ms = B.time_launches(0, reps, A=A, x=x, y=y)
     achieved = bytes_local / (k_ms * 1e-3) / 1e9
-    nstream = 1 << 27  # 1 GiB per array
-    sa = torch.empty(nstream, dtype=torch.float64, device=dev)
-    sb = torch.ones(2 * nstream, dtype=torch.float64, device=dev)
-    part = torch.empty(8192, dtype=torch.float64, device=dev)
-    B.time_launches(1, 3, x=sb, y=sa, n=nstream)
-    copy_gbs = 16.0 * nstream / (B.time_launches(1, 20, x=sb, y=sa, n=nstream) * 1e-3) / 1e9
-    triad_gbs = 24.0 * nstream / (B.time_launches(2, 20, x=sb, y=sa, n=nstream) * 1e-3) / 1e9
-    read_gbs = 8.0 * nstream / (B.time_launches(3, 20, x=sb, y=part, n=nstream) * 1e-3) / 1e9
-    del sa, sb
-
-    traffic = None
-    if not args.mtx:
-        key = f"stencil27-{args.grid}x{args.grid}x{args.grid * world if args.scaling == 'weak' else args.grid}-c{args.chunk}-s{args.sigma}-f64-n{world}"
-        try:  # HBM bytes per launch measured with rocprofv3 PMC passes of this very command (profiles/)
+    stream = stream_rates(B, torch, dev)
+    kind, n_tiles, n_planned = A.plan_info()
+    kname = {0: "scs_spmv_rows<double,32,8>", 1: "scs_spmv_tlc<double,32>", 2: "scs_spmv_sweep<double>"}[kind if pkg.get_tuning("tlc") else 0]
+    if traffic is None and not args.mtx:
+        key = f"stencil27-{args.grid or 253}x{args.grid or 253}x{args.grid or 253}-c{args.chunk}-s{args.sigma}-f64-n1"
+        try:
             traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}).get("traffic_bytes")
+            traffic_note = f"NOT measured in this run ({traffic_note}); value from profiles/traffic.json (rocprofv3 PMC passes of an earlier run of this command)"
         except (OSError, ValueError):
             traffic = None
     out = {
         "metric": "SpMV GFLOP/s (SELL-32-512 dp; achieved HBM GB/s in roofline)",
-        "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic" if not args.mtx else "file",
         "config": {"workload": workload, "C": args.chunk, "sigma": args.sigma, "n_rows": n_global, "nnz": total_nnz,
-                   "beta": round(s.nnz / s.n_elements, 6), "x": "5.0 (DefaultValues)",
-                   "partition": args.seg if world > 1 else "none", "halo_overlap": (not args.no_overlap) and world > 1,
-                   "kernel": "tile-local-column (LDS-staged x, 16-bit local indices)" if d.use_tiles or (world == 1 and d.A.tlc_staged) else "lane-per-row gather",
-                   "tlc_tiles_staged": [d.A.tlc_staged, d.A.tlc_tiles],
-                   "tuning": {k: pkg.get_tuning(k) for k in ("unroll", "nontemporal", "xcd_remap", "block", "spmv_variant", "tlc")}},
+                   "beta": round(s.nnz / s.n_elements, 6), "x": "5.0 (DefaultValues)", "partition": "none", "halo_overlap": False,
+                   "kernel": {0: "lane-per-row gather", 1: "tile-local-column (LDS-staged x lines, 16-bit local indices)",
+                              2: "column-window sweep (LDS-staged x windows, compacted stream)"}[kind],
+                   "plan_tiles_planned": [n_planned, n_tiles], "tuning": tuning},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "scs_spmv_tlc<double,32>" if d.A.tlc_staged and pkg.get_tuning("tlc") else "scs_spmv_rows<double,32,8>",
-                     "kernel_ms": round(k_ms, 5),
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": traffic, "traffic_source": traffic_note,
+                     "achieved_physical": None if not traffic else round(traffic / (k_ms * 1e-3) / 1e9, 1),
+                     "frac_physical": None if not traffic else round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "kernel": kname, "kernel_ms": round(k_ms, 5),
                      "algorithmic_bytes_per_launch": int(bytes_local),
-                     "frac_of_stream_copy": round(achieved / copy_gbs, 4),
-                     "stream_same_run_GBs": {"copy": round(copy_gbs, 1), "triad": round(triad_gbs, 1), "read": round(read_gbs, 1)}},
+                     "note": "achieved/frac = algorithmic bytes (SURVEY 8d formula, 12 B per non-zero) / kernel time; achieved_physical/frac_physical = "
+                             "HBM bytes really moved (PMC) / kernel time -- the plan kernels stream 10 B per non-zero",
+                     "stream_same_run_GBs": stream,
+                     "frac_physical_of_stream_read": None if not traffic else round(traffic / (k_ms * 1e-3) / 1e9 / stream["read"], 4)},
         "setup_s": round(t_setup, 1),
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         a = s.arrays()
         out["cpu_baseline"] = cpu_baseline(a, s.C, s.n_chunks, s.nnz, x.cpu().numpy(), args.cpu_seconds)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -83,6 +83,9 @@ void uspmv_coo_free(uspmv_coo_t *m);
  * off-diagonal magnitudes log-uniformly over that many decades (HV15R-class, for -ap splits). */
 int uspmv_gen_stencil27(int64_t nx, int64_t ny, int64_t nz, int dof, uint64_t seed, double magnitude_decades,
                         int64_t row_begin, int64_t row_end, uspmv_coo_t **out);
+/* entries per row of that matrix for rows [row_begin,row_end) -- with uspmv_seg_from_row_counts the ranks of a distributed
+ * run agree on the partition without anybody generating the whole matrix */
+int uspmv_gen_stencil27_row_counts(int64_t nx, int64_t ny, int64_t nz, int dof, int64_t row_begin, int64_t row_end, int32_t *out);
 /* Banded-random matrix of SURVEY.md 8(d) (HV15R-class: n = 2 017 169, 140 entries per row, band +-50 000, magnitudes
  * over 10 decades): the diagonal plus nnz_per_row - 1 hashed distinct columns in [i - band, i + band], general
  * pattern, columns ascending inside a row; the irregular counterpart of the stencil generator. */
@@ -154,6 +157,21 @@ int uspmv_dmat_optimize_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t
  * whose tiles fit, C = 32 or 64; other widths and chunk heights keep the gather kernels
  * (*n_staged = 0).  Results are bit-identical with and without the plan. */
 int uspmv_dmat_optimize_block(uspmv_dmat_t *m, const uspmv_scs_t *s, int block_vec_size, int64_t *n_tiles, int64_t *n_staged);
+
+/* Column-window sweep plan (no reference counterpart): for matrices with wide, irregular rows, where a
+ * 256-row tile touches more x lines than LDS holds.  x is cut into windows of 2^wlog elements; a tile of tile_rows
+ * (256 | 512 | 1024) rows whose rows all visit the windows in non-decreasing slot order (column-sorted rows do) is
+ * processed by one workgroup that stages window after window in LDS and runs every row's entries of the staged
+ * window -- same slot-ordered FMA chain, bit-identical y.  The plan holds a private, padding-free copy of the entries
+ * (sizeof(VT) + 2 bytes per non-zero).  Tiles that do not qualify keep the gather kernel inside the same uspmv_spmv call.
+ * wlog / tile_rows 0 = defaults (64 KiB windows, 1024 rows).  uspmv_dmat_optimize[_ap] tries this by itself when the
+ * tile-local-column plan stages less than half of the tiles.  n_tiles / n_sweep report the outcome (may be NULL). */
+int uspmv_dmat_optimize_sweep(uspmv_dmat_t *m, const uspmv_scs_t *s, int wlog, int tile_rows, int64_t *n_tiles, int64_t *n_sweep);
+int uspmv_dmat_optimize_sweep_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t *s_dp, const uspmv_scs_t *s_sp, int wlog,
+                                 int tile_rows, int64_t *n_tiles, int64_t *n_sweep);
+/* Which single-vector plan uspmv_spmv / uspmv_spmv_ap will use: kind 0 none (gather kernel), 1 tile-local-column, 2 column-window
+ * sweep; tiles of that plan and how many of them it covers (any pointer may be NULL). */
+int uspmv_dmat_plan_info(const uspmv_dmat_t *m, int *kind, int64_t *n_tiles, int64_t *n_planned);
 
 /* The same plan built ON THE DEVICE from the handle's own arrays: for handles without a host struct
  * (uspmv_dmat_wrap around the reference's cudaMalloc'ed arrays, uspmv_convert_to_scs_device).  Chunk heights that
@@ -227,6 +245,10 @@ int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_
  *   "spmmv_variant" 0 (auto) | 1 (generic) | 2 (row-major, transposing X phase) | 3 (row-major, lane per row)
  *                   | 4 (block plan where present; 0 prefers it too, 2 and 3 ignore it),
  *   "spmmv_swizzle" 0|1 bank-swizzled LDS rows in the block-plan kernel,
+ *   "spmmv_reorder" 1|0 NEXT uspmv_dmat_optimize_block: undo the sigma sort's tie scrambling in the plan's private copy of the entries,
+ *   "sweep" 1|0 use a handle's column-window sweep plan, "sweep_nbuf" 2|1 LDS buffers, "sweep_unroll" 2|4|8, "sweep_remap" tiles per XCD group,
+ *   "sweep_wlog" / "sweep_tile_rows" / "sweep_max_stage" defaults of the NEXT sweep plan (window = 2^wlog elements; rows per tile;
+ *   largest staging cost in bytes per non-zero for a tile to qualify, 0 = 24),
  *   "raw_plan_cache" 0|1 uspmv_scs_gpu_f64/f32 keep a device-built plan per set of array addresses (the caller
  *   promises not to put another matrix behind the same pointers; uspmv_raw_plan_cache_clear() otherwise),
  *   "spmmv_tile_rows" 0 (auto) | 32 | 64 rows per tile and "spmmv_lds_kb" 0 (= 80) | LDS KiB per tile of the NEXT
@@ -241,6 +263,8 @@ int uspmv_get_tuning(const char *key, int *value);
 /* ------------------------------------------------------------------ L4: halo exchange     */
 /* seg_work_sharing_arr (code/mpi_funcs.hpp:424-622), seg-rows and seg-nnz: wsa[P+1]. */
 int uspmv_seg_work_sharing_arr(const uspmv_coo_t *total, int seg_method, int P, int32_t *wsa);
+/* the same rule from per-row entry counts alone (bit-identical wsa to the call above on the row-sorted COO) */
+int uspmv_seg_from_row_counts(const int32_t *row_nnz, int64_t n_rows, int seg_method, int P, int32_t *wsa);
 /* seg_mtx_struct + localize_row_idx (code/mpi_funcs.hpp:636-674, :862-877): rows
  * [wsa[rank], wsa[rank+1]) with process-local row ids and GLOBAL column ids. */
 int uspmv_seg_local_coo(const uspmv_coo_t *total, const int32_t *wsa, int rank, uspmv_coo_t **out);
@@ -264,6 +288,48 @@ void uspmv_free(void *p);
  * device sync per neighbour). */
 int uspmv_pack_send_buf(const void *d_x, const int32_t *d_perm, const int32_t *d_send_idxs, int64_t n,
                         int64_t block_offset, void *d_send, int dtype, void *stream);
+
+/* ------------------------------------------------------------------ L4b: the distributed step on RCCL */
+/* One process per GPU.  Replaces the per-iteration MPI flow of the reference -- init_local_structs (code/main.cpp:1075-1334),
+ * collect_comm_info (code/mpi_funcs.hpp:1061-1124), init/finalize_halo_exchange (code/classes_structs.hpp:857-995) and the
+ * exchange-then-kernel iteration of bench_spmv (code/main.cpp:458-474) -- by a C++ object that owns an RCCL communicator:
+ * per SpMV one pack kernel, one grouped ncclSend/ncclRecv landing in the tail of x on a side stream, the interior tiles /
+ * chunks meanwhile, the boundary ones after it; uspmv_dist_run replays the whole step from ONE captured hipGraph. */
+typedef struct uspmv_dist uspmv_dist_t;
+#define USPMV_COMM_ID_BYTES 128
+/* ncclGetUniqueId on the root rank; the bytes reach the other ranks by any side channel (a file, torch.distributed, MPI_Bcast) */
+int uspmv_comm_unique_id(void *id128);
+/* Partition block `rank` of P on communicator rank comm_rank of comm_size.  comm_size == P (one rank per block), or comm_size == 1
+ * with P > 1: LOOPBACK -- this process plays block `rank` and every neighbour is itself (RCCL self send/recv of the ids it asked
+ * for); with an x that repeats with the block height that reproduces the multi-rank result of the block's rows on one GPU.
+ * A / halo / the id lists are the caller's (A must outlive the object): halo from uspmv_halo_discover, old_to_new_idx the row
+ * permutation of the local struct, interior / boundary ids from uspmv_scs_split_chunks (chunk ids) or tile ids of A's plan. */
+int uspmv_dist_create(const void *comm_id, int comm_rank, int comm_size, int rank, int P, uspmv_dmat_t *A, const uspmv_halo_t *halo,
+                      const int32_t *old_to_new_idx, const int32_t *interior_ids, int64_t n_interior, const int32_t *boundary_ids,
+                      int64_t n_boundary, int ids_are_tiles, uspmv_dist_t **out);
+/* The whole of init_local_structs for one block: convert_to_scs -> halo discovery -> column permutation -> upload -> plan ->
+ * interior / boundary split -> uspmv_dist_create.  `local` = rows [wsa[rank], wsa[rank+1]) with local row ids and GLOBAL
+ * column ids (uspmv_seg_local_coo or a generator's row range).  The object owns everything it built. */
+int uspmv_dist_create_from_coo(const void *comm_id, int comm_rank, int comm_size, int rank, int P, const uspmv_coo_t *local,
+                               const int32_t *wsa, int64_t C, int64_t sigma, int dtype, int tlc, uspmv_dist_t **out);
+/* meta[12] = n_local, n_halo, padded_vec_size, n_send, n_interior, n_boundary, ids_are_tiles, n_rows_padded, loopback,
+ *            graph captured, graph launches so far, eager steps so far */
+int uspmv_dist_info(const uspmv_dist_t *d, int64_t meta[12]);
+/* borrowed handles of an object made by uspmv_dist_create_from_coo (NULL scs / halo otherwise) */
+int uspmv_dist_parts(const uspmv_dist_t *d, const uspmv_scs_t **scs, const uspmv_dmat_t **A, const uspmv_halo_t **halo);
+int uspmv_dist_set_overlap(uspmv_dist_t *d, int overlap);
+/* -no_pack 1 of the reference (code/classes_structs.hpp:941): skip the pack kernel, the exchange ships a stale buffer (timing only) */
+int uspmv_dist_set_no_pack(uspmv_dist_t *d, int no_pack);
+/* one step, issued eagerly: d_x (padded_vec_size elements; its halo tail is written), d_y (n_rows_padded written) */
+int uspmv_dist_spmv(uspmv_dist_t *d, void *d_x, void *d_y, int comm_halos, void *stream);
+/* n_steps steps back to back.  use_graph != 0: the step is captured once per (d_x, d_y, stream) into a hipGraph and
+ * replayed (needs an explicit stream); falls back to eager steps when the runtime refuses the capture. */
+int uspmv_dist_run(uspmv_dist_t *d, void *d_x, void *d_y, int n_steps, int use_graph, void *stream);
+/* MPI_Barrier / MPI_Allreduce(MAX) / MPI_Allgather twins on the object's communicator (bench loop, code/main.cpp:461-474) */
+int uspmv_dist_barrier(uspmv_dist_t *d, void *stream);
+int uspmv_dist_allreduce_max(uspmv_dist_t *d, double *value, void *stream);
+int uspmv_dist_allgather_i64(uspmv_dist_t *d, int64_t value, int64_t *all /* comm_size (loopback: P) */, void *stream);
+void uspmv_dist_free(uspmv_dist_t *d);
 
 /* ------------------------------------------------------------------ measurement helpers   */
 /* Device STREAM kernels (copy: a=b, triad: a=b+s*c, read: sum-reduce b) used as the roofline

@@ -373,7 +373,7 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                 if C not in (32, 64) or row_bytes not in (16, 32, 64, 128):
                     assert A.block_staged == 0
                 else:
-                    tr = 32 if (C == 32 and row_bytes >= 64 and not tile64) else 64
+                    tr = 32 if (C == 32 and row_bytes >= 128 and not tile64) else 64
                     assert A.block_tiles == (s.n_rows_padded + tr - 1) // tr and 0 <= A.block_staged <= A.block_tiles
                     seen_partial |= 0 < A.block_staged < A.block_tiles
                     seen_full |= A.block_staged == A.block_tiles
@@ -385,10 +385,14 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                     pkg.spmmv(A0, _dev(t, X), Y0, b, ld, lay)
                     pkg.set_tuning(spmmv_variant=0)
                     for swz in (0, 1):                     # plan kernel for every width it supports, both LDS layouts
-                        pkg.set_tuning(spmmv_variant=4, spmmv_swizzle=swz)
-                        Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
-                        pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
-                        assert t.equal(Y, Y0), (name, C, code, b, rowwise, swz)
+                        for var, pd in ((4, 0), (6, 2), (6, 4), (6, 8), (5, 0)):   # single-wave tiles; four lanes per row (64-byte rows); gather over the re-ordered copy
+                            if (var, swz) == (5, 1):
+                                continue
+                            pkg.set_tuning(spmmv_variant=var, spmmv_swizzle=swz, spmmv_unroll=pd)
+                            Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
+                            pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
+                            assert t.equal(Y, Y0), (name, C, code, b, rowwise, swz, var, pd)
+                    pkg.set_tuning(spmmv_unroll=0)
                     pkg.set_tuning(spmmv_variant=0, spmmv_swizzle=0)
                     Y.fill_(-3.0)                          # and whatever auto picks
                     pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)

@@ -64,7 +64,7 @@ def main():
             s = prep(coo, vdt)
             a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
             b, ld = 8, s.n_rows_padded
-            A = pkg.DeviceMatrix(s, block_tlc=b if (args.sp and not args.no_block_plan) else 0)
+            A = pkg.DeviceMatrix(s, block_tlc=b if not args.no_block_plan else 0)
             xp = np.zeros(ld, ndt); xp[:s.n_rows] = pkg.apply_permutation((1.0 + 1e-3 * (np.arange(s.n_rows) % 1000)).astype(ndt), a["new_to_old_idx"])
             res = {}
             for lay, nm in ((pkg.COLWISE, "colwise"), (pkg.ROWWISE, "rowwise")):
@@ -123,10 +123,14 @@ def main():
             # same matrix in plain dp for comparison
             s = prep(coo, pkg.F64); a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"])
             A = pkg.DeviceMatrix(s)
-            out["gather_kernel_ms"] = round(ms_gather, 5); out["tlc_tiles_staged"] = [ns_, nt_]
+            out["gather_kernel_ms"] = round(ms_gather, 5); out["tlc_tiles_staged"] = [ns_, nt_]; out["ap_plan_kind_tiles_planned"] = list(Ad.plan_info())
             out["plain_dp_gather_ms"] = round(B.time_launches(0, args.reps, A=A, x=x, y=y), 5)
+            y3 = t.zeros_like(y); pkg.spmv(A, x, y3)
             A.optimize(s)
+            y4 = t.zeros_like(y); pkg.spmv(A, x, y4)
+            out["plain_dp_plan_bitexact_vs_gather"] = bool(t.equal(y3, y4)); out["plain_dp_plan_kind_tiles_planned"] = list(A.plan_info())
             out["plain_dp_tlc_ms"] = round(B.time_launches(0, args.reps, A=A, x=x, y=y), 5)
+            out["plain_dp_plan_frac_of_8TBs"] = round((s.n_elements * 12 + 8 * s.n_chunks + 8 * (s.n_rows + s.n_rows_padded)) / out["plain_dp_tlc_ms"] / 1e6 / 8000, 4)
             flops = 2.0 * coo.nnz
             ycpu = np.zeros(ds.n_rows_padded); yspc = np.zeros(ds.n_rows_padded, np.float32); xspc = xp.astype(np.float32)
             cpu_fn = lambda R: R.lib("colwise").ref_spmv_omp_scs_ap_adv(32, ds.n_chunks, da["chunk_ptrs"], da["chunk_lengths"], da["col_idxs"], da["values"], xp, ycpu,

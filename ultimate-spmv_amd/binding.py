@@ -86,6 +86,9 @@ _SIGS = {
     "uspmv_dmat_plan_download": (C.c_int, [_vp, C.POINTER(_i64), _vp, _vp, _vp, _vp]),
     "uspmv_dmat_optimize_block": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_optimize_ap": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
+    "uspmv_dmat_optimize_sweep": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
+    "uspmv_dmat_optimize_sweep_ap": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
+    "uspmv_dmat_plan_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp]),
     "uspmv_spmv_ap": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "uspmv_spmv_ap_generic": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
@@ -106,6 +109,21 @@ _SIGS = {
                                          C.POINTER(_i64)]),
     "uspmv_free": (None, [_vp]),
     "uspmv_pack_send_buf": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, C.c_int, _vp]),
+    "uspmv_seg_from_row_counts": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp]),
+    "uspmv_gen_stencil27_row_counts": (C.c_int, [_i64, _i64, _i64, C.c_int, _i64, _i64, _vp]),
+    "uspmv_comm_unique_id": (C.c_int, [_vp]),
+    "uspmv_dist_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp, _i64, C.c_int, C.POINTER(_vp)]),
+    "uspmv_dist_create_from_coo": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64, _i64, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "uspmv_dist_info": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "uspmv_dist_parts": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "uspmv_dist_set_overlap": (C.c_int, [_vp, C.c_int]),
+    "uspmv_dist_set_no_pack": (C.c_int, [_vp, C.c_int]),
+    "uspmv_dist_spmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "uspmv_dist_run": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "uspmv_dist_barrier": (C.c_int, [_vp, _vp]),
+    "uspmv_dist_allreduce_max": (C.c_int, [_vp, C.POINTER(C.c_double), _vp]),
+    "uspmv_dist_allgather_i64": (C.c_int, [_vp, _i64, C.POINTER(_i64), _vp]),
+    "uspmv_dist_free": (None, [_vp]),
     "uspmv_stream_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
     "uspmv_stream_triad": (C.c_int, [_vp, _vp, _vp, C.c_double, _i64, _vp]),
     "uspmv_stream_read": (C.c_int, [_vp, _i64, _vp, _vp]),
@@ -312,6 +330,125 @@ def seg_local_coo(coo, wsa, rank):
     return Coo(h)
 
 
+def seg_from_row_counts(row_nnz, method, P):
+    """work_sharing_arr from per-row entry counts alone (uspmv_seg_from_row_counts)."""
+    rn = np.ascontiguousarray(row_nnz, np.int32)
+    wsa = np.zeros(P + 1, np.int32)
+    m = {"seg-rows": SEG_ROWS, "seg-nnz": SEG_NNZ}.get(method, method)
+    _ck(lib().uspmv_seg_from_row_counts(_np_ptr(rn), len(rn), m, P, _np_ptr(wsa)))
+    return wsa
+
+
+def gen_stencil27_row_counts(nx, ny, nz, dof=1, row_begin=0, row_end=None):
+    n = nx * ny * nz * dof
+    row_end = n if row_end is None else row_end
+    out = np.empty(row_end - row_begin, np.int32)
+    _ck(lib().uspmv_gen_stencil27_row_counts(nx, ny, nz, dof, row_begin, row_end, _np_ptr(out)))
+    return out
+
+
+def comm_unique_id():
+    """128 bytes of an RCCL unique id (rank 0 makes it, every rank of the communicator gets a copy)."""
+    buf = (C.c_ubyte * 128)()
+    _ck(lib().uspmv_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class _BorrowedScs(Scs):
+    """Scs view of a struct owned by another library object (kept alive through `owner`)."""
+
+    def __init__(self, handle, owner):
+        super().__init__(handle)
+        self._owner = owner
+
+    def __del__(self):
+        self.h = None
+
+
+class DistNative:
+    """The distributed SpMV object of the C ABI (uspmv_dist_*, csrc/uspmv_dist_api.hip): partition block `rank` of P on an RCCL
+    communicator of comm_size ranks (comm_size == P, or 1 = loopback).  Everything per step happens in C++; with use_graph the
+    step is one hipGraphLaunch."""
+
+    def __init__(self, local_coo, wsa, C_, sigma, rank, P, comm_id, comm_rank=None, comm_size=None, dtype=F64, tlc=True):
+        import torch
+        self.rank, self.P = rank, P
+        wsa = np.ascontiguousarray(wsa, np.int32)
+        h = _vp()
+        idbuf = (C.c_ubyte * 128).from_buffer_copy(comm_id)
+        _ck(lib().uspmv_dist_create_from_coo(idbuf, rank if comm_rank is None else comm_rank, P if comm_size is None else comm_size,
+                                             rank, P, local_coo.h, _np_ptr(wsa), C_, sigma, dtype, int(bool(tlc)), C.byref(h)))
+        self.h = h
+        s, a, hl = _vp(), _vp(), _vp()
+        _ck(lib().uspmv_dist_parts(h, C.byref(s), C.byref(a), C.byref(hl)))
+        self.scs = _BorrowedScs(s, self)
+        self._A = a
+        self.tdtype = torch.float64 if dtype == F64 else torch.float32
+        self.stream = torch.cuda.Stream()
+        self._refresh()
+        arr = self.scs.arrays()
+        self.old_to_new = arr["old_to_new_idx"].copy()
+        self.new_to_old = arr["new_to_old_idx"].copy()
+
+    def _refresh(self):
+        m = (_i64 * 12)()
+        _ck(lib().uspmv_dist_info(self.h, m))
+        (self.n_local, self.n_halo, self.padded_vec_size, self.n_send, self.n_interior, self.n_boundary, tiles, self.n_rows_padded,
+         loop, graph, self.graph_launches, self.eager_steps) = [int(v) for v in m]
+        self.use_tiles, self.loopback, self.graph_captured = bool(tiles), bool(loop), bool(graph)
+
+    def plan_info(self):
+        k, a, b = C.c_int(), _i64(), _i64()
+        _ck(lib().uspmv_dmat_plan_info(self._A, C.byref(k), C.byref(a), C.byref(b)))
+        return k.value, a.value, b.value
+
+    def new_x(self, x_local_orig):
+        import torch
+        xp = apply_permutation(np.ascontiguousarray(x_local_orig, self.scs.np_dtype), self.new_to_old)
+        x = torch.zeros(self.padded_vec_size, dtype=self.tdtype, device="cuda")
+        x[:self.n_local] = torch.from_numpy(xp).cuda()
+        return x
+
+    def new_y(self):
+        import torch
+        return torch.zeros(self.padded_vec_size, dtype=self.tdtype, device="cuda")
+
+    def y_to_original_order(self, y):
+        return apply_permutation(y.detach().cpu().numpy(), self.old_to_new)
+
+    def set_overlap(self, on):
+        _ck(lib().uspmv_dist_set_overlap(self.h, int(bool(on))))
+
+    def spmv(self, x, y, comm_halos=True):
+        """one eager step on the object's stream"""
+        _ck(lib().uspmv_dist_spmv(self.h, _dp(x), _dp(y), int(bool(comm_halos)), self.stream.cuda_stream))
+        return y
+
+    def run(self, x, y, n_steps, use_graph=True):
+        _ck(lib().uspmv_dist_run(self.h, _dp(x), _dp(y), int(n_steps), int(bool(use_graph)), self.stream.cuda_stream))
+        return y
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def barrier(self):
+        _ck(lib().uspmv_dist_barrier(self.h, self.stream.cuda_stream))
+
+    def allreduce_max(self, v):
+        d = C.c_double(float(v))
+        _ck(lib().uspmv_dist_allreduce_max(self.h, C.byref(d), self.stream.cuda_stream))
+        return d.value
+
+    def close(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            self.scs = None
+            _LIB.uspmv_dist_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 class HaloPlan:
     """Result of collect_local_needed_heri on one rank (code/mpi_funcs.hpp:242-415)."""
 
@@ -432,6 +569,18 @@ class DeviceMatrix:
         self.block_tiles, self.block_staged = a.value, b.value
         return a.value, b.value
 
+    def optimize_sweep(self, scs, wlog=0, tile_rows=0):
+        """Build the column-window sweep plan (uspmv_dmat_optimize_sweep); returns (n_tiles, n_sweep_tiles)."""
+        a, b = _i64(), _i64()
+        _ck(lib().uspmv_dmat_optimize_sweep(self.h, scs.h, int(wlog), int(tile_rows), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def plan_info(self):
+        """(kind, n_tiles, n_planned) of the single-vector plan in use: kind 0 none, 1 tile-local-column, 2 column-window sweep."""
+        k, a, b = C.c_int(), _i64(), _i64()
+        _ck(lib().uspmv_dmat_plan_info(self.h, C.byref(k), C.byref(a), C.byref(b)))
+        return k.value, a.value, b.value
+
     def optimize(self, scs, max_lines=0):
         """Build the tile-local-column plan (uspmv_dmat_optimize); returns (n_tiles, n_staged_tiles)."""
         a, b = _i64(), _i64()
@@ -475,6 +624,13 @@ def optimize_ap(A_dp, A_sp, scs_dp, scs_sp, max_lines=0):
     _ck(lib().uspmv_dmat_optimize_ap(A_dp.h, A_sp.h, scs_dp.h, scs_sp.h, max_lines, C.byref(a), C.byref(b)))
     for A in (A_dp, A_sp):
         A.tlc_tiles, A.tlc_staged = a.value, b.value
+    return a.value, b.value
+
+
+def optimize_sweep_ap(A_dp, A_sp, scs_dp, scs_sp, wlog=0, tile_rows=0):
+    """Shared column-window sweep plan for an ap[dp_sp] pair; returns (n_tiles, n_sweep_tiles)."""
+    a, b = _i64(), _i64()
+    _ck(lib().uspmv_dmat_optimize_sweep_ap(A_dp.h, A_sp.h, scs_dp.h, scs_sp.h, int(wlog), int(tile_rows), C.byref(a), C.byref(b)))
     return a.value, b.value
 
 

@@ -115,19 +115,22 @@ __global__ void __launch_bounds__(1024) scs_spmv_ap_tlc(const long n_chunks, con
 // times the DOUBLE x, accumulated in double), y = dp + sp  (code/ap_kernels.hpp:59-75).
 // SPX: the generic-C reference kernel spmv_omp_scs_ap multiplies the sp values with the FLOAT copy
 // of x (float product, rounded, then widened and added; code/ap_kernels.hpp:619-623).
-template <int U, bool NT, bool SPX, int CT>
+template <int U, bool NT, bool SPX, int CT, bool IDS = false>
 __global__ void scs_spmv_ap_rows(const long n_chunks, const int C_rt, const int *__restrict__ dp_cp,
                                  const int *__restrict__ dp_cl, const int *__restrict__ dp_ci,
                                  const double *__restrict__ dp_va, const int *__restrict__ sp_cp,
                                  const int *__restrict__ sp_cl, const int *__restrict__ sp_ci,
                                  const float *__restrict__ sp_va, const double *__restrict__ x,
-                                 const float *__restrict__ x_sp, double *__restrict__ y, const int xcd_remap) {
+                                 const float *__restrict__ x_sp, double *__restrict__ y, const int xcd_remap,
+                                 const int *__restrict__ chunk_ids = nullptr) {
     const int C = CT > 0 ? CT : C_rt;        // CT = 32: slot strides become immediate offsets
     const unsigned lb = remap_block(blockIdx.x, gridDim.x, xcd_remap);
-    const long row = (long)lb * blockDim.x + threadIdx.x;
-    const long c = row / C;
-    const int i = (int)(row - c * C);
-    if (c >= n_chunks) return;
+    const long vrow = (long)lb * blockDim.x + threadIdx.x;
+    const long vc = vrow / C;                // IDS: virtual chunk vc -> chunk_ids[vc] (the chunks a sweep plan leaves over)
+    const int i = (int)(vrow - vc * C);
+    if (vc >= n_chunks) return;
+    const long c = IDS ? (long)chunk_ids[vc] : vc;
+    const long row = c * C + i;
     double dt = 0.0, st = 0.0;
     const long dcs = dp_cp[c], scs_ = sp_cp[c];
     const int Ld = dp_cl[c], Ls = sp_cl[c];
@@ -204,8 +207,29 @@ __global__ void scs_spmv_ap_rows(const long n_chunks, const int C_rt, const int 
 
 namespace uspmv_dev {
 
+int launch_spmv_ap_chunks(const uspmv_dmat *dp, const uspmv_dmat *sp, const int *chunk_ids, long n_ids, const double *d_x,
+                          double *d_y, hipStream_t stream) {
+    if (n_ids == 0) return USPMV_OK;
+    const unsigned grid = grid_for(n_ids * dp->C, 256);
+    if (g_tune.nontemporal)
+        hipLaunchKernelGGL((scs_spmv_ap_rows<4, true, false, 0, true>), dim3(grid), dim3(256), 0, stream, n_ids, (int)dp->C, dp->chunk_ptrs,
+                           dp->chunk_lengths, dp->col_idxs, (const double *)dp->values, sp->chunk_ptrs, sp->chunk_lengths, sp->col_idxs,
+                           (const float *)sp->values, d_x, (const float *)nullptr, d_y, g_tune.xcd_remap, chunk_ids);
+    else
+        hipLaunchKernelGGL((scs_spmv_ap_rows<4, false, false, 0, true>), dim3(grid), dim3(256), 0, stream, n_ids, (int)dp->C, dp->chunk_ptrs,
+                           dp->chunk_lengths, dp->col_idxs, (const double *)dp->values, sp->chunk_ptrs, sp->chunk_lengths, sp->col_idxs,
+                           (const float *)sp->values, d_x, (const float *)nullptr, d_y, g_tune.xcd_remap, chunk_ids);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
 int launch_spmv_ap(const uspmv_dmat *dp, const uspmv_dmat *sp, const double *d_x, const float *d_x_sp, double *d_y,
                    hipStream_t stream) {
+    if (!d_x_sp && dp->sw && sp->sw && dp->sw_tile_ids && dp->sw_idx_b && dp->sw_plan_id == sp->sw_plan_id && g_tune.sweep &&
+        ((uintptr_t)d_x % 16 == 0)) {
+        if (int rc = launch_spmv_sweep_ap(dp, d_x, d_y, stream)) return rc;
+        return launch_spmv_ap_chunks(dp, sp, dp->sw_rest, (long)dp->sw_n_rest, d_x, d_y, stream);
+    }
     if (!d_x_sp && dp->tlc && sp->tlc && dp->tlc_plan_id != 0 && dp->tlc_plan_id == sp->tlc_plan_id && g_tune.tlc &&
         ((uintptr_t)d_x % 16 == 0)) {
         const size_t lds = (size_t)dp->tlc_max_lines * 16 * sizeof(double);

@@ -59,7 +59,7 @@ template <typename VT, int B, int U, bool NT, bool YCOL, bool PF>
 __global__ void __launch_bounds__(256) scs_spmmv_rowmajor(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
                                    const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs,
                                    const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y,
-                                   const long ld, const int xcd_remap, const long n_store) {
+                                   const long ld, const int xcd_remap, const long n_store, const int *__restrict__ row_map = nullptr) {
     constexpr int VW = 16 / (int)sizeof(VT);  // elements per 16-byte load
     constexpr int NV = B / VW;
     typedef VT vec_t __attribute__((ext_vector_type(VW)));
@@ -144,12 +144,13 @@ __global__ void __launch_bounds__(256) scs_spmmv_rowmajor(const long n_chunks, c
             for (int w = 0; w < VW; ++w) acc[k * VW + w] = fma_t(a, xv[w], acc[k * VW + w]);
         }
     }
-    if (row >= n_store) return;               // (re-chunked handles: rows past the caller's padded rows)
+    const long yrow = row_map ? (long)row_map[row] : row;   // (tie-reordered private copy: plan row -> caller's row)
+    if (yrow >= n_store) return;              // (re-chunked handles: rows past the caller's padded rows)
     if (YCOL) {
 #pragma unroll
-        for (int v = 0; v < B; ++v) st_y<NT>(Y + (row + (long)v * ld), acc[v]);
+        for (int v = 0; v < B; ++v) st_y<NT>(Y + (yrow + (long)v * ld), acc[v]);
     } else {
-        vec_t *yp = (vec_t *)(Y + row * B);
+        vec_t *yp = (vec_t *)(Y + yrow * B);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             vec_t t;
@@ -276,7 +277,8 @@ __global__ void __launch_bounds__(64) scs_spmmv_tlc(const long n_chunks, const i
         const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const VT *__restrict__ values,
         const VT *__restrict__ X, VT *__restrict__ Y, const long ld, const int *__restrict__ tile_line_ptr,
         const int *__restrict__ tile_xrows, const unsigned *__restrict__ c16_ptrs,
-        const unsigned short *__restrict__ col16, const long x_rows, const int xcd_remap, const long n_store, const int x_bytes) {
+        const unsigned short *__restrict__ col16, const long x_rows, const int xcd_remap, const long n_store, const int x_bytes,
+        const int *__restrict__ row_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tlc_smem[];
     constexpr int VW = 16 / (int)sizeof(VT);  // elements per 16-byte piece
     constexpr int NV = B / VW;                // pieces per X row (1, 2, 4, 8)
@@ -408,12 +410,14 @@ __global__ void __launch_bounds__(64) scs_spmmv_tlc(const long n_chunks, const i
         for (int j = 0; j < L; ++j)
             fma_row(ld_stream<NT>(vp + (long)j * C), (const vec_t *)(X + (long)ld_stream<NT>(cp + (long)j * C) * B), 0u);
     }
-    if (!valid || row >= n_store) return;
+    if (!valid) return;
+    const long yrow = row_map ? (long)row_map[row] : row;   // (plan rows are a permutation of the caller's rows)
+    if (yrow >= n_store) return;
     if (YCOL) {
 #pragma unroll
-        for (int v = 0; v < BH; ++v) st_y<NT>(Y + (row + (long)(h * BH + v) * ld), acc[v]);
+        for (int v = 0; v < BH; ++v) st_y<NT>(Y + (yrow + (long)(h * BH + v) * ld), acc[v]);
     } else {
-        vec_t *yp = (vec_t *)(Y + row * B) + h * NVH;
+        vec_t *yp = (vec_t *)(Y + yrow * B) + h * NVH;
 #pragma unroll
         for (int k = 0; k < NVH; ++k) {
             vec_t t;
@@ -421,6 +425,145 @@ __global__ void __launch_bounds__(64) scs_spmmv_tlc(const long n_chunks, const i
             for (int w = 0; w < VW; ++w) t[w] = acc[k * VW + w];
             yp[k] = t;
         }
+    }
+}
+
+
+// Row-major SpMMV over the block plan, FOUR LANES PER ROW (rows of four 16-byte pieces: b = 8 in double, 16 in single
+// precision).  The single-wave form above keeps a whole 64-byte X row per lane: B accumulators, deep register batches
+// (it compiles to 486 registers, 700 accvgpr moves per tile) and ONE wave per 50 KB of LDS -- three waves per CU whose
+// compute phase cannot overlap anything.  Here a 64-row tile is a 256-thread workgroup: wave w owns rows 16w..16w+15, lane
+// (r, q) owns piece q (two doubles) of row r's accumulators.  The matrix stream stays coalesced -- lane (r, q) loads slot
+// 4g+q of row r, one 8-byte value and one 2-byte local index -- and a slot's (value, index) reaches the row's four lanes by
+// a DPP quad broadcast (no LDS traffic); the X operand is one ds_read_b128 per lane and slot.  Per (row, column) the FMA
+// chain still runs over the slots in order: bit-identical to block_spmv_omp_scs_general (code/kernels.hpp:306-398).
+// Four waves share one staged copy of the tile's X rows, ~25 registers each, so a CU holds 12 waves on 3 tiles and the
+// arithmetic of a tile takes a quarter of the time.
+template <int U>
+__device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(v, v, U * 0x55, 0xf, 0xf, false); }   // (all lanes written: `old` is dead)
+template <int U>
+__device__ __forceinline__ double quad_bcast(double v) {
+    return __hiloint2double(quad_bcast<U>(__double2hiint(v)), quad_bcast<U>(__double2loint(v)));
+}
+template <int U>
+__device__ __forceinline__ float quad_bcast(float v) { return __int_as_float(quad_bcast<U>(__float_as_int(v))); }
+
+template <typename VT, int B, bool NT, bool YCOL, int C, bool SWZ, int PD>
+__global__ void __launch_bounds__(256) scs_spmmv_quad(const long n_chunks, const int *__restrict__ chunk_ptrs,
+        const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const VT *__restrict__ values,
+        const VT *__restrict__ X, VT *__restrict__ Y, const long ld, const int *__restrict__ tile_line_ptr,
+        const int *__restrict__ tile_xrows, const unsigned *__restrict__ c16_ptrs, const unsigned short *__restrict__ col16,
+        const int xcd_remap, const long n_store, const int x_bytes, const int *__restrict__ row_map) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tlc_smem[];
+    constexpr int VW = 16 / (int)sizeof(VT);
+    static_assert(B == 4 * VW, "four 16-byte pieces per X row");
+    typedef VT vec_t __attribute__((ext_vector_type(VW)));
+    const unsigned tile = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+    const int lp0 = tile_line_ptr[tile];
+    const int nl = tile_line_ptr[tile + 1] - lp0;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int r = lane >> 2, q = lane & 3;
+    const long row = (long)tile * 64 + wave * 16 + r;       // plan row (16 | C: a wave's rows sit in one chunk)
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    const bool valid = c < n_chunks;
+    int cs = 0, L = 0;
+    unsigned q0 = 0;
+    if (valid) { cs = chunk_ptrs[c]; L = chunk_lengths[c]; q0 = c16_ptrs[c]; }
+    L = __builtin_amdgcn_readfirstlane(L);                   // (wave-uniform; an invalid wave has L = 0)
+    vec_t acc;
+#pragma unroll
+    for (int w = 0; w < VW; ++w) acc[w] = VT(0);
+    const int ng = (L + 3) >> 2;                             // groups of four slots (the last one may be partial)
+    const VT *vp = values + (long)cs + i + (long)q * C;     // slot 4g+q of this lane's row: + g*4*C
+    if (nl > 0) {
+        // ---- 1. the tile's X-row list -> LDS (behind the X rows), by DMA
+        int *rl = (int *)(tlc_smem + x_bytes);
+#pragma unroll 1
+        for (int r0 = wave * 64; r0 < nl; r0 += 256)
+            if (r0 + lane < nl)
+                __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(tile_xrows + lp0 + r0 + lane), (lds_void_t *)(rl + r0), 4, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- 2. the first PD groups of matrix entries are requested before the X rows
+        const unsigned short *ip = col16 + q0 + (long)i * 4 + q;   // + g*4*C
+        VT a[PD];
+        unsigned ix[PD];
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            a[d] = VT(0); ix[d] = 0u;
+            if (d < ng) {
+                ix[d] = ld_stream<NT>(ip + (long)d * 4 * C);
+                if (4 * d + q < L) a[d] = ld_stream<NT>(vp + (long)d * 4 * C);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 3. X rows -> LDS by DMA: piece p = (list position p >> 2, 16-byte piece p & 3), 64 pieces per wave-instruction
+        const int np = nl << 2;
+#pragma unroll 1
+        for (int t0 = wave; t0 * 64 < np; t0 += 4) {
+            const int p = t0 * 64 + lane;
+            if (p < np) {
+                const unsigned k = (unsigned)p >> 2;
+                const unsigned piece = ((unsigned)p & 3u) ^ (SWZ ? (k >> 2) & 3u : 0u);
+                __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(X + (long)rl[k] * B + piece * VW), (lds_void_t *)(tlc_smem + t0 * 1024), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- 4. arithmetic: group g from registers, group g + PD requested behind it
+        const vec_t *xs = (const vec_t *)tlc_smem;
+        auto use = [&](const VT av, const unsigned iv, const int nu) {
+#define QUAD_STEP(UU)                                                                                         \
+            if (UU < nu) {                                                                                    \
+                const VT aa = quad_bcast<UU>(av);                                                             \
+                const unsigned li = (unsigned)quad_bcast<UU>((int)iv);                                        \
+                const vec_t xv = xs[li * 4 + ((unsigned)q ^ (SWZ ? (li >> 2) & 3u : 0u))];                    \
+                _Pragma("unroll") for (int w = 0; w < VW; ++w) acc[w] = fma_t(aa, xv[w], acc[w]);             \
+            }
+            QUAD_STEP(0) QUAD_STEP(1) QUAD_STEP(2) QUAD_STEP(3)
+#undef QUAD_STEP
+        };
+        for (int g0 = 0; g0 < ng; g0 += PD) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                const int g = g0 + d;
+                if (g < ng) {
+                    use(a[d], ix[d], min(4, L - 4 * g));
+                    const int gn = g + PD;
+                    if (gn < ng) {
+                        ix[d] = ld_stream<NT>(ip + (long)gn * 4 * C);
+                        a[d] = (4 * gn + q < L) ? ld_stream<NT>(vp + (long)gn * 4 * C) : VT(0);
+                    }
+                }
+            }
+        }
+    } else if (L > 0) {   // wide-footprint tile: 32-bit columns, X pieces gathered from global memory
+        const int *cp = col_idxs + (long)cs + i + (long)q * C;
+        for (int g = 0; g < ng; ++g) {
+            VT av = VT(0);
+            int cv = 0;
+            if (4 * g + q < L) { av = ld_stream<NT>(vp + (long)g * 4 * C); cv = ld_stream<NT>(cp + (long)g * 4 * C); }
+            const int nu = min(4, L - 4 * g);
+#define QUAD_STEP(UU)                                                                                         \
+            if (UU < nu) {                                                                                    \
+                const VT aa = quad_bcast<UU>(av);                                                             \
+                const long col = quad_bcast<UU>(cv);                                                          \
+                const vec_t xv = *((const vec_t *)(X + col * B) + q);                                         \
+                _Pragma("unroll") for (int w = 0; w < VW; ++w) acc[w] = fma_t(aa, xv[w], acc[w]);             \
+            }
+            QUAD_STEP(0) QUAD_STEP(1) QUAD_STEP(2) QUAD_STEP(3)
+#undef QUAD_STEP
+        }
+    }
+    if (!valid) return;
+    const long yrow = row_map ? (long)row_map[row] : row;
+    if (yrow >= n_store) return;
+    if (YCOL) {
+#pragma unroll
+        for (int w = 0; w < VW; ++w) st_y<NT>(Y + (yrow + (long)(q * VW + w) * ld), acc[w]);
+    } else {
+        *((vec_t *)(Y + yrow * B) + q) = acc;
     }
 }
 
@@ -462,16 +605,22 @@ template <typename VT, int B, int U>
 void launch_spmmv_rowmajor_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
     const int block = std::min(g_tune.block, 256);      // (__launch_bounds__(256): deep batches may use > 128 VGPRs)
     const unsigned grid = grid_for(A->n_chunks * A->C, block);
+    // variant 5: the gather kernel over the block plan's tie-reordered copy of the entries (neighbouring lanes then read
+    // neighbouring X rows, which is what L1 can exploit)
+    const bool ro = g_tune.spmmv_variant == 5 && A->bt_values && A->bt_cols && A->bt_row_map;
+    const int *cols = ro ? A->bt_cols : A->col_idxs;
+    const VT *vals = (const VT *)(ro ? A->bt_values : A->values);
+    const int *rmap = ro ? A->bt_row_map : nullptr;
 #define RM_LAUNCH(NTV, YC)                                                                                          \
     do {                                                                                                            \
         if (g_tune.spmmv_prefetch)                                                                                  \
             hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, NTV, YC, true>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
-                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
-                               g_tune.xcd_remap, (long)A->n_store);                                                                   \
+                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, cols, vals, X, Y, ld, \
+                               g_tune.xcd_remap, (long)A->n_store, rmap);                                                             \
         else                                                                                                        \
             hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, NTV, YC, false>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
-                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, \
-                               g_tune.xcd_remap, (long)A->n_store);                                                                   \
+                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, cols, vals, X, Y, ld, \
+                               g_tune.xcd_remap, (long)A->n_store, rmap);                                                             \
     } while (0)
     if (g_tune.nontemporal) { if (ycol) RM_LAUNCH(true, true); else RM_LAUNCH(true, false); }
     else { if (ycol) RM_LAUNCH(false, true); else RM_LAUNCH(false, false); }
@@ -507,17 +656,57 @@ void launch_spmmv_tlc_g(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool y
         auto kfn = scs_spmmv_tlc<VT, B, NTV, YC, G, CT, HS, SWZ>;                                                                \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)A->bt_n_tiles), dim3(64), lds, st, (long)A->n_chunks,                    \
-                           A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, ld, A->bt_line_ptr, \
-                           A->bt_xrows, A->bt_c16_ptrs, A->bt_col16, ld, g_tune.xcd_remap, (long)A->n_store, (int)x_bytes); \
+                           A->chunk_ptrs, A->chunk_lengths, A->bt_cols ? A->bt_cols : A->col_idxs,                       \
+                           (const VT *)(A->bt_values ? A->bt_values : A->values), X, Y, ld, A->bt_line_ptr,                \
+                           A->bt_xrows, A->bt_c16_ptrs, A->bt_col16, ld, g_tune.xcd_remap, (long)A->n_store, (int)x_bytes, \
+                           (const int *)A->bt_row_map);                                                                   \
     } while (0)
     if (g_tune.nontemporal) { if (ycol) BT_LAUNCH(true, true); else BT_LAUNCH(true, false); }
     else { if (ycol) BT_LAUNCH(false, true); else BT_LAUNCH(false, false); }
 #undef BT_LAUNCH
 }
 
+
+template <typename VT, int B, int CT, bool SWZ, int PD>
+void launch_spmmv_quad_g(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    const size_t x_bytes = (size_t)A->bt_max_rows * B * sizeof(VT);
+    const size_t lds = x_bytes + (((size_t)A->bt_max_rows * 4 + 15) & ~(size_t)15);
+#define QD_LAUNCH(NTV, YC)                                                                                              \
+    do {                                                                                                                \
+        auto kfn = scs_spmmv_quad<VT, B, NTV, YC, CT, SWZ, PD>;                                                         \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)A->bt_n_tiles), dim3(256), lds, st, (long)A->n_chunks,                   \
+                           A->chunk_ptrs, A->chunk_lengths, A->bt_cols ? A->bt_cols : A->col_idxs,                       \
+                           (const VT *)(A->bt_values ? A->bt_values : A->values), X, Y, ld, A->bt_line_ptr,                \
+                           A->bt_xrows, A->bt_c16_ptrs, A->bt_col16, g_tune.xcd_remap, (long)A->n_store, (int)x_bytes,    \
+                           (const int *)A->bt_row_map);                                                                   \
+    } while (0)
+    if (g_tune.nontemporal) { if (ycol) QD_LAUNCH(true, true); else QD_LAUNCH(true, false); }
+    else { if (ycol) QD_LAUNCH(false, true); else QD_LAUNCH(false, false); }
+#undef QD_LAUNCH
+}
+
+template <typename VT, int B>
+void launch_spmmv_quad(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    const bool swz = g_tune.spmmv_swizzle != 0;
+    const int pd = g_tune.spmmv_unroll == 2 ? 2 : g_tune.spmmv_unroll == 8 ? 8 : 4;
+#define QD_PD(CTV, SW) do { if (pd == 2) launch_spmmv_quad_g<VT, B, CTV, SW, 2>(A, X, Y, ld, ycol, st); else if (pd == 8) launch_spmmv_quad_g<VT, B, CTV, SW, 8>(A, X, Y, ld, ycol, st); \
+                            else launch_spmmv_quad_g<VT, B, CTV, SW, 4>(A, X, Y, ld, ycol, st); } while (0)
+    if (A->C == 32) { if (swz) QD_PD(32, true); else QD_PD(32, false); }
+    else { if (swz) QD_PD(64, true); else QD_PD(64, false); }
+#undef QD_PD
+}
+
 template <typename VT, int B>
 void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
     constexpr int RB = B * (int)sizeof(VT);          // bytes per X row
+    if constexpr (RB == 64) {
+        // 64-byte rows: the four-lanes-per-row kernel over 64-row tiles of the block plan (variant 6; auto when the plan is there)
+        if (A->bt && A->bt_tile_rows == 64 && (g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 6) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
+            launch_spmmv_quad<VT, B>(A, X, Y, ld, ycol, st);
+            return;
+        }
+    }
     if constexpr (RB >= 16 && RB <= 128) {
         // block plan staged in LDS, if the handle carries one whose tiles fit this row width
         // auto takes the plan for rows of <= 32 bytes only: there 4+ tiles fit a CU and the kernel is 12-15 % ahead of

@@ -421,6 +421,11 @@ int launch_spmv_scs(const uspmv_dmat *A, const int *chunk_ids, long n_ids, const
     if (nwc == 0) return USPMV_OK;
     const int C = (int)A->C;
     const int block = g_tune.block;
+    if (!ids && A->sw && A->sw_tile_ids && !A->sw_idx_b && g_tune.sweep && !g_tune.ablate && g_tune.spmv_variant == 0 && ((uintptr_t)x % 16 == 0)) {
+        // column-window sweep over the tiles that qualify, lane-per-row gather kernel over the chunks that are left
+        if (int rc = launch_spmv_sweep<VT>(A, x, y, st)) return rc;
+        return A->sw_n_rest ? launch_spmv_scs<VT>(A, A->sw_rest, (long)A->sw_n_rest, x, y, st) : USPMV_OK;
+    }
     if (!ids && A->tlc && A->tlc_plan_id == 0 && g_tune.tlc && !g_tune.ablate && g_tune.spmv_variant == 0 && ((uintptr_t)x % 16 == 0))
         return launch_spmv_tlc<VT>(A, nullptr, A->tlc_n_tiles, x, y, st);
     if (!ids && C == 32 && g_tune.spmv_variant == 1) {

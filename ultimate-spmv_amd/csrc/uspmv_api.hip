@@ -64,15 +64,43 @@ __global__ void gather_kernel(VT *__restrict__ out, const VT *__restrict__ in, c
     if (i < n) out[i] = in[(long)perm[idx ? idx[i] : (int)i] + offset];
 }
 
-// STREAM-style calibrators: 16 bytes per lane, grid-stride.
-__global__ void stream_copy_kernel(double2 *__restrict__ a, const double2 *__restrict__ b, const long n2) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) a[i] = b[i];
+// STREAM-style calibrators.  copy / triad: every thread moves eight 16-byte pieces, all loads issued before the first store
+// (32 KiB in flight per 256-thread workgroup), non-temporal loads and stores -- the shape the guide's 6.3 TB/s copy has; the
+// grid-stride form of round 1 (one 16-byte piece in flight per thread, plain stores) stopped at 4.9 TB/s.
+__global__ void __launch_bounds__(256) stream_copy_kernel(double2 *__restrict__ a, const double2 *__restrict__ b, const long n2) {
+    const long base = (long)blockIdx.x * (256 * 8) + threadIdx.x;
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long i = base + u * 256;
+        if (i < n2) { const double *p = (const double *)(b + i); v[2 * u] = __builtin_nontemporal_load(p); v[2 * u + 1] = __builtin_nontemporal_load(p + 1); }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long i = base + u * 256;
+        if (i < n2) { double *p = (double *)(a + i); __builtin_nontemporal_store(v[2 * u], p); __builtin_nontemporal_store(v[2 * u + 1], p + 1); }
+    }
 }
-__global__ void stream_triad_kernel(double2 *__restrict__ a, const double2 *__restrict__ b,
-                                    const double2 *__restrict__ c, const double s, const long n2) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
-        double2 bb = b[i], cc = c[i];
-        a[i] = make_double2(bb.x + s * cc.x, bb.y + s * cc.y);
+__global__ void __launch_bounds__(256) stream_triad_kernel(double2 *__restrict__ a, const double2 *__restrict__ b,
+                                                          const double2 *__restrict__ c, const double s, const long n2) {
+    const long base = (long)blockIdx.x * (256 * 4) + threadIdx.x;
+    double vb[8], vc[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = base + u * 256;
+        if (i < n2) {
+            const double *pb = (const double *)(b + i), *pc = (const double *)(c + i);
+            vb[2 * u] = __builtin_nontemporal_load(pb); vb[2 * u + 1] = __builtin_nontemporal_load(pb + 1);
+            vc[2 * u] = __builtin_nontemporal_load(pc); vc[2 * u + 1] = __builtin_nontemporal_load(pc + 1);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = base + u * 256;
+        if (i < n2) {
+            double *p = (double *)(a + i);
+            __builtin_nontemporal_store(vb[2 * u] + s * vc[2 * u], p); __builtin_nontemporal_store(vb[2 * u + 1] + s * vc[2 * u + 1], p + 1);
+        }
     }
 }
 __global__ void stream_read_kernel(const double2 *__restrict__ b, const long n2, double *__restrict__ partial) {
@@ -125,11 +153,25 @@ int uspmv_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "ablate")) g_tune.ablate = value;
     else if (!strcmp(key, "spmmv_prefetch")) g_tune.spmmv_prefetch = value != 0;
     else if (!strcmp(key, "spmmv_swizzle")) g_tune.spmmv_swizzle = value != 0;
+    else if (!strcmp(key, "spmmv_reorder")) g_tune.spmmv_reorder = value != 0;
+    else if (!strcmp(key, "sweep")) g_tune.sweep = value != 0;
+    else if (!strcmp(key, "sweep_nbuf")) g_tune.sweep_nbuf = value == 1 ? 1 : 2;
+    else if (!strcmp(key, "sweep_unroll")) g_tune.sweep_unroll = value >= 8 ? 8 : value >= 4 ? 4 : 2;
+    else if (!strcmp(key, "sweep_remap")) g_tune.sweep_remap = value < 0 ? 0 : value;
+    else if (!strcmp(key, "sweep_wlog")) {
+        if (value != 0 && (value < 8 || value > 16)) return uspmv::fail(USPMV_ERR_INVALID, "sweep_wlog must be 0 or 8..16");
+        g_tune.sweep_wlog = value;
+    }
+    else if (!strcmp(key, "sweep_tile_rows")) {
+        if (value != 0 && value != 256 && value != 512 && value != 1024) return uspmv::fail(USPMV_ERR_INVALID, "sweep_tile_rows must be 0|256|512|1024");
+        g_tune.sweep_tile_rows = value;
+    }
+    else if (!strcmp(key, "sweep_max_stage")) g_tune.sweep_max_stage = value < 0 ? 0 : value;
     else if (!strcmp(key, "raw_plan_cache")) g_tune.raw_plan_cache = value != 0;
     else if (!strcmp(key, "spmmv_tile_rows")) g_tune.spmmv_tile_rows = value == 64 ? 64 : value == 32 ? 32 : 0;
     else if (!strcmp(key, "spmmv_lds_kb")) g_tune.spmmv_lds_kb = value < 0 ? 0 : value;
     else if (!strcmp(key, "spmmv_variant")) {
-        if (value < 0 || value > 4) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0|1|2|3|4");
+        if (value < 0 || value > 6) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0..6");
         g_tune.spmmv_variant = value;
     }
     else if (!strcmp(key, "tail_batch")) g_tune.tail_batch = value != 0;
@@ -165,6 +207,14 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "ablate")) *value = g_tune.ablate;
     else if (!strcmp(key, "spmmv_prefetch")) *value = g_tune.spmmv_prefetch;
     else if (!strcmp(key, "spmmv_swizzle")) *value = g_tune.spmmv_swizzle;
+    else if (!strcmp(key, "spmmv_reorder")) *value = g_tune.spmmv_reorder;
+    else if (!strcmp(key, "sweep")) *value = g_tune.sweep;
+    else if (!strcmp(key, "sweep_nbuf")) *value = g_tune.sweep_nbuf;
+    else if (!strcmp(key, "sweep_unroll")) *value = g_tune.sweep_unroll;
+    else if (!strcmp(key, "sweep_remap")) *value = g_tune.sweep_remap;
+    else if (!strcmp(key, "sweep_wlog")) *value = g_tune.sweep_wlog;
+    else if (!strcmp(key, "sweep_tile_rows")) *value = g_tune.sweep_tile_rows;
+    else if (!strcmp(key, "sweep_max_stage")) *value = g_tune.sweep_max_stage;
     else if (!strcmp(key, "raw_plan_cache")) *value = g_tune.raw_plan_cache;
     else if (!strcmp(key, "spmmv_tile_rows")) *value = g_tune.spmmv_tile_rows;
     else if (!strcmp(key, "spmmv_lds_kb")) *value = g_tune.spmmv_lds_kb;
@@ -302,6 +352,9 @@ int uspmv_dmat_download(const uspmv_dmat_t *A, int32_t *chunk_ptrs, int32_t *chu
     return USPMV_OK;
 }
 
+static void sw_release(uspmv_dmat_t *A);
+static int sweep_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, const uspmv_scs_t *s, const uspmv_scs_t *sB, int wlog, int tile_rows,
+                              int64_t *n_tiles, int64_t *n_sweep, const char *who);
 static void tlc_release(uspmv_dmat_t *A) {
     (void)hipFree(A->tlc_line_ptr); (void)hipFree(A->tlc_lines); (void)hipFree(A->tlc_c16_ptrs); (void)hipFree(A->tlc_col16);
     A->tlc_line_ptr = A->tlc_lines = nullptr; A->tlc_c16_ptrs = nullptr; A->tlc_col16 = nullptr;
@@ -339,6 +392,15 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
     if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] tlc plan: tile_rows=%d tiles=%lld staged=%lld max_lines=%d lines_total=%zu col16=%zu\n",
                                          p.tile_rows, (long long)p.n_tiles, (long long)p.n_staged_tiles, p.max_lines_used, p.tile_lines.size(), p.col16.size());
+    if (A->sw) sw_release(A);
+    if ((!p.valid || p.n_staged_tiles * 2 < p.n_tiles) && g_tune.sweep) {
+        // wide, irregular rows: most tiles touch too many x lines to stage them.  Try the column-window sweep; it takes over
+        // when it covers at least half of the rows.
+        int64_t swt = 0, sws = 0;
+        if (int rc = sweep_plan_install(A, nullptr, s, nullptr, 0, 0, &swt, &sws, "uspmv_dmat_optimize")) return rc;
+        if (A->sw && sws * 2 >= swt) return USPMV_OK;
+        if (A->sw) sw_release(A);
+    }
     if (!p.valid) return USPMV_OK;                              // nothing worth staging: plain kernel stays
     auto up = [&](const void *h, size_t bytes, void **d) -> hipError_t {
         hipError_t e = hipMalloc(d, bytes ? bytes : 4);
@@ -448,6 +510,8 @@ int uspmv_dmat_plan_download(const uspmv_dmat_t *A, int64_t meta[4], int32_t *ti
 
 static void bt_release(uspmv_dmat_t *A) {
     (void)hipFree(A->bt_line_ptr); (void)hipFree(A->bt_xrows); (void)hipFree(A->bt_c16_ptrs); (void)hipFree(A->bt_col16);
+    (void)hipFree(A->bt_values); (void)hipFree(A->bt_cols); (void)hipFree(A->bt_row_map);
+    A->bt_values = nullptr; A->bt_cols = A->bt_row_map = nullptr;
     A->bt_line_ptr = A->bt_xrows = nullptr; A->bt_c16_ptrs = nullptr; A->bt_col16 = nullptr;
     A->bt = false;
 }
@@ -468,9 +532,12 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
     const size_t cap = g_tune.spmmv_lds_kb > 0 ? std::min<size_t>((size_t)g_tune.spmmv_lds_kb * 1024, BT_LDS_CAP) : BT_LDS_CAP;
     const int max_rows = (int)(cap / row_bytes);
     // rows of >= 64 bytes on C = 32: 32-row tiles, two lanes per row (half the LDS per tile, twice the tiles per CU)
-    const int tile_rows = (s->C == 32 && g_tune.spmmv_tile_rows != 64 && (row_bytes >= 64 || (row_bytes >= 32 && g_tune.spmmv_tile_rows == 32))) ? 32 : 64;
+    const int tile_rows = (s->C == 32 && g_tune.spmmv_tile_rows != 64 && (row_bytes >= 128 || (row_bytes >= 32 && g_tune.spmmv_tile_rows == 32))) ? 32 : 64;
     uspmv_tlc_plan p;
-    if (int rc = uspmv_build_tlc_plan(s, nullptr, max_rows, tile_rows, &p, /*line_shift=*/0)) return rc;
+    uspmv_scs r;                       // private copy with the sigma sort's ties undone (only kept when rows moved)
+    std::vector<int32_t> row_map;
+    const bool moved = g_tune.spmmv_reorder && uspmv_scs_reorder_ties(s, &r, &row_map) == 1;
+    if (int rc = uspmv_build_tlc_plan(moved ? &r : s, nullptr, max_rows, tile_rows, &p, /*line_shift=*/0)) return rc;
     if (n_tiles) *n_tiles = p.n_tiles;
     if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
     if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] block plan: b=%d tile_rows=%d tiles=%lld staged=%lld max_rows=%d (cap %d) rows_total=%zu\n",
@@ -485,6 +552,11 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
     if (e == hipSuccess) e = up(p.tile_lines.data(), p.tile_lines.size() * 4, (void **)&A->bt_xrows);
     if (e == hipSuccess) e = up(p.c16_ptrs.data(), p.c16_ptrs.size() * 4, (void **)&A->bt_c16_ptrs);
     if (e == hipSuccess) e = up(p.col16.data(), p.col16.size() * 2, (void **)&A->bt_col16);
+    if (e == hipSuccess && moved) {
+        e = up(r.values_ptr(), (size_t)r.n_elements * (r.dtype == USPMV_F64 ? 8 : 4), &A->bt_values);
+        if (e == hipSuccess) e = up(row_map.data(), row_map.size() * 4, (void **)&A->bt_row_map);
+        if (e == hipSuccess && (p.n_staged_tiles < p.n_tiles || g_tune.spmmv_variant == 5)) e = up(r.col_idxs.data(), (size_t)r.n_elements * 4, (void **)&A->bt_cols);
+    }
     if (e != hipSuccess) {
         bt_release(A);
         return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_block: device copy failed: %s", hipGetErrorString(e));
@@ -511,6 +583,14 @@ int uspmv_dmat_optimize_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t
     if (int rc = uspmv_build_tlc_plan(s_dp, s_sp, max_lines, g_tune.tlc_tile_rows, &p)) return rc;
     if (n_tiles) *n_tiles = p.n_tiles;
     if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
+    if (dp->sw) sw_release(dp);
+    if (sp->sw) sw_release(sp);
+    if ((!p.valid || p.n_staged_tiles * 2 < p.n_tiles) && g_tune.sweep) {   // as in uspmv_dmat_optimize
+        int64_t swt = 0, sws = 0;
+        if (int rc = sweep_plan_install(dp, sp, s_dp, s_sp, 0, 0, &swt, &sws, "uspmv_dmat_optimize_ap")) return rc;
+        if (dp->sw && sws * 2 >= swt) return USPMV_OK;
+        if (dp->sw) { sw_release(dp); sw_release(sp); }
+    }
     if (!p.valid) return USPMV_OK;
     auto up = [&](const void *h, size_t bytes, void **d) -> hipError_t {
         hipError_t e = hipMalloc(d, bytes ? bytes : 4);
@@ -536,8 +616,98 @@ int uspmv_dmat_optimize_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t
     return USPMV_OK;
 }
 
+
+static void sw_release(uspmv_dmat_t *A) {
+    (void)hipFree(A->sw_tile_ids); (void)hipFree(A->sw_smin); (void)hipFree(A->sw_S); (void)hipFree(A->sw_pad); (void)hipFree(A->sw_pad_b);
+    (void)hipFree(A->sw_rest); (void)hipFree(A->sw_cnt_off); (void)hipFree(A->sw_wave_off); (void)hipFree(A->sw_wave_off_b);
+    (void)hipFree(A->sw_cnt); (void)hipFree(A->sw_cnt_b); (void)hipFree(A->sw_vals); (void)hipFree(A->sw_vals_b); (void)hipFree(A->sw_idx); (void)hipFree(A->sw_idx_b);
+    A->sw_tile_ids = A->sw_smin = A->sw_S = A->sw_pad = A->sw_pad_b = A->sw_rest = nullptr;
+    A->sw_cnt_off = nullptr; A->sw_wave_off = A->sw_wave_off_b = nullptr; A->sw_cnt = A->sw_cnt_b = nullptr;
+    A->sw_vals = nullptr; A->sw_vals_b = nullptr; A->sw_idx = A->sw_idx_b = nullptr;
+    A->sw = false; A->sw_plan_id = 0; A->sw_n_tiles = A->sw_all_tiles = A->sw_n_rest = 0;
+}
+
+// builds and uploads a sweep plan for A (and, when B/sB are given, for the dp+sp pair A/B); returns the number of sweep tiles
+static int sweep_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, const uspmv_scs_t *s, const uspmv_scs_t *sB, int wlog, int tile_rows,
+                              int64_t *n_tiles, int64_t *n_sweep, const char *who) {
+    if (A->sw) sw_release(A);
+    if (B && B->sw) sw_release(B);
+    if (n_tiles) *n_tiles = 0;
+    if (n_sweep) *n_sweep = 0;
+    const size_t vsz = s->dtype == USPMV_F64 ? 8 : 4;
+    if (wlog <= 0) wlog = g_tune.sweep_wlog;
+    if (wlog <= 0) wlog = vsz == 8 ? 13 : 14;                         // 64 KiB windows
+    if (((size_t)1 << wlog) * vsz > 80 * 1024) return uspmv::fail(USPMV_ERR_INVALID, "%s: a window of 2^%d elements does not fit two LDS buffers", who, wlog);
+    if (tile_rows <= 0) tile_rows = g_tune.sweep_tile_rows;
+    if (tile_rows <= 0) tile_rows = 1024;
+    uspmv_sweep_plan p;
+    const double max_stage = g_tune.sweep_max_stage > 0 ? (double)g_tune.sweep_max_stage : 24.0;
+    if (int rc = uspmv_build_sweep_plan(s, sB, wlog, tile_rows, max_stage, &p)) return rc;
+    if (n_tiles) *n_tiles = p.n_tiles;
+    if (n_sweep) *n_sweep = p.valid ? p.n_sweep_tiles : 0;
+    if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] sweep plan: tile_rows=%d wlog=%d tiles=%lld sweep=%lld rest_chunks=%zu elements=%zu cnt_bytes=%zu\n",
+                                         p.tile_rows, p.wlog, (long long)p.n_tiles, (long long)p.n_sweep_tiles, p.rest_chunks.size(), p.idx.size(), p.cnt.size());
+    if (!p.valid) return USPMV_OK;
+    hipError_t e = hipSuccess;
+    auto up = [&](const void *h, size_t bytes, void **d) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(d, bytes ? bytes : 4);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+    };
+    up(p.tile_ids.data(), p.tile_ids.size() * 4, (void **)&A->sw_tile_ids);
+    up(p.t_smin.data(), p.t_smin.size() * 4, (void **)&A->sw_smin);
+    up(p.t_S.data(), p.t_S.size() * 4, (void **)&A->sw_S);
+    up(p.t_cnt_off.data(), p.t_cnt_off.size() * 8, (void **)&A->sw_cnt_off);
+    up(p.wave_off.data(), p.wave_off.size() * 4, (void **)&A->sw_wave_off);
+    up(p.cnt.data(), p.cnt.size(), (void **)&A->sw_cnt);
+    up(vsz == 8 ? (const void *)p.vals_f64.data() : (const void *)p.vals_f32.data(), p.idx.size() * vsz, &A->sw_vals);
+    up(p.idx.data(), p.idx.size() * 2, (void **)&A->sw_idx);
+    up(p.pad_col.data(), p.pad_col.size() * 4, (void **)&A->sw_pad);
+    up(p.rest_chunks.data(), p.rest_chunks.size() * 4, (void **)&A->sw_rest);
+    if (B) {
+        up(p.wave_off_b.data(), p.wave_off_b.size() * 4, (void **)&A->sw_wave_off_b);
+        up(p.cnt_b.data(), p.cnt_b.size(), (void **)&A->sw_cnt_b);
+        up(p.vals_b_f32.data(), p.idx_b.size() * 4, (void **)&A->sw_vals_b);
+        up(p.idx_b.data(), p.idx_b.size() * 2, (void **)&A->sw_idx_b);
+        up(p.pad_col_b.data(), p.pad_col_b.size() * 4, (void **)&A->sw_pad_b);
+    }
+    if (e != hipSuccess) {
+        sw_release(A);
+        return uspmv::fail(USPMV_ERR_ALLOC, "%s: device copy failed: %s", who, hipGetErrorString(e));
+    }
+    static uint64_t next_sweep_id = 1;
+    const uint64_t id = next_sweep_id++;
+    A->sw = true; A->sw_tile_rows = p.tile_rows; A->sw_wlog = p.wlog; A->sw_n_tiles = p.n_sweep_tiles; A->sw_all_tiles = p.n_tiles;
+    A->sw_x_len = p.x_len_min; A->sw_n_rest = (int64_t)p.rest_chunks.size(); A->sw_plan_id = id;
+    if (B) { B->sw = true; B->sw_plan_id = id; B->sw_n_tiles = p.n_sweep_tiles; B->sw_all_tiles = p.n_tiles; }
+    return USPMV_OK;
+}
+
+int uspmv_dmat_optimize_sweep(uspmv_dmat_t *A, const uspmv_scs_t *s, int wlog, int tile_rows, int64_t *n_tiles, int64_t *n_sweep) {
+    if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_sweep: NULL argument");
+    if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_sweep: layout-only struct; the plan builder needs the host entries");
+    if (A->C != s->C || A->n_chunks != s->n_chunks || A->dtype != s->dtype)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_sweep: handle and host struct do not describe the same matrix");
+    if (int rc = require_device()) return rc;
+    return sweep_plan_install(A, nullptr, s, nullptr, wlog, tile_rows, n_tiles, n_sweep, "uspmv_dmat_optimize_sweep");
+}
+
+int uspmv_dmat_optimize_sweep_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t *s_dp, const uspmv_scs_t *s_sp, int wlog, int tile_rows,
+                                 int64_t *n_tiles, int64_t *n_sweep) {
+    if (!dp || !sp || !s_dp || !s_sp) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_sweep_ap: NULL argument");
+    if (!uspmv::scs_has_entries(s_dp) || !uspmv::scs_has_entries(s_sp))
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_sweep_ap: layout-only struct; the plan builder needs the host entries");
+    if (dp->C != s_dp->C || dp->n_chunks != s_dp->n_chunks || dp->dtype != USPMV_F64 || s_dp->dtype != USPMV_F64 ||
+        sp->C != s_sp->C || sp->n_chunks != s_sp->n_chunks || sp->dtype != USPMV_F32 || s_sp->dtype != USPMV_F32 ||
+        dp->C != sp->C || dp->n_chunks != sp->n_chunks)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_sweep_ap: handles / host structs do not form a dp+sp pair");
+    if (int rc = require_device()) return rc;
+    return sweep_plan_install(dp, sp, s_dp, s_sp, wlog, tile_rows, n_tiles, n_sweep, "uspmv_dmat_optimize_sweep_ap");
+}
+
 void uspmv_dmat_free(uspmv_dmat_t *A) {
     if (!A) return;
+    if (A->sw) sw_release(A);
     if (A->alt) { uspmv_dmat_free(A->alt); A->alt = nullptr; }
     if (A->tlc) tlc_release(A);
     if (A->bt) bt_release(A);
@@ -596,6 +766,18 @@ int uspmv_spmv_tiles(const uspmv_dmat_t *A, const int32_t *d_tile_ids, int64_t n
     if (int rc = require_device()) return rc;
     if (A->dtype == USPMV_F64) return launch_spmv_tlc<double>(A, d_tile_ids, (long)n_ids, (const double *)d_x, (double *)d_y, (hipStream_t)stream);
     return launch_spmv_tlc<float>(A, d_tile_ids, (long)n_ids, (const float *)d_x, (float *)d_y, (hipStream_t)stream);
+}
+
+int uspmv_dmat_plan_info(const uspmv_dmat_t *A, int *kind, int64_t *n_tiles, int64_t *n_planned) {
+    if (!A) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_plan_info: NULL matrix");
+    const uspmv_dmat_t *M = A->alt ? A->alt : A;
+    int k = 0; int64_t nt = 0, np = 0;
+    if (M->sw) { k = 2; nt = M->sw_all_tiles; np = M->sw_n_tiles; }
+    else if (M->tlc) { k = 1; nt = M->tlc_n_tiles; np = M->tlc_staged; }
+    if (kind) *kind = k;
+    if (n_tiles) *n_tiles = nt;
+    if (n_planned) *n_planned = np;
+    return USPMV_OK;
 }
 
 int uspmv_dmat_tile_rows(const uspmv_dmat_t *A, int *tile_rows) {
@@ -741,7 +923,7 @@ int uspmv_pack_send_buf(const void *d_x, const int32_t *d_perm, const int32_t *d
 int uspmv_stream_copy(double *a, const double *b, int64_t n, void *stream) {
     if (!a || !b || n < 0 || (n & 1)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_stream_copy: bad argument (n must be even)");
     if (int rc = require_device()) return rc;
-    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (double2 *)a, (const double2 *)b, (long)(n / 2));
+    hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)((n / 2 + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, (double2 *)a, (const double2 *)b, (long)(n / 2));
     HIP_TRY(hipGetLastError());
     return USPMV_OK;
 }
@@ -749,7 +931,7 @@ int uspmv_stream_copy(double *a, const double *b, int64_t n, void *stream) {
 int uspmv_stream_triad(double *a, const double *b, const double *c, double s, int64_t n, void *stream) {
     if (!a || !b || !c || n < 0 || (n & 1)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_stream_triad: bad argument (n must be even)");
     if (int rc = require_device()) return rc;
-    hipLaunchKernelGGL(stream_triad_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (double2 *)a, (const double2 *)b, (const double2 *)c, s, (long)(n / 2));
+    hipLaunchKernelGGL(stream_triad_kernel, dim3((unsigned)((n / 2 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, (double2 *)a, (const double2 *)b, (const double2 *)c, s, (long)(n / 2));
     HIP_TRY(hipGetLastError());
     return USPMV_OK;
 }

@@ -40,6 +40,24 @@ struct uspmv_dmat {
     int32_t *bt_line_ptr = nullptr, *bt_xrows = nullptr;
     uint32_t *bt_c16_ptrs = nullptr;
     uint16_t *bt_col16 = nullptr;
+    // the plan's private copy of the entries with ties of the sigma sort back in original-row order
+    // (uspmv_scs_reorder_ties): values (+ 32-bit columns when some tile keeps the gather path) and
+    // row_map[plan row] = row of y.  All null when the caller's order is kept.
+    void *bt_values = nullptr;
+    int32_t *bt_cols = nullptr, *bt_row_map = nullptr;
+    // column-window sweep plan (host/sweep_plan.cpp, uspmv_dmat_optimize_sweep[_ap]); the _b arrays are the sp part of
+    // an ap[dp_sp] pair and live on the dp handle, the sp handle only carries the plan id
+    bool sw = false;
+    int sw_tile_rows = 1024, sw_wlog = 13;
+    int64_t sw_n_tiles = 0, sw_all_tiles = 0, sw_x_len = 0, sw_n_rest = 0;
+    uint64_t sw_plan_id = 0;
+    int32_t *sw_tile_ids = nullptr, *sw_smin = nullptr, *sw_S = nullptr, *sw_pad = nullptr, *sw_pad_b = nullptr, *sw_rest = nullptr;
+    uint64_t *sw_cnt_off = nullptr;
+    uint32_t *sw_wave_off = nullptr, *sw_wave_off_b = nullptr;
+    uint8_t *sw_cnt = nullptr, *sw_cnt_b = nullptr;
+    void *sw_vals = nullptr;
+    float *sw_vals_b = nullptr;
+    uint16_t *sw_idx = nullptr, *sw_idx_b = nullptr;
 };
 
 namespace uspmv_dev {
@@ -64,6 +82,14 @@ struct Tuning {
     int spmmv_swizzle = 0;  // block-plan kernel: 1 = piece-swizzled X rows in LDS (all 64 banks); 0 = plain layout, which
                             // needs ~10 fewer address instructions per non-zero and measures 5-7 % faster (spmmv_probe16.txt)
     int spmmv_prefetch = 1; // row-major lane-per-row kernel: request batch k+1's matrix entries behind batch k's X rows
+    int sweep = 1;          // use the column-window sweep kernel when the handle carries a sweep plan
+    int sweep_nbuf = 2;     // LDS buffers per workgroup (2: window s+1 lands while window s is consumed)
+    int sweep_unroll = 8;   // rounds per batch
+    int sweep_remap = 8;    // consecutive sweep tiles per XCD (neighbouring tiles share their x windows)
+    int sweep_wlog = 0;     // NEXT uspmv_dmat_optimize_sweep: log2 of the window width in elements (0 = 64 KiB of VT)
+    int sweep_tile_rows = 0;  // NEXT uspmv_dmat_optimize_sweep: 256 | 512 | 1024 rows per tile (0 = 1024)
+    int sweep_max_stage = 0;  // NEXT plan: largest staging cost in bytes per non-zero for a tile to sweep (0 = 24)
+    int spmmv_reorder = 1;  // block plan: rows of equal-length chunks of a sigma window back in original order (private copy of the entries)
     int spmmv_variant = 0;  // 0 = auto (= 3 where a B-specialised kernel exists); 1 = generic kernel; 2 = row-major with transposing X phase; 3 = row-major, lane per row
 };
 extern Tuning g_tune;   // uspmv_api.hip
@@ -85,6 +111,11 @@ template <typename VT>
 int launch_spmmv(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int layout, hipStream_t st);            // spmmv_kernels.hip
 int launch_spmv_ap(const uspmv_dmat *dp, const uspmv_dmat *sp, const double *d_x, const float *d_x_sp, double *d_y,
                    hipStream_t stream);                                                                           // ap_kernels.hip
+template <typename VT>
+int launch_spmv_sweep(const uspmv_dmat *A, const VT *x, VT *y, hipStream_t st);                                    // sweep_kernels.hip (sweep tiles only)
+int launch_spmv_sweep_ap(const uspmv_dmat *dp, const double *x, double *y, hipStream_t st);                       // sweep_kernels.hip
+int launch_spmv_ap_chunks(const uspmv_dmat *dp, const uspmv_dmat *sp, const int *chunk_ids, long n_ids, const double *d_x,
+                          double *d_y, hipStream_t stream);                                                        // ap_kernels.hip
 
 int launch_plan_count(const uspmv_dmat *A, long n_tiles, int max_lines, int *d_n_lines, int *d_max_col, hipStream_t st);      // plan_kernels.hip
 int launch_plan_write(const uspmv_dmat *A, long n_tiles, const int *d_tile_line_ptr, const unsigned *d_c16_ptrs, int *d_tile_lines,

@@ -1,0 +1,366 @@
+// Distributed SpMV step on RCCL (xGMI), in C++ behind the C ABI (include/uspmv.h, section L4b).
+//
+// Replaces the per-iteration part of the reference's MPI flow for the single-vector one-precision path:
+//   init_local_structs            code/main.cpp:1075-1334      (partition block -> SELL-C-sigma, halo discovery)
+//   collect_comm_info             code/mpi_funcs.hpp:1061-1124 (who sends what to whom)
+//   init/finalize_halo_exchange   code/classes_structs.hpp:857-995
+//   the iteration of bench_spmv   code/main.cpp:458-474        (exchange, then kernel)
+// One process per GPU.  Per SpMV: ONE pack kernel over the concatenated send list, ONE grouped ncclSend/ncclRecv with every
+// receive landing directly in x[n_local + recv_cumsum[p]] (the reference's halo numbering) on a side stream, the tiles /
+// chunks that touch no halo column meanwhile on the caller's stream, the boundary ones after the exchange.  The whole step
+// (two streams, two events, three kernels, the RCCL group) can be captured once into a hipGraph and replayed: per step the
+// host then pays one hipGraphLaunch instead of ~12 runtime calls (the strong-scaling regime of BASELINE config 5, where a
+// rank's kernel takes < 0.2 ms).
+//
+// Loopback (comm_size == 1 and P > 1): this process plays logical rank `rank` of a P-way partition and every neighbour is
+// itself -- sends and receives become RCCL self send/recv pairs of the ids it asked for.  With an x that repeats with the
+// block height this reproduces the true multi-rank result for the rank's rows; it is how a single-GPU box exercises the
+// RCCL path end to end (tests/test_dist_native_gpu.py).
+#include <rccl/rccl.h>
+
+#include <string>
+
+#include "uspmv_device.hpp"
+
+struct uspmv_dist {
+    int rank = 0, P = 1, comm_rank = 0, comm_size = 1;
+    bool loopback = false, overlap = true, tiles = false, owns_setup = false, no_pack = false;
+    ncclComm_t comm = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_main = nullptr, ev_comm = nullptr;
+    uspmv_dmat_t *A = nullptr;
+    uspmv_scs_t *scs = nullptr;       // owned when built by uspmv_dist_create_from_coo
+    uspmv_halo_t *halo = nullptr;
+    int dtype = USPMV_F64;
+    int64_t n_local = 0, n_halo = 0, n_send = 0, n_int = 0, n_bnd = 0, vec_len = 0, n_rows_padded = 0;
+    std::vector<int64_t> send_off, recv_off;
+    std::vector<int32_t> recv_counts;
+    int32_t *d_send_idxs = nullptr, *d_perm = nullptr, *d_int = nullptr, *d_bnd = nullptr;
+    void *d_send = nullptr;
+    int *d_scratch = nullptr;
+    // captured step
+    hipGraphExec_t gexec = nullptr;
+    void *g_x = nullptr, *g_y = nullptr;
+    hipStream_t g_stream = nullptr;
+    bool graph_failed = false;
+    int64_t graph_launches = 0, eager_steps = 0;
+};
+
+namespace {
+
+#define NCCL_TRY(call)                                                                                           \
+    do {                                                                                                         \
+        ncclResult_t r_ = (call);                                                                                \
+        if (r_ != ncclSuccess) return uspmv::fail(USPMV_ERR_HIP, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+inline int peer(const uspmv_dist *D, int p) { return D->loopback ? 0 : p; }
+inline ncclDataType_t nccl_vt(const uspmv_dist *D) { return D->dtype == USPMV_F64 ? ncclDouble : ncclFloat; }
+
+int exchange(uspmv_dist *D, void *d_x, hipStream_t st) {
+    const size_t vsz = D->dtype == USPMV_F64 ? 8 : 4;
+    if (!D->no_pack)
+        if (int rc = uspmv_pack_send_buf(d_x, D->d_perm, D->d_send_idxs, D->n_send, 0, D->d_send, D->dtype, st)) return rc;
+    NCCL_TRY(ncclGroupStart());
+    for (int p = 0; p < D->P; ++p) {
+        const int64_t ns = D->send_off[(size_t)p + 1] - D->send_off[(size_t)p], nr = D->recv_counts[(size_t)p];
+        if (nr) NCCL_TRY(ncclRecv((char *)d_x + (size_t)(D->n_local + D->recv_off[(size_t)p]) * vsz, (size_t)nr, nccl_vt(D), peer(D, p), D->comm, st));
+        if (ns) NCCL_TRY(ncclSend((const char *)D->d_send + (size_t)D->send_off[(size_t)p] * vsz, (size_t)ns, nccl_vt(D), peer(D, p), D->comm, st));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return USPMV_OK;
+}
+
+int part(uspmv_dist *D, const int32_t *ids, int64_t n, const void *x, void *y, hipStream_t st) {
+    if (n == 0) return USPMV_OK;
+    return D->tiles ? uspmv_spmv_tiles(D->A, ids, n, x, y, st) : uspmv_spmv_chunks(D->A, ids, n, x, y, st);
+}
+
+// one SpMV: exchange on the side stream, interior meanwhile, boundary after it
+int step(uspmv_dist *D, void *d_x, void *d_y, hipStream_t main, bool comm_halos) {
+    if (D->P == 1 || !comm_halos) return uspmv_spmv(D->A, d_x, d_y, main);
+    if (!D->overlap) {
+        if (int rc = exchange(D, d_x, main)) return rc;
+        return uspmv_spmv(D->A, d_x, d_y, main);
+    }
+    HIP_TRY(hipEventRecord(D->ev_main, main));
+    HIP_TRY(hipStreamWaitEvent(D->comm_stream, D->ev_main, 0));
+    if (int rc = exchange(D, d_x, D->comm_stream)) return rc;
+    HIP_TRY(hipEventRecord(D->ev_comm, D->comm_stream));
+    if (int rc = part(D, D->d_int, D->n_int, d_x, d_y, main)) return rc;
+    HIP_TRY(hipStreamWaitEvent(main, D->ev_comm, 0));
+    return part(D, D->d_bnd, D->n_bnd, d_x, d_y, main);
+}
+
+void drop_graph(uspmv_dist *D) {
+    if (D->gexec) (void)hipGraphExecDestroy(D->gexec);
+    D->gexec = nullptr; D->g_x = D->g_y = nullptr; D->g_stream = nullptr;
+}
+
+int capture(uspmv_dist *D, void *d_x, void *d_y, hipStream_t main) {
+    drop_graph(D);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamBeginCapture(main, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) { (void)hipGetLastError(); return uspmv::fail(USPMV_ERR_HIP, "uspmv_dist_run: hipStreamBeginCapture: %s", hipGetErrorString(e)); }
+    const int rc = step(D, d_x, d_y, main, true);
+    e = hipStreamEndCapture(main, &g);
+    if (rc != USPMV_OK || e != hipSuccess || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        return rc != USPMV_OK ? rc : uspmv::fail(USPMV_ERR_HIP, "uspmv_dist_run: hipStreamEndCapture: %s", hipGetErrorString(e));
+    }
+    e = hipGraphInstantiate(&D->gexec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { D->gexec = nullptr; (void)hipGetLastError(); return uspmv::fail(USPMV_ERR_HIP, "uspmv_dist_run: hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    D->g_x = d_x; D->g_y = d_y; D->g_stream = main;
+    return USPMV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uspmv_comm_unique_id(void *id128) {
+    if (!id128) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_comm_unique_id: NULL argument");
+    static_assert(sizeof(ncclUniqueId) == USPMV_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return USPMV_OK;
+}
+
+void uspmv_dist_free(uspmv_dist_t *D) {
+    if (!D) return;
+    drop_graph(D);
+    (void)hipFree(D->d_send_idxs); (void)hipFree(D->d_perm); (void)hipFree(D->d_int); (void)hipFree(D->d_bnd); (void)hipFree(D->d_send); (void)hipFree(D->d_scratch);
+    if (D->ev_main) (void)hipEventDestroy(D->ev_main);
+    if (D->ev_comm) (void)hipEventDestroy(D->ev_comm);
+    if (D->comm_stream) (void)hipStreamDestroy(D->comm_stream);
+    if (D->comm) (void)ncclCommDestroy(D->comm);
+    if (D->owns_setup) { uspmv_dmat_free(D->A); uspmv_halo_free(D->halo); uspmv_scs_free(D->scs); }
+    delete D;
+}
+
+int uspmv_dist_create(const void *comm_id, int comm_rank, int comm_size, int rank, int P, uspmv_dmat_t *A, const uspmv_halo_t *halo,
+                      const int32_t *old_to_new_idx, const int32_t *interior_ids, int64_t n_interior, const int32_t *boundary_ids,
+                      int64_t n_boundary, int ids_are_tiles, uspmv_dist_t **out) {
+    if (!comm_id || !A || !halo || !out || P < 1 || rank < 0 || rank >= P || comm_size < 1 || comm_rank < 0 || comm_rank >= comm_size ||
+        n_interior < 0 || n_boundary < 0 || (n_interior > 0 && !interior_ids) || (n_boundary > 0 && !boundary_ids))
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: bad argument");
+    if (!(comm_size == P && comm_rank == rank) && !(comm_size == 1 && comm_rank == 0))
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: the communicator must have one rank per partition block (comm_size == P) or a single rank (loopback)");
+    if (halo->P != P || halo->rank != rank) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: halo description belongs to another partition");
+    if (halo->n_local > 0 && !old_to_new_idx) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: NULL permutation");
+    if (int rc = uspmv_dev::check_dmat(A, "uspmv_dist_create")) return rc;
+    if (int rc = uspmv_dev::require_device()) return rc;
+    auto *D = new uspmv_dist;
+    D->rank = rank; D->P = P; D->comm_rank = comm_rank; D->comm_size = comm_size; D->loopback = comm_size == 1 && P > 1;
+    D->A = A; D->dtype = A->dtype; D->tiles = ids_are_tiles != 0;
+    D->n_local = halo->n_local; D->n_halo = halo->n_halo; D->n_int = n_interior; D->n_bnd = n_boundary;
+    D->recv_counts = halo->recv_counts;
+    D->recv_off.assign((size_t)P + 1, 0); D->send_off.assign((size_t)P + 1, 0);
+    for (int p = 0; p < P; ++p) D->recv_off[(size_t)p + 1] = D->recv_off[(size_t)p] + D->recv_counts[(size_t)p];
+    int rc = USPMV_OK;
+    auto bail = [&](int code) { uspmv_dist_free(D); return code; };
+#define D_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bail(uspmv::fail(USPMV_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__)); } while (0)
+#define D_NCCL(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return bail(uspmv::fail(USPMV_ERR_HIP, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__)); } while (0)
+    ncclUniqueId id;
+    memcpy(&id, comm_id, sizeof id);
+    D_NCCL(ncclCommInitRank(&D->comm, comm_size, id, comm_rank));
+    D_HIP(hipStreamCreateWithFlags(&D->comm_stream, hipStreamNonBlocking));
+    D_HIP(hipEventCreateWithFlags(&D->ev_main, hipEventDisableTiming));
+    D_HIP(hipEventCreateWithFlags(&D->ev_comm, hipEventDisableTiming));
+    D_HIP(hipMalloc((void **)&D->d_scratch, 256));
+    D_HIP(hipMemset(D->d_scratch, 0, 256));
+    hipStream_t st = D->comm_stream;
+    // ---- who sends what to whom (collect_comm_info): all-gather of the recv counts, then the requested ids travel to their owners
+    std::vector<int32_t> counts_all((size_t)P * P, 0);
+    if (D->loopback) {
+        for (int p = 0; p < P; ++p) counts_all[(size_t)p * P + rank] = D->recv_counts[(size_t)p];   // "p needs from me" := what I asked p for
+    } else {
+        int32_t *d_c = nullptr, *d_all = nullptr;
+        D_HIP(hipMalloc((void **)&d_c, 4 * (size_t)P));
+        D_HIP(hipMalloc((void **)&d_all, 4 * (size_t)P * P));
+        D_HIP(hipMemcpy(d_c, D->recv_counts.data(), 4 * (size_t)P, hipMemcpyHostToDevice));
+        D_NCCL(ncclAllGather(d_c, d_all, (size_t)P, ncclInt32, D->comm, st));
+        D_HIP(hipStreamSynchronize(st));
+        D_HIP(hipMemcpy(counts_all.data(), d_all, 4 * counts_all.size(), hipMemcpyDeviceToHost));
+        (void)hipFree(d_c); (void)hipFree(d_all);
+    }
+    for (int p = 0; p < P; ++p) D->send_off[(size_t)p + 1] = D->send_off[(size_t)p] + counts_all[(size_t)p * P + rank];
+    D->n_send = D->send_off[(size_t)P];
+    int32_t *d_recv_idxs = nullptr;
+    D_HIP(hipMalloc((void **)&d_recv_idxs, 4 * (size_t)std::max<int64_t>(D->n_halo, 1)));
+    D_HIP(hipMalloc((void **)&D->d_send_idxs, 4 * (size_t)std::max<int64_t>(D->n_send, 1)));
+    if (D->n_halo) D_HIP(hipMemcpy(d_recv_idxs, halo->recv_idxs.data(), 4 * (size_t)D->n_halo, hipMemcpyHostToDevice));
+    if (P > 1) {
+        D_NCCL(ncclGroupStart());
+        for (int p = 0; p < P; ++p) {
+            const int64_t ns = D->send_off[(size_t)p + 1] - D->send_off[(size_t)p], nr = D->recv_counts[(size_t)p];
+            if (nr) D_NCCL(ncclSend(d_recv_idxs + D->recv_off[(size_t)p], (size_t)nr, ncclInt32, peer(D, p), D->comm, st));
+            if (ns) D_NCCL(ncclRecv(D->d_send_idxs + D->send_off[(size_t)p], (size_t)ns, ncclInt32, peer(D, p), D->comm, st));
+        }
+        D_NCCL(ncclGroupEnd());
+        D_HIP(hipStreamSynchronize(st));
+    }
+    (void)hipFree(d_recv_idxs);
+    // ---- device state of the step
+    const size_t vsz = D->dtype == USPMV_F64 ? 8 : 4;
+    D_HIP(hipMalloc((void **)&D->d_perm, 4 * (size_t)std::max<int64_t>(D->n_local, 1)));
+    if (D->n_local) D_HIP(hipMemcpy(D->d_perm, old_to_new_idx, 4 * (size_t)D->n_local, hipMemcpyHostToDevice));
+    D_HIP(hipMalloc((void **)&D->d_int, 4 * (size_t)std::max<int64_t>(n_interior, 1)));
+    D_HIP(hipMalloc((void **)&D->d_bnd, 4 * (size_t)std::max<int64_t>(n_boundary, 1)));
+    if (n_interior) D_HIP(hipMemcpy(D->d_int, interior_ids, 4 * (size_t)n_interior, hipMemcpyHostToDevice));
+    if (n_boundary) D_HIP(hipMemcpy(D->d_bnd, boundary_ids, 4 * (size_t)n_boundary, hipMemcpyHostToDevice));
+    D_HIP(hipMalloc(&D->d_send, vsz * (size_t)std::max<int64_t>(D->n_send, 1)));
+    D->n_rows_padded = A->n_chunks * A->C;
+    D->vec_len = D->n_local + std::max(D->n_rows_padded - D->n_local, D->n_halo);       // padded_vec_size (code/main.cpp:1406-1412)
+#undef D_HIP
+#undef D_NCCL
+    (void)rc;
+    *out = D;
+    return USPMV_OK;
+}
+
+int uspmv_dist_create_from_coo(const void *comm_id, int comm_rank, int comm_size, int rank, int P, const uspmv_coo_t *local,
+                               const int32_t *wsa, int64_t C, int64_t sigma, int dtype, int tlc, uspmv_dist_t **out) {
+    if (!local || !wsa || !out) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create_from_coo: NULL argument");
+    if (P < 1 || rank < 0 || rank >= P) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create_from_coo: bad rank / P");
+    if (int rc = uspmv_dev::require_device()) return rc;
+    uspmv_scs_t *scs = nullptr;
+    uspmv_halo_t *halo = nullptr;
+    uspmv_dmat_t *A = nullptr;
+    int32_t *interior = nullptr, *boundary = nullptr;
+    auto cleanup = [&]() { uspmv_dmat_free(A); uspmv_halo_free(halo); uspmv_scs_free(scs); uspmv_free(interior); uspmv_free(boundary); };
+    // order of the reference: convert -> halo discovery (rewrites columns) -> column permutation (code/main.cpp:1128, :1271-1308)
+    int rc = uspmv_convert_to_scs(local, C, sigma, dtype, nullptr, &scs);
+    if (!rc) rc = uspmv_halo_discover(scs, wsa, rank, P, &halo);
+    const int32_t *o2n = nullptr;
+    if (!rc) rc = uspmv_scs_arrays(scs, nullptr, nullptr, nullptr, nullptr, &o2n, nullptr);
+    if (!rc) rc = uspmv_permute_scs_cols(scs, o2n);
+    if (!rc) rc = uspmv_dmat_upload(scs, &A);
+    int64_t n_tiles = 0, n_staged = 0;
+    if (!rc && tlc) rc = uspmv_dmat_optimize(A, scs, 0, &n_tiles, &n_staged);
+    int tile_rows = 0;
+    if (!rc) rc = uspmv_dmat_tile_rows(A, &tile_rows);
+    const int64_t n_local = wsa[rank + 1] - wsa[rank];
+    int64_t n_int = 0, n_bnd = 0;
+    if (!rc) rc = uspmv_scs_split_chunks(scs, n_local, &interior, &n_int, &boundary, &n_bnd);
+    if (rc) { cleanup(); return rc; }
+    std::vector<int32_t> ids_int, ids_bnd;
+    const bool use_tiles = tile_rows > 0 && n_staged > 0 && !A->alt;
+    if (use_tiles) {   // interior / boundary at tile granularity (a tile = tile_rows/C chunks)
+        const int64_t cpt = tile_rows / C;
+        std::vector<char> is_b((size_t)n_tiles, 0);
+        for (int64_t k = 0; k < n_bnd; ++k) is_b[(size_t)(boundary[k] / cpt)] = 1;
+        for (int64_t t = 0; t < n_tiles; ++t) (is_b[(size_t)t] ? ids_bnd : ids_int).push_back((int32_t)t);
+    } else {
+        ids_int.assign(interior, interior + n_int);
+        ids_bnd.assign(boundary, boundary + n_bnd);
+    }
+    uspmv_free(interior); uspmv_free(boundary); interior = boundary = nullptr;
+    uspmv_dist_t *D = nullptr;
+    rc = uspmv_dist_create(comm_id, comm_rank, comm_size, rank, P, A, halo, o2n, ids_int.data(), (int64_t)ids_int.size(), ids_bnd.data(),
+                           (int64_t)ids_bnd.size(), use_tiles ? 1 : 0, &D);
+    if (rc) { cleanup(); return rc; }
+    D->owns_setup = true; D->scs = scs; D->halo = halo;
+    *out = D;
+    return USPMV_OK;
+}
+
+int uspmv_dist_info(const uspmv_dist_t *D, int64_t meta[12]) {
+    if (!D || !meta) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_info: NULL argument");
+    meta[0] = D->n_local; meta[1] = D->n_halo; meta[2] = D->vec_len; meta[3] = D->n_send; meta[4] = D->n_int; meta[5] = D->n_bnd;
+    meta[6] = D->tiles; meta[7] = D->n_rows_padded; meta[8] = D->loopback; meta[9] = D->gexec != nullptr; meta[10] = D->graph_launches;
+    meta[11] = D->eager_steps;
+    return USPMV_OK;
+}
+
+int uspmv_dist_parts(const uspmv_dist_t *D, const uspmv_scs_t **scs, const uspmv_dmat_t **A, const uspmv_halo_t **halo) {
+    if (!D) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_parts: NULL argument");
+    if (scs) *scs = D->scs;
+    if (A) *A = D->A;
+    if (halo) *halo = D->halo;
+    return USPMV_OK;
+}
+
+int uspmv_dist_set_overlap(uspmv_dist_t *D, int overlap) {
+    if (!D) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_overlap: NULL argument");
+    if ((overlap != 0) != D->overlap) drop_graph(D);
+    D->overlap = overlap != 0;
+    return USPMV_OK;
+}
+
+int uspmv_dist_set_no_pack(uspmv_dist_t *D, int no_pack) {
+    if (!D) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_no_pack: NULL argument");
+    if ((no_pack != 0) != D->no_pack) drop_graph(D);
+    D->no_pack = no_pack != 0;
+    return USPMV_OK;
+}
+
+int uspmv_dist_spmv(uspmv_dist_t *D, void *d_x, void *d_y, int comm_halos, void *stream) {
+    if (!D || !d_x || !d_y) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_spmv: NULL argument");
+    ++D->eager_steps;
+    return step(D, d_x, d_y, (hipStream_t)stream, comm_halos != 0);
+}
+
+int uspmv_dist_run(uspmv_dist_t *D, void *d_x, void *d_y, int n_steps, int use_graph, void *stream) {
+    if (!D || !d_x || !d_y || n_steps < 0) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_run: bad argument");
+    hipStream_t main = (hipStream_t)stream;
+    if (use_graph && D->P > 1 && !D->graph_failed) {
+        if (!main) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_run: graph replay needs an explicit (non-default) stream");
+        if (!D->gexec || D->g_x != d_x || D->g_y != d_y || D->g_stream != main) {
+            // RCCL sets up its p2p channels at the first use of a pair: one eager step before the capture
+            if (int rc = step(D, d_x, d_y, main, true)) return rc;
+            HIP_TRY(hipStreamSynchronize(main));
+            if (capture(D, d_x, d_y, main) != USPMV_OK) {
+                D->graph_failed = true;
+                if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] dist: graph capture unavailable (%s); eager steps\n", uspmv_last_error());
+            }
+        }
+        if (D->gexec) {
+            for (int k = 0; k < n_steps; ++k) HIP_TRY(hipGraphLaunch(D->gexec, main));
+            D->graph_launches += n_steps;
+            return USPMV_OK;
+        }
+    }
+    for (int k = 0; k < n_steps; ++k)
+        if (int rc = step(D, d_x, d_y, main, true)) return rc;
+    D->eager_steps += n_steps;
+    return USPMV_OK;
+}
+
+int uspmv_dist_barrier(uspmv_dist_t *D, void *stream) {
+    if (!D) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_barrier: NULL argument");
+    NCCL_TRY(ncclAllReduce(D->d_scratch, D->d_scratch, 1, ncclInt32, ncclSum, D->comm, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return USPMV_OK;
+}
+
+int uspmv_dist_allreduce_max(uspmv_dist_t *D, double *value, void *stream) {
+    if (!D || !value) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_allreduce_max: NULL argument");
+    double *d_t = (double *)(D->d_scratch + 16);
+    HIP_TRY(hipMemcpy(d_t, value, 8, hipMemcpyHostToDevice));
+    NCCL_TRY(ncclAllReduce(d_t, d_t, 1, ncclDouble, ncclMax, D->comm, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(value, d_t, 8, hipMemcpyDeviceToHost));
+    return USPMV_OK;
+}
+
+int uspmv_dist_allgather_i64(uspmv_dist_t *D, int64_t value, int64_t *all, void *stream) {
+    if (!D || !all) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_allgather_i64: NULL argument");
+    if (D->loopback) { for (int p = 0; p < D->P; ++p) all[p] = value; return USPMV_OK; }
+    int64_t *d_v = nullptr, *d_all = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_v, 8));
+    HIP_TRY(hipMalloc((void **)&d_all, 8 * (size_t)D->comm_size));
+    HIP_TRY(hipMemcpy(d_v, &value, 8, hipMemcpyHostToDevice));
+    ncclResult_t r = ncclAllGather(d_v, d_all, 1, ncclInt64, D->comm, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (r == ncclSuccess && e == hipSuccess) e = hipMemcpy(all, d_all, 8 * (size_t)D->comm_size, hipMemcpyDeviceToHost);
+    (void)hipFree(d_v); (void)hipFree(d_all);
+    if (r != ncclSuccess) return uspmv::fail(USPMV_ERR_HIP, "uspmv_dist_allgather_i64: %s", ncclGetErrorString(r));
+    if (e != hipSuccess) return uspmv::fail(USPMV_ERR_HIP, "uspmv_dist_allgather_i64: %s", hipGetErrorString(e));
+    return USPMV_OK;
+}
+
+}  // extern "C"

@@ -89,6 +89,20 @@ extern "C" int uspmv_gen_stencil27(int64_t nx, int64_t ny, int64_t nz, int dof, 
     return USPMV_OK;
 }
 
+// entries per row of uspmv_gen_stencil27's matrix for rows [row_begin, row_end) (nothing else is generated)
+extern "C" int uspmv_gen_stencil27_row_counts(int64_t nx, int64_t ny, int64_t nz, int dof, int64_t row_begin, int64_t row_end, int32_t *out) {
+    if (!out || nx < 1 || ny < 1 || nz < 1 || dof < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_gen_stencil27_row_counts: bad argument");
+    const int64_t n = nx * ny * nz * dof;
+    if (row_begin < 0 || row_end > n || row_begin > row_end) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_gen_stencil27_row_counts: bad row range");
+    auto span = [](int64_t c, int64_t nc) { return (int64_t)1 + (c > 0) + (c < nc - 1); };
+#pragma omp parallel for schedule(static)
+    for (int64_t r = row_begin; r < row_end; ++r) {
+        const int64_t node = r / dof, x = node % nx, y = (node / nx) % ny, z = node / (nx * ny);
+        out[r - row_begin] = (int32_t)(span(x, nx) * span(y, ny) * span(z, nz) * dof);
+    }
+    return USPMV_OK;
+}
+
 // Banded-random matrix (the HV15R-class stand-in of SURVEY.md 8(d)): row i holds the diagonal plus
 // nnz_per_row - 1 distinct columns drawn by hash from [i - band, i + band] (clipped), ascending inside the row;
 // general (non-symmetric) pattern; off-diagonal magnitudes 10^(2 - D*u) with hashed sign when

@@ -58,6 +58,40 @@ int uspmv_seg_work_sharing_arr(const uspmv_coo_t *t, int seg_method, int P, int3
     return USPMV_OK;
 }
 
+// The same rule from per-row entry counts only, so that the ranks of a distributed run can agree on the partition of a
+// generated matrix without anybody materialising it: in uspmv_seg_work_sharing_arr's entry loop every segment consumes
+// nnz/P counted entries plus the one at which the cut is taken, so cut k falls after the row of entry k*(nnz/P + 1) - 1.
+int uspmv_seg_from_row_counts(const int32_t *row_nnz, int64_t n_rows, int seg_method, int P, int32_t *wsa) {
+    if (!row_nnz || !wsa || P < 1 || n_rows < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_seg_from_row_counts: bad argument");
+    if (n_rows < P) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_seg_from_row_counts: n_rows < number of ranks");
+    if (n_rows > INT32_MAX) return uspmv::fail(USPMV_ERR_OVERFLOW, "uspmv_seg_from_row_counts: rows exceed int32");
+    int64_t nnz = 0, last_row_p1 = 0;
+    for (int64_t r = 0; r < n_rows; ++r) { nnz += row_nnz[r]; if (row_nnz[r] > 0) last_row_p1 = r + 1; }
+    if (nnz < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_seg_from_row_counts: empty matrix");
+    for (int s = 0; s <= P; ++s) wsa[s] = 0;
+    if (seg_method == USPMV_SEG_ROWS) {
+        const int64_t per = n_rows / P;
+        for (int s = 1; s <= P; ++s) wsa[s] = (int32_t)(s * per);
+    } else if (seg_method == USPMV_SEG_NNZ) {
+        const int64_t per = nnz / P;
+        int64_t seen = 0, r = 0;
+        for (int k = 1; k <= P; ++k) {
+            const int64_t g = (int64_t)k * (per + 1) - 1;       // entry index at which cut k is taken
+            if (g >= nnz) break;
+            while (seen + row_nnz[r] <= g) seen += row_nnz[r++];
+            wsa[k] = (int32_t)(r + 1);
+        }
+    } else {
+        return uspmv::fail(USPMV_ERR_UNSUPPORTED, "uspmv_seg_from_row_counts: unknown seg method %d", seg_method);
+    }
+    wsa[P] = (int32_t)last_row_p1;
+    if (P > 1 && wsa[P - 1] == wsa[P])
+        for (int r = 1; r < P; ++r) wsa[r] -= 1;
+    for (int i = 1; i <= P; ++i)
+        if (wsa[i] < wsa[i - 1]) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_seg_from_row_counts: flaw in work_sharing_arr");
+    return USPMV_OK;
+}
+
 int uspmv_seg_local_coo(const uspmv_coo_t *t, const int32_t *wsa, int rank, uspmv_coo_t **out) {
     if (!t || !wsa || !out || rank < 0) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_seg_local_coo: bad argument");
     const int32_t lo = wsa[rank], hi = wsa[rank + 1];

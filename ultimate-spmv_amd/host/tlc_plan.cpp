@@ -189,3 +189,61 @@ int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *o) {
     }
     return USPMV_OK;
 }
+
+// Tie re-ordering for the block (SpMMV) plan.  convert_to_scs sorts the rows of a sigma window by length with
+// std::sort (code/utilities.hpp:1930-1941), which leaves rows of EQUAL length in an arbitrary order: a 64-row
+// tile of a 512-row window then holds rows from all over the window and touches almost twice the X rows a tile
+// of neighbouring rows would.  Rows that sit in chunks of equal length can be exchanged without changing any
+// chunk length or pointer, so the plan's private copy of the entries puts them back in original-row order
+// inside every run of equal-length chunks of a window; row_map[new position] = position in the caller's
+// struct (= where y goes).  Per-row slot order is untouched, hence the same FMA chain per (row, column).
+int uspmv_scs_reorder_ties(const uspmv_scs *s, uspmv_scs *r, std::vector<int32_t> *row_map) {
+    const int64_t C = s->C, nc = s->n_chunks, n_pad = nc * C;
+    row_map->resize((size_t)n_pad);
+    for (int64_t q = 0; q < n_pad; ++q) (*row_map)[(size_t)q] = (int32_t)q;
+    const int64_t W = std::max<int64_t>(s->sigma, C);
+    bool changed = false;
+    if (s->sigma > 1 && W % C == 0 && (int64_t)s->new_to_old_idx.size() >= s->n_rows) {
+        const int64_t cpw = W / C;
+        const int32_t *n2o = s->new_to_old_idx.data();
+        const int64_t n_rows = s->n_rows;
+        std::vector<char> ch((size_t)((nc + cpw - 1) / cpw), 0);
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t w = 0; w < (nc + cpw - 1) / cpw; ++w) {
+            const int64_t c_end = std::min(nc, (w + 1) * cpw);
+            int64_t c0 = w * cpw;
+            while (c0 < c_end) {
+                int64_t c1 = c0 + 1;
+                while (c1 < c_end && s->chunk_lengths[(size_t)c1] == s->chunk_lengths[(size_t)c0]) ++c1;
+                int32_t *b = row_map->data() + c0 * C, *e = row_map->data() + c1 * C;
+                auto key = [&](int32_t q) { return q < n_rows ? (int64_t)n2o[q] : (int64_t)INT32_MAX + q; };
+                if (!std::is_sorted(b, e, [&](int32_t a, int32_t bb) { return key(a) < key(bb); })) {
+                    std::sort(b, e, [&](int32_t a, int32_t bb) { return key(a) < key(bb); });
+                    ch[(size_t)w] = 1;
+                }
+                c0 = c1;
+            }
+        }
+        for (char v : ch) changed = changed || v;
+    }
+    r->C = C; r->sigma = s->sigma; r->n_rows = s->n_rows; r->n_cols = s->n_cols; r->nnz = s->nnz; r->dtype = s->dtype;
+    r->n_chunks = nc; r->n_rows_padded = s->n_rows_padded; r->n_elements = s->n_elements;
+    r->chunk_ptrs = s->chunk_ptrs; r->chunk_lengths = s->chunk_lengths;
+    r->col_idxs.resize((size_t)s->n_elements);
+    if (s->dtype == USPMV_F64) r->values_f64.resize((size_t)s->n_elements); else r->values_f32.resize((size_t)s->n_elements);
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < nc; ++c) {
+        const int64_t cs = s->chunk_ptrs[(size_t)c], L = s->chunk_lengths[(size_t)c];
+        for (int64_t i = 0; i < C; ++i) {
+            const int64_t src_row = (*row_map)[(size_t)(c * C + i)];
+            const int64_t sc = src_row / C, si = src_row % C, scs = s->chunk_ptrs[(size_t)sc];
+            for (int64_t j = 0; j < L; ++j) {
+                const int64_t src = scs + j * C + si, dst = cs + j * C + i;
+                r->col_idxs[(size_t)dst] = s->col_idxs[(size_t)src];
+                if (s->dtype == USPMV_F64) r->values_f64[(size_t)dst] = s->values_f64[(size_t)src];
+                else r->values_f32[(size_t)dst] = s->values_f32[(size_t)src];
+            }
+        }
+    }
+    return changed ? 1 : 0;
+}

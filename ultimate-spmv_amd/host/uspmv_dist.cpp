@@ -5,21 +5,23 @@
 //   collect_comm_info             code/mpi_funcs.hpp:1061-1124 (who sends what to whom)
 //   init/finalize_halo_exchange   code/classes_structs.hpp:857-995 (per-iteration exchange)
 //   bench loop with barriers      code/main.cpp:458-474
+// All of it lives behind the C ABI (uspmv_dist_* in include/uspmv.h, csrc/uspmv_dist_api.hip); this file is the harness around it:
+// rank discovery, the RCCL id hand-off, the per-rank matrix block, the bench protocol and the report.
 //
 // Launch: any launcher that exports RANK / WORLD_SIZE / LOCAL_RANK (torchrun, srun with a wrapper,
 // `for r in ...; do RANK=$r WORLD_SIZE=$N LOCAL_RANK=$r uspmv ... & done`).  The RCCL unique id travels
 // through a file under $USPMV_ID_DIR (default /tmp) keyed by $MASTER_PORT / $USPMV_JOB_ID.
 //
-// Per SpMV: pack kernel over the concatenated send list -> grouped ncclSend/ncclRecv
-// with every receive landing directly in x[n_local + recv_cumsum[p]] (the reference's halo numbering)
-// on a side stream, overlapped with the interior tiles; boundary tiles after the exchange.
+// Every rank holds ONLY its row block: generated matrices (gen:...) are generated per block (the partition comes from the
+// analytic row counts); a .mtx file is read by rank 0 alone, which writes one binary block per rank next to the id file --
+// the reference's root-reads-and-scatters (code/mpi_funcs.hpp:739-860) without MPI.
 //
-// STATUS: exercised on hardware with WORLD_SIZE = 1 only (the development box has one GPU and RCCL
-// refuses several ranks per device); the partition / discovery / packing functions it calls are the
-// ones tested bit-exactly against the reference, and the same orchestration is tested with 2-8 ranks in
-// the Python driver (tests/test_distributed_cpu.py, tests/test_distributed_gpu.py).
+// Single-GPU rehearsal of the whole path: USPMV_LOOPBACK=P (with WORLD_SIZE unset) makes this process block
+// $USPMV_LOOPBACK_RANK (default 0) of a P-way partition whose neighbours are itself (RCCL self send/recv).
+// USPMV_DIST_X=ramp sets x_local[i] = 1 + 1e-3 * (i mod 1000) in ORIGINAL local row order on every rank (the default is the
+// reference's constant 5.0); USPMV_DUMP_Y=<prefix> writes y of the local rows in original order to <prefix>.<rank> (raw
+// doubles) after one step.  tests/test_dist_native_gpu.py checks that output against the oracle.
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -37,13 +39,15 @@
 
 namespace {
 
-[[noreturn]] void die(int rank, const std::string &msg) {
-    fprintf(stderr, "[rank %d] ERROR: %s\n", rank, msg.c_str());
+struct Ctx { int rank = 0; };
+Ctx g;
+
+[[noreturn]] void die(const std::string &msg) {
+    fprintf(stderr, "[rank %d] ERROR: %s\n", g.rank, msg.c_str());
     exit(1);
 }
-#define CK(call) do { int rc_ = (call); if (rc_ != USPMV_OK) die(D.rank, std::string(#call) + ": " + uspmv_last_error()); } while (0)
-#define HK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) die(D.rank, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
-#define NK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) die(D.rank, std::string(#call) + ": " + ncclGetErrorString(r_)); } while (0)
+#define CK(call) do { int rc_ = (call); if (rc_ != USPMV_OK) die(std::string(#call) + ": " + uspmv_last_error()); } while (0)
+#define HK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) die(std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
 int env_int(const char *a, const char *b, int dflt) {
     const char *v = getenv(a);
@@ -51,229 +55,205 @@ int env_int(const char *a, const char *b, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-struct Dist {
-    int rank = 0, P = 1, local_rank = 0;
-    ncclComm_t comm = nullptr;
-    hipStream_t main_stream = nullptr, comm_stream = nullptr;
-    hipEvent_t ev_main = nullptr, ev_comm = nullptr;
-    int *d_scratch = nullptr;
-};
+std::string side_path(const std::string &what) {
+    const char *dir = getenv("USPMV_ID_DIR");
+    const char *job = getenv("USPMV_JOB_ID") ? getenv("USPMV_JOB_ID") : getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0";
+    return std::string(dir ? dir : "/tmp") + "/uspmv_" + job + "_" + what;
+}
 
-void barrier(Dist &D) {  // MPI_Barrier twin: a tiny all-reduce, then a host wait
-    NK(ncclAllReduce(D.d_scratch, D.d_scratch, 1, ncclInt32, ncclSum, D.comm, D.main_stream));
-    HK(hipStreamSynchronize(D.main_stream));
+bool wait_for(const std::string &path, int seconds) {
+    for (int tries = 0; tries < seconds * 100; ++tries) {
+        if (access(path.c_str(), R_OK) == 0) return true;
+        std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    }
+    return false;
+}
+
+void publish(const std::string &path, const void *data, size_t bytes) {
+    const std::string tmp = path + ".tmp";
+    { std::ofstream f(tmp, std::ios::binary); f.write((const char *)data, (std::streamsize)bytes); }
+    if (rename(tmp.c_str(), path.c_str()) != 0) die("cannot publish " + path);
 }
 
 }  // namespace
 
-bool uspmv_dist_requested() { return env_int("WORLD_SIZE", "USPMV_WORLD_SIZE", 1) > 1 || getenv("USPMV_FORCE_DIST"); }
+bool uspmv_dist_requested() {
+    return env_int("WORLD_SIZE", "USPMV_WORLD_SIZE", 1) > 1 || getenv("USPMV_FORCE_DIST") || env_int("USPMV_LOOPBACK", nullptr, 0) > 1;
+}
 
-int uspmv_run_distributed(const DistConfig &c, uspmv_coo_t *total) {
-    Dist D;
-    D.rank = env_int("RANK", "USPMV_RANK", 0);
-    D.P = env_int("WORLD_SIZE", "USPMV_WORLD_SIZE", 1);
-    D.local_rank = env_int("LOCAL_RANK", "USPMV_LOCAL_RANK", D.rank);
+int uspmv_run_distributed(const DistConfig &c) {
+    const int comm_rank = env_int("RANK", "USPMV_RANK", 0), comm_size = env_int("WORLD_SIZE", "USPMV_WORLD_SIZE", 1);
+    const int local_rank = env_int("LOCAL_RANK", "USPMV_LOCAL_RANK", comm_rank);
+    const int loop_P = env_int("USPMV_LOOPBACK", nullptr, 0);
+    if (loop_P > 1 && comm_size != 1) die("USPMV_LOOPBACK needs WORLD_SIZE = 1");
+    const int P = loop_P > 1 ? loop_P : comm_size;
+    const int rank = loop_P > 1 ? env_int("USPMV_LOOPBACK_RANK", nullptr, 0) : comm_rank;
+    if (rank < 0 || rank >= P) die("bad rank");
+    g.rank = rank;
     int ndev = 0;
     CK(uspmv_device_count(&ndev));
-    if (ndev < 1) die(D.rank, "no HIP device visible");
-    CK(uspmv_set_device(D.local_rank % ndev));  // device = my_rank % num_devices (code/main.cpp:1838-1842)
+    if (ndev < 1) die("no HIP device visible");
+    CK(uspmv_set_device(local_rank % ndev));  // device = my_rank % num_devices (code/main.cpp:1838-1842)
 
-    // ---- RCCL bootstrap through a file
-    ncclUniqueId id;
-    const char *dir = getenv("USPMV_ID_DIR");
-    const char *job = getenv("USPMV_JOB_ID") ? getenv("USPMV_JOB_ID") : getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0";
-    const std::string path = std::string(dir ? dir : "/tmp") + "/uspmv_rccl_" + job + ".id";
-    if (D.rank == 0) {
-        NK(ncclGetUniqueId(&id));
-        const std::string tmp = path + ".tmp";
-        { std::ofstream f(tmp, std::ios::binary); f.write((const char *)&id, sizeof id); }
-        if (rename(tmp.c_str(), path.c_str()) != 0) die(D.rank, "cannot publish the RCCL id at " + path);
+    // ---- RCCL id through a file
+    unsigned char id[USPMV_COMM_ID_BYTES];
+    const std::string id_path = side_path("rccl.id");
+    if (comm_rank == 0) {
+        CK(uspmv_comm_unique_id(id));
+        publish(id_path, id, sizeof id);
     } else {
-        for (int tries = 0;; ++tries) {
-            std::ifstream f(path, std::ios::binary);
-            if (f && f.read((char *)&id, sizeof id)) break;
-            if (tries > 6000) die(D.rank, "timed out waiting for " + path);
-            std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        if (!wait_for(id_path, 120)) die("timed out waiting for " + id_path);
+        std::ifstream f(id_path, std::ios::binary);
+        if (!f.read((char *)id, sizeof id)) die("cannot read " + id_path);
+    }
+
+    // ---- this rank's row block (and nothing else)
+    std::vector<int32_t> wsa((size_t)P + 1, 0);
+    uspmv_coo_t *local = nullptr;
+    int64_t n_rows_g = 0, nnz_g = 0;
+    const int seg = c.seg_nnz ? USPMV_SEG_NNZ : USPMV_SEG_ROWS;
+    if (c.matrix_name.rfind("gen:", 0) == 0) {
+        long nx = 0, ny = 0, nz = 0; int dof = 1; double dec = 0.0;
+        if (sscanf(c.matrix_name.c_str() + 4, "%ldx%ldx%ld:%d:%lf", &nx, &ny, &nz, &dof, &dec) < 3) die("generator syntax: gen:NXxNYxNZ[:dof[:decades]]");
+        n_rows_g = (int64_t)nx * ny * nz * dof;
+        {
+            std::vector<int32_t> counts((size_t)n_rows_g);
+            CK(uspmv_gen_stencil27_row_counts(nx, ny, nz, dof, 0, n_rows_g, counts.data()));
+            for (int32_t v : counts) nnz_g += v;
+            CK(uspmv_seg_from_row_counts(counts.data(), n_rows_g, seg, P, wsa.data()));
+        }
+        CK(uspmv_gen_stencil27(nx, ny, nz, dof, 0x5EED, dec, wsa[(size_t)rank], wsa[(size_t)rank + 1], &local));
+    } else {
+        const std::string meta_path = side_path("blocks.meta");
+        auto block_path = [&](int r) { return side_path("block" + std::to_string(r) + ".uspmvcoo"); };
+        if (comm_rank == 0) {
+            uspmv_coo_t *total = nullptr;
+            CK(uspmv_read_mtx(c.matrix_name.c_str(), &total));
+            int64_t nc;
+            CK(uspmv_coo_dims(total, &n_rows_g, &nc, &nnz_g));
+            CK(uspmv_seg_work_sharing_arr(total, seg, P, wsa.data()));
+            for (int r = 0; r < P; ++r) {
+                uspmv_coo_t *blk = nullptr;
+                CK(uspmv_seg_local_coo(total, wsa.data(), r, &blk));
+                if (r == rank) local = blk;
+                else {
+                    if (comm_size > 1) CK(uspmv_coo_save(blk, block_path(r).c_str()));
+                    uspmv_coo_free(blk);
+                }
+            }
+            uspmv_coo_free(total);
+            std::vector<int64_t> meta((size_t)P + 3);
+            meta[0] = n_rows_g; meta[1] = nnz_g;
+            for (int r = 0; r <= P; ++r) meta[(size_t)r + 2] = wsa[(size_t)r];
+            if (comm_size > 1) publish(meta_path, meta.data(), meta.size() * 8);
+        } else {
+            if (!wait_for(meta_path, 3600)) die("timed out waiting for " + meta_path);
+            std::vector<int64_t> meta((size_t)P + 3);
+            std::ifstream f(meta_path, std::ios::binary);
+            if (!f.read((char *)meta.data(), (std::streamsize)(meta.size() * 8))) die("cannot read " + meta_path);
+            n_rows_g = meta[0]; nnz_g = meta[1];
+            for (int r = 0; r <= P; ++r) wsa[(size_t)r] = (int32_t)meta[(size_t)r + 2];
+            CK(uspmv_coo_load(block_path(rank).c_str(), &local));
+            unlink(block_path(rank).c_str());
         }
     }
-    NK(ncclCommInitRank(&D.comm, D.P, id, D.rank));
-    HK(hipStreamCreate(&D.main_stream));
-    HK(hipStreamCreate(&D.comm_stream));
-    HK(hipEventCreateWithFlags(&D.ev_main, hipEventDisableTiming));
-    HK(hipEventCreateWithFlags(&D.ev_comm, hipEventDisableTiming));
-    HK(hipMalloc((void **)&D.d_scratch, 64));
-    HK(hipMemset(D.d_scratch, 0, 64));
-    barrier(D);
-    if (D.rank == 0) unlink(path.c_str());
 
-    // ---- partition + local structs (every rank holds the global COO; the reference scatters from rank 0)
-    int64_t n_rows_g, n_cols_g, nnz_g;
-    CK(uspmv_coo_dims(total, &n_rows_g, &n_cols_g, &nnz_g));
-    std::vector<int32_t> wsa((size_t)D.P + 1);
-    CK(uspmv_seg_work_sharing_arr(total, c.seg_nnz ? USPMV_SEG_NNZ : USPMV_SEG_ROWS, D.P, wsa.data()));
-    uspmv_coo_t *local = nullptr;
-    CK(uspmv_seg_local_coo(total, wsa.data(), D.rank, &local));
-    uspmv_scs_t *scs = nullptr;
-    CK(uspmv_convert_to_scs(local, c.C, c.sigma, USPMV_F64, nullptr, &scs));
-    uspmv_halo_t *halo = nullptr;
-    CK(uspmv_halo_discover(scs, wsa.data(), D.rank, D.P, &halo));
+    // ---- the distributed object: convert, halo discovery, upload, plan, communicator (init_local_structs + collect_comm_info)
+    uspmv_dist_t *D = nullptr;
+    CK(uspmv_dist_create_from_coo(id, comm_rank, comm_size, rank, P, local, wsa.data(), c.C, c.sigma, USPMV_F64, c.tlc ? 1 : 0, &D));
+    uspmv_coo_free(local);
+    hipStream_t st = nullptr;
+    HK(hipStreamCreate(&st));
+    CK(uspmv_dist_barrier(D, st));
+    if (comm_rank == 0) { unlink(id_path.c_str()); unlink(side_path("blocks.meta").c_str()); }
+    if (c.no_overlap) CK(uspmv_dist_set_overlap(D, 0));
+    if (c.no_pack) CK(uspmv_dist_set_no_pack(D, 1));   // -no_pack 1: the exchange sends a stale buffer (code/classes_structs.hpp:941)
+    int64_t meta[12];
+    CK(uspmv_dist_info(D, meta));
+    const int64_t n_local = meta[0], n_halo = meta[1], vec_len = meta[2], n_send = meta[3];
+    const uspmv_scs_t *scs = nullptr;
+    CK(uspmv_dist_parts(D, &scs, nullptr, nullptr));
+    int64_t sm[8];
+    CK(uspmv_scs_meta(scs, sm));
+    const int64_t n_pad = sm[4], n_chunks = sm[5], n_el = sm[6];
     const int32_t *o2n, *n2o;
     CK(uspmv_scs_arrays(scs, nullptr, nullptr, nullptr, nullptr, &o2n, &n2o));
-    CK(uspmv_permute_scs_cols(scs, o2n));
-    int64_t meta[8];
-    CK(uspmv_scs_meta(scs, meta));
-    const int64_t n_local = wsa[(size_t)D.rank + 1] - wsa[(size_t)D.rank], n_pad = meta[4], n_chunks = meta[5], n_el = meta[6];
-    int64_t n_halo;
-    const int32_t *recv_cumsum, *recv_idxs, *recv_counts;
-    CK(uspmv_halo_meta(halo, &n_halo, &recv_cumsum, &recv_idxs, &recv_counts));
-    const int64_t vec_len = n_local + std::max(n_pad - n_local, n_halo);  // padded_vec_size (code/main.cpp:1406-1412)
 
-    // ---- who sends what to whom: all-gather of the recv counts, then grouped index send/recv
-    int32_t *d_counts_all = nullptr, *d_counts = nullptr;
-    HK(hipMalloc((void **)&d_counts_all, sizeof(int32_t) * (size_t)D.P * D.P));
-    HK(hipMalloc((void **)&d_counts, sizeof(int32_t) * (size_t)D.P));
-    HK(hipMemcpy(d_counts, recv_counts, sizeof(int32_t) * (size_t)D.P, hipMemcpyHostToDevice));
-    NK(ncclAllGather(d_counts, d_counts_all, (size_t)D.P, ncclInt32, D.comm, D.main_stream));
-    HK(hipStreamSynchronize(D.main_stream));
-    std::vector<int32_t> counts_all((size_t)D.P * D.P);
-    HK(hipMemcpy(counts_all.data(), d_counts_all, sizeof(int32_t) * counts_all.size(), hipMemcpyDeviceToHost));
-    std::vector<int64_t> send_off((size_t)D.P + 1, 0), recv_off((size_t)D.P + 1, 0);
-    for (int p = 0; p < D.P; ++p) {
-        send_off[(size_t)p + 1] = send_off[(size_t)p] + counts_all[(size_t)p * D.P + D.rank];  // what p needs from me
-        recv_off[(size_t)p + 1] = recv_off[(size_t)p] + recv_counts[p];
-    }
-    const int64_t n_send = send_off[(size_t)D.P];
-    int32_t *d_recv_idxs = nullptr, *d_send_idxs = nullptr;
-    HK(hipMalloc((void **)&d_recv_idxs, sizeof(int32_t) * (size_t)std::max<int64_t>(n_halo, 1)));
-    HK(hipMalloc((void **)&d_send_idxs, sizeof(int32_t) * (size_t)std::max<int64_t>(n_send, 1)));
-    HK(hipMemcpy(d_recv_idxs, recv_idxs, sizeof(int32_t) * (size_t)n_halo, hipMemcpyHostToDevice));
-    NK(ncclGroupStart());
-    for (int p = 0; p < D.P; ++p) {
-        const int64_t ns = send_off[(size_t)p + 1] - send_off[(size_t)p], nr = recv_counts[p];
-        if (nr) NK(ncclSend(d_recv_idxs + recv_off[(size_t)p], (size_t)nr, ncclInt32, p, D.comm, D.main_stream));
-        if (ns) NK(ncclRecv(d_send_idxs + send_off[(size_t)p], (size_t)ns, ncclInt32, p, D.comm, D.main_stream));
-    }
-    NK(ncclGroupEnd());
-    HK(hipStreamSynchronize(D.main_stream));
-
-    // ---- device state
-    uspmv_dmat_t *A = nullptr;
-    CK(uspmv_dmat_upload(scs, &A));
-    int64_t n_tiles = 0, n_staged = 0;
-    if (c.tlc) CK(uspmv_dmat_optimize(A, scs, 0, &n_tiles, &n_staged));
-    int tile_rows = 0;
-    CK(uspmv_dmat_tile_rows(A, &tile_rows));
-    int32_t *interior = nullptr, *boundary = nullptr;
-    int64_t n_int = 0, n_bnd = 0;
-    CK(uspmv_scs_split_chunks(scs, n_local, &interior, &n_int, &boundary, &n_bnd));
-    const bool use_tiles = tile_rows > 0 && n_staged > 0;
-    std::vector<int32_t> ids_int, ids_bnd;
-    if (use_tiles) {  // interior / boundary at tile granularity
-        const int64_t cpt = tile_rows / c.C;
-        std::vector<char> is_b((size_t)n_tiles, 0);
-        for (int64_t k = 0; k < n_bnd; ++k) is_b[(size_t)(boundary[k] / cpt)] = 1;
-        for (int64_t t = 0; t < n_tiles; ++t) (is_b[(size_t)t] ? ids_bnd : ids_int).push_back((int32_t)t);
-    } else {
-        ids_int.assign(interior, interior + n_int);
-        ids_bnd.assign(boundary, boundary + n_bnd);
-    }
-    uspmv_free(interior); uspmv_free(boundary);
-    int32_t *d_int = nullptr, *d_bnd = nullptr, *d_perm = nullptr;
-    HK(hipMalloc((void **)&d_int, sizeof(int32_t) * std::max<size_t>(ids_int.size(), 1)));
-    HK(hipMalloc((void **)&d_bnd, sizeof(int32_t) * std::max<size_t>(ids_bnd.size(), 1)));
-    HK(hipMalloc((void **)&d_perm, sizeof(int32_t) * (size_t)std::max<int64_t>(n_local, 1)));
-    HK(hipMemcpy(d_int, ids_int.data(), sizeof(int32_t) * ids_int.size(), hipMemcpyHostToDevice));
-    HK(hipMemcpy(d_bnd, ids_bnd.data(), sizeof(int32_t) * ids_bnd.size(), hipMemcpyHostToDevice));
-    HK(hipMemcpy(d_perm, o2n, sizeof(int32_t) * (size_t)n_local, hipMemcpyHostToDevice));
-    double *d_x = nullptr, *d_y = nullptr, *d_send = nullptr;
+    // ---- vectors: x = DefaultValues::x = 5.0 on the local rows (or the test ramp), permuted (code/main.cpp:86-93); 0 elsewhere
+    double *d_x = nullptr, *d_y = nullptr;
     HK(hipMalloc((void **)&d_x, sizeof(double) * (size_t)vec_len));
     HK(hipMalloc((void **)&d_y, sizeof(double) * (size_t)vec_len));
-    HK(hipMalloc((void **)&d_send, sizeof(double) * (size_t)std::max<int64_t>(n_send, 1)));
     HK(hipMemset(d_y, 0, sizeof(double) * (size_t)vec_len));
-    {   // x = DefaultValues::x = 5.0 on the local rows (permutation of a constant is the constant), 0 elsewhere
-        std::vector<double> hx((size_t)vec_len, 0.0);
-        std::fill(hx.begin(), hx.begin() + n_local, 5.0);
+    {
+        std::vector<double> xo((size_t)n_local, 5.0), hx((size_t)vec_len, 0.0);
+        const char *xk = getenv("USPMV_DIST_X");
+        if (xk && !strcmp(xk, "ramp")) for (int64_t i = 0; i < n_local; ++i) xo[(size_t)i] = 1.0 + 1e-3 * (double)(i % 1000);
+        CK(uspmv_apply_permutation(hx.data(), xo.data(), n2o, n_local, USPMV_F64));
         HK(hipMemcpy(d_x, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
     }
-
-    auto step = [&]() {
-        if (c.comm_halos && D.P > 1) {
-            HK(hipEventRecord(D.ev_main, D.main_stream));
-            HK(hipStreamWaitEvent(D.comm_stream, D.ev_main, 0));
-            CK(uspmv_pack_send_buf(d_x, d_perm, d_send_idxs, n_send, 0, d_send, USPMV_F64, D.comm_stream));
-            NK(ncclGroupStart());
-            for (int p = 0; p < D.P; ++p) {
-                const int64_t ns = send_off[(size_t)p + 1] - send_off[(size_t)p], nr = recv_counts[p];
-                if (nr) NK(ncclRecv(d_x + n_local + recv_cumsum[p], (size_t)nr, ncclDouble, p, D.comm, D.comm_stream));
-                if (ns) NK(ncclSend(d_send + send_off[(size_t)p], (size_t)ns, ncclDouble, p, D.comm, D.comm_stream));
-            }
-            NK(ncclGroupEnd());
-            HK(hipEventRecord(D.ev_comm, D.comm_stream));
-            if (use_tiles) CK(uspmv_spmv_tiles(A, d_int, (int64_t)ids_int.size(), d_x, d_y, D.main_stream));
-            else CK(uspmv_spmv_chunks(A, d_int, (int64_t)ids_int.size(), d_x, d_y, D.main_stream));
-            HK(hipStreamWaitEvent(D.main_stream, D.ev_comm, 0));
-            if (use_tiles) CK(uspmv_spmv_tiles(A, d_bnd, (int64_t)ids_bnd.size(), d_x, d_y, D.main_stream));
-            else CK(uspmv_spmv_chunks(A, d_bnd, (int64_t)ids_bnd.size(), d_x, d_y, D.main_stream));
-        } else {
-            CK(uspmv_spmv(A, d_x, d_y, D.main_stream));
-        }
-        if (c.ba_synch && D.P > 1) NK(ncclAllReduce(D.d_scratch, D.d_scratch, 1, ncclInt32, ncclSum, D.comm, D.main_stream));
+    const int comm_halos = c.comm_halos ? 1 : 0;
+    auto steps = [&](int n) {
+        if (comm_halos && c.use_graph) CK(uspmv_dist_run(D, d_x, d_y, n, 1, st));
+        else for (int k = 0; k < n; ++k) CK(uspmv_dist_spmv(D, d_x, d_y, comm_halos, st));
     };
 
+    if (const char *dump = getenv("USPMV_DUMP_Y")) {   // one step, y of the local rows back in original order (copy_back_result)
+        steps(1);
+        HK(hipStreamSynchronize(st));
+        std::vector<double> hy((size_t)vec_len), yo((size_t)n_local);
+        HK(hipMemcpy(hy.data(), d_y, sizeof(double) * hy.size(), hipMemcpyDeviceToHost));
+        CK(uspmv_apply_permutation(yo.data(), hy.data(), o2n, n_local, USPMV_F64));
+        publish(std::string(dump) + "." + std::to_string(rank), yo.data(), yo.size() * 8);
+    }
+
     // ---- bench loop (code/main.cpp:408-474): 100 warm-ups, doubling batches, barriers around each batch
-    for (int k = 0; k < 100; ++k) step();
-    barrier(D);
+    steps(100);
+    CK(uspmv_dist_barrier(D, st));
     int n_iter = 2;
     double runtime = 0;
     do {
-        barrier(D);
+        CK(uspmv_dist_barrier(D, st));
         auto t0 = std::chrono::steady_clock::now();
-        for (int k = 0; k < n_iter; ++k) step();
-        barrier(D);
+        steps(n_iter);
+        CK(uspmv_dist_barrier(D, st));
         runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         n_iter *= 2;
-        // every rank must take the same decision: agree on the slowest rank's clock
-        double *d_t = (double *)(D.d_scratch + 8);
-        HK(hipMemcpy(d_t, &runtime, sizeof(double), hipMemcpyHostToDevice));
-        NK(ncclAllReduce(d_t, d_t, 1, ncclDouble, ncclMax, D.comm, D.main_stream));
-        HK(hipStreamSynchronize(D.main_stream));
-        HK(hipMemcpy(&runtime, d_t, sizeof(double), hipMemcpyDeviceToHost));
+        CK(uspmv_dist_allreduce_max(D, &runtime, st));   // every rank must take the same decision: the slowest rank's clock
     } while (runtime < c.bench_time);
     n_iter /= 2;
     const double perf = (double)nnz_g * 2.0 / (runtime / n_iter) / 1e9;
 
     // ---- report
-    std::vector<int32_t> halos((size_t)D.P, 0);
-    {
-        int32_t h = (int32_t)n_halo;
-        HK(hipMemcpy(d_counts, &h, sizeof(int32_t), hipMemcpyHostToDevice));
-        NK(ncclAllGather(d_counts, d_counts_all, 1, ncclInt32, D.comm, D.main_stream));
-        HK(hipStreamSynchronize(D.main_stream));
-        HK(hipMemcpy(halos.data(), d_counts_all, sizeof(int32_t) * (size_t)D.P, hipMemcpyDeviceToHost));
-    }
-    if (D.rank == 0) {
-        const double bytes = n_el * 12.0 + 8.0 * n_chunks + 8.0 * (n_local + n_halo) + 8.0 * n_pad;  // rank 0's share
+    std::vector<int64_t> halos((size_t)std::max(P, comm_size), 0), sends((size_t)std::max(P, comm_size), 0);
+    CK(uspmv_dist_allgather_i64(D, n_halo, halos.data(), st));
+    CK(uspmv_dist_allgather_i64(D, n_send, sends.data(), st));
+    CK(uspmv_dist_info(D, meta));
+    if (comm_rank == 0) {
+        const double bytes = n_el * 12.0 + 8.0 * n_chunks + 8.0 * (n_local + n_halo) + 8.0 * n_pad;  // this rank's share
         std::ofstream f("spmv_bench.txt", std::ios::app);
-        f << c.matrix_name << " with " << D.P << " RCCL ranks (one per GPU), halo exchange " << (c.comm_halos ? "on" : "off") << std::endl;
+        f << c.matrix_name << " with " << P << " RCCL ranks (one per GPU), halo exchange " << (c.comm_halos ? "on" : "off") << std::endl;
         f << "kernel: scs, block_vec_size: 1, C: " << c.C << " sigma: " << c.sigma << ", data_type: double, revisions: " << n_iter
           << ", seg_method: " << (c.seg_nnz ? "seg-nnz" : "seg-rows") << ", MPI_mode: singlevec" << std::endl << std::endl;
         char buf[256];
         snprintf(buf, sizeof buf, "%-32s%-32s\n%-32s%-32s\n%-32.16g%-32.16g\n\n", "Total Gflops:", "Total Walltime:", "-------------",
                  "-------------", perf, runtime);
         f << buf;
-        if (c.verbose) {
-            f << "Rank Idx:                       Per rank Elems Recvd:\n---------                       -------------\n";
-            for (int p = 0; p < D.P; ++p) f << p << "                               " << halos[(size_t)p] << "\n";
+        if (c.verbose || c.print_comm_vol) {   // -print_comm_vol: elements received / sent per rank and step (code/classes_structs.hpp:941)
+            f << "Rank Idx:                       Per rank Elems Recvd:           Per rank Elems Sent:\n---------                       -------------                   -------------\n";
+            for (int p = 0; p < P; ++p) {
+                snprintf(buf, sizeof buf, "%-32d%-32ld%-32ld\n", p, (long)halos[(size_t)p], (long)sends[(size_t)p]);
+                f << buf;
+            }
             f << std::endl;
         }
-        printf("%d ranks, n = %ld, nnz = %ld: Total Gflops: %.4f (%d iterations in %.4f s, %.6f ms per SpMV); rank 0: %.1f GB/s algorithmic, "
-               "%ld halo elements, %zu interior + %zu boundary %s\n", D.P, (long)n_rows_g, (long)nnz_g, perf, n_iter, runtime,
-               runtime / n_iter * 1e3, bytes / (runtime / n_iter) / 1e9, (long)n_halo, ids_int.size(), ids_bnd.size(), use_tiles ? "tiles" : "chunks");
+        printf("%d ranks%s, n = %ld, nnz = %ld: Total Gflops: %.4f (%d iterations in %.4f s, %.6f ms per SpMV); rank %d: %.1f GB/s algorithmic, "
+               "%ld halo elements, %ld interior + %ld boundary %s, %s\n", P, meta[8] ? " (loopback)" : "", (long)n_rows_g, (long)nnz_g, perf, n_iter, runtime,
+               runtime / n_iter * 1e3, rank, bytes / (runtime / n_iter) / 1e9, (long)n_halo, (long)meta[4], (long)meta[5], meta[6] ? "tiles" : "chunks",
+               meta[9] ? "hipGraph replay" : "eager steps");
     }
-    barrier(D);
-    uspmv_dmat_free(A); uspmv_halo_free(halo); uspmv_scs_free(scs); uspmv_coo_free(local);
-    (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_send); (void)hipFree(d_int); (void)hipFree(d_bnd); (void)hipFree(d_perm);
-    (void)hipFree(d_recv_idxs); (void)hipFree(d_send_idxs); (void)hipFree(d_counts); (void)hipFree(d_counts_all); (void)hipFree(D.d_scratch);
-    ncclCommDestroy(D.comm);
+    CK(uspmv_dist_barrier(D, st));
+    (void)hipFree(d_x); (void)hipFree(d_y);
+    uspmv_dist_free(D);
+    (void)hipStreamDestroy(st);
     return 0;
 }

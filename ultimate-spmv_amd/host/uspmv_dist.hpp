@@ -7,9 +7,10 @@
 struct DistConfig {
     long C = 32, sigma = 1;
     bool seg_nnz = false, comm_halos = true, ba_synch = true, tlc = true, verbose = false;
+    bool no_overlap = false, use_graph = true, print_comm_vol = false, no_pack = false;
     double bench_time = 5.0;
     std::string matrix_name;
 };
 
-bool uspmv_dist_requested();                                        // WORLD_SIZE > 1 (or USPMV_FORCE_DIST)
-int uspmv_run_distributed(const DistConfig &c, uspmv_coo_t *total); // bench mode, scs, -dp, single vector
+bool uspmv_dist_requested();                                        // WORLD_SIZE > 1, USPMV_FORCE_DIST or USPMV_LOOPBACK=P
+int uspmv_run_distributed(const DistConfig &c);   // bench mode, scs, -dp, single vector; every rank builds only its row block

@@ -53,7 +53,28 @@ struct uspmv_tlc_plan {
 };
 int uspmv_build_tlc_plan(const uspmv_scs *s, const uspmv_scs *s2, int max_lines, int tile_rows, uspmv_tlc_plan *plan, int line_shift = 4);
 
+// Column-window sweep plan (host copy), see host/sweep_plan.cpp
+struct uspmv_sweep_plan {
+    bool valid = false;
+    int tile_rows = 1024, wlog = 13;
+    int64_t n_tiles = 0, n_sweep_tiles = 0, x_len_min = 0;
+    std::vector<int32_t> tile_ids, t_smin, t_S;   // per sweep tile: tile number, first window, number of windows
+    std::vector<uint64_t> t_cnt_off;              // per sweep tile: offset of its S*tile_rows count bytes
+    std::vector<uint32_t> wave_off, wave_off_b;   // per (sweep tile, wave): first element of the wave's compacted stream
+    std::vector<uint8_t> cnt, cnt_b;              // [tile][window][row]: entries of the row in the window
+    std::vector<uint16_t> idx, idx_b;             // column - window start
+    std::vector<double> vals_f64, vals_b_f64;
+    std::vector<float> vals_f32, vals_b_f32;
+    std::vector<int32_t> pad_col, pad_col_b;      // per (sweep tile, row): column of the stripped trailing padding, -1 = none
+    std::vector<int32_t> rest_chunks;             // chunks of the tiles that do not sweep (gather kernel)
+};
+int uspmv_build_sweep_plan(const uspmv_scs *s, const uspmv_scs *s2, int wlog, int tile_rows, double max_stage_bytes_per_nnz,
+                           uspmv_sweep_plan *plan);   // host/sweep_plan.cpp
+
 int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *out);   // host/tlc_plan.cpp
+// private copy of the entries with the rows of equal-length chunks of a sigma window back in original order;
+// returns 1 when anything moved, 0 when the copy is identical (row_map = identity)
+int uspmv_scs_reorder_ties(const uspmv_scs *s, uspmv_scs *r, std::vector<int32_t> *row_map);   // host/tlc_plan.cpp
 
 int uspmv_scs_layout(const uspmv_coo *m, int64_t C, int64_t sigma, int dtype, const int32_t *fixed_permutation,
                      uspmv_scs *s, std::vector<int64_t> *row_start, const char *who);   // host/scs_convert.cpp

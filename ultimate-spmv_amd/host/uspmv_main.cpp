@@ -376,10 +376,11 @@ int main(int argc, char **argv) {
         d.C = c.chunk_size; d.sigma = c.sigma; d.seg_nnz = c.seg_method == "seg-nnz"; d.comm_halos = c.comm_halos != 0;
         d.ba_synch = c.ba_synch != 0; d.tlc = c.tlc != 0; d.verbose = c.verbose != 0; d.bench_time = c.bench_time;
         d.matrix_name = c.matrix_file_name;
-        uspmv_coo_t *coo = load_matrix(c);
-        int rc = uspmv_run_distributed(d, coo);
-        uspmv_coo_free(coo);
-        return rc;
+        d.use_graph = c.use_graph != 0; d.print_comm_vol = c.print_comm_vol != 0; d.no_pack = c.no_pack != 0;
+        d.no_overlap = getenv("USPMV_NO_OVERLAP") != nullptr;
+        if (c.equilibrate) die("-equilibrate is a single-rank option in this round");
+        // (-par_pack: on the device the send buffer is packed by one kernel either way, as in the reference's device branch, code/classes_structs.hpp:787-806)
+        return uspmv_run_distributed(d);   // every rank generates / receives only its row block
     }
     int ndev = 0;
     ck(uspmv_device_count(&ndev), "uspmv_device_count");
