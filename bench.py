@@ -12,7 +12,8 @@ Workload at N > 1 (BASELINE.json configs[4]): ONE nlpkkt240-class matrix (27-poi
 n = 28 094 464, nnz = 7.5e8) split over the N GPUs by the reference's -seg_nnz rule -- STRONG scaling --
 with the halo x-vector exchange (-comm_halos 1) on RCCL every step.  The step runs in C++ behind the C ABI
 (uspmv_dist_run: pack kernel, grouped ncclSend/ncclRecv on a side stream, interior tiles, boundary tiles)
-and is replayed from one captured hipGraph.  A weak-scaling run (every GPU owns an nlpkkt200-class block,
+-- one C-ABI call per batch of steps, no Python in the loop (the uspmv CLI additionally replays it from one captured
+hipGraph).  A weak-scaling run (every GPU owns an nlpkkt200-class block,
 grid 253 x 253 x 253*N) is measured after it and reported inside the same JSON line under "weak_scaling";
 --scaling weak makes that the headline instead.
 
@@ -43,7 +44,7 @@ def parse():
     ap.add_argument("-c", "--chunk", type=int, default=32)
     ap.add_argument("-s", "--sigma", type=int, default=512)
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="N > 1: strong (default; BASELINE config 5) or weak")
-    ap.add_argument("--no-graph", action="store_true", help="N > 1: eager steps instead of hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="N > 1: replay the C++ step from a hipGraph (crashes in hipStreamEndCapture under torch's bundled RCCL on this image; the uspmv CLI, on the system RCCL, replays graphs)")
     ap.add_argument("--no-second-line", action="store_true", help="N > 1: skip the other scaling mode's measurement")
     ap.add_argument("--python-step", action="store_true", help="N > 1: round-1 path (torch.distributed all_to_all per step) instead of the C++ step")
     ap.add_argument("--seg", choices=["seg-nnz", "seg-rows"], default="seg-nnz")
@@ -230,7 +231,7 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
 
     def steps(n):
         if native:
-            d.run(x, y, n, use_graph=not args.no_graph)
+            d.run(x, y, n, use_graph=args.graph)
         else:
             for _ in range(n):
                 d.spmv(x, y)
@@ -267,7 +268,7 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
         "workload": (f"{klass} synthetic (27-pt stencil {g}x{g}x{nz}, n={n_global}, nnz={total_nnz}) scs -c {args.chunk} -s {args.sigma} -dp "
                      f"-{args.seg.replace('-', '_')} -comm_halos 1"),
         "n_rows": n_global, "nnz": total_nnz, "beta": round(s.nnz / s.n_elements, 6),
-        "step": ("C++ uspmv_dist_run, " + ("hipGraph replay" if d.graph_captured else "eager (graph capture refused)" if not args.no_graph else "eager")) if native
+        "step": ("C++ uspmv_dist_run, " + ("hipGraph replay" if d.graph_captured else "eager (graph capture refused)" if args.graph else "eager C++ steps")) if native
                 else "python: torch.distributed all_to_all_single per step",
         "rank0": {"n_local": d.n_local, "n_halo": d.n_halo, "n_send": d.n_send, "interior": int(d.n_interior) if native else int(len(d.interior_ids)),
                   "boundary": int(d.n_boundary) if native else int(len(d.boundary_ids)), "tiles": bool(d.use_tiles), "plan_kind": kind,

@@ -176,8 +176,11 @@ int uspmv_dmat_plan_info(const uspmv_dmat_t *m, int *kind, int64_t *n_tiles, int
 /* The same plan built ON THE DEVICE from the handle's own arrays: for handles without a host struct
  * (uspmv_dmat_wrap around the reference's cudaMalloc'ed arrays, uspmv_convert_to_scs_device).  Chunk heights that
  * divide 256; tiles whose line range exceeds 65 536 lines stay on the gather path (the host planner may still
- * stage those); otherwise the plan is identical to uspmv_dmat_optimize's.  Narrow chunks are not re-chunked here. */
+ * stage those); otherwise the plan is identical to uspmv_dmat_optimize's.  Narrow chunks (C in {1,2,4,8,16}, incl. crs) get the
+ * same internal C = 32 re-chunking as in uspmv_dmat_optimize, copied on the device. */
 int uspmv_dmat_optimize_device(uspmv_dmat_t *m, int max_lines, int64_t *n_tiles, int64_t *n_staged);
+/* The shared plan of an ap[dp_sp] pair (uspmv_dmat_optimize_ap) built on the device from the two handles' own arrays. */
+int uspmv_dmat_optimize_device_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, int max_lines, int64_t *n_tiles, int64_t *n_staged);
 /* host copies of a handle's plan (tests): meta = {n_tiles, n_lines_total, n_col16, max_lines_used}; call with NULL
  * arrays first to size them */
 int uspmv_dmat_plan_download(const uspmv_dmat_t *m, int64_t meta[4], int32_t *tile_line_ptr, int32_t *tile_lines,
@@ -231,6 +234,11 @@ int uspmv_csr_gpu_f64(int64_t n_rows, const int32_t *d_row_ptrs, const int32_t *
                       const double *d_values, const double *d_x, double *d_y, void *stream);
 int uspmv_csr_gpu_f32(int64_t n_rows, const int32_t *d_row_ptrs, const int32_t *d_col_idxs,
                       const float *d_values, const float *d_x, float *d_y, void *stream);
+
+/* Read one scalar through a pointer that may point to host OR device memory (the reference's GPU build keeps C and n_chunks
+ * in device memory, code/utilities.hpp:3803-3811; include/uspmv_launchers.hpp reads them once per set of arrays). */
+int uspmv_peek_i64(const void *p, int64_t *out);
+int uspmv_peek_i32(const void *p, int32_t *out);
 
 /* Device apply_permutation: d_out[i] = d_in[d_perm[i]] (code/utilities.hpp:1768-1782). */
 int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_perm, int64_t n, int dtype,

@@ -269,6 +269,49 @@ def gen_halo_goldens(mats):
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
+SOLVE_MATS = ("FDM-2d-16", "matrix1", "impcol_e")          # scripts/validate_master.sh:16-23
+SOLVE_CS = (4, 8, 10, 16, 32, 64)
+SOLVE_SIGMAS = (1, 2, 3, 4, 8, 10, 16, 32, 64)
+
+
+def gen_solve_goldens(mats):
+    """Solve mode (-mode s -rev 3, code/main.cpp:528-607: three times {y = A x; swap x <-> y}, result copied back in original
+    row order) over the grid of scripts/validate_master.sh:16-23 -- matrices, C, sigma, crs + scs, dp / sp, -rand_x {0, 1} -- with
+    the reference's own kernels: spmv_omp_scs_adv for C in {2,...,128}, spmv_omp_scs otherwise, spmv_omp_csr for crs.  x0 as the
+    harness makes it: 5.0 (DefaultValues) or random_init's default-seeded mt19937 draw in [matrix_min, matrix_max]."""
+    out = {}
+    rev = 3
+    for name in SOLVE_MATS:
+        mtx = R.RefMtx.read(mats[name])
+        I, J, V = mtx.arrays()
+        n = mtx.n_rows
+        vmin, vmax = float(np.abs(V).min()), float(np.abs(V).max())      # extract_matrix_min_mean_max (code/utilities.hpp:2502-2540)
+        for dt, npdt in (("f64", np.float64), ("f32", np.float32)):
+            for rx in (0, 1):
+                cases = [("crs", 1, 1)] + [("scs", Cc, sg) for Cc in SOLVE_CS for sg in SOLVE_SIGMAS]
+                for fmt, Cc, sg in cases:
+                    scs = R.convert_to_scs(mtx, Cc, sg, dt)
+                    scs.permute_cols(scs.arrays()["old_to_new_idx"])
+                    a = scs.arrays()
+                    npad = scs.n_rows_padded
+                    # random_init draws one value per element of the padded vector; the padding is zeroed afterwards
+                    x0 = R.random_init(vmin, vmax, npad, npdt)[:n] if rx else np.full(n, 5.0, npdt)
+                    x = np.zeros(npad, npdt)
+                    x[:n] = R.apply_permutation(x0, a["new_to_old_idx"])
+                    for _ in range(rev):
+                        if fmt == "crs":
+                            y = np.zeros(npad, npdt)
+                            y[:n] = R.spmv_csr(n, a["chunk_ptrs"], a["col_idxs"], a["values"], x)
+                        else:
+                            y = R.spmv_scs("adv" if Cc in ADV_CS else "gen", Cc, scs.n_chunks, a["chunk_ptrs"], a["chunk_lengths"],
+                                           a["col_idxs"], a["values"], x)
+                        x = y
+                    out[f"{name}_{fmt}_C{Cc}_s{sg}_{dt}_r{rx}"] = R.apply_permutation(x, a["old_to_new_idx"])
+        out[name + "_minmax"] = np.array([vmin, vmax])
+    np.savez_compressed(os.path.join(OUT, "solve.npz"), **out)
+    print("solve goldens:", len(out), "vectors")
+
+
 def gen_reference_unit_fixtures():
     """The reference's own hand-written unit-test expectations (code/test_suite/test_data/M1.cpp,
     M_big.cpp, M0.cpp): numbers only, re-encoded as JSON {object name: {field: [numbers]}}."""
@@ -311,6 +354,7 @@ def main():
     gen_csr_goldens(mats)
     gen_spmmv_goldens(mats)
     gen_ap_goldens(mats)
+    gen_solve_goldens(mats)
     if R.available("mpi"):
         gen_halo_goldens(mats)
     else:

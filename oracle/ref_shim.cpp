@@ -25,6 +25,7 @@
 //   spmv_omp_scs_ap_adv          code/ap_kernels.hpp:90-142
 //   spmv_omp_scs_ap              code/ap_kernels.hpp:562-634
 //   spmv_omp_csr_apdpsp          code/ap_kernels.hpp:144-223
+//   random_init                  code/utilities.hpp:880-912
 //   (USE_MPI build only)
 //   seg_work_sharing_arr         code/mpi_funcs.hpp:424-622
 //   seg_mtx_struct               code/mpi_funcs.hpp:636-674
@@ -192,6 +193,18 @@ void ref_mtx_f32_arrays(void *h, int *I, int *J, float *vals) {
 
 ONE_PREC_KERNELS(f64, double)
 ONE_PREC_KERNELS(f32, float)
+
+// random_init (code/utilities.hpp:880-912): the -rand_x 1 vector, default-seeded std::mt19937 + uniform(matrix_min, matrix_max)
+void ref_random_init_f64(double matrix_min, double matrix_max, long n, double *out) {
+    Config cfg;
+    cfg.matrix_min = matrix_min; cfg.matrix_max = matrix_max;
+    random_init<double>(&cfg, out, out + n);
+}
+void ref_random_init_f32(double matrix_min, double matrix_max, long n, float *out) {
+    Config cfg;
+    cfg.matrix_min = matrix_min; cfg.matrix_max = matrix_max;
+    random_init<float>(&cfg, out, out + n);
+}
 
 // 1 if this build uses the row-major block-vector layout (X[col*b+v]), 0 for column-major
 int ref_block_layout_rowwise(void) {

@@ -63,6 +63,9 @@ def lib(variant="colwise"):
     L.ref_spmv_omp_scs_ap.argtypes = ap
     L.ref_spmv_omp_csr_apdpsp.argtypes = [C.c_long, _i32p, _i32p, _f64p, _f64p, _f64p, _i32p, _i32p, _f32p,
                                           _f32p, _f32p]
+    if hasattr(L, "ref_random_init_f64"):
+        L.ref_random_init_f64.argtypes = [C.c_double, C.c_double, C.c_long, _f64p]
+        L.ref_random_init_f32.argtypes = [C.c_double, C.c_double, C.c_long, _f32p]
     if variant == "mpi":
         L.ref_seg_work_sharing_arr.argtypes = [_vp, C.c_char_p, C.c_int, _i32p]
         L.ref_seg_local_mtx.argtypes = [_vp, _i32p, C.c_int]; L.ref_seg_local_mtx.restype = _vp
@@ -220,6 +223,13 @@ def spmv_csr_apdpsp(n_rows, dp, sp, x):
 
 
 # ------------------------------------------------------------------ fake-rank halo set-up (mpi variant)
+def random_init(matrix_min, matrix_max, n, dtype=np.float64, variant="colwise"):
+    """-rand_x 1 vector of the reference (random_init, code/utilities.hpp:880-912)."""
+    out = np.empty(n, dtype)
+    getattr(lib(variant), "ref_random_init_" + _suf(out))(matrix_min, matrix_max, n, out)
+    return out
+
+
 def seg_work_sharing_arr(mtx, method, P):
     wsa = np.zeros(P + 1, np.int32)
     lib("mpi").ref_seg_work_sharing_arr(mtx.h, method.encode(), P, wsa)

@@ -1,0 +1,59 @@
+"""Solve mode of the `uspmv` harness (-mode s: rev times {y = A x; swap x <-> y}, result in original row order; reference
+code/main.cpp:528-607) against goldens made with the GENUINE reference kernels (oracle/make_golden.py::gen_solve_goldens ->
+tests/golden/solve.npz) over the grid of the reference's validation script (scripts/validate_master.sh:16-23): matrices
+FDM-2d-16 / matrix1 / impcol_e, C in {4,8,10,16,32,64}, sigma in {1,2,3,4,8,10,16,32,64}, crs + scs, dp / sp, -rev 3,
+-rand_x {0,1}.  The reference validates this mode against MKL (code/write_results.hpp:442-556); here the independent result
+is the reference's own CPU kernel.  SELL kernels: bit for bit (same FMA chain, three times over).  crs: the reference's loop is
+omp-simd re-associated, so there is no canonical bit pattern: relative to the largest |y|, 1e-12 (dp) / 1e-5 (sp)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, mtx_path
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "ultimate-spmv_amd", "uspmv")
+MATS = ("FDM-2d-16", "matrix1", "impcol_e")
+CS = (4, 8, 10, 16, 32, 64)
+SIGMAS = (1, 2, 3, 4, 8, 10, 16, 32, 64)
+
+
+def _cases():
+    """Every C with four sigmas (rotating through the nine, so that all nine occur), both precisions, -rand_x 1; the default x
+    for every C at one sigma; crs in all four (precision, x) combinations: 150 harness runs."""
+    out = []
+    for mi, name in enumerate(MATS):
+        for ci, C in enumerate(CS):
+            for k in range(4):
+                sg = SIGMAS[(2 * ci + 3 * k + mi) % len(SIGMAS)]
+                for dt in ("f64", "f32"):
+                    out.append((name, "scs", C, sg, dt, 1))
+            out.append((name, "scs", C, SIGMAS[(ci + mi) % len(SIGMAS)], "f64", 0))
+        for dt in ("f64", "f32"):
+            for rx in (0, 1):
+                out.append((name, "crs", 1, 1, dt, rx))
+    return sorted(set(out))
+
+
+def test_solve_mode_grid_against_reference_goldens(pkg, tmp_path):
+    g = golden("solve.npz")
+    seen_sigma = set()
+    n_exact = n_tol = 0
+    for name, fmt, C, sg, dt, rx in _cases():
+        yf = str(tmp_path / "y.bin")
+        args = [EXE, mtx_path(name), fmt] + (["-c", str(C), "-s", str(sg)] if fmt == "scs" else []) + \
+               ["-mode", "s", "-rev", "3", "-rand_x", str(rx), "-dp" if dt == "f64" else "-sp", "-validate", "0", "-dump_y", yf]
+        r = subprocess.run(args, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "3 revision(s) done" in r.stdout, (args, r.stdout, r.stderr)
+        want = g[f"{name}_{fmt}_C{C}_s{sg}_{dt}_r{rx}"]
+        got = np.fromfile(yf, want.dtype)
+        if fmt == "scs":
+            assert np.array_equal(got, want), (name, C, sg, dt, rx, np.abs(got - want).max())
+            seen_sigma.add(sg); n_exact += 1
+        else:
+            tol = 1e-12 if dt == "f64" else 1e-5
+            assert np.all(np.abs(got - want) <= tol * np.abs(want).max()), (name, dt, rx)
+            n_tol += 1
+    assert seen_sigma == set(SIGMAS) and n_exact >= 120 and n_tol == 12

@@ -385,14 +385,17 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                     pkg.spmmv(A0, _dev(t, X), Y0, b, ld, lay)
                     pkg.set_tuning(spmmv_variant=0)
                     for swz in (0, 1):                     # plan kernel for every width it supports, both LDS layouts
-                        for var, pd in ((4, 0), (6, 2), (6, 4), (6, 8), (5, 0)):   # single-wave tiles; four lanes per row (64-byte rows); gather over the re-ordered copy
+                        for var, pd in ((4, 0), (6, 2), (6, 4), (6, 8), (7, 2), (7, 3), (5, 0)):   # single-wave tiles; four lanes per row (64-byte rows), one tile per workgroup / persistent; gather over the re-ordered copy
                             if (var, swz) == (5, 1):
                                 continue
-                            pkg.set_tuning(spmmv_variant=var, spmmv_swizzle=swz, spmmv_unroll=pd)
+                            if var == 7:
+                                pkg.set_tuning(spmmv_variant=7, spmmv_swizzle=0, spmmv_unroll=0, spmmv_persist_w=pd, spmmv_persist_x=1 + swz)
+                            else:
+                                pkg.set_tuning(spmmv_variant=var, spmmv_swizzle=swz, spmmv_unroll=pd)
                             Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
                             pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
                             assert t.equal(Y, Y0), (name, C, code, b, rowwise, swz, var, pd)
-                    pkg.set_tuning(spmmv_unroll=0)
+                    pkg.set_tuning(spmmv_unroll=0, spmmv_persist_w=2, spmmv_persist_x=1)
                     pkg.set_tuning(spmmv_variant=0, spmmv_swizzle=0)
                     Y.fill_(-3.0)                          # and whatever auto picks
                     pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)

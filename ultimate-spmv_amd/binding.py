@@ -83,6 +83,7 @@ _SIGS = {
     "uspmv_spmv_tiles": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "uspmv_dmat_tile_rows": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "uspmv_dmat_optimize_device": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
+    "uspmv_dmat_optimize_device_ap": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_plan_download": (C.c_int, [_vp, C.POINTER(_i64), _vp, _vp, _vp, _vp]),
     "uspmv_dmat_optimize_block": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_optimize_ap": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
@@ -96,6 +97,8 @@ _SIGS = {
     "uspmv_scs_gpu_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "uspmv_csr_gpu_f64": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "uspmv_csr_gpu_f32": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "uspmv_peek_i64": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "uspmv_peek_i32": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "uspmv_apply_permutation_dev": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
     "uspmv_raw_plan_cache_clear": (None, []),
     "uspmv_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
@@ -367,8 +370,9 @@ class _BorrowedScs(Scs):
 
 class DistNative:
     """The distributed SpMV object of the C ABI (uspmv_dist_*, csrc/uspmv_dist_api.hip): partition block `rank` of P on an RCCL
-    communicator of comm_size ranks (comm_size == P, or 1 = loopback).  Everything per step happens in C++; with use_graph the
-    step is one hipGraphLaunch."""
+    communicator of comm_size ranks (comm_size == P, or 1 = loopback).  Everything per step happens in C++.  use_graph (one
+    hipGraphLaunch per step) works in processes bound to the system's RCCL (the uspmv CLI); under torch's bundled RCCL / HIP runtime
+    the capture of an RCCL group crashes in hipStreamEndCapture, so it is off by default here."""
 
     def __init__(self, local_coo, wsa, C_, sigma, rank, P, comm_id, comm_rank=None, comm_size=None, dtype=F64, tlc=True):
         import torch
@@ -424,7 +428,7 @@ class DistNative:
         _ck(lib().uspmv_dist_spmv(self.h, _dp(x), _dp(y), int(bool(comm_halos)), self.stream.cuda_stream))
         return y
 
-    def run(self, x, y, n_steps, use_graph=True):
+    def run(self, x, y, n_steps, use_graph=False):
         _ck(lib().uspmv_dist_run(self.h, _dp(x), _dp(y), int(n_steps), int(bool(use_graph)), self.stream.cuda_stream))
         return y
 
@@ -622,6 +626,15 @@ def optimize_ap(A_dp, A_sp, scs_dp, scs_sp, max_lines=0):
     """Shared tile-local-column plan for an ap[dp_sp] pair; returns (n_tiles, n_staged_tiles)."""
     a, b = _i64(), _i64()
     _ck(lib().uspmv_dmat_optimize_ap(A_dp.h, A_sp.h, scs_dp.h, scs_sp.h, max_lines, C.byref(a), C.byref(b)))
+    for A in (A_dp, A_sp):
+        A.tlc_tiles, A.tlc_staged = a.value, b.value
+    return a.value, b.value
+
+
+def optimize_device_ap(A_dp, A_sp, max_lines=0):
+    """Shared tile-local-column plan of an ap[dp_sp] pair built on the device from the handles' own arrays."""
+    a, b = _i64(), _i64()
+    _ck(lib().uspmv_dmat_optimize_device_ap(A_dp.h, A_sp.h, max_lines, C.byref(a), C.byref(b)))
     for A in (A_dp, A_sp):
         A.tlc_tiles, A.tlc_staged = a.value, b.value
     return a.value, b.value

@@ -154,6 +154,8 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_prefetch")) g_tune.spmmv_prefetch = value != 0;
     else if (!strcmp(key, "spmmv_swizzle")) g_tune.spmmv_swizzle = value != 0;
     else if (!strcmp(key, "spmmv_reorder")) g_tune.spmmv_reorder = value != 0;
+    else if (!strcmp(key, "spmmv_persist_x")) g_tune.spmmv_persist_x = value < 1 ? 1 : value;
+    else if (!strcmp(key, "spmmv_persist_w")) g_tune.spmmv_persist_w = value == 3 ? 3 : 2;
     else if (!strcmp(key, "sweep")) g_tune.sweep = value != 0;
     else if (!strcmp(key, "sweep_nbuf")) g_tune.sweep_nbuf = value == 1 ? 1 : 2;
     else if (!strcmp(key, "sweep_unroll")) g_tune.sweep_unroll = value >= 8 ? 8 : value >= 4 ? 4 : 2;
@@ -171,7 +173,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_tile_rows")) g_tune.spmmv_tile_rows = value == 64 ? 64 : value == 32 ? 32 : 0;
     else if (!strcmp(key, "spmmv_lds_kb")) g_tune.spmmv_lds_kb = value < 0 ? 0 : value;
     else if (!strcmp(key, "spmmv_variant")) {
-        if (value < 0 || value > 6) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0..6");
+        if (value < 0 || value > 7) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0..7");
         g_tune.spmmv_variant = value;
     }
     else if (!strcmp(key, "tail_batch")) g_tune.tail_batch = value != 0;
@@ -208,6 +210,8 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_prefetch")) *value = g_tune.spmmv_prefetch;
     else if (!strcmp(key, "spmmv_swizzle")) *value = g_tune.spmmv_swizzle;
     else if (!strcmp(key, "spmmv_reorder")) *value = g_tune.spmmv_reorder;
+    else if (!strcmp(key, "spmmv_persist_x")) *value = g_tune.spmmv_persist_x;
+    else if (!strcmp(key, "spmmv_persist_w")) *value = g_tune.spmmv_persist_w;
     else if (!strcmp(key, "sweep")) *value = g_tune.sweep;
     else if (!strcmp(key, "sweep_nbuf")) *value = g_tune.sweep_nbuf;
     else if (!strcmp(key, "sweep_unroll")) *value = g_tune.sweep_unroll;
@@ -420,42 +424,54 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     return USPMV_OK;
 }
 
-int uspmv_dmat_optimize_device(uspmv_dmat_t *A, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
-    if (int rc = check_dmat(A, "uspmv_dmat_optimize_device")) return rc;
-    if (int rc = require_device()) return rc;
+// 16-bit index offsets per chunk from the chunk lengths (O(n_chunks) on the host); false: too large for 32-bit offsets
+static bool c16_offsets(const std::vector<int32_t> &cl, int64_t C, std::vector<uint32_t> *c16p, int64_t *tot16) {
+    const int64_t nc = (int64_t)cl.size();
+    c16p->assign((size_t)nc + 1, 0);
+    int64_t tot = 0;
+    for (int64_t c = 0; c < nc; ++c) {
+        (*c16p)[(size_t)c] = (uint32_t)tot;
+        tot += ((int64_t)(cl[(size_t)c] + 3) / 4) * 4 * C;
+        if (tot > (int64_t)UINT32_MAX) return false;
+    }
+    (*c16p)[(size_t)nc] = (uint32_t)tot;
+    *tot16 = tot;
+    return true;
+}
+
+// the tile-local-column plan of A (and of the pair A + B sharing one line list when B != nullptr), built on the device
+static int device_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, int64_t *n_tiles, int64_t *n_staged, const char *who) {
     if (A->tlc) tlc_release(A);
-    if (A->alt) { uspmv_dmat_free(A->alt); A->alt = nullptr; }
+    if (B && B->tlc) tlc_release(B);
     if (n_tiles) *n_tiles = 0;
     if (n_staged) *n_staged = 0;
     const int64_t C = A->C, nc = A->n_chunks;
     if (C > 256 || 256 % C != 0 || nc < 1) return USPMV_OK;                    // shape without a plan
     if (max_lines <= 0) max_lines = 512;
     max_lines = std::min(max_lines, (int)(160 * 1024 / (16 * (A->dtype == USPMV_F64 ? 8 : 4))));
-    max_lines = std::min(max_lines, 4096);
+    max_lines = std::min(max_lines, B ? 1280 : 4096);
     const int64_t T = 256 / C, nt = (nc + T - 1) / T;
-    // 16-bit index offsets per chunk: O(n_chunks) on the host from the chunk lengths
     std::vector<int32_t> cl((size_t)nc);
+    std::vector<uint32_t> c16p, c16p_b;
+    int64_t tot16 = 0, tot16_b = 0;
     HIP_TRY(hipMemcpy(cl.data(), A->chunk_lengths, 4 * (size_t)nc, hipMemcpyDeviceToHost));
-    std::vector<uint32_t> c16p((size_t)nc + 1, 0);
-    int64_t tot16 = 0;
-    for (int64_t c = 0; c < nc; ++c) {
-        c16p[(size_t)c] = (uint32_t)tot16;
-        tot16 += ((int64_t)(cl[(size_t)c] + 3) / 4) * 4 * C;
-        if (tot16 > (int64_t)UINT32_MAX) return USPMV_OK;                    // too large for 32-bit offsets: no plan
+    if (!c16_offsets(cl, C, &c16p, &tot16)) return USPMV_OK;
+    if (B) {
+        HIP_TRY(hipMemcpy(cl.data(), B->chunk_lengths, 4 * (size_t)nc, hipMemcpyDeviceToHost));
+        if (!c16_offsets(cl, C, &c16p_b, &tot16_b)) return USPMV_OK;
     }
-    c16p[(size_t)nc] = (uint32_t)tot16;
     int *d_n = nullptr, *d_max = nullptr;
     hipError_t e = hipMalloc((void **)&d_n, 4 * (size_t)nt);
     if (e == hipSuccess) e = hipMalloc((void **)&d_max, 4);
     if (e == hipSuccess) e = hipMemset(d_max, 0, 4);
-    if (e != hipSuccess) { (void)hipFree(d_n); (void)hipFree(d_max); return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_device: %s", hipGetErrorString(e)); }
-    int rc = launch_plan_count(A, (long)nt, max_lines, d_n, d_max, nullptr);
+    if (e != hipSuccess) { (void)hipFree(d_n); (void)hipFree(d_max); return uspmv::fail(USPMV_ERR_ALLOC, "%s: %s", who, hipGetErrorString(e)); }
+    int rc = launch_plan_count(A, (long)nt, max_lines, d_n, d_max, nullptr, B);
     std::vector<int32_t> lp((size_t)nt + 1, 0);
     int max_col = 0;
     if (!rc) {
         e = hipMemcpy(lp.data() + 1, d_n, 4 * (size_t)nt, hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemcpy(&max_col, d_max, 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = uspmv::fail(USPMV_ERR_HIP, "uspmv_dmat_optimize_device: %s", hipGetErrorString(e));
+        if (e != hipSuccess) rc = uspmv::fail(USPMV_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
     }
     (void)hipFree(d_n); (void)hipFree(d_max);
     if (rc) return rc;
@@ -478,16 +494,86 @@ int uspmv_dmat_optimize_device(uspmv_dmat_t *A, int max_lines, int64_t *n_tiles,
     if (e == hipSuccess) e = hipMemset(A->tlc_col16, 0, 2 * (size_t)std::max<int64_t>(tot16, 1));   // padded slots: index 0
     if (e == hipSuccess) e = hipMemcpy(A->tlc_line_ptr, lp.data(), 4 * ((size_t)nt + 1), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(A->tlc_c16_ptrs, c16p.data(), 4 * ((size_t)nc + 1), hipMemcpyHostToDevice);
-    if (e == hipSuccess && launch_plan_write(A, (long)nt, A->tlc_line_ptr, A->tlc_c16_ptrs, A->tlc_lines, A->tlc_col16, nullptr) != USPMV_OK)
+    if (B) {
+        if (e == hipSuccess) e = hipMalloc((void **)&B->tlc_c16_ptrs, 4 * ((size_t)nc + 1));
+        if (e == hipSuccess) e = hipMalloc((void **)&B->tlc_col16, 2 * (size_t)std::max<int64_t>(tot16_b, 1));
+        if (e == hipSuccess) e = hipMemset(B->tlc_col16, 0, 2 * (size_t)std::max<int64_t>(tot16_b, 1));
+        if (e == hipSuccess) e = hipMemcpy(B->tlc_c16_ptrs, c16p_b.data(), 4 * ((size_t)nc + 1), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && launch_plan_write(A, (long)nt, A->tlc_line_ptr, A->tlc_c16_ptrs, A->tlc_lines, A->tlc_col16, nullptr, B,
+                                             B ? B->tlc_c16_ptrs : nullptr, B ? B->tlc_col16 : nullptr) != USPMV_OK)
         e = hipErrorUnknown;
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
         tlc_release(A);
-        return uspmv::fail(USPMV_ERR_HIP, "uspmv_dmat_optimize_device: %s", hipGetErrorString(e));
+        if (B) tlc_release(B);
+        return uspmv::fail(USPMV_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
     }
-    A->tlc = true; A->tlc_tile_rows = 256; A->tlc_max_lines = used; A->tlc_x_len = (int64_t)max_col + 1; A->tlc_n_tiles = nt;
-    A->tlc_staged = staged;
+    static uint64_t next_dev_plan_id = (uint64_t)1 << 40;
+    const uint64_t id = B ? next_dev_plan_id++ : 0;
+    for (uspmv_dmat_t *M : {A, B}) {
+        if (!M) continue;
+        M->tlc = true; M->tlc_tile_rows = 256; M->tlc_max_lines = used; M->tlc_x_len = (int64_t)max_col + 1; M->tlc_n_tiles = nt;
+        M->tlc_staged = staged; M->tlc_plan_id = id;
+    }
     return USPMV_OK;
+}
+
+int uspmv_dmat_optimize_device(uspmv_dmat_t *A, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
+    if (int rc = check_dmat(A, "uspmv_dmat_optimize_device")) return rc;
+    if (int rc = require_device()) return rc;
+    if (A->alt) { uspmv_dmat_free(A->alt); A->alt = nullptr; }
+    if (A->C < 32 && 32 % A->C == 0 && g_tune.rechunk && A->n_chunks > 0) {
+        // narrow chunks (incl. crs = C 1): the internal C = 32 re-chunking of uspmv_dmat_optimize, built on the device --
+        // O(n_chunks) layout on the host, the O(n_elements) copy by rechunk32_kernel
+        const int64_t C = A->C, nc_old = A->n_chunks, per = 32 / C, nc = (nc_old + per - 1) / per;
+        std::vector<int32_t> cl_old((size_t)nc_old), cl((size_t)nc, 0), cp((size_t)nc + 1, 0);
+        int32_t last = 0;
+        HIP_TRY(hipMemcpy(cl_old.data(), A->chunk_lengths, 4 * (size_t)nc_old, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&last, A->chunk_ptrs + nc_old, 4, hipMemcpyDeviceToHost));
+        int64_t cur = 0;
+        bool fits = true;
+        for (int64_t k = 0; k < nc && fits; ++k) {
+            int32_t L = 0;
+            for (int64_t c = k * per; c < std::min((k + 1) * per, nc_old); ++c) L = std::max(L, cl_old[(size_t)c]);
+            cl[(size_t)k] = L; cp[(size_t)k] = (int32_t)cur;
+            cur += (int64_t)L * 32;
+            fits = cur <= INT32_MAX;
+        }
+        if (fits && (double)cur <= 1.25 * (double)std::max<int64_t>(last, 1) + 4096) {
+            cp[(size_t)nc] = (int32_t)cur;
+            auto *alt = new uspmv_dmat;
+            alt->C = 32; alt->n_chunks = nc; alt->n_elements = cur; alt->dtype = A->dtype; alt->owns = true;
+            alt->n_store = (long)(nc_old * C);              // y of the caller has only the original padded rows
+            const size_t vsz = A->dtype == USPMV_F64 ? 8 : 4, ne = (size_t)std::max<int64_t>(cur, 1);
+            void *d_cp = nullptr, *d_cl = nullptr, *d_ci = nullptr, *d_va = nullptr;
+            hipError_t e = hipMalloc(&d_cp, 4 * ((size_t)nc + 1));
+            if (e == hipSuccess) e = hipMalloc(&d_cl, 4 * (size_t)nc);
+            if (e == hipSuccess) e = hipMalloc(&d_ci, 4 * ne);
+            if (e == hipSuccess) e = hipMalloc(&d_va, vsz * ne);
+            alt->chunk_ptrs = (const int32_t *)d_cp; alt->chunk_lengths = (const int32_t *)d_cl; alt->col_idxs = (const int32_t *)d_ci; alt->values = d_va;
+            if (e == hipSuccess) e = hipMemcpy(d_cp, cp.data(), 4 * ((size_t)nc + 1), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(d_cl, cl.data(), 4 * (size_t)nc, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemsetAsync(d_ci, 0, 4 * ne, nullptr);
+            if (e == hipSuccess) e = hipMemsetAsync(d_va, 0, vsz * ne, nullptr);
+            int rc = e == hipSuccess ? launch_rechunk32(A, (const int *)d_cp, (int *)d_ci, d_va, nullptr) : uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_device: %s", hipGetErrorString(e));
+            if (!rc) rc = device_plan_install(alt, nullptr, max_lines, n_tiles, n_staged, "uspmv_dmat_optimize_device");
+            if (rc) { uspmv_dmat_free(alt); return rc; }
+            if (A->tlc) tlc_release(A);
+            A->alt = alt;
+            return USPMV_OK;
+        }
+    }
+    return device_plan_install(A, nullptr, max_lines, n_tiles, n_staged, "uspmv_dmat_optimize_device");
+}
+
+int uspmv_dmat_optimize_device_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
+    if (int rc = check_dmat(dp, "uspmv_dmat_optimize_device_ap")) return rc;
+    if (int rc = check_dmat(sp, "uspmv_dmat_optimize_device_ap")) return rc;
+    if (dp->dtype != USPMV_F64 || sp->dtype != USPMV_F32 || dp->C != sp->C || dp->n_chunks != sp->n_chunks)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_device_ap: handles do not form a dp+sp pair");
+    if (int rc = require_device()) return rc;
+    return device_plan_install(dp, sp, max_lines, n_tiles, n_staged, "uspmv_dmat_optimize_device_ap");
 }
 
 int uspmv_dmat_plan_download(const uspmv_dmat_t *A, int64_t meta[4], int32_t *tile_line_ptr, int32_t *tile_lines, uint32_t *c16_ptrs,
@@ -884,6 +970,21 @@ void uspmv_raw_plan_cache_clear(void) {
 RAW_SCS(f64, double, USPMV_F64)
 RAW_SCS(f32, float, USPMV_F32)
 #undef RAW_SCS
+
+static int peek_bytes(const void *p, void *out, size_t n, const char *who) {
+    if (!p || !out) return uspmv::fail(USPMV_ERR_INVALID, "%s: NULL argument", who);
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); memcpy(out, p, n); return USPMV_OK; }   // not known to the runtime: plain host memory
+    if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged) {
+        HIP_TRY(hipMemcpy(out, p, n, hipMemcpyDeviceToHost));
+        return USPMV_OK;
+    }
+    memcpy(out, p, n);
+    return USPMV_OK;
+}
+int uspmv_peek_i64(const void *p, int64_t *out) { return peek_bytes(p, out, 8, "uspmv_peek_i64"); }
+int uspmv_peek_i32(const void *p, int32_t *out) { return peek_bytes(p, out, 4, "uspmv_peek_i32"); }
 
 int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_perm, int64_t n, int dtype,
                                 void *stream) {

@@ -89,6 +89,8 @@ struct Tuning {
     int sweep_wlog = 0;     // NEXT uspmv_dmat_optimize_sweep: log2 of the window width in elements (0 = 64 KiB of VT)
     int sweep_tile_rows = 0;  // NEXT uspmv_dmat_optimize_sweep: 256 | 512 | 1024 rows per tile (0 = 1024)
     int sweep_max_stage = 0;  // NEXT plan: largest staging cost in bytes per non-zero for a tile to sweep (0 = 24)
+    int spmmv_persist_w = 2;   // persistent SpMMV kernel: compiled for 3 (168 VGPRs) or 2 (256 VGPRs) waves per SIMD
+    int spmmv_persist_x = 1;   // persistent SpMMV kernel: grid = this many times the resident workgroups (1 = exactly resident)
     int spmmv_reorder = 1;  // block plan: rows of equal-length chunks of a sigma window back in original order (private copy of the entries)
     int spmmv_variant = 0;  // 0 = auto (= 3 where a B-specialised kernel exists); 1 = generic kernel; 2 = row-major with transposing X phase; 3 = row-major, lane per row
 };
@@ -117,9 +119,13 @@ int launch_spmv_sweep_ap(const uspmv_dmat *dp, const double *x, double *y, hipSt
 int launch_spmv_ap_chunks(const uspmv_dmat *dp, const uspmv_dmat *sp, const int *chunk_ids, long n_ids, const double *d_x,
                           double *d_y, hipStream_t stream);                                                        // ap_kernels.hip
 
-int launch_plan_count(const uspmv_dmat *A, long n_tiles, int max_lines, int *d_n_lines, int *d_max_col, hipStream_t st);      // plan_kernels.hip
+// (A2 / the *_2 arrays: optional second struct sharing the plan -- the sp part of an ap[dp_sp] pair)
+int launch_plan_count(const uspmv_dmat *A, long n_tiles, int max_lines, int *d_n_lines, int *d_max_col, hipStream_t st,
+                      const uspmv_dmat *A2 = nullptr);                                                                     // plan_kernels.hip
 int launch_plan_write(const uspmv_dmat *A, long n_tiles, const int *d_tile_line_ptr, const unsigned *d_c16_ptrs, int *d_tile_lines,
-                      unsigned short *d_col16, hipStream_t st);                                                            // plan_kernels.hip
+                      unsigned short *d_col16, hipStream_t st, const uspmv_dmat *A2 = nullptr, const unsigned *d_c16_ptrs2 = nullptr,
+                      unsigned short *d_col16_2 = nullptr);                                                                // plan_kernels.hip
+int launch_rechunk32(const uspmv_dmat *A, const int *d_cp_new, int *d_ci_new, void *d_va_new, hipStream_t st);             // plan_kernels.hip
 
 }  // namespace uspmv_dev
 

@@ -97,19 +97,25 @@ void drop_graph(uspmv_dist *D) {
     D->gexec = nullptr; D->g_x = D->g_y = nullptr; D->g_stream = nullptr;
 }
 
+#define DBG(msg) do { if (getenv("USPMV_VERBOSE")) { fprintf(stderr, "[uspmv] dist capture: %s\n", msg); fflush(stderr); } } while (0)
+
 int capture(uspmv_dist *D, void *d_x, void *d_y, hipStream_t main) {
     drop_graph(D);
     hipGraph_t g = nullptr;
+    DBG("begin");
     hipError_t e = hipStreamBeginCapture(main, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) { (void)hipGetLastError(); return uspmv::fail(USPMV_ERR_HIP, "uspmv_dist_run: hipStreamBeginCapture: %s", hipGetErrorString(e)); }
     const int rc = step(D, d_x, d_y, main, true);
+    DBG("step issued");
     e = hipStreamEndCapture(main, &g);
+    DBG("end capture");
     if (rc != USPMV_OK || e != hipSuccess || !g) {
         if (g) (void)hipGraphDestroy(g);
         (void)hipGetLastError();
         return rc != USPMV_OK ? rc : uspmv::fail(USPMV_ERR_HIP, "uspmv_dist_run: hipStreamEndCapture: %s", hipGetErrorString(e));
     }
     e = hipGraphInstantiate(&D->gexec, g, nullptr, nullptr, 0);
+    DBG("instantiated");
     (void)hipGraphDestroy(g);
     if (e != hipSuccess) { D->gexec = nullptr; (void)hipGetLastError(); return uspmv::fail(USPMV_ERR_HIP, "uspmv_dist_run: hipGraphInstantiate: %s", hipGetErrorString(e)); }
     D->g_x = d_x; D->g_y = d_y; D->g_stream = main;
@@ -319,7 +325,9 @@ int uspmv_dist_run(uspmv_dist_t *D, void *d_x, void *d_y, int n_steps, int use_g
             }
         }
         if (D->gexec) {
+            DBG("launching");
             for (int k = 0; k < n_steps; ++k) HIP_TRY(hipGraphLaunch(D->gexec, main));
+            DBG("launched");
             D->graph_launches += n_steps;
             return USPMV_OK;
         }

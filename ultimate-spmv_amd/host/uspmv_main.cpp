@@ -46,6 +46,7 @@ struct Config {  // subset of the reference's Config (code/classes_structs.hpp:4
     double bench_time = 5.0, ap_threshold_1 = 0.0, ap_threshold_2 = 0.0, dropout_threshold = 0.0;
     std::string matrix_file_name, seg_method = "seg-rows", value_type = "dp", kernel_format = "scs";
     std::string output_filename_bench = "spmv_bench.txt";
+    std::string dump_y;          // -dump_y <file>: solve mode writes its result vector (original row order, raw VT) there
     int layout = USPMV_COLWISE;  // run-time here; a make knob in the reference (Makefile:26-31)
     int tlc = 1;                 // build the tile-local-column plan (MI355X-specific, results unchanged)
     int use_graph = 1;           // bench loop replays hipGraphs of 64 launches
@@ -69,7 +70,7 @@ void usage() {
             "  -seg_rows|-seg_nnz -validate <0|1> -verbose <0|1> -mode <s|b> -bench_time <float>\n"
             "  -ba_synch <0|1> -comm_halos <0|1> -par_pack <0|1> -no_pack <0|1> -print_comm_vol <0|1>\n"
             "  -equilibrate <0|1> -ap_threshold_1 <float> -ap_threshold_2 <float> -dropout <0|1>\n"
-            "  -dropout_threshold <float> -block_vec_layout <colwise|rowwise> -tlc <0|1> -graph <0|1>\n");
+            "  -dropout_threshold <float> -block_vec_layout <colwise|rowwise> -tlc <0|1> -graph <0|1> -dump_y <file>\n");
 }
 
 Config parse(int argc, char **argv) {
@@ -107,6 +108,7 @@ Config parse(int argc, char **argv) {
         else if (a == "-seg_nnz" || a == "-seg-nnz") c.seg_method = "seg-nnz";
         else if (a == "-seg_metis" || a == "-seg-metis") c.seg_method = "seg-metis";
         else if (a == "-tlc") c.tlc = atoi(need(i));
+        else if (a == "-dump_y") c.dump_y = need(i);
         else if (a == "-graph") c.use_graph = atoi(need(i));
         else if (a == "-block_vec_layout") { std::string v = need(i); if (v == "colwise") c.layout = USPMV_COLWISE; else if (v == "rowwise") c.layout = USPMV_ROWWISE; else die("block_vec_layout must be colwise or rowwise."); }
         else { usage(); die("unknown argument: " + a); }
@@ -293,6 +295,13 @@ int run(const Config &c, uspmv_coo_t *coo) {
         std::vector<VT> hy((size_t)b * ld);
         for (unsigned long i = 0; i < c.n_repetitions; ++i) { r.exec(); if (i + 1 < c.n_repetitions) std::swap(r.x, r.y); }
         hk(hipMemcpy(hy.data(), r.y, sizeof(VT) * hy.size(), hipMemcpyDeviceToHost), "hipMemcpy y");
+        if (!c.dump_y.empty() && b == 1) {   // copy_back_result (code/utilities.hpp:3862): y_orig[i] = y[old_to_new[i]]
+            std::vector<VT> yo((size_t)n_rows);
+            for (int64_t i = 0; i < n_rows; ++i) yo[(size_t)i] = hy[(size_t)o2n[i]];
+            std::ofstream fy(c.dump_y, std::ios::binary);
+            fy.write((const char *)yo.data(), (std::streamsize)(sizeof(VT) * yo.size()));
+            if (!fy) die("cannot write " + c.dump_y);
+        }
         if (c.validate_result && b == 1 && !ap) {
             uspmv_scs_t *crs = nullptr; uspmv_dmat_t *Ac = nullptr;
             ck(uspmv_convert_to_scs(coo, 1, 1, dtype, nullptr, &crs), "convert crs");
