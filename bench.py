@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("-c", "--chunk", type=int, default=32)
     ap.add_argument("-s", "--sigma", type=int, default=512)
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="N > 1: strong (default; BASELINE config 5) or weak")
+    ap.add_argument("--grid2", type=int, default=0, help="N > 1: grid edge of the second (other scaling mode) measurement (default 253 weak / 304 strong)")
     ap.add_argument("--graph", action="store_true", help="N > 1: replay the C++ step from a hipGraph (crashes in hipStreamEndCapture under torch's bundled RCCL on this image; the uspmv CLI, on the system RCCL, replays graphs)")
     ap.add_argument("--no-second-line", action="store_true", help="N > 1: skip the other scaling mode's measurement")
     ap.add_argument("--python-step", action="store_true", help="N > 1: round-1 path (torch.distributed all_to_all per step) instead of the C++ step")
@@ -207,15 +208,27 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
     del counts
     loc = pkg.gen_stencil27(g, g, nz, row_begin=int(wsa[rank]), row_end=int(wsa[rank + 1]))
     native = not args.python_step and not os.environ.get("USPMV_BENCH_ONE_DEVICE")
+    native_error = None
     if native:
         idt = torch.zeros(128, dtype=torch.uint8, device=dev)
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
-        d = pkg.DistNative(loc, wsa, args.chunk, args.sigma, rank, world, bytes(idt.cpu().numpy().tobytes()), tlc=not args.no_tlc)
-        if args.no_overlap:
-            d.set_overlap(False)
-    else:
+        try:
+            d = pkg.DistNative(loc, wsa, args.chunk, args.sigma, rank, world, bytes(idt.cpu().numpy().tobytes()), tlc=not args.no_tlc)
+            if args.no_overlap:
+                d.set_overlap(False)
+        except Exception as e:          # e.g. ncclCommInitRank refused: every rank must take the same road, and the line must say so
+            native_error = f"{type(e).__name__}: {e}"
+            d = None
+        bad = torch.tensor([1 if d is None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            native_error = native_error or "another rank could not create the C++ step object"
+            if d is not None:
+                d.close()
+            native = False
+    if not native:
         d = DistSpmv(loc, wsa, args.chunk, args.sigma, B.F64, device=dev, overlap=not args.no_overlap, tlc=not args.no_tlc)
     del loc
     x = d.new_x(np.full(d.n_local, 5.0))          # DefaultValues::x (code/classes_structs.hpp:1799-1800)
@@ -269,7 +282,7 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
                      f"-{args.seg.replace('-', '_')} -comm_halos 1"),
         "n_rows": n_global, "nnz": total_nnz, "beta": round(s.nnz / s.n_elements, 6),
         "step": ("C++ uspmv_dist_run, " + ("hipGraph replay" if d.graph_captured else "eager (graph capture refused)" if args.graph else "eager C++ steps")) if native
-                else "python: torch.distributed all_to_all_single per step",
+                else "python: torch.distributed all_to_all_single per step" + (f" (C++ step object unavailable: {native_error})" if native_error else ""),
         "rank0": {"n_local": d.n_local, "n_halo": d.n_halo, "n_send": d.n_send, "interior": int(d.n_interior) if native else int(len(d.interior_ids)),
                   "boundary": int(d.n_boundary) if native else int(len(d.boundary_ids)), "tiles": bool(d.use_tiles), "plan_kind": kind,
                   "local_kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(bytes_local),
@@ -330,7 +343,7 @@ def main():
         other = None
         if not args.no_second_line:
             second = "weak" if first == "strong" else "strong"
-            other = run_distributed(args, pkg, B, torch, dist, dev, world, rank, second, 253 if second == "weak" else 304)
+            other = run_distributed(args, pkg, B, torch, dist, dev, world, rank, second, args.grid2 or (253 if second == "weak" else 304))
         r0 = res["rank0"]
         out = {
             "metric": "SpMV GFLOP/s (SELL-32-512 dp; achieved HBM GB/s in roofline)",
@@ -344,7 +357,7 @@ def main():
                          "frac": round(r0["local_kernel_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "rank 0's local SpMV (interior + boundary tiles, no exchange): " + ("scs_spmv_tlc<double,32>" if r0["plan_kind"] == 1 else "scs_spmv_rows<double,32,8>"),
                          "kernel_ms": r0["local_kernel_ms"], "algorithmic_bytes_per_launch": r0["algorithmic_bytes"],
-                         "step_frac_of_n_gpu_roofline": round(sum([r0["algorithmic_bytes"]]) / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                         "rank0_step_frac": round(r0["algorithmic_bytes"] / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "setup_s": res["setup_s"],
         }
         if other is not None:

@@ -264,8 +264,15 @@ def test_device_plan_builder_matches_host_planner(pkg, orc, torch_cuda):
             s, a, xp = _prep(pkg, m, C, sigma, code, make_x(m.n_rows))
             pkg.set_tuning(rechunk=0)                         # compare like with like: no internal C = 32 re-chunking
             Ah = pkg.DeviceMatrix(s); Ah.optimize(s, max_lines)
-            pkg.set_tuning(rechunk=1)
             Ad = pkg.DeviceMatrix(s); Ad.optimize_device(max_lines)
+            pkg.set_tuning(rechunk=1)
+            if C < 32:                                        # narrow chunks: the device builder re-chunks to C = 32 like the host one
+                Ar = pkg.DeviceMatrix(s); Ar.optimize_device(max_lines)
+                Ahr = pkg.DeviceMatrix(s); Ahr.optimize(s, max_lines)
+                assert Ar.plan_info() == Ahr.plan_info() and Ar.plan_info()[0] == 1
+                yr = t.full((s.n_rows_padded,), 3.0, dtype=Ar.torch_dtype, device="cuda")
+                pkg.spmv(Ar, _dev(t, xp), yr)
+                assert np.array_equal(yr.cpu().numpy(), orc.spmv_scs(s.C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)), (name, C, code, "device re-chunk")
             assert (Ad.tlc_tiles, Ad.tlc_staged) == (Ah.tlc_tiles, Ah.tlc_staged), (name, C, code)
             ph, pd = Ah.plan_download(), Ad.plan_download()
             assert (ph is None) == (pd is None)

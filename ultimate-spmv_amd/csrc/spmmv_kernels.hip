@@ -448,7 +448,7 @@ __device__ __forceinline__ double quad_bcast(double v) {
 template <int U>
 __device__ __forceinline__ float quad_bcast(float v) { return __int_as_float(quad_bcast<U>(__float_as_int(v))); }
 
-template <typename VT, int B, bool NT, bool YCOL, int C, bool SWZ, int NG>
+template <typename VT, int B, bool NT, bool YCOL, int C, bool SWZ, int NG, int MAXP>
 __global__ void __launch_bounds__(256) scs_spmmv_quad(const long n_chunks, const int *__restrict__ chunk_ptrs,
         const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const VT *__restrict__ values,
         const VT *__restrict__ X, VT *__restrict__ Y, const long ld, const int *__restrict__ tile_line_ptr,
@@ -502,30 +502,28 @@ __global__ void __launch_bounds__(256) scs_spmmv_quad(const long n_chunks, const
                 }
             }
         };
+        // ---- 1. the X-row list entries this lane needs for its DMA pieces, straight into registers (piece p = (wave + 4k)*64 + lane
+        //         <-> list entry p >> 2): the one round trip nothing else can overlap
+        const int np = (ablate == 1 || ablate == 3) ? 0 : nl << 2;
+        int xr[MAXP];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const int p = (wave + 4 * k) * 64 + lane;
+            xr[k] = -1;
+            if (p < np) xr[k] = tile_xrows[lp0 + (p >> 2)];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- 2. X rows -> LDS by DMA (64 pieces of 16 bytes per wave-instruction) and, behind them, the wave's whole share of
+        //         matrix entries: both bursts are in flight together
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k)
+            if (xr[k] >= 0) {
+                const unsigned kk = (unsigned)((wave + 4 * k) * 64 + lane) >> 2;
+                const unsigned piece = (unsigned)q ^ (SWZ ? (kk >> 2) & 3u : 0u);
+                __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(X + (long)xr[k] * B + piece * VW), (lds_void_t *)(tlc_smem + (wave + 4 * k) * 1024), 16, 0, 0);
+            }
         load_pass(0);
         if (rem) { ixt = ld_stream<NT>(ip + (long)ngf * 4 * C); if (q < rem) at = ld_stream<NT>(vp + (long)ngf * 4 * C); }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- 2. the tile's X-row list -> LDS (behind the X rows), by DMA
-        int *rl = (int *)(tlc_smem + x_bytes);
-        if (ablate != 3) {
-#pragma unroll 1
-            for (int r0 = wave * 64; r0 < nl; r0 += 256)
-                if (r0 + lane < nl)
-                    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(tile_xrows + lp0 + r0 + lane), (lds_void_t *)(rl + r0), 4, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (retires in order: also the entries requested above)
-            __syncthreads();
-        }
-        // ---- 3. X rows -> LDS by DMA: piece p = (list position p >> 2, 16-byte piece p & 3), 64 pieces per wave-instruction
-        const int np = (ablate == 1 || ablate == 3) ? 0 : nl << 2;
-#pragma unroll 1
-        for (int t0 = wave; t0 * 64 < np; t0 += 4) {
-            const int p = t0 * 64 + lane;
-            if (p < np) {
-                const unsigned k = (unsigned)p >> 2;
-                const unsigned piece = ((unsigned)p & 3u) ^ (SWZ ? (k >> 2) & 3u : 0u);
-                __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(X + (long)rl[k] * B + piece * VW), (lds_void_t *)(tlc_smem + t0 * 1024), 16, 0, 0);
-            }
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // ---- 4. arithmetic from registers
@@ -831,13 +829,13 @@ void launch_spmmv_tlc_g(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool y
 }
 
 
-template <typename VT, int B, int CT, bool SWZ, int PD>
-void launch_spmmv_quad_g(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
-    const size_t x_bytes = (size_t)A->bt_max_rows * B * sizeof(VT);
-    const size_t lds = x_bytes + (((size_t)A->bt_max_rows * 4 + 15) & ~(size_t)15);
+template <typename VT, int B, int CT, bool SWZ, int PD, int MAXP>
+void launch_spmmv_quad_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    const size_t x_bytes = (size_t)MAXP * 4 * 1024;          // whole DMA pieces: MAXP per wave, four waves
+    const size_t lds = x_bytes;
 #define QD_LAUNCH(NTV, YC)                                                                                              \
     do {                                                                                                                \
-        auto kfn = scs_spmmv_quad<VT, B, NTV, YC, CT, SWZ, PD>;                                                         \
+        auto kfn = scs_spmmv_quad<VT, B, NTV, YC, CT, SWZ, PD, MAXP>;                                                   \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)A->bt_n_tiles), dim3(256), lds, st, (long)A->n_chunks,                   \
                            A->chunk_ptrs, A->chunk_lengths, A->bt_cols ? A->bt_cols : A->col_idxs,                       \
@@ -850,12 +848,18 @@ void launch_spmmv_quad_g(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool 
 #undef QD_LAUNCH
 }
 
+template <typename VT, int B, int CT, bool SWZ, int PD>
+void launch_spmmv_quad_g(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    const int pieces = (A->bt_max_rows * 4 + 255) / 256;     // DMA pieces per wave for the largest tile (BT_LDS_CAP = 80 KiB: <= 20)
+    if (pieces <= 8) launch_spmmv_quad_m<VT, B, CT, SWZ, PD, 8>(A, X, Y, ld, ycol, st);
+    else if (pieces <= 13) launch_spmmv_quad_m<VT, B, CT, SWZ, PD, 13>(A, X, Y, ld, ycol, st);
+    else launch_spmmv_quad_m<VT, B, CT, SWZ, PD, 20>(A, X, Y, ld, ycol, st);
+}
+
 template <typename VT, int B>
 void launch_spmmv_quad(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
     const bool swz = g_tune.spmmv_swizzle != 0;
-    const int pd = g_tune.spmmv_unroll == 2 ? 8 : g_tune.spmmv_unroll == 8 ? 28 : 20;    // groups of four slots held in registers per pass
-#define QD_PD(CTV, SW) do { if (pd == 8) launch_spmmv_quad_g<VT, B, CTV, SW, 8>(A, X, Y, ld, ycol, st); else if (pd == 28) launch_spmmv_quad_g<VT, B, CTV, SW, 28>(A, X, Y, ld, ycol, st); \
-                            else launch_spmmv_quad_g<VT, B, CTV, SW, 20>(A, X, Y, ld, ycol, st); } while (0)
+#define QD_PD(CTV, SW) launch_spmmv_quad_g<VT, B, CTV, SW, 20>(A, X, Y, ld, ycol, st)   /* 20 groups of four slots per lane and pass */
     if (A->C == 32) { if (swz) QD_PD(32, true); else QD_PD(32, false); }
     else { if (swz) QD_PD(64, true); else QD_PD(64, false); }
 #undef QD_PD
@@ -907,8 +911,9 @@ void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
     if constexpr (RB == 64) {
         // 64-byte rows: the four-lanes-per-row kernel over 64-row tiles of the block plan (variant 6; auto when the plan is there)
         if (A->bt && A->bt_tile_rows == 64 && (g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 6 || g_tune.spmmv_variant == 7) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
-            // variant 7 (and auto): persistent, pipelined over tiles; variant 6: one tile per workgroup
-            if (g_tune.spmmv_variant != 6 && !g_tune.spmmv_swizzle && !g_tune.ablate && launch_spmmv_quadp<VT, B>(A, X, Y, ld, ycol, st)) return;
+            // variant 6 (and auto): one tile per workgroup, three workgroups per CU; variant 7: persistent and pipelined over tiles, but 222
+            // registers -> two workgroups per CU, which measures 5-7 % slower (profiles/r02/spmmv_variants.txt)
+            if (g_tune.spmmv_variant == 7 && !g_tune.spmmv_swizzle && !g_tune.ablate && launch_spmmv_quadp<VT, B>(A, X, Y, ld, ycol, st)) return;
             launch_spmmv_quad<VT, B>(A, X, Y, ld, ycol, st);
             return;
         }

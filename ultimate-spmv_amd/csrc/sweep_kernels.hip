@@ -25,34 +25,62 @@ __device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-// One window of one wave: rounds of U slots; AT = type of the stored values (float for the sp part of ap[dp_sp]),
-// XT = type of x and of the accumulator.
-template <typename AT, typename XT, int U, bool NT>
-__device__ __forceinline__ void sweep_window(const XT *__restrict__ xs, const int c, unsigned &base, const AT *__restrict__ vals,
-                                             const unsigned short *__restrict__ idx, XT &acc) {
+// One window of one wave: batches of U rounds.  AT = type of the stored values (float for the sp part of ap[dp_sp]), XT = type
+// of x and of the accumulator.  vp / ip point at the wave's next element of the compacted stream and stay WAVE-UNIFORM (scalar
+// registers): in round u the active lanes are those with more than k0+u entries in this window -- one ballot m[u] --, a lane's
+// element sits `lanes below it in m[u]` behind the round's first element, and the round's first element is popcount(m[0..u-1])
+// behind vp.  An inactive lane must not even add a signed zero.
+// LOOP 0: loads under the lane mask, FMA result selected (the form measured first: 0.63 / 0.66 ms on config 4b);
+// LOOP 1: scalar stream pointers (`scalar base + 32-bit lane offset` loads) and both loads and FMAs under the lane mask.
+// (A branch-free form -- inactive lanes load the batch's first element, every FMA selected -- let the compiler request the whole
+// batch before the first wait, but measured 0.92 / 0.84 ms: the rounds it cannot skip cost more than the waits it saves.)
+template <typename AT, typename XT, int U, bool NT, int LOOP>
+__device__ __forceinline__ void sweep_window(const XT *__restrict__ xs, const int c, const AT *__restrict__ &vp,
+                                             const unsigned short *__restrict__ &ip, XT &acc) {
     for (int k0 = 0;; k0 += U) {
-        if (__ballot(k0 < c) == 0ull) break;             // wave-uniform: every row of the wave is through this window
+        unsigned long long m[U];
+        unsigned first[U + 1];
+        first[0] = 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            m[u] = __ballot(k0 + u < c);
+            first[u + 1] = first[u] + (unsigned)__popcll(m[u]);
+        }
+        if (m[0] == 0ull) break;                             // wave-uniform: every row of the wave is through this window
         AT v[U];
         unsigned ix[U];
-        bool act[U];
+        if constexpr (LOOP == 0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            act[u] = k0 + u < c;
-            const unsigned long long m = __ballot(act[u]);
-            const unsigned off = base + lanes_below(m);
-            base += (unsigned)__popcll(m);
-            v[u] = AT(0); ix[u] = 0u;
-            if (act[u]) { v[u] = ld_stream<NT>(vals + off); ix[u] = ld_stream<NT>(idx + off); }
-        }
+            for (int u = 0; u < U; ++u) {
+                v[u] = AT(0); ix[u] = 0u;
+                if (k0 + u < c) {
+                    const unsigned off = first[u] + lanes_below(m[u]);
+                    v[u] = ld_stream<NT>(vp + off); ix[u] = ld_stream<NT>(ip + off);
+                }
+            }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const XT t = fma_t((XT)v[u], xs[ix[u]], acc);
-            acc = act[u] ? t : acc;                          // (an inactive lane must not even add a signed zero)
+            for (int u = 0; u < U; ++u) {
+                const XT t = fma_t((XT)v[u], xs[ix[u]], acc);
+                acc = (k0 + u < c) ? t : acc;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k0 + u < c) {
+                    const unsigned off = first[u] + lanes_below(m[u]);
+                    v[u] = ld_stream<NT>(vp + off); ix[u] = ld_stream<NT>(ip + off);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k0 + u < c) acc = fma_t((XT)v[u], xs[ix[u]], acc);
         }
+        vp += first[U];
+        ip += first[U];
     }
 }
 
-template <typename VT, bool AP, bool NT, int NBUF, int U>
+template <typename VT, bool AP, bool NT, int NBUF, int U, int LOOP>
 __global__ void __launch_bounds__(1024) scs_spmv_sweep(const int wlog, const int *__restrict__ tile_ids, const int *__restrict__ t_smin,
         const int *__restrict__ t_S, const unsigned long long *__restrict__ t_cnt_off,
         const unsigned *__restrict__ wave_off, const unsigned char *__restrict__ cnt, const VT *__restrict__ vals, const unsigned short *__restrict__ idx,
@@ -72,8 +100,14 @@ __global__ void __launch_bounds__(1024) scs_spmv_sweep(const int wlog, const int
     const int n_pieces = (int)(W / EPP);
     const unsigned char *cp = cnt + t_cnt_off[bt] + threadIdx.x;
     const unsigned char *cpb = AP ? cnt_b + t_cnt_off[bt] + threadIdx.x : nullptr;
-    unsigned base = __builtin_amdgcn_readfirstlane(wave_off[bt * nw + wave]);
-    unsigned base_b = AP ? __builtin_amdgcn_readfirstlane(wave_off_b[bt * nw + wave]) : 0u;
+    const VT *__restrict__ vp = vals + (unsigned)__builtin_amdgcn_readfirstlane(wave_off[bt * nw + wave]);
+    const unsigned short *__restrict__ ip = idx + (unsigned)__builtin_amdgcn_readfirstlane(wave_off[bt * nw + wave]);
+    const float *__restrict__ vpb = vals_b;
+    const unsigned short *__restrict__ ipb = idx_b;
+    if constexpr (AP) {
+        vpb = vals_b + (unsigned)__builtin_amdgcn_readfirstlane(wave_off_b[bt * nw + wave]);
+        ipb = idx_b + (unsigned)__builtin_amdgcn_readfirstlane(wave_off_b[bt * nw + wave]);
+    }
     VT *const xs_all = (VT *)sweep_smem;                 // buffer b starts at element b * W
 
     auto stage = [&](const int s, const int b) {
@@ -111,8 +145,8 @@ __global__ void __launch_bounds__(1024) scs_spmv_sweep(const int wlog, const int
             c_next = cp[(long)(s + 1) * R];
             if (AP) cb_next = cpb[(long)(s + 1) * R];
         }
-        sweep_window<VT, VT, U, NT>(cur, c_cur, base, vals, idx, acc);
-        if constexpr (AP) sweep_window<float, double, U, NT>((const double *)cur, cb_cur, base_b, vals_b, idx_b, acc_b);
+        sweep_window<VT, VT, U, NT, LOOP>(cur, c_cur, vp, ip, acc);
+        if constexpr (AP) sweep_window<float, double, U, NT, LOOP>((const double *)cur, cb_cur, vpb, ipb, acc_b);
         c_cur = c_next; cb_cur = cb_next;
     }
     // trailing padding of the row, applied once (see sweep_plan.cpp)
@@ -134,7 +168,7 @@ int launch_sweep(const uspmv_dmat *A, const VT *x, VT *y, hipStream_t st) {
     const int remap = g_tune.sweep_remap;
 #define SW_LAUNCH(NTV, NB, UU)                                                                                              \
     do {                                                                                                                    \
-        auto kfn = scs_spmv_sweep<VT, AP, NTV, NB, UU>;                                                                     \
+        auto kfn = g_tune.sweep_loop == 1 ? scs_spmv_sweep<VT, AP, NTV, NB, UU, 1> : scs_spmv_sweep<VT, AP, NTV, NB, UU, 0>;                 \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)A->sw_n_tiles), dim3(A->sw_tile_rows), lds, st, A->sw_wlog, A->sw_tile_ids,   \
                            A->sw_smin, A->sw_S, (const unsigned long long *)A->sw_cnt_off, A->sw_wave_off, A->sw_cnt,        \

@@ -160,6 +160,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "sweep_nbuf")) g_tune.sweep_nbuf = value == 1 ? 1 : 2;
     else if (!strcmp(key, "sweep_unroll")) g_tune.sweep_unroll = value >= 8 ? 8 : value >= 4 ? 4 : 2;
     else if (!strcmp(key, "sweep_remap")) g_tune.sweep_remap = value < 0 ? 0 : value;
+    else if (!strcmp(key, "sweep_loop")) g_tune.sweep_loop = value == 1 ? 1 : 0;
     else if (!strcmp(key, "sweep_wlog")) {
         if (value != 0 && (value < 8 || value > 16)) return uspmv::fail(USPMV_ERR_INVALID, "sweep_wlog must be 0 or 8..16");
         g_tune.sweep_wlog = value;
@@ -216,6 +217,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "sweep_nbuf")) *value = g_tune.sweep_nbuf;
     else if (!strcmp(key, "sweep_unroll")) *value = g_tune.sweep_unroll;
     else if (!strcmp(key, "sweep_remap")) *value = g_tune.sweep_remap;
+    else if (!strcmp(key, "sweep_loop")) *value = g_tune.sweep_loop;
     else if (!strcmp(key, "sweep_wlog")) *value = g_tune.sweep_wlog;
     else if (!strcmp(key, "sweep_tile_rows")) *value = g_tune.sweep_tile_rows;
     else if (!strcmp(key, "sweep_max_stage")) *value = g_tune.sweep_max_stage;

@@ -83,8 +83,10 @@ struct Tuning {
                             // needs ~10 fewer address instructions per non-zero and measures 5-7 % faster (spmmv_probe16.txt)
     int spmmv_prefetch = 1; // row-major lane-per-row kernel: request batch k+1's matrix entries behind batch k's X rows
     int sweep = 1;          // use the column-window sweep kernel when the handle carries a sweep plan
-    int sweep_nbuf = 2;     // LDS buffers per workgroup (2: window s+1 lands while window s is consumed)
+    int sweep_nbuf = 1;     // LDS buffers per workgroup: 1 = two 1024-thread workgroups per CU cover each other's staging (0.63 vs 0.72 ms on
+                            // config 4b); 2 = one workgroup, window s+1 lands while window s is consumed
     int sweep_unroll = 8;   // rounds per batch
+    int sweep_loop = 0;     // inner loop form (csrc/sweep_kernels.hip): 0 = masked loads + selected FMA, 1 = scalar stream pointers, all masked
     int sweep_remap = 8;    // consecutive sweep tiles per XCD (neighbouring tiles share their x windows)
     int sweep_wlog = 0;     // NEXT uspmv_dmat_optimize_sweep: log2 of the window width in elements (0 = 64 KiB of VT)
     int sweep_tile_rows = 0;  // NEXT uspmv_dmat_optimize_sweep: 256 | 512 | 1024 rows per tile (0 = 1024)

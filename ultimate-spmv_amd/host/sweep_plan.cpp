@@ -148,14 +148,15 @@ int uspmv_build_sweep_plan(const uspmv_scs *s, const uspmv_scs *s2, int wlog, in
         if (tot[w] > (int64_t)UINT32_MAX) return USPMV_OK;
     }
     p->cnt.assign((size_t)cnt_bytes, 0);
-    p->idx.assign((size_t)tot[0], 0);
+    constexpr size_t SPARE = 64;   // inactive lanes of the kernel load the batch's first element: keep that address valid at the very end
+    p->idx.assign((size_t)tot[0] + SPARE, 0);
     p->pad_col.assign((size_t)(nsw * R), -1);
-    if (s->dtype == USPMV_F64) p->vals_f64.assign((size_t)tot[0], 0.0); else p->vals_f32.assign((size_t)tot[0], 0.0f);
+    if (s->dtype == USPMV_F64) p->vals_f64.assign((size_t)tot[0] + SPARE, 0.0); else p->vals_f32.assign((size_t)tot[0] + SPARE, 0.0f);
     if (s2) {
         p->cnt_b.assign((size_t)cnt_bytes, 0);
-        p->idx_b.assign((size_t)tot[1], 0);
+        p->idx_b.assign((size_t)tot[1] + SPARE, 0);
         p->pad_col_b.assign((size_t)(nsw * R), -1);
-        if (s2->dtype == USPMV_F64) p->vals_b_f64.assign((size_t)tot[1], 0.0); else p->vals_b_f32.assign((size_t)tot[1], 0.0f);
+        if (s2->dtype == USPMV_F64) p->vals_b_f64.assign((size_t)tot[1] + SPARE, 0.0); else p->vals_b_f32.assign((size_t)tot[1] + SPARE, 0.0f);
     }
     // ---- pass 2: counts and the compacted entry stream
 #pragma omp parallel

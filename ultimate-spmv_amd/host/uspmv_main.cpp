@@ -222,12 +222,15 @@ int run(const Config &c, uspmv_coo_t *coo) {
     // ---- x, y (DefaultValues x = 5.0, code/classes_structs.hpp:1799-1800; random: default-seeded mt19937)
     std::vector<VT> hx((size_t)b * ld, VT(0)), xo((size_t)n_rows), xp((size_t)n_rows);
     std::mt19937 engine;
-    std::uniform_real_distribution<double> dist(vmin, vmax);
+    // random_init (code/utilities.hpp:880-912) draws dist(engine) = canonical * (max - min) + min.  The reference is built -O3
+    // -march=native (Makefile), which contracts that into ONE fused multiply-add; this file may be compiled without FMA code
+    // generation, so the fused form is spelled out -- the -rand_x 1 vector is then bit-identical to the reference's.
+    auto draw = [&]() { return std::fma(std::generate_canonical<double, 53>(engine), vmax - vmin, vmin); };
     for (int v = 0; v < b; ++v) {
         // random_init draws for every element of the padded vector, padding is zeroed afterwards
         // (code/utilities.hpp:880-912, :955-980): consume ld draws per vector, keep the first n_rows
         for (int64_t i = 0; i < ld; ++i) {
-            const VT val = c.random_init_x == '1' ? (VT)dist(engine) : c.random_init_x == 'm' ? (VT)vmean : (VT)5.0;
+            const VT val = c.random_init_x == '1' ? (VT)draw() : c.random_init_x == 'm' ? (VT)vmean : (VT)5.0;
             if (i < n_rows) xo[(size_t)i] = val;
         }
         ck(uspmv_apply_permutation(xp.data(), xo.data(), n2o, n_rows, dtype), "uspmv_apply_permutation");
@@ -308,7 +311,7 @@ int run(const Config &c, uspmv_coo_t *coo) {
             ck(uspmv_dmat_upload(crs, &Ac), "upload crs");
             ck(uspmv_dmat_set_crs(Ac, 1), "set crs");
             std::vector<VT> xr((size_t)n_rows, c.random_init_x == 'm' ? (VT)vmean : (VT)5.0), yr((size_t)n_rows);
-            if (c.random_init_x == '1') { std::mt19937 e2; for (auto &v : xr) v = (VT)dist(e2); }
+            if (c.random_init_x == '1') { std::mt19937 e2; for (auto &v : xr) v = (VT)std::fma(std::generate_canonical<double, 53>(e2), vmax - vmin, vmin); }
             VT *dxr = dev_alloc<VT>((size_t)n_rows), *dyr = dev_alloc<VT>((size_t)n_rows);
             hk(hipMemcpy(dxr, xr.data(), sizeof(VT) * xr.size(), hipMemcpyHostToDevice), "hipMemcpy");
             for (unsigned long i = 0; i < c.n_repetitions; ++i) { ck(uspmv_spmv(Ac, dxr, dyr, nullptr), "crs spmv"); if (i + 1 < c.n_repetitions) std::swap(dxr, dyr); }
