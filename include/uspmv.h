@@ -164,7 +164,7 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *m, const uspmv_scs_t *s, int block_v
  * processed by one workgroup that stages window after window in LDS and runs every row's entries of the staged
  * window -- same slot-ordered FMA chain, bit-identical y.  The plan holds a private, padding-free copy of the entries
  * (sizeof(VT) + 2 bytes per non-zero).  Tiles that do not qualify keep the gather kernel inside the same uspmv_spmv call.
- * wlog / tile_rows 0 = defaults (64 KiB windows, 1024 rows).  uspmv_dmat_optimize[_ap] tries this by itself when the
+ * wlog / tile_rows 0 = defaults (64 KiB windows; 2048 rows, 1024 for an ap pair).  uspmv_dmat_optimize[_ap] tries this by itself when the
  * tile-local-column plan stages less than half of the tiles.  n_tiles / n_sweep report the outcome (may be NULL). */
 int uspmv_dmat_optimize_sweep(uspmv_dmat_t *m, const uspmv_scs_t *s, int wlog, int tile_rows, int64_t *n_tiles, int64_t *n_sweep);
 int uspmv_dmat_optimize_sweep_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t *s_dp, const uspmv_scs_t *s_sp, int wlog,
@@ -251,10 +251,12 @@ int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_
  *   per row, C=32 only), "csr_lanes" 0 (auto) | 1..64 lanes per row of the CRS kernel,
  *   "tlc" 1|0 use the tile-local-column kernel when the handle has a plan, "tail_batch" 0|1,
  *   "spmmv_variant" 0 (auto) | 1 (generic) | 2 (row-major, transposing X phase) | 3 (row-major, lane per row)
- *                   | 4 (block plan where present; 0 prefers it too, 2 and 3 ignore it),
+ *                   | 4 (single-wave block-plan tiles) | 5 (3 over the plan's tie-re-ordered copy) | 6 (four lanes per row, 64-byte rows)
+ *                   | 7 (6, persistent) | 8 (four lanes per row over the phased plan; what auto picks for 64-byte rows),
+ *   "spmmv_phased" 1|0 and "spmmv_phase_rows" 256|512: NEXT uspmv_dmat_optimize_block with 64-byte rows also builds the phased plan,
  *   "spmmv_swizzle" 0|1 bank-swizzled LDS rows in the block-plan kernel,
  *   "spmmv_reorder" 1|0 NEXT uspmv_dmat_optimize_block: undo the sigma sort's tie scrambling in the plan's private copy of the entries,
- *   "sweep" 1|0 use a handle's column-window sweep plan, "sweep_nbuf" 2|1 LDS buffers, "sweep_unroll" 2|4|8, "sweep_remap" tiles per XCD group,
+ *   "sweep" 1|0 use a handle's column-window sweep plan, "sweep_nbuf" 1|2 LDS buffers, "sweep_unroll" 2|4|8, "sweep_remap" tiles per XCD group,
  *   "sweep_wlog" / "sweep_tile_rows" / "sweep_max_stage" defaults of the NEXT sweep plan (window = 2^wlog elements; rows per tile;
  *   largest staging cost in bytes per non-zero for a tile to qualify, 0 = 24),
  *   "raw_plan_cache" 0|1 uspmv_scs_gpu_f64/f32 keep a device-built plan per set of array addresses (the caller

@@ -123,6 +123,8 @@ int main() {
     run(9999, 23, 700, 16, 64, 8, 512, false, false);
     run(5000, 300, 2400, 32, 1, 11, 256, false, false);   // > 255 entries per window possible: such tiles must not sweep
     run(20000, 40, 3000, 32, 512, 9, 1024, true, false);
+    run(20000, 40, 3000, 32, 512, 10, 2048, true, false);   // several rows per lane in the kernel: tiles above 1 024 rows
+    run(9999, 23, 700, 16, 64, 9, 4096, false, true);
     run(7777, 31, 900, 64, 128, 8, 256, true, true);
     printf(fails ? "FAILED\n" : "OK\n");
     return fails ? 1 : 0;

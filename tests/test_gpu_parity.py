@@ -392,7 +392,7 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                     pkg.spmmv(A0, _dev(t, X), Y0, b, ld, lay)
                     pkg.set_tuning(spmmv_variant=0)
                     for swz in (0, 1):                     # plan kernel for every width it supports, both LDS layouts
-                        for var, pd in ((4, 0), (6, 2), (6, 4), (6, 8), (7, 2), (7, 3), (5, 0)):   # single-wave tiles; four lanes per row (64-byte rows), one tile per workgroup / persistent; gather over the re-ordered copy
+                        for var, pd in ((4, 0), (6, 0), (7, 2), (7, 3), (8, 0), (5, 0)):   # single-wave tiles; four lanes per row (64-byte rows): one tile per workgroup / persistent / phased plan; gather over the re-ordered copy
                             if (var, swz) == (5, 1):
                                 continue
                             if var == 7:

@@ -44,13 +44,13 @@ def test_sweep_banded_random_bitexact(pkg, orc, torch_cuda, dt):
         y_or = orc.spmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
         x = t.from_numpy(xp).cuda()
         A = pkg.DeviceMatrix(s)
-        for wlog, rows in ((10, 256), (11, 512), (12, 1024), (0, 0)):
+        for wlog, rows in ((10, 256), (11, 512), (12, 1024), (12, 2048), (11, 4096), (0, 0)):
             if sigma > 1 and wlog and (1 << wlog) % sigma:
                 continue
             nt, nsw = A.optimize_sweep(s, wlog, rows)
             assert nsw == nt and A.plan_info()[0] == 2, (C, sigma, wlog, rows, nt, nsw)
             for nbuf in (2, 1):
-                for un in (8, 4, 2):
+                for un in (8, 4):
                     pkg.set_tuning(sweep_nbuf=nbuf, sweep_unroll=un)
                     y = t.full((s.n_rows_padded,), -7.0, dtype=A.torch_dtype, device="cuda")
                     pkg.spmv(A, x, y)
@@ -77,7 +77,7 @@ def test_sweep_ap_banded_random_bitexact(pkg, orc, torch_cuda):
             Ad, As = pkg.DeviceMatrix(ds), pkg.DeviceMatrix(ss)
             y0 = t.zeros(ds.n_rows_padded, dtype=t.float64, device="cuda")
             pkg.spmv_ap(Ad, As, x, y0)                                  # gather kernel
-            for wlog, rows in ((11, 256), (12, 1024), (0, 0)):
+            for wlog, rows in ((11, 256), (12, 1024), (12, 2048), (0, 0)):
                 nt, nsw = pkg.optimize_sweep_ap(Ad, As, ds, ss, wlog, rows)
                 assert nsw == nt
                 for nbuf in (2, 1):

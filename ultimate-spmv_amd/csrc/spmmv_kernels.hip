@@ -729,6 +729,102 @@ __global__ void __launch_bounds__(256, WPE) scs_spmmv_quadp(const long n_tiles, 
 #undef QUAD_STEP
 }
 
+// Four lanes per row over the PHASED block plan (uspmv_build_phased_plan): the arithmetic of scs_spmmv_quad, but a tile's slots are
+// processed phase by phase -- at most NGP groups of four slots whose entries touch at most MAXP*64 distinct X rows -- and only the
+// current phase's X rows are staged: 16 KB of LDS and 40 registers per 256-thread workgroup instead of 50 KB and 88, so EIGHT
+// workgroups (the wave limit) instead of three share a CU and one workgroup's round trips (list, X rows + its matrix entries) hide
+// behind the arithmetic of seven others.  Every row still walks its slots in order: bit-identical FMA chains.
+template <typename VT, int B, bool NT, bool YCOL, int C, int NGP, int MAXP>
+__global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, const int *__restrict__ chunk_ptrs,
+        const int *__restrict__ chunk_lengths, const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y, const long ld,
+        const int *__restrict__ ph_ptr, const int *__restrict__ ph_g0, const int *__restrict__ ph_list_ptr, const int *__restrict__ xrows,
+        const unsigned *__restrict__ c16_ptrs, const unsigned short *__restrict__ col16, const int xcd_remap, const long n_store,
+        const int *__restrict__ row_map) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tlc_smem[];
+    constexpr int VW = 16 / (int)sizeof(VT);
+    static_assert(B == 4 * VW, "four 16-byte pieces per X row");
+    typedef VT vec_t __attribute__((ext_vector_type(VW)));
+    const unsigned tile = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int r = lane >> 2, q = lane & 3;
+    const long row = (long)tile * 64 + wave * 16 + r;
+    const long c = row / C;
+    const int i = (int)(row - c * C);
+    const bool valid = c < n_chunks;
+    int cs = 0, L = 0;
+    unsigned q0 = 0;
+    if (valid) { cs = chunk_ptrs[c]; L = chunk_lengths[c]; q0 = c16_ptrs[c]; }
+    L = __builtin_amdgcn_readfirstlane(L);
+    const int ngf = L >> 2, rem = L & 3;
+    const int p0 = ph_ptr[tile], p1 = ph_ptr[tile + 1];
+    vec_t acc;
+#pragma unroll
+    for (int w = 0; w < VW; ++w) acc[w] = VT(0);
+    const VT *vp = values + (long)cs + i + (long)q * C;
+    const unsigned short *ip = col16 + q0 + (long)i * 4 + q;
+    const vec_t *xs = (const vec_t *)tlc_smem;
+#define QUAD_STEP(UU, AV, IV)                                                                                 \
+    {                                                                                                         \
+        const VT aa = quad_bcast<UU>(AV);                                                                     \
+        const unsigned li = (unsigned)quad_bcast<UU>((int)(IV));                                              \
+        const vec_t xv = xs[li * 4 + (unsigned)q];                                                            \
+        _Pragma("unroll") for (int w = 0; w < VW; ++w) acc[w] = fma_t(aa, xv[w], acc[w]);                     \
+    }
+    int g0 = p0 < p1 ? ph_g0[p0] : 0, lp = p0 < p1 ? ph_list_ptr[p0] : 0;
+    for (int ph = p0; ph < p1; ++ph) {
+        const int g1 = ph + 1 < p1 ? ph_g0[ph + 1] : 0x7fffffff;
+        const int lp1 = ph_list_ptr[ph + 1];
+        const int np = (lp1 - lp) << 2;
+        // ---- the list entries this lane needs for its DMA pieces (piece p = (wave + 4k)*64 + lane <-> list entry p >> 2)
+        int xr[MAXP];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const int pp = (wave + 4 * k) * 64 + lane;
+            xr[k] = -1;
+            if (pp < np) xr[k] = xrows[lp + (pp >> 2)];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ph > p0) __syncthreads();                        // every wave is through with the previous phase's rows
+        // ---- X rows of the phase -> LDS by DMA, and behind them this wave's matrix entries of the phase
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k)
+            if (xr[k] >= 0)
+                __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(X + (long)xr[k] * B + q * VW), (lds_void_t *)(tlc_smem + (wave + 4 * k) * 1024), 16, 0, 0);
+        const int ge = min(g1, ngf);                         // full groups of this wave's rows in the phase: [g0, ge)
+        VT a[NGP], at = VT(0);
+        unsigned ix[NGP], ixt = 0u;
+#pragma unroll
+        for (int d = 0; d < NGP; ++d) {
+            a[d] = VT(0); ix[d] = 0u;
+            if (g0 + d < ge) { ix[d] = ld_stream<NT>(ip + (long)(g0 + d) * 4 * C); a[d] = ld_stream<NT>(vp + (long)(g0 + d) * 4 * C); }
+        }
+        const bool tail_here = rem && ngf >= g0 && ngf < g1;  // the partial last group of this wave's rows belongs to this phase
+        if (tail_here) { ixt = ld_stream<NT>(ip + (long)ngf * 4 * C); if (q < rem) at = ld_stream<NT>(vp + (long)ngf * 4 * C); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < NGP; ++d) {
+            if (g0 + d < ge) { QUAD_STEP(0, a[d], ix[d]) QUAD_STEP(1, a[d], ix[d]) QUAD_STEP(2, a[d], ix[d]) QUAD_STEP(3, a[d], ix[d]) }
+        }
+        if (tail_here) {
+            if (rem > 0) QUAD_STEP(0, at, ixt)
+            if (rem > 1) QUAD_STEP(1, at, ixt)
+            if (rem > 2) QUAD_STEP(2, at, ixt)
+        }
+        g0 = g1; lp = lp1;
+    }
+#undef QUAD_STEP
+    if (!valid) return;
+    const long yrow = row_map ? (long)row_map[row] : row;
+    if (yrow >= n_store) return;
+    if (YCOL) {
+#pragma unroll
+        for (int w = 0; w < VW; ++w) st_y<NT>(Y + (yrow + (long)(q * VW + w) * ld), acc[w]);
+    } else {
+        *((vec_t *)(Y + yrow * B) + q) = acc;
+    }
+}
+
 // colwise (b vectors of leading dimension ld) <-> row-major (n rows of B) re-layout, one lane per row
 template <typename VT, int B, bool TO_ROWMAJOR>
 __global__ void block_vector_relayout(const VT *__restrict__ in, VT *__restrict__ out, const long n, const long ld) {
@@ -905,10 +1001,39 @@ bool launch_spmmv_quadp(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool y
     return true;
 }
 
+template <typename VT, int B, int CT, int MAXP>
+void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    const size_t lds = (size_t)MAXP * 4 * 1024;
+#define QH_LAUNCH(NTV, YC)                                                                                              \
+    do {                                                                                                                \
+        auto kfn = scs_spmmv_quadph<VT, B, NTV, YC, CT, 8, MAXP>;                                                       \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)A->pb_n_tiles), dim3(256), lds, st, (long)A->n_chunks, A->chunk_ptrs, A->chunk_lengths, \
+                           (const VT *)(A->bt_values ? A->bt_values : A->values), X, Y, ld, A->pb_ph_ptr, A->pb_g0, A->pb_list_ptr,   \
+                           A->pb_xrows, A->pb_c16_ptrs, A->pb_col16, g_tune.xcd_remap, (long)A->n_store, (const int *)A->bt_row_map);  \
+    } while (0)
+    if (g_tune.nontemporal) { if (ycol) QH_LAUNCH(true, true); else QH_LAUNCH(true, false); }
+    else { if (ycol) QH_LAUNCH(false, true); else QH_LAUNCH(false, false); }
+#undef QH_LAUNCH
+}
+
+// false: the handle's phased plan does not fit the compiled shapes
+template <typename VT, int B>
+bool launch_spmmv_quadph(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    if (!A->pb || A->pb_ngp > 8) return false;
+    const int pieces = (A->pb_max_rows * 4 + 255) / 256;
+#define QH_C(CTV) do { if (pieces <= 4) launch_spmmv_quadph_m<VT, B, CTV, 4>(A, X, Y, ld, ycol, st); else if (pieces <= 8) launch_spmmv_quadph_m<VT, B, CTV, 8>(A, X, Y, ld, ycol, st); else return false; } while (0)
+    if (A->C == 32) QH_C(32); else if (A->C == 64) QH_C(64); else if (A->C == 16) QH_C(16); else return false;
+#undef QH_C
+    return true;
+}
+
 template <typename VT, int B>
 void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
     constexpr int RB = B * (int)sizeof(VT);          // bytes per X row
     if constexpr (RB == 64) {
+        // 64-byte rows, phased plan (variant 8; auto when the handle carries one): eight workgroups per CU
+        if ((g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 8) && !g_tune.ablate && launch_spmmv_quadph<VT, B>(A, X, Y, ld, ycol, st)) return;
         // 64-byte rows: the four-lanes-per-row kernel over 64-row tiles of the block plan (variant 6; auto when the plan is there)
         if (A->bt && A->bt_tile_rows == 64 && (g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 6 || g_tune.spmmv_variant == 7) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
             // variant 6 (and auto): one tile per workgroup, three workgroups per CU; variant 7: persistent and pipelined over tiles, but 222

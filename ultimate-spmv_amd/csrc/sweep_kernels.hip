@@ -29,12 +29,13 @@ __device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
 // of x and of the accumulator.  vp / ip point at the wave's next element of the compacted stream and stay WAVE-UNIFORM (scalar
 // registers): in round u the active lanes are those with more than k0+u entries in this window -- one ballot m[u] --, a lane's
 // element sits `lanes below it in m[u]` behind the round's first element, and the round's first element is popcount(m[0..u-1])
-// behind vp.  An inactive lane must not even add a signed zero.
-// LOOP 0: loads under the lane mask, FMA result selected (the form measured first: 0.63 / 0.66 ms on config 4b);
-// LOOP 1: scalar stream pointers (`scalar base + 32-bit lane offset` loads) and both loads and FMAs under the lane mask.
-// (A branch-free form -- inactive lanes load the batch's first element, every FMA selected -- let the compiler request the whole
-// batch before the first wait, but measured 0.92 / 0.84 ms: the rounds it cannot skip cost more than the waits it saves.)
-template <typename AT, typename XT, int U, bool NT, int LOOP>
+// behind vp.  Loads run under the lane mask; the FMA result is selected (an inactive lane must not even add a signed zero).
+// Forms that were built, measured on config 4b and dropped (profiles/r02/config4b_sweep_variants.txt): both loads and FMAs under the
+// lane mask (0.72 / 0.84 ms against 0.62 / 0.65); a branch-free form in which inactive lanes load the batch's first element, so
+// that the compiler requests the whole batch before its first wait (0.92 / 0.84: the rounds it cannot skip cost more than the
+// waits it saves); the first batch of window s+1 requested before the barrier that ends window s (dp 0.649 vs 0.667, but the
+// registers cost the ap kernel its second workgroup per CU: 0.81).
+template <typename AT, typename XT, int U, bool NT>
 __device__ __forceinline__ void sweep_window(const XT *__restrict__ xs, const int c, const AT *__restrict__ &vp,
                                              const unsigned short *__restrict__ &ip, XT &acc) {
     for (int k0 = 0;; k0 += U) {
@@ -49,38 +50,27 @@ __device__ __forceinline__ void sweep_window(const XT *__restrict__ xs, const in
         if (m[0] == 0ull) break;                             // wave-uniform: every row of the wave is through this window
         AT v[U];
         unsigned ix[U];
-        if constexpr (LOOP == 0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                v[u] = AT(0); ix[u] = 0u;
-                if (k0 + u < c) {
-                    const unsigned off = first[u] + lanes_below(m[u]);
-                    v[u] = ld_stream<NT>(vp + off); ix[u] = ld_stream<NT>(ip + off);
-                }
+        for (int u = 0; u < U; ++u) {
+            v[u] = AT(0); ix[u] = 0u;
+            if (k0 + u < c) {
+                const unsigned off = first[u] + lanes_below(m[u]);
+                v[u] = ld_stream<NT>(vp + off); ix[u] = ld_stream<NT>(ip + off);
             }
+        }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const XT t = fma_t((XT)v[u], xs[ix[u]], acc);
-                acc = (k0 + u < c) ? t : acc;
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (k0 + u < c) {
-                    const unsigned off = first[u] + lanes_below(m[u]);
-                    v[u] = ld_stream<NT>(vp + off); ix[u] = ld_stream<NT>(ip + off);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (k0 + u < c) acc = fma_t((XT)v[u], xs[ix[u]], acc);
+        for (int u = 0; u < U; ++u) {
+            const XT t = fma_t((XT)v[u], xs[ix[u]], acc);
+            acc = (k0 + u < c) ? t : acc;
         }
         vp += first[U];
         ip += first[U];
     }
 }
 
-template <typename VT, bool AP, bool NT, int NBUF, int U, int LOOP>
+// RPL rows per lane: a tile is RPL * blockDim.x rows, lane <-> rows tid, tid + blockDim.x, ...  The windows of x are staged once per
+// tile, so RPL = 2 halves the staging traffic per non-zero (the workgroup is already 1 024 threads).
+template <typename VT, bool AP, bool NT, int NBUF, int U, int RPL>
 __global__ void __launch_bounds__(1024) scs_spmv_sweep(const int wlog, const int *__restrict__ tile_ids, const int *__restrict__ t_smin,
         const int *__restrict__ t_S, const unsigned long long *__restrict__ t_cnt_off,
         const unsigned *__restrict__ wave_off, const unsigned char *__restrict__ cnt, const VT *__restrict__ vals, const unsigned short *__restrict__ idx,
@@ -92,21 +82,27 @@ __global__ void __launch_bounds__(1024) scs_spmv_sweep(const int wlog, const int
     constexpr int EPL = 16 / (int)sizeof(VT);           // elements per 16-byte DMA lane
     constexpr int EPP = 1024 / (int)sizeof(VT);         // elements per 1-KiB piece (one wave-instruction)
     const unsigned bt = remap_block(blockIdx.x, gridDim.x, xcd_remap);
-    const int R = blockDim.x, nw = R >> 6;
+    const int T = blockDim.x, nw = T >> 6;              // threads, waves of the workgroup
+    const long R = (long)T * RPL;                       // rows of the tile
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int tile = tile_ids[bt], smin = t_smin[bt], S = t_S[bt];
-    const long row = (long)tile * R + threadIdx.x;
     const long W = 1L << wlog;
     const int n_pieces = (int)(W / EPP);
-    const unsigned char *cp = cnt + t_cnt_off[bt] + threadIdx.x;
+    const unsigned char *cp = cnt + t_cnt_off[bt] + threadIdx.x;                 // + h*T + s*R
     const unsigned char *cpb = AP ? cnt_b + t_cnt_off[bt] + threadIdx.x : nullptr;
-    const VT *__restrict__ vp = vals + (unsigned)__builtin_amdgcn_readfirstlane(wave_off[bt * nw + wave]);
-    const unsigned short *__restrict__ ip = idx + (unsigned)__builtin_amdgcn_readfirstlane(wave_off[bt * nw + wave]);
-    const float *__restrict__ vpb = vals_b;
-    const unsigned short *__restrict__ ipb = idx_b;
-    if constexpr (AP) {
-        vpb = vals_b + (unsigned)__builtin_amdgcn_readfirstlane(wave_off_b[bt * nw + wave]);
-        ipb = idx_b + (unsigned)__builtin_amdgcn_readfirstlane(wave_off_b[bt * nw + wave]);
+    const VT *__restrict__ vp[RPL];
+    const unsigned short *__restrict__ ip[RPL];
+    const float *__restrict__ vpb[RPL];
+    const unsigned short *__restrict__ ipb[RPL];
+#pragma unroll
+    for (int h = 0; h < RPL; ++h) {
+        const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(wave_off[bt * (nw * RPL) + h * nw + wave]);
+        vp[h] = vals + o; ip[h] = idx + o;
+        vpb[h] = vals_b; ipb[h] = idx_b;
+        if constexpr (AP) {
+            const unsigned ob = (unsigned)__builtin_amdgcn_readfirstlane(wave_off_b[bt * (nw * RPL) + h * nw + wave]);
+            vpb[h] = vals_b + ob; ipb[h] = idx_b + ob;
+        }
     }
     VT *const xs_all = (VT *)sweep_smem;                 // buffer b starts at element b * W
 
@@ -125,10 +121,14 @@ __global__ void __launch_bounds__(1024) scs_spmv_sweep(const int wlog, const int
         }
     };
 
-    VT acc = VT(0);
-    double acc_b = 0.0;
-    int c_cur = 0, cb_cur = 0;
-    if (S > 0) { c_cur = cp[0]; if (AP) cb_cur = cpb[0]; }
+    VT acc[RPL];
+    double acc_b[RPL];
+    int c_cur[RPL], cb_cur[RPL];
+#pragma unroll
+    for (int h = 0; h < RPL; ++h) {
+        acc[h] = VT(0); acc_b[h] = 0.0; c_cur[h] = 0; cb_cur[h] = 0;
+        if (S > 0) { c_cur[h] = cp[h * T]; if (AP) cb_cur[h] = cpb[h * T]; }
+    }
     if (NBUF == 2 && S > 0) stage(0, 0);
     for (int s = 0; s < S; ++s) {
         const int cb = NBUF == 2 ? (s & 1) : 0;
@@ -139,46 +139,61 @@ __global__ void __launch_bounds__(1024) scs_spmv_sweep(const int wlog, const int
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's share of window s has landed
         __syncthreads();
-        int c_next = 0, cb_next = 0;
+        int c_next[RPL], cb_next[RPL];
+#pragma unroll
+        for (int h = 0; h < RPL; ++h) { c_next[h] = 0; cb_next[h] = 0; }
         if (s + 1 < S) {
             if (NBUF == 2) stage(s + 1, cb ^ 1);              // that buffer was read last in window s-1: all waves are past it
-            c_next = cp[(long)(s + 1) * R];
-            if (AP) cb_next = cpb[(long)(s + 1) * R];
+#pragma unroll
+            for (int h = 0; h < RPL; ++h) {
+                c_next[h] = cp[(long)(s + 1) * R + h * T];
+                if (AP) cb_next[h] = cpb[(long)(s + 1) * R + h * T];
+            }
         }
-        sweep_window<VT, VT, U, NT, LOOP>(cur, c_cur, vp, ip, acc);
-        if constexpr (AP) sweep_window<float, double, U, NT, LOOP>((const double *)cur, cb_cur, vpb, ipb, acc_b);
-        c_cur = c_next; cb_cur = cb_next;
+#pragma unroll
+        for (int h = 0; h < RPL; ++h) {
+            sweep_window<VT, VT, U, NT>(cur, c_cur[h], vp[h], ip[h], acc[h]);
+            if constexpr (AP) sweep_window<float, double, U, NT>((const double *)cur, cb_cur[h], vpb[h], ipb[h], acc_b[h]);
+            c_cur[h] = c_next[h]; cb_cur[h] = cb_next[h];
+        }
     }
     // trailing padding of the row, applied once (see sweep_plan.cpp)
-    const int pc = pad_col[(long)bt * R + threadIdx.x];
-    if (pc >= 0) acc = fma_t(VT(0), x[pc], acc);
-    if constexpr (AP) {
-        const int pcb = pad_col_b[(long)bt * R + threadIdx.x];
-        if (pcb >= 0) acc_b = __builtin_fma((double)0.0f, (double)x[pcb], acc_b);
-        acc = (VT)((double)acc + acc_b);
+#pragma unroll
+    for (int h = 0; h < RPL; ++h) {
+        const long row = (long)tile * R + h * T + threadIdx.x;
+        const int pc = pad_col[(long)bt * R + h * T + threadIdx.x];
+        if (pc >= 0) acc[h] = fma_t(VT(0), x[pc], acc[h]);
+        if constexpr (AP) {
+            const int pcb = pad_col_b[(long)bt * R + h * T + threadIdx.x];
+            if (pcb >= 0) acc_b[h] = __builtin_fma((double)0.0f, (double)x[pcb], acc_b[h]);
+            acc[h] = (VT)((double)acc[h] + acc_b[h]);
+        }
+        if (row < n_store) st_y<NT>(y + row, acc[h]);
     }
-    if (row < n_store) st_y<NT>(y + row, acc);
 }
 
 template <typename VT, bool AP>
 int launch_sweep(const uspmv_dmat *A, const VT *x, VT *y, hipStream_t st) {
     const long W = 1L << A->sw_wlog;
-    const int nbuf = g_tune.sweep_nbuf == 1 ? 1 : 2;
+    const int nbuf = g_tune.sweep_nbuf == 2 ? 2 : 1;
     const size_t lds = (size_t)nbuf * (size_t)W * sizeof(VT);
     const int remap = g_tune.sweep_remap;
-#define SW_LAUNCH(NTV, NB, UU)                                                                                              \
+    const int rpl = A->sw_tile_rows > 1024 ? A->sw_tile_rows / 1024 : 1, threads = A->sw_tile_rows / rpl;
+#define SW_LAUNCH(NTV, NB, UU, RP)                                                                                          \
     do {                                                                                                                    \
-        auto kfn = g_tune.sweep_loop == 1 ? scs_spmv_sweep<VT, AP, NTV, NB, UU, 1> : scs_spmv_sweep<VT, AP, NTV, NB, UU, 0>;                 \
+        auto kfn = scs_spmv_sweep<VT, AP, NTV, NB, UU, RP>;                                                                 \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kfn, dim3((unsigned)A->sw_n_tiles), dim3(A->sw_tile_rows), lds, st, A->sw_wlog, A->sw_tile_ids,   \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)A->sw_n_tiles), dim3(threads), lds, st, A->sw_wlog, A->sw_tile_ids,           \
                            A->sw_smin, A->sw_S, (const unsigned long long *)A->sw_cnt_off, A->sw_wave_off, A->sw_cnt,        \
                            (const VT *)A->sw_vals, A->sw_idx, A->sw_pad, A->sw_wave_off_b, A->sw_cnt_b, A->sw_vals_b,        \
                            A->sw_idx_b, A->sw_pad_b, x, y, (long)A->sw_x_len, (long)A->n_store, remap);                      \
     } while (0)
-#define SW_LAUNCH_U(NTV, NB) do { if (g_tune.sweep_unroll >= 8) SW_LAUNCH(NTV, NB, 8); else if (g_tune.sweep_unroll >= 4) SW_LAUNCH(NTV, NB, 4); else SW_LAUNCH(NTV, NB, 2); } while (0)
+#define SW_LAUNCH_R(NTV, NB, UU) do { if (rpl == 4) SW_LAUNCH(NTV, NB, UU, 4); else if (rpl == 2) SW_LAUNCH(NTV, NB, UU, 2); else SW_LAUNCH(NTV, NB, UU, 1); } while (0)
+#define SW_LAUNCH_U(NTV, NB) do { if (g_tune.sweep_unroll >= 8) SW_LAUNCH_R(NTV, NB, 8); else SW_LAUNCH_R(NTV, NB, 4); } while (0)
     if (g_tune.nontemporal) { if (nbuf == 2) SW_LAUNCH_U(true, 2); else SW_LAUNCH_U(true, 1); }
     else { if (nbuf == 2) SW_LAUNCH_U(false, 2); else SW_LAUNCH_U(false, 1); }
 #undef SW_LAUNCH_U
+#undef SW_LAUNCH_R
 #undef SW_LAUNCH
     HIP_TRY(hipGetLastError());
     return USPMV_OK;

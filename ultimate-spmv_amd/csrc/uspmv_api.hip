@@ -155,18 +155,19 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_swizzle")) g_tune.spmmv_swizzle = value != 0;
     else if (!strcmp(key, "spmmv_reorder")) g_tune.spmmv_reorder = value != 0;
     else if (!strcmp(key, "spmmv_persist_x")) g_tune.spmmv_persist_x = value < 1 ? 1 : value;
+    else if (!strcmp(key, "spmmv_phased")) g_tune.spmmv_phased = value != 0;
+    else if (!strcmp(key, "spmmv_phase_rows")) g_tune.spmmv_phase_rows = value == 512 ? 512 : 256;
     else if (!strcmp(key, "spmmv_persist_w")) g_tune.spmmv_persist_w = value == 3 ? 3 : 2;
     else if (!strcmp(key, "sweep")) g_tune.sweep = value != 0;
     else if (!strcmp(key, "sweep_nbuf")) g_tune.sweep_nbuf = value == 1 ? 1 : 2;
     else if (!strcmp(key, "sweep_unroll")) g_tune.sweep_unroll = value >= 8 ? 8 : value >= 4 ? 4 : 2;
     else if (!strcmp(key, "sweep_remap")) g_tune.sweep_remap = value < 0 ? 0 : value;
-    else if (!strcmp(key, "sweep_loop")) g_tune.sweep_loop = value == 1 ? 1 : 0;
     else if (!strcmp(key, "sweep_wlog")) {
         if (value != 0 && (value < 8 || value > 16)) return uspmv::fail(USPMV_ERR_INVALID, "sweep_wlog must be 0 or 8..16");
         g_tune.sweep_wlog = value;
     }
     else if (!strcmp(key, "sweep_tile_rows")) {
-        if (value != 0 && value != 256 && value != 512 && value != 1024) return uspmv::fail(USPMV_ERR_INVALID, "sweep_tile_rows must be 0|256|512|1024");
+        if (value != 0 && value != 256 && value != 512 && value != 1024 && value != 2048 && value != 4096) return uspmv::fail(USPMV_ERR_INVALID, "sweep_tile_rows must be 0|256|512|1024|2048|4096");
         g_tune.sweep_tile_rows = value;
     }
     else if (!strcmp(key, "sweep_max_stage")) g_tune.sweep_max_stage = value < 0 ? 0 : value;
@@ -174,7 +175,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_tile_rows")) g_tune.spmmv_tile_rows = value == 64 ? 64 : value == 32 ? 32 : 0;
     else if (!strcmp(key, "spmmv_lds_kb")) g_tune.spmmv_lds_kb = value < 0 ? 0 : value;
     else if (!strcmp(key, "spmmv_variant")) {
-        if (value < 0 || value > 7) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0..7");
+        if (value < 0 || value > 8) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0..8");
         g_tune.spmmv_variant = value;
     }
     else if (!strcmp(key, "tail_batch")) g_tune.tail_batch = value != 0;
@@ -212,12 +213,13 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_swizzle")) *value = g_tune.spmmv_swizzle;
     else if (!strcmp(key, "spmmv_reorder")) *value = g_tune.spmmv_reorder;
     else if (!strcmp(key, "spmmv_persist_x")) *value = g_tune.spmmv_persist_x;
+    else if (!strcmp(key, "spmmv_phased")) *value = g_tune.spmmv_phased;
+    else if (!strcmp(key, "spmmv_phase_rows")) *value = g_tune.spmmv_phase_rows;
     else if (!strcmp(key, "spmmv_persist_w")) *value = g_tune.spmmv_persist_w;
     else if (!strcmp(key, "sweep")) *value = g_tune.sweep;
     else if (!strcmp(key, "sweep_nbuf")) *value = g_tune.sweep_nbuf;
     else if (!strcmp(key, "sweep_unroll")) *value = g_tune.sweep_unroll;
     else if (!strcmp(key, "sweep_remap")) *value = g_tune.sweep_remap;
-    else if (!strcmp(key, "sweep_loop")) *value = g_tune.sweep_loop;
     else if (!strcmp(key, "sweep_wlog")) *value = g_tune.sweep_wlog;
     else if (!strcmp(key, "sweep_tile_rows")) *value = g_tune.sweep_tile_rows;
     else if (!strcmp(key, "sweep_max_stage")) *value = g_tune.sweep_max_stage;
@@ -600,6 +602,8 @@ static void bt_release(uspmv_dmat_t *A) {
     (void)hipFree(A->bt_line_ptr); (void)hipFree(A->bt_xrows); (void)hipFree(A->bt_c16_ptrs); (void)hipFree(A->bt_col16);
     (void)hipFree(A->bt_values); (void)hipFree(A->bt_cols); (void)hipFree(A->bt_row_map);
     A->bt_values = nullptr; A->bt_cols = A->bt_row_map = nullptr;
+    (void)hipFree(A->pb_ph_ptr); (void)hipFree(A->pb_g0); (void)hipFree(A->pb_list_ptr); (void)hipFree(A->pb_xrows); (void)hipFree(A->pb_c16_ptrs); (void)hipFree(A->pb_col16);
+    A->pb_ph_ptr = A->pb_g0 = A->pb_list_ptr = A->pb_xrows = nullptr; A->pb_c16_ptrs = nullptr; A->pb_col16 = nullptr; A->pb = false;
     A->bt_line_ptr = A->bt_xrows = nullptr; A->bt_c16_ptrs = nullptr; A->bt_col16 = nullptr;
     A->bt = false;
 }
@@ -645,10 +649,26 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
         if (e == hipSuccess) e = up(row_map.data(), row_map.size() * 4, (void **)&A->bt_row_map);
         if (e == hipSuccess && (p.n_staged_tiles < p.n_tiles || g_tune.spmmv_variant == 5)) e = up(r.col_idxs.data(), (size_t)r.n_elements * 4, (void **)&A->bt_cols);
     }
+    uspmv_phased_plan pp;
+    if (e == hipSuccess && row_bytes == 64 && tile_rows == 64 && g_tune.spmmv_phased) {
+        // 64-byte rows: the phased plan over the same (tie-re-ordered) entries -- what uspmv_spmmv runs by default
+        if (int rc = uspmv_build_phased_plan(moved ? &r : s, g_tune.spmmv_phase_rows, 8, &pp)) { bt_release(A); return rc; }
+        if (pp.valid) {
+            e = up(pp.ph_ptr.data(), pp.ph_ptr.size() * 4, (void **)&A->pb_ph_ptr);
+            if (e == hipSuccess) e = up(pp.ph_g0.data(), pp.ph_g0.size() * 4, (void **)&A->pb_g0);
+            if (e == hipSuccess) e = up(pp.ph_list_ptr.data(), pp.ph_list_ptr.size() * 4, (void **)&A->pb_list_ptr);
+            if (e == hipSuccess) e = up(pp.xrows.data(), pp.xrows.size() * 4, (void **)&A->pb_xrows);
+            if (e == hipSuccess) e = up(pp.c16_ptrs.data(), pp.c16_ptrs.size() * 4, (void **)&A->pb_c16_ptrs);
+            if (e == hipSuccess) e = up(pp.col16.data(), pp.col16.size() * 2, (void **)&A->pb_col16);
+            if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] phased block plan: tiles=%lld phases=%lld rows_total=%zu max_rows=%d (cap %d)\n",
+                                                 (long long)pp.n_tiles, (long long)pp.n_phases, pp.xrows.size(), pp.max_rows_used, pp.cap_rows);
+        }
+    }
     if (e != hipSuccess) {
         bt_release(A);
         return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_block: device copy failed: %s", hipGetErrorString(e));
     }
+    if (pp.valid) { A->pb = true; A->pb_cap_rows = pp.cap_rows; A->pb_ngp = pp.ngp; A->pb_max_rows = pp.max_rows_used; A->pb_n_tiles = pp.n_tiles; A->pb_n_phases = pp.n_phases; }
     A->bt = true; A->bt_tile_rows = p.tile_rows; A->bt_max_rows = p.max_lines_used; A->bt_n_tiles = p.n_tiles; A->bt_staged = p.n_staged_tiles;
     return USPMV_OK;
 }
@@ -727,7 +747,9 @@ static int sweep_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, const uspmv_scs_
     if (wlog <= 0) wlog = vsz == 8 ? 13 : 14;                         // 64 KiB windows
     if (((size_t)1 << wlog) * vsz > 80 * 1024) return uspmv::fail(USPMV_ERR_INVALID, "%s: a window of 2^%d elements does not fit two LDS buffers", who, wlog);
     if (tile_rows <= 0) tile_rows = g_tune.sweep_tile_rows;
-    if (tile_rows <= 0) tile_rows = 1024;
+    // one precision: two rows per lane (the windows are staged once per 2 048 rows: 0.611 vs 0.650 ms on config 4b); ap[dp_sp]: one
+    // row per lane (four dependent chains per window and lane measured slower: 0.70 vs 0.63 ms)
+    if (tile_rows <= 0) tile_rows = B ? 1024 : 2048;
     uspmv_sweep_plan p;
     const double max_stage = g_tune.sweep_max_stage > 0 ? (double)g_tune.sweep_max_stage : 24.0;
     if (int rc = uspmv_build_sweep_plan(s, sB, wlog, tile_rows, max_stage, &p)) return rc;

@@ -45,6 +45,13 @@ struct uspmv_dmat {
     // row_map[plan row] = row of y.  All null when the caller's order is kept.
     void *bt_values = nullptr;
     int32_t *bt_cols = nullptr, *bt_row_map = nullptr;
+    // phased block plan (uspmv_build_phased_plan; 64-byte X rows): per tile a run of phases, each with its own X-row list
+    bool pb = false;
+    int pb_cap_rows = 0, pb_ngp = 0, pb_max_rows = 0;
+    int64_t pb_n_tiles = 0, pb_n_phases = 0;
+    int32_t *pb_ph_ptr = nullptr, *pb_g0 = nullptr, *pb_list_ptr = nullptr, *pb_xrows = nullptr;
+    uint32_t *pb_c16_ptrs = nullptr;
+    uint16_t *pb_col16 = nullptr;
     // column-window sweep plan (host/sweep_plan.cpp, uspmv_dmat_optimize_sweep[_ap]); the _b arrays are the sp part of
     // an ap[dp_sp] pair and live on the dp handle, the sp handle only carries the plan id
     bool sw = false;
@@ -86,11 +93,12 @@ struct Tuning {
     int sweep_nbuf = 1;     // LDS buffers per workgroup: 1 = two 1024-thread workgroups per CU cover each other's staging (0.63 vs 0.72 ms on
                             // config 4b); 2 = one workgroup, window s+1 lands while window s is consumed
     int sweep_unroll = 8;   // rounds per batch
-    int sweep_loop = 0;     // inner loop form (csrc/sweep_kernels.hip): 0 = masked loads + selected FMA, 1 = scalar stream pointers, all masked
     int sweep_remap = 8;    // consecutive sweep tiles per XCD (neighbouring tiles share their x windows)
     int sweep_wlog = 0;     // NEXT uspmv_dmat_optimize_sweep: log2 of the window width in elements (0 = 64 KiB of VT)
-    int sweep_tile_rows = 0;  // NEXT uspmv_dmat_optimize_sweep: 256 | 512 | 1024 rows per tile (0 = 1024)
+    int sweep_tile_rows = 0;  // NEXT uspmv_dmat_optimize_sweep: 256 | 512 | 1024 | 2048 | 4096 rows per tile (0 = default; above 1024: several rows per lane)
     int sweep_max_stage = 0;  // NEXT plan: largest staging cost in bytes per non-zero for a tile to sweep (0 = 24)
+    int spmmv_phased = 1;      // NEXT uspmv_dmat_optimize_block with 64-byte rows: also build the phased plan (eight workgroups per CU)
+    int spmmv_phase_rows = 256;  // ... X rows per phase (256 | 512)
     int spmmv_persist_w = 2;   // persistent SpMMV kernel: compiled for 3 (168 VGPRs) or 2 (256 VGPRs) waves per SIMD
     int spmmv_persist_x = 1;   // persistent SpMMV kernel: grid = this many times the resident workgroups (1 = exactly resident)
     int spmmv_reorder = 1;  // block plan: rows of equal-length chunks of a sigma window back in original order (private copy of the entries)

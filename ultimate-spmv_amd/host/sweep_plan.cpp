@@ -57,7 +57,7 @@ int uspmv_build_sweep_plan(const uspmv_scs *s, const uspmv_scs *s2, int wlog, in
                            uspmv_sweep_plan *p) {
     p->valid = false;
     const int64_t C = s->C, nc = s->n_chunks;
-    if (tile_rows != 256 && tile_rows != 512 && tile_rows != 1024) tile_rows = 1024;
+    if (tile_rows != 256 && tile_rows != 512 && tile_rows != 1024 && tile_rows != 2048 && tile_rows != 4096) tile_rows = 1024;
     if (C < 1 || C > 64 || 64 % C != 0 || nc < 1) return USPMV_OK;          // a wave covers whole chunks
     if (s2 && (s2->C != C || s2->n_chunks != nc)) return USPMV_OK;
     if (wlog < 8 || wlog > 16) return USPMV_OK;                              // 16-bit local indices

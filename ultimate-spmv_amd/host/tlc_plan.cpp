@@ -247,3 +247,109 @@ int uspmv_scs_reorder_ties(const uspmv_scs *s, uspmv_scs *r, std::vector<int32_t
     }
     return changed ? 1 : 0;
 }
+
+// Phased block plan (SpMMV with 64-byte X rows, csrc/spmmv_kernels.hip: scs_spmmv_quadph).  The one-list-per-tile block plan
+// needs 40-50 KB of LDS per 64-row tile for b = 8 in double precision: three workgroups per CU, whose phases (list, X rows,
+// matrix entries, arithmetic) barely overlap.  Here a tile's slot range is cut into PHASES -- runs of at most `ngp` groups of four
+// slots whose entries touch at most `cap_rows` distinct X rows -- and every phase has its own sorted X-row list and phase-local
+// 16-bit indices.  The workgroup stages one phase at a time (cap_rows * row bytes of LDS: 16 KB -> eight workgroups per CU) and
+// still walks every row's slots in order, so the FMA chains are unchanged.  An X row needed in two phases is staged twice; for
+// matrices whose rows are column-sorted the phases' row sets are (nearly) disjoint.
+int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_phased_plan *p) {
+    p->valid = false;
+    const int64_t C = s->C, nc = s->n_chunks;
+    if ((C != 32 && C != 64 && C != 16) || nc < 1 || cap_rows < 256 || cap_rows > 65536 || ngp < 1) return USPMV_OK;
+    if (s->n_cols > (int64_t)INT32_MAX) return USPMV_OK;
+    const int64_t TR = 64, T = TR / C, n_tiles = (nc + T - 1) / T;
+    p->cap_rows = cap_rows; p->ngp = ngp; p->n_tiles = n_tiles;
+    p->c16_ptrs.assign((size_t)nc + 1, 0);
+    int64_t tot16 = 0;
+    for (int64_t c = 0; c < nc; ++c) {
+        p->c16_ptrs[(size_t)c] = (uint32_t)tot16;
+        tot16 += ((int64_t)(s->chunk_lengths[(size_t)c] + 3) / 4) * 4 * C;
+        if (tot16 > (int64_t)UINT32_MAX) return USPMV_OK;
+    }
+    p->c16_ptrs[(size_t)nc] = (uint32_t)tot16;
+    p->col16.assign((size_t)tot16, 0);
+    std::vector<std::vector<int32_t>> t_g0((size_t)n_tiles), t_len((size_t)n_tiles), t_rows((size_t)n_tiles);
+    int64_t max_col_seen = 0;
+    for (int64_t k = 0; k < s->n_elements; ++k) max_col_seen = std::max<int64_t>(max_col_seen, s->col_idxs[(size_t)k]);
+    const size_t ncol = (size_t)max_col_seen + 1;
+#pragma omp parallel
+    {
+        std::vector<int64_t> stamp(ncol, -1), gstamp(ncol, -1);
+        std::vector<int32_t> pos(ncol, 0), gc, cur;
+        int64_t phase_id = 0, group_id = 0;
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t t = 0; t < n_tiles; ++t) {
+            const int64_t c0 = t * T, c1 = std::min(c0 + T, nc);
+            int64_t ng = 0;
+            for (int64_t c = c0; c < c1; ++c) ng = std::max<int64_t>(ng, (s->chunk_lengths[(size_t)c] + 3) / 4);
+            auto &g0s = t_g0[(size_t)t]; auto &lens = t_len[(size_t)t]; auto &rows = t_rows[(size_t)t];
+            if (ng == 0) continue;
+            auto close_phase = [&](int64_t first_group, int64_t end_group) {
+                // sorted row list of the phase, phase-local indices of its entries
+                std::sort(cur.begin(), cur.end());
+                for (size_t k = 0; k < cur.size(); ++k) pos[(size_t)cur[k]] = (int32_t)k;
+                for (int64_t c = c0; c < c1; ++c) {
+                    const int64_t cs = s->chunk_ptrs[(size_t)c], L = s->chunk_lengths[(size_t)c];
+                    uint16_t *q = p->col16.data() + p->c16_ptrs[(size_t)c];
+                    for (int64_t j = first_group * 4; j < std::min(end_group * 4, L); ++j)
+                        for (int64_t i = 0; i < C; ++i)
+                            q[(j / 4) * 4 * C + i * 4 + (j % 4)] = (uint16_t)pos[(size_t)s->col_idxs[(size_t)(cs + j * C + i)]];
+                }
+                g0s.push_back((int32_t)first_group); lens.push_back((int32_t)cur.size());
+                rows.insert(rows.end(), cur.begin(), cur.end());
+                cur.clear();
+            };
+            int64_t first = 0;
+            ++phase_id;
+            for (int64_t g = 0; g < ng; ++g) {
+                gc.clear(); ++group_id;
+                for (int64_t c = c0; c < c1; ++c) {
+                    const int64_t cs = s->chunk_ptrs[(size_t)c], L = s->chunk_lengths[(size_t)c];
+                    for (int64_t j = g * 4; j < std::min(g * 4 + 4, L); ++j)
+                        for (int64_t i = 0; i < C; ++i) {
+                            const int32_t col = s->col_idxs[(size_t)(cs + j * C + i)];
+                            if (gstamp[(size_t)col] != group_id) { gstamp[(size_t)col] = group_id; gc.push_back(col); }
+                        }
+                }
+                int64_t fresh = 0;
+                for (int32_t col : gc) fresh += stamp[(size_t)col] != phase_id;
+                if (g > first && ((int64_t)cur.size() + fresh > cap_rows || g - first >= ngp)) {
+                    close_phase(first, g);
+                    first = g; ++phase_id;
+                }
+                for (int32_t col : gc)
+                    if (stamp[(size_t)col] != phase_id) { stamp[(size_t)col] = phase_id; cur.push_back(col); }
+            }
+            close_phase(first, ng);
+        }
+    }
+    p->ph_ptr.assign((size_t)n_tiles + 1, 0);
+    int64_t n_ph = 0, n_rows_tot = 0;
+    int mx = 0;
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        p->ph_ptr[(size_t)t] = (int32_t)n_ph;
+        n_ph += (int64_t)t_g0[(size_t)t].size();
+        n_rows_tot += (int64_t)t_rows[(size_t)t].size();
+        if (n_ph > INT32_MAX || n_rows_tot > INT32_MAX) return USPMV_OK;
+    }
+    p->ph_ptr[(size_t)n_tiles] = (int32_t)n_ph;
+    p->ph_g0.resize((size_t)n_ph); p->ph_list_ptr.resize((size_t)n_ph + 1); p->xrows.resize((size_t)n_rows_tot);
+    int64_t ph = 0, off = 0;
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        size_t ro = 0;
+        for (size_t k = 0; k < t_g0[(size_t)t].size(); ++k, ++ph) {
+            p->ph_g0[(size_t)ph] = t_g0[(size_t)t][k];
+            p->ph_list_ptr[(size_t)ph] = (int32_t)off;
+            const int len = t_len[(size_t)t][k];
+            std::copy(t_rows[(size_t)t].begin() + (long)ro, t_rows[(size_t)t].begin() + (long)(ro + (size_t)len), p->xrows.begin() + off);
+            ro += (size_t)len; off += len; mx = std::max(mx, len);
+        }
+    }
+    p->ph_list_ptr[(size_t)n_ph] = (int32_t)off;
+    p->n_phases = n_ph; p->max_rows_used = mx;
+    p->valid = n_ph > 0;
+    return USPMV_OK;
+}
