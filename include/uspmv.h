@@ -335,6 +335,12 @@ int uspmv_dist_spmv(uspmv_dist_t *d, void *d_x, void *d_y, int comm_halos, void 
 /* n_steps steps back to back.  use_graph != 0: the step is captured once per (d_x, d_y, stream) into a hipGraph and
  * replayed (needs an explicit stream); falls back to eager steps when the runtime refuses the capture. */
 int uspmv_dist_run(uspmv_dist_t *d, void *d_x, void *d_y, int n_steps, int use_graph, void *stream);
+/* Block vectors: Y = A X with the halo exchange of the b vectors in one of the reference's message patterns (compile-time modes
+ * there: SINGLEVEC / MULTIVEC / BULKVEC_MPI_MODE, code/classes_structs.hpp:875-924, code/mpi_funcs.hpp:35-60), then uspmv_spmmv on
+ * the block (ld = padded_vec_size).  Column-wise X: all three; row-wise X: USPMV_BULKVEC (its per-neighbour block IS the halo
+ * region of X, no staging).  No interior / boundary split: the exchange completes first, as in the reference. */
+typedef enum { USPMV_BULKVEC = 0, USPMV_MULTIVEC = 1, USPMV_SINGLEVEC = 2 } uspmv_vecmode;
+int uspmv_dist_spmmv(uspmv_dist_t *d, void *d_X, void *d_Y, int b, int layout, int mode, int comm_halos, void *stream);
 /* MPI_Barrier / MPI_Allreduce(MAX) / MPI_Allgather twins on the object's communicator (bench loop, code/main.cpp:461-474) */
 int uspmv_dist_barrier(uspmv_dist_t *d, void *stream);
 int uspmv_dist_allreduce_max(uspmv_dist_t *d, double *value, void *stream);

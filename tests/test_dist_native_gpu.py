@@ -16,13 +16,13 @@ pytestmark = pytest.mark.gpu
 EXE = os.path.join(ROOT, "ultimate-spmv_amd", "uspmv")
 
 
-def _global_reference(pkg, orc, shape, P, C, sigma):
+def _global_reference(pkg, orc, shape, P, C, sigma, scale=1.0):
     """y of the whole matrix for x_global = P copies of the ramp over one block (seg-rows, equal blocks), original order."""
     coo = pkg.gen_stencil27(*shape)
     n = coo.n_rows
     assert n % P == 0
     nl = n // P
-    xg = np.tile(make_x(nl), P)
+    xg = np.tile(make_x(nl) * scale, P)
     s = pkg.convert_to_scs(coo, C, sigma)
     a = s.arrays()
     pkg.permute_scs_cols(s, a["old_to_new_idx"])
@@ -75,6 +75,35 @@ def test_native_step_loopback_bitexact(pkg, orc, P, shape, C, sigma):
         d.close()
 
 
+def test_native_block_vector_exchange_loopback_bitexact(pkg, orc):
+    """uspmv_dist_spmmv: the halo exchange of b vectors in the reference's three message patterns (bulkvec / multivec / singlevec,
+    code/classes_structs.hpp:875-924) + the SpMMV kernel, per column against the oracle's single-rank SpMV of the whole matrix."""
+    import torch
+    torch.cuda.set_device(0)
+    P, shape, C, sigma, b = 3, (12, 10, 27), 32, 512, 4
+    refs = [_global_reference(pkg, orc, shape, P, C, sigma, scale=1.0 + v / 8.0) for v in range(b)]
+    nl = refs[0][1]
+    counts = pkg.gen_stencil27_row_counts(*shape)
+    wsa = pkg.seg_from_row_counts(counts, "seg-rows", P)
+    for rank in range(P):
+        loc = pkg.gen_stencil27(*shape, row_begin=int(wsa[rank]), row_end=int(wsa[rank + 1]))
+        d = pkg.DistNative(loc, wsa, C, sigma, rank, P, pkg.comm_unique_id(), comm_rank=0, comm_size=1)
+        Xo = [make_x(nl) * (1.0 + v / 8.0) for v in range(b)]
+        ld = d.padded_vec_size
+        for layout, mode in ((pkg.COLWISE, 0), (pkg.COLWISE, 1), (pkg.COLWISE, 2), (pkg.ROWWISE, 0)):
+            X = d.new_X(Xo, b, layout)
+            Y = torch.zeros(b * ld, dtype=torch.float64, device="cuda")
+            d.spmmv(X, Y, b, layout, mode); d.synchronize()
+            Yh = Y.cpu().numpy()
+            for v in range(b):
+                col = Yh[v:d.n_rows_padded * b:b] if layout == pkg.ROWWISE else Yh[v * ld:v * ld + d.n_rows_padded]
+                got = pkg.apply_permutation(np.ascontiguousarray(col), d.old_to_new)[:nl]
+                assert np.array_equal(got, refs[v][0][wsa[rank]:wsa[rank + 1]]), (rank, layout, mode, v)
+        with pytest.raises(pkg.UspmvError):
+            d.spmmv(d.new_X(Xo, b, pkg.ROWWISE), torch.zeros(b * ld, dtype=torch.float64, device="cuda"), b, pkg.ROWWISE, 1)
+        d.close()
+
+
 def test_cli_distributed_loopback_dumps_the_right_y(pkg, orc, tmp_path):
     """`uspmv gen:... scs -seg_rows -comm_halos 1` through host/uspmv_dist.cpp with USPMV_LOOPBACK=2: per-rank generation, the
     bench loop on hipGraph replays, the spmv_bench.txt block -- and y of the block against the oracle."""
@@ -93,3 +122,15 @@ def test_cli_distributed_loopback_dumps_the_right_y(pkg, orc, tmp_path):
         assert y.shape == (nl,) and np.array_equal(y, y_ref[rank * nl:(rank + 1) * nl])
     txt = open(tmp_path / "spmv_bench.txt").read()
     assert "with 2 RCCL ranks" in txt and "seg_method: seg-rows" in txt and "Per rank Elems Recvd" in txt
+    # block vectors through the harness: -block_vec_size 2 -mpi_mode multivec, vector v = ramp * (1 + v/8)
+    pre = str(tmp_path / "Y")
+    env = dict(os.environ, USPMV_LOOPBACK="2", USPMV_LOOPBACK_RANK="1", USPMV_DIST_X="ramp", USPMV_DUMP_Y=pre, USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID="tb")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([EXE, "gen:24x24x24", "scs", "-c", "32", "-s", "512", "-seg_rows", "-comm_halos", "1", "-bench_time", "0.05", "-block_vec_size", "2",
+                        "-mpi_mode", "multivec"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    Y = np.fromfile(pre + ".1", np.float64).reshape(2, nl)
+    for v in range(2):
+        yv, _ = _global_reference(pkg, orc, shape, P, 32, 512, scale=1.0 + v / 8.0)
+        assert np.array_equal(Y[v], yv[nl:2 * nl]), v
+    assert "block_vec_size: 2" in open(tmp_path / "spmv_bench.txt").read() and "MPI_mode: multivec" in open(tmp_path / "spmv_bench.txt").read()

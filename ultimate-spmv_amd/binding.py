@@ -123,6 +123,7 @@ _SIGS = {
     "uspmv_dist_set_no_pack": (C.c_int, [_vp, C.c_int]),
     "uspmv_dist_spmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "uspmv_dist_run": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "uspmv_dist_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "uspmv_dist_barrier": (C.c_int, [_vp, _vp]),
     "uspmv_dist_allreduce_max": (C.c_int, [_vp, C.POINTER(C.c_double), _vp]),
     "uspmv_dist_allgather_i64": (C.c_int, [_vp, _i64, C.POINTER(_i64), _vp]),
@@ -427,6 +428,23 @@ class DistNative:
         """one eager step on the object's stream"""
         _ck(lib().uspmv_dist_spmv(self.h, _dp(x), _dp(y), int(bool(comm_halos)), self.stream.cuda_stream))
         return y
+
+    def spmmv(self, X, Y, b, layout=COLWISE, mode=0, comm_halos=True):
+        """Y = A X for b vectors of leading dimension padded_vec_size; mode 0 bulkvec | 1 multivec | 2 singlevec (uspmv_dist_spmmv)."""
+        _ck(lib().uspmv_dist_spmmv(self.h, _dp(X), _dp(Y), int(b), int(layout), int(mode), int(bool(comm_halos)), self.stream.cuda_stream))
+        return Y
+
+    def new_X(self, X_local_orig, b, layout=COLWISE):
+        import torch
+        ld = self.padded_vec_size
+        X = torch.zeros(b * ld, dtype=self.tdtype, device="cuda")
+        for v in range(b):
+            xp = torch.from_numpy(apply_permutation(np.ascontiguousarray(X_local_orig[v], self.scs.np_dtype), self.new_to_old)).cuda()
+            if layout == ROWWISE:
+                X[v:self.n_local * b:b] = xp
+            else:
+                X[v * ld:v * ld + self.n_local] = xp
+        return X
 
     def run(self, x, y, n_steps, use_graph=False):
         _ck(lib().uspmv_dist_run(self.h, _dp(x), _dp(y), int(n_steps), int(bool(use_graph)), self.stream.cuda_stream))

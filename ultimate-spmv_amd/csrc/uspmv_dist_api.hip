@@ -44,6 +44,15 @@ struct uspmv_dist {
     hipStream_t g_stream = nullptr;
     bool graph_failed = false;
     int64_t graph_launches = 0, eager_steps = 0;
+    // block-vector exchange plans, one per (b, layout, mode) used so far
+    struct BlockPlan {
+        int b = 0, layout = 0, mode = 0;
+        int32_t *d_src = nullptr;                    // wire order of the send buffer: send[i] = X[d_src[i]]
+        std::vector<int32_t *> d_unpack;             // staged receive (bulk, column-wise): per vector, halo slot -> position in d_recv
+        void *d_send = nullptr, *d_recv = nullptr;
+    };
+    std::vector<BlockPlan> block_plans;
+    std::vector<int32_t> h_send_idxs, h_perm;        // host copies for building those plans
 };
 
 namespace {
@@ -138,6 +147,10 @@ int uspmv_comm_unique_id(void *id128) {
 void uspmv_dist_free(uspmv_dist_t *D) {
     if (!D) return;
     drop_graph(D);
+    for (auto &bp : D->block_plans) {
+        (void)hipFree(bp.d_src); (void)hipFree(bp.d_send); (void)hipFree(bp.d_recv);
+        for (int32_t *u : bp.d_unpack) (void)hipFree(u);
+    }
     (void)hipFree(D->d_send_idxs); (void)hipFree(D->d_perm); (void)hipFree(D->d_int); (void)hipFree(D->d_bnd); (void)hipFree(D->d_send); (void)hipFree(D->d_scratch);
     if (D->ev_main) (void)hipEventDestroy(D->ev_main);
     if (D->ev_comm) (void)hipEventDestroy(D->ev_comm);
@@ -210,6 +223,9 @@ int uspmv_dist_create(const void *comm_id, int comm_rank, int comm_size, int ran
         D_HIP(hipStreamSynchronize(st));
     }
     (void)hipFree(d_recv_idxs);
+    D->h_send_idxs.resize((size_t)D->n_send);
+    if (D->n_send) D_HIP(hipMemcpy(D->h_send_idxs.data(), D->d_send_idxs, 4 * (size_t)D->n_send, hipMemcpyDeviceToHost));
+    D->h_perm.assign(old_to_new_idx, old_to_new_idx + D->n_local);
     // ---- device state of the step
     const size_t vsz = D->dtype == USPMV_F64 ? 8 : 4;
     D_HIP(hipMalloc((void **)&D->d_perm, 4 * (size_t)std::max<int64_t>(D->n_local, 1)));
@@ -372,3 +388,109 @@ int uspmv_dist_allgather_i64(uspmv_dist_t *D, int64_t value, int64_t *all, void 
 }
 
 }  // extern "C"
+
+// ---- block vectors (SpMMV): the halo exchange of b vectors in the reference's three message patterns
+//   USPMV_BULKVEC   one message per neighbour carrying all b vectors           (code/classes_structs.hpp:909-924, :971-981)
+//   USPMV_MULTIVEC  one message per neighbour and vector, all posted together  (:893-907, :953-960)
+//   USPMV_SINGLEVEC one exchange per vector, one after the other               (:875-891, :943-951; the loop of code/mpi_funcs.hpp:35-60)
+// Row-wise X ([element][v]): a neighbour's bulk block is exactly the row-wise halo region, so it lands in the tail of X directly.
+// Column-wise X: per-vector messages land in the halo region of their column directly; the bulk block ([v][element] per neighbour)
+// lands in a staging buffer and b small gathers move it.  Row-wise X with per-vector messages would need strided receives: refused.
+namespace {
+
+uspmv_dist::BlockPlan *block_plan(uspmv_dist *D, int b, int layout, int mode) {
+    for (auto &bp : D->block_plans)
+        if (bp.b == b && bp.layout == layout && bp.mode == mode) return &bp;
+    uspmv_dist::BlockPlan bp;
+    bp.b = b; bp.layout = layout; bp.mode = mode;
+    const int64_t ld = D->vec_len, ns = D->n_send, nh = D->n_halo;
+    const size_t vsz = D->dtype == USPMV_F64 ? 8 : 4;
+    if ((int64_t)b * std::max(ld, (int64_t)1) > INT32_MAX) { uspmv::fail(USPMV_ERR_OVERFLOW, "uspmv_dist_spmmv: b * padded_vec_size exceeds int32"); return nullptr; }
+    std::vector<int32_t> src((size_t)(ns * b));
+    if (layout == USPMV_ROWWISE) {                         // wire = [element][v] (bulk only)
+        for (int64_t i = 0; i < ns; ++i)
+            for (int v = 0; v < b; ++v) src[(size_t)(i * b + v)] = (int32_t)((int64_t)D->h_perm[(size_t)D->h_send_idxs[(size_t)i]] * b + v);
+    } else if (mode == USPMV_BULKVEC) {                    // wire = per neighbour [v][element]
+        size_t o = 0;
+        for (int p = 0; p < D->P; ++p)
+            for (int v = 0; v < b; ++v)
+                for (int64_t i = D->send_off[(size_t)p]; i < D->send_off[(size_t)p + 1]; ++i)
+                    src[o++] = (int32_t)(D->h_perm[(size_t)D->h_send_idxs[(size_t)i]] + (int64_t)v * ld);
+    } else {                                               // wire = [v][element over all neighbours]
+        for (int v = 0; v < b; ++v)
+            for (int64_t i = 0; i < ns; ++i) src[(size_t)(v * ns + i)] = (int32_t)(D->h_perm[(size_t)D->h_send_idxs[(size_t)i]] + (int64_t)v * ld);
+    }
+    hipError_t e = hipMalloc((void **)&bp.d_src, 4 * std::max<size_t>(src.size(), 1));
+    if (e == hipSuccess && !src.empty()) e = hipMemcpy(bp.d_src, src.data(), 4 * src.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&bp.d_send, vsz * std::max<size_t>((size_t)(ns * b), 1));
+    if (e == hipSuccess && layout == USPMV_COLWISE && mode == USPMV_BULKVEC) {
+        e = hipMalloc(&bp.d_recv, vsz * std::max<size_t>((size_t)(nh * b), 1));
+        std::vector<int32_t> un((size_t)nh);
+        for (int v = 0; v < b && e == hipSuccess; ++v) {
+            for (int p = 0; p < D->P; ++p) {
+                const int64_t nr = D->recv_counts[(size_t)p], ro = D->recv_off[(size_t)p];
+                for (int64_t k = 0; k < nr; ++k) un[(size_t)(ro + k)] = (int32_t)((int64_t)b * ro + (int64_t)v * nr + k);
+            }
+            int32_t *d_u = nullptr;
+            e = hipMalloc((void **)&d_u, 4 * std::max<size_t>(un.size(), 1));
+            if (e == hipSuccess && nh) e = hipMemcpy(d_u, un.data(), 4 * un.size(), hipMemcpyHostToDevice);
+            bp.d_unpack.push_back(d_u);
+        }
+    }
+    if (e != hipSuccess) { uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dist_spmmv: %s", hipGetErrorString(e)); return nullptr; }
+    D->block_plans.push_back(bp);
+    return &D->block_plans.back();
+}
+
+int exchange_block(uspmv_dist *D, void *d_X, int b, int layout, int mode, hipStream_t st) {
+    uspmv_dist::BlockPlan *bp = block_plan(D, b, layout, mode);
+    if (!bp) return USPMV_ERR_ALLOC;
+    const size_t vsz = D->dtype == USPMV_F64 ? 8 : 4;
+    const int64_t ld = D->vec_len, ns = D->n_send;
+    if (ns * b > 0)
+        if (int rc = uspmv_apply_permutation_dev(bp->d_send, d_X, bp->d_src, ns * b, D->dtype, st)) return rc;
+    char *X = (char *)d_X;
+    const char *S = (const char *)bp->d_send;
+    auto group = [&](int v0, int v1) -> int {                // per-vector messages of vectors [v0, v1)
+        NCCL_TRY(ncclGroupStart());
+        for (int v = v0; v < v1; ++v)
+            for (int p = 0; p < D->P; ++p) {
+                const int64_t nsp = D->send_off[(size_t)p + 1] - D->send_off[(size_t)p], nr = D->recv_counts[(size_t)p];
+                if (nr) NCCL_TRY(ncclRecv(X + (size_t)(v * ld + D->n_local + D->recv_off[(size_t)p]) * vsz, (size_t)nr, nccl_vt(D), peer(D, p), D->comm, st));
+                if (nsp) NCCL_TRY(ncclSend(S + (size_t)(v * ns + D->send_off[(size_t)p]) * vsz, (size_t)nsp, nccl_vt(D), peer(D, p), D->comm, st));
+            }
+        NCCL_TRY(ncclGroupEnd());
+        return USPMV_OK;
+    };
+    if (mode == USPMV_SINGLEVEC) {
+        for (int v = 0; v < b; ++v) if (int rc = group(v, v + 1)) return rc;
+        return USPMV_OK;
+    }
+    if (mode == USPMV_MULTIVEC) return group(0, b);
+    // bulk: one message per neighbour
+    char *R = layout == USPMV_ROWWISE ? X + (size_t)D->n_local * b * vsz : (char *)bp->d_recv;
+    NCCL_TRY(ncclGroupStart());
+    for (int p = 0; p < D->P; ++p) {
+        const int64_t nsp = D->send_off[(size_t)p + 1] - D->send_off[(size_t)p], nr = D->recv_counts[(size_t)p];
+        if (nr) NCCL_TRY(ncclRecv(R + (size_t)(D->recv_off[(size_t)p] * b) * vsz, (size_t)(nr * b), nccl_vt(D), peer(D, p), D->comm, st));
+        if (nsp) NCCL_TRY(ncclSend(S + (size_t)(D->send_off[(size_t)p] * b) * vsz, (size_t)(nsp * b), nccl_vt(D), peer(D, p), D->comm, st));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    if (layout == USPMV_COLWISE && D->n_halo)
+        for (int v = 0; v < b; ++v)
+            if (int rc = uspmv_apply_permutation_dev(X + (size_t)(v * ld + D->n_local) * vsz, bp->d_recv, bp->d_unpack[(size_t)v], D->n_halo, D->dtype, st)) return rc;
+    return USPMV_OK;
+}
+
+}  // namespace
+
+extern "C" int uspmv_dist_spmmv(uspmv_dist_t *D, void *d_X, void *d_Y, int b, int layout, int mode, int comm_halos, void *stream) {
+    if (!D || !d_X || !d_Y || b < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_spmmv: bad argument");
+    if (layout != USPMV_COLWISE && layout != USPMV_ROWWISE) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_spmmv: unknown layout %d", layout);
+    if (mode != USPMV_BULKVEC && mode != USPMV_MULTIVEC && mode != USPMV_SINGLEVEC) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_spmmv: unknown mode %d", mode);
+    if (layout == USPMV_ROWWISE && mode != USPMV_BULKVEC)
+        return uspmv::fail(USPMV_ERR_UNSUPPORTED, "uspmv_dist_spmmv: row-wise block vectors travel in one message per neighbour (bulkvec) only");
+    if (D->P > 1 && comm_halos)
+        if (int rc = exchange_block(D, d_X, b, layout, mode, (hipStream_t)stream)) return rc;
+    return uspmv_spmmv(D->A, d_X, d_Y, b, D->vec_len, layout, stream);
+}

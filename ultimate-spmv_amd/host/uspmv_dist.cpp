@@ -179,30 +179,40 @@ int uspmv_run_distributed(const DistConfig &c) {
     const int32_t *o2n, *n2o;
     CK(uspmv_scs_arrays(scs, nullptr, nullptr, nullptr, nullptr, &o2n, &n2o));
 
-    // ---- vectors: x = DefaultValues::x = 5.0 on the local rows (or the test ramp), permuted (code/main.cpp:86-93); 0 elsewhere
+    // ---- vectors: x = DefaultValues::x = 5.0 on the local rows (or the test ramp, scaled by 1 + v/8 for vector v), permuted
+    //      (code/main.cpp:86-93); 0 elsewhere.  Block vectors: b * padded_vec_size elements, column- or row-wise.
+    const int b = c.block_vec_size;
     double *d_x = nullptr, *d_y = nullptr;
-    HK(hipMalloc((void **)&d_x, sizeof(double) * (size_t)vec_len));
-    HK(hipMalloc((void **)&d_y, sizeof(double) * (size_t)vec_len));
-    HK(hipMemset(d_y, 0, sizeof(double) * (size_t)vec_len));
+    HK(hipMalloc((void **)&d_x, sizeof(double) * (size_t)vec_len * b));
+    HK(hipMalloc((void **)&d_y, sizeof(double) * (size_t)vec_len * b));
+    HK(hipMemset(d_y, 0, sizeof(double) * (size_t)vec_len * b));
     {
-        std::vector<double> xo((size_t)n_local, 5.0), hx((size_t)vec_len, 0.0);
+        std::vector<double> xo((size_t)n_local), xp((size_t)n_local), hx((size_t)vec_len * b, 0.0);
         const char *xk = getenv("USPMV_DIST_X");
-        if (xk && !strcmp(xk, "ramp")) for (int64_t i = 0; i < n_local; ++i) xo[(size_t)i] = 1.0 + 1e-3 * (double)(i % 1000);
-        CK(uspmv_apply_permutation(hx.data(), xo.data(), n2o, n_local, USPMV_F64));
+        const bool ramp = xk && !strcmp(xk, "ramp");
+        for (int v = 0; v < b; ++v) {
+            for (int64_t i = 0; i < n_local; ++i) xo[(size_t)i] = ramp ? (1.0 + 1e-3 * (double)(i % 1000)) * (1.0 + v / 8.0) : 5.0;
+            CK(uspmv_apply_permutation(xp.data(), xo.data(), n2o, n_local, USPMV_F64));
+            for (int64_t i = 0; i < n_local; ++i) hx[(size_t)(c.layout == USPMV_ROWWISE ? i * b + v : (int64_t)v * vec_len + i)] = xp[(size_t)i];
+        }
         HK(hipMemcpy(d_x, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
     }
     const int comm_halos = c.comm_halos ? 1 : 0;
     auto steps = [&](int n) {
-        if (comm_halos && c.use_graph) CK(uspmv_dist_run(D, d_x, d_y, n, 1, st));
+        if (b > 1) for (int k = 0; k < n; ++k) CK(uspmv_dist_spmmv(D, d_x, d_y, b, c.layout, c.vec_mode, comm_halos, st));
+        else if (comm_halos && c.use_graph) CK(uspmv_dist_run(D, d_x, d_y, n, 1, st));
         else for (int k = 0; k < n; ++k) CK(uspmv_dist_spmv(D, d_x, d_y, comm_halos, st));
     };
 
-    if (const char *dump = getenv("USPMV_DUMP_Y")) {   // one step, y of the local rows back in original order (copy_back_result)
+    if (const char *dump = getenv("USPMV_DUMP_Y")) {   // one step, y of the local rows back in original order (copy_back_result), vector after vector
         steps(1);
         HK(hipStreamSynchronize(st));
-        std::vector<double> hy((size_t)vec_len), yo((size_t)n_local);
+        std::vector<double> hy((size_t)vec_len * b), col((size_t)n_pad), yo((size_t)n_local * b);
         HK(hipMemcpy(hy.data(), d_y, sizeof(double) * hy.size(), hipMemcpyDeviceToHost));
-        CK(uspmv_apply_permutation(yo.data(), hy.data(), o2n, n_local, USPMV_F64));
+        for (int v = 0; v < b; ++v) {
+            for (int64_t i = 0; i < n_pad; ++i) col[(size_t)i] = hy[(size_t)(c.layout == USPMV_ROWWISE ? i * b + v : (int64_t)v * vec_len + i)];
+            CK(uspmv_apply_permutation(yo.data() + (size_t)v * n_local, col.data(), o2n, n_local, USPMV_F64));
+        }
         publish(std::string(dump) + "." + std::to_string(rank), yo.data(), yo.size() * 8);
     }
 
@@ -221,7 +231,7 @@ int uspmv_run_distributed(const DistConfig &c) {
         CK(uspmv_dist_allreduce_max(D, &runtime, st));   // every rank must take the same decision: the slowest rank's clock
     } while (runtime < c.bench_time);
     n_iter /= 2;
-    const double perf = (double)nnz_g * 2.0 / (runtime / n_iter) / 1e9;
+    const double perf = (double)nnz_g * 2.0 * b / (runtime / n_iter) / 1e9;
 
     // ---- report
     std::vector<int64_t> halos((size_t)std::max(P, comm_size), 0), sends((size_t)std::max(P, comm_size), 0);
@@ -229,11 +239,11 @@ int uspmv_run_distributed(const DistConfig &c) {
     CK(uspmv_dist_allgather_i64(D, n_send, sends.data(), st));
     CK(uspmv_dist_info(D, meta));
     if (comm_rank == 0) {
-        const double bytes = n_el * 12.0 + 8.0 * n_chunks + 8.0 * (n_local + n_halo) + 8.0 * n_pad;  // this rank's share
+        const double bytes = n_el * 12.0 + 8.0 * n_chunks + 8.0 * b * (n_local + n_halo) + 8.0 * b * n_pad;  // this rank's share
         std::ofstream f("spmv_bench.txt", std::ios::app);
         f << c.matrix_name << " with " << P << " RCCL ranks (one per GPU), halo exchange " << (c.comm_halos ? "on" : "off") << std::endl;
-        f << "kernel: scs, block_vec_size: 1, C: " << c.C << " sigma: " << c.sigma << ", data_type: double, revisions: " << n_iter
-          << ", seg_method: " << (c.seg_nnz ? "seg-nnz" : "seg-rows") << ", MPI_mode: singlevec" << std::endl << std::endl;
+        f << "kernel: scs, block_vec_size: " << b << ", C: " << c.C << " sigma: " << c.sigma << ", data_type: double, revisions: " << n_iter
+          << ", seg_method: " << (c.seg_nnz ? "seg-nnz" : "seg-rows") << ", MPI_mode: " << (b == 1 || c.vec_mode == USPMV_SINGLEVEC ? "singlevec" : c.vec_mode == USPMV_MULTIVEC ? "multivec" : "bulkvec") << std::endl << std::endl;
         char buf[256];
         snprintf(buf, sizeof buf, "%-32s%-32s\n%-32s%-32s\n%-32.16g%-32.16g\n\n", "Total Gflops:", "Total Walltime:", "-------------",
                  "-------------", perf, runtime);

@@ -8,6 +8,7 @@ struct DistConfig {
     long C = 32, sigma = 1;
     bool seg_nnz = false, comm_halos = true, ba_synch = true, tlc = true, verbose = false;
     bool no_overlap = false, use_graph = true, print_comm_vol = false, no_pack = false;
+    int block_vec_size = 1, layout = USPMV_COLWISE, vec_mode = USPMV_BULKVEC;   // -block_vec_size, -block_vec_layout, -mpi_mode
     double bench_time = 5.0;
     std::string matrix_name;
 };

@@ -50,6 +50,7 @@ struct Config {  // subset of the reference's Config (code/classes_structs.hpp:4
     int layout = USPMV_COLWISE;  // run-time here; a make knob in the reference (Makefile:26-31)
     int tlc = 1;                 // build the tile-local-column plan (MI355X-specific, results unchanged)
     int use_graph = 1;           // bench loop replays hipGraphs of 64 launches
+    int vec_mode = USPMV_BULKVEC;  // -mpi_mode: message pattern of the block-vector halo exchange (a make knob in the reference, Makefile / config.mk)
 };
 
 [[noreturn]] void die(const std::string &msg) {
@@ -70,7 +71,8 @@ void usage() {
             "  -seg_rows|-seg_nnz -validate <0|1> -verbose <0|1> -mode <s|b> -bench_time <float>\n"
             "  -ba_synch <0|1> -comm_halos <0|1> -par_pack <0|1> -no_pack <0|1> -print_comm_vol <0|1>\n"
             "  -equilibrate <0|1> -ap_threshold_1 <float> -ap_threshold_2 <float> -dropout <0|1>\n"
-            "  -dropout_threshold <float> -block_vec_layout <colwise|rowwise> -tlc <0|1> -graph <0|1> -dump_y <file>\n");
+            "  -dropout_threshold <float> -block_vec_layout <colwise|rowwise> -tlc <0|1> -graph <0|1> -dump_y <file>\n"
+            "  -mpi_mode <singlevec|multivec|bulkvec>\n");
 }
 
 Config parse(int argc, char **argv) {
@@ -109,6 +111,7 @@ Config parse(int argc, char **argv) {
         else if (a == "-seg_metis" || a == "-seg-metis") c.seg_method = "seg-metis";
         else if (a == "-tlc") c.tlc = atoi(need(i));
         else if (a == "-dump_y") c.dump_y = need(i);
+        else if (a == "-mpi_mode") { std::string v = need(i); if (v == "singlevec") c.vec_mode = USPMV_SINGLEVEC; else if (v == "multivec") c.vec_mode = USPMV_MULTIVEC; else if (v == "bulkvec") c.vec_mode = USPMV_BULKVEC; else die("mpi_mode must be singlevec, multivec or bulkvec."); }
         else if (a == "-graph") c.use_graph = atoi(need(i));
         else if (a == "-block_vec_layout") { std::string v = need(i); if (v == "colwise") c.layout = USPMV_COLWISE; else if (v == "rowwise") c.layout = USPMV_ROWWISE; else die("block_vec_layout must be colwise or rowwise."); }
         else { usage(); die("unknown argument: " + a); }
@@ -381,13 +384,15 @@ int run(const Config &c, uspmv_coo_t *coo) {
 int main(int argc, char **argv) {
     Config c = parse(argc, argv);
     if (uspmv_dist_requested()) {  // one process per GPU, halo exchange on RCCL (uspmv_dist.cpp)
-        if (c.mode != 'b' || c.kernel_format != "scs" || c.value_type != "dp" || c.block_vec_size != 1)
-            die("multi-rank runs support `scs -dp -mode b` with a single vector in this round "
+        if (c.mode != 'b' || c.kernel_format != "scs" || c.value_type != "dp")
+            die("multi-rank runs support `scs -dp -mode b` (single vector or -block_vec_size b) in this round "
                 "(the reference also refuses ap with MPI, code/utilities.hpp:1443-1450)");
+        if (c.layout == USPMV_ROWWISE && c.vec_mode != USPMV_BULKVEC) die("row-wise block vectors are exchanged in bulkvec mode only.");
         DistConfig d;
         d.C = c.chunk_size; d.sigma = c.sigma; d.seg_nnz = c.seg_method == "seg-nnz"; d.comm_halos = c.comm_halos != 0;
         d.ba_synch = c.ba_synch != 0; d.tlc = c.tlc != 0; d.verbose = c.verbose != 0; d.bench_time = c.bench_time;
         d.matrix_name = c.matrix_file_name;
+        d.block_vec_size = c.block_vec_size; d.layout = c.layout; d.vec_mode = c.vec_mode;
         d.use_graph = c.use_graph != 0; d.print_comm_vol = c.print_comm_vol != 0; d.no_pack = c.no_pack != 0;
         d.no_overlap = getenv("USPMV_NO_OVERLAP") != nullptr;
         if (c.equilibrate) die("-equilibrate is a single-rank option in this round");
