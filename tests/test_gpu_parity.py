@@ -403,7 +403,11 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                             pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
                             assert t.equal(Y, Y0), (name, C, code, b, rowwise, swz, var, pd)
                     pkg.set_tuning(spmmv_unroll=0, spmmv_persist_w=2, spmmv_persist_x=1)
-                    pkg.set_tuning(spmmv_variant=0, spmmv_swizzle=0)
+                    pkg.set_tuning(spmmv_variant=8, spmmv_swizzle=0, spmmv_xcol=1)   # phased kernel assembling its X rows from the column-major vector itself
+                    Y.fill_(-3.0)
+                    pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
+                    assert t.equal(Y, Y0), (name, C, code, b, rowwise, "xcol=1")
+                    pkg.set_tuning(spmmv_variant=0, spmmv_swizzle=0, spmmv_xcol=0)
                     Y.fill_(-3.0)                          # and whatever auto picks
                     pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
                     assert t.equal(Y, Y0), (name, C, code, b, rowwise, "auto")

@@ -734,7 +734,10 @@ __global__ void __launch_bounds__(256, WPE) scs_spmmv_quadp(const long n_tiles, 
 // current phase's X rows are staged: 16 KB of LDS and 40 registers per 256-thread workgroup instead of 50 KB and 88, so EIGHT
 // workgroups (the wave limit) instead of three share a CU and one workgroup's round trips (list, X rows + its matrix entries) hide
 // behind the arithmetic of seven others.  Every row still walks its slots in order: bit-identical FMA chains.
-template <typename VT, int B, bool NT, bool YCOL, int C, int NGP, int MAXP>
+// XCOL: X is the caller's COLUMN-MAJOR block vector (X[col + v*ld]) -- no re-layout pass, no workspace: a phase's X rows are
+// assembled in LDS by the workgroup itself (thread <-> list entry: B coalesced element loads, one per column, written as one
+// row of LDS; rows sit 16 bytes apart from a power-of-two stride so that the column-strided writes spread over the banks).
+template <typename VT, int B, bool NT, bool YCOL, int C, int NGP, int MAXP, bool XCOL>
 __global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, const int *__restrict__ chunk_ptrs,
         const int *__restrict__ chunk_lengths, const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y, const long ld,
         const int *__restrict__ ph_ptr, const int *__restrict__ ph_g0, const int *__restrict__ ph_list_ptr, const int *__restrict__ xrows,
@@ -763,11 +766,12 @@ __global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, con
     const VT *vp = values + (long)cs + i + (long)q * C;
     const unsigned short *ip = col16 + q0 + (long)i * 4 + q;
     const vec_t *xs = (const vec_t *)tlc_smem;
+    constexpr unsigned RS = XCOL ? 5u : 4u;                  // 16-byte pieces per staged row (XCOL: 80-byte row stride)
 #define QUAD_STEP(UU, AV, IV)                                                                                 \
     {                                                                                                         \
         const VT aa = quad_bcast<UU>(AV);                                                                     \
         const unsigned li = (unsigned)quad_bcast<UU>((int)(IV));                                              \
-        const vec_t xv = xs[li * 4 + (unsigned)q];                                                            \
+        const vec_t xv = xs[li * RS + (unsigned)q];                                                           \
         _Pragma("unroll") for (int w = 0; w < VW; ++w) acc[w] = fma_t(aa, xv[w], acc[w]);                     \
     }
     int g0 = p0 < p1 ? ph_g0[p0] : 0, lp = p0 < p1 ? ph_list_ptr[p0] : 0;
@@ -775,21 +779,48 @@ __global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, con
         const int g1 = ph + 1 < p1 ? ph_g0[ph + 1] : 0x7fffffff;
         const int lp1 = ph_list_ptr[ph + 1];
         const int np = (lp1 - lp) << 2;
-        // ---- the list entries this lane needs for its DMA pieces (piece p = (wave + 4k)*64 + lane <-> list entry p >> 2)
-        int xr[MAXP];
+        if constexpr (!XCOL) {
+            // ---- the list entries this lane needs for its DMA pieces (piece p = (wave + 4k)*64 + lane <-> list entry p >> 2)
+            int xr[MAXP];
 #pragma unroll
-        for (int k = 0; k < MAXP; ++k) {
-            const int pp = (wave + 4 * k) * 64 + lane;
-            xr[k] = -1;
-            if (pp < np) xr[k] = xrows[lp + (pp >> 2)];
+            for (int k = 0; k < MAXP; ++k) {
+                const int pp = (wave + 4 * k) * 64 + lane;
+                xr[k] = -1;
+                if (pp < np) xr[k] = xrows[lp + (pp >> 2)];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ph > p0) __syncthreads();                    // every wave is through with the previous phase's rows
+            // ---- X rows of the phase -> LDS by DMA, and behind them this wave's matrix entries of the phase
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k)
+                if (xr[k] >= 0)
+                    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(X + (long)xr[k] * B + q * VW), (lds_void_t *)(tlc_smem + (wave + 4 * k) * 1024), 16, 0, 0);
+        } else {
+            // ---- column-major X: thread <-> list entry (MAXP*64/256 entries per thread), its B elements loaded column by column
+            constexpr int EPT = MAXP / 4;                    // list entries per thread (cap rows / 256 threads)
+            int xe[EPT];
+            VT xv_[EPT][B];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int e = k * 256 + (int)threadIdx.x;
+                xe[k] = -1;
+                if (e < (np >> 2)) xe[k] = xrows[lp + e];
+            }
+#pragma unroll
+            for (int k = 0; k < EPT; ++k)
+                if (xe[k] >= 0) {
+#pragma unroll
+                    for (int v = 0; v < B; ++v) xv_[k][v] = X[(long)xe[k] + (long)v * ld];
+                }
+            if (ph > p0) __syncthreads();                    // every wave is through with the previous phase's rows
+#pragma unroll
+            for (int k = 0; k < EPT; ++k)
+                if (xe[k] >= 0) {
+                    VT *dst = (VT *)(tlc_smem + (size_t)(k * 256 + (int)threadIdx.x) * (RS * 16));
+#pragma unroll
+                    for (int v = 0; v < B; ++v) dst[v] = xv_[k][v];
+                }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (ph > p0) __syncthreads();                        // every wave is through with the previous phase's rows
-        // ---- X rows of the phase -> LDS by DMA, and behind them this wave's matrix entries of the phase
-#pragma unroll
-        for (int k = 0; k < MAXP; ++k)
-            if (xr[k] >= 0)
-                __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(X + (long)xr[k] * B + q * VW), (lds_void_t *)(tlc_smem + (wave + 4 * k) * 1024), 16, 0, 0);
         const int ge = min(g1, ngf);                         // full groups of this wave's rows in the phase: [g0, ge)
         VT a[NGP], at = VT(0);
         unsigned ix[NGP], ixt = 0u;
@@ -1002,11 +1033,11 @@ bool launch_spmmv_quadp(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool y
 }
 
 template <typename VT, int B, int CT, int MAXP>
-void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
-    const size_t lds = (size_t)MAXP * 4 * 1024;
+void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, bool xcol, hipStream_t st) {
+    const size_t lds = xcol ? (size_t)MAXP * 64 * 80 : (size_t)MAXP * 4 * 1024;   // MAXP*64 rows of 64 (row-major X, DMA pieces) or 80 bytes
 #define QH_LAUNCH(NTV, YC)                                                                                              \
     do {                                                                                                                \
-        auto kfn = scs_spmmv_quadph<VT, B, NTV, YC, CT, 8, MAXP>;                                                       \
+        auto kfn = xcol ? scs_spmmv_quadph<VT, B, NTV, YC, CT, 8, MAXP, true> : scs_spmmv_quadph<VT, B, NTV, YC, CT, 8, MAXP, false>; \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)A->pb_n_tiles), dim3(256), lds, st, (long)A->n_chunks, A->chunk_ptrs, A->chunk_lengths, \
                            (const VT *)(A->bt_values ? A->bt_values : A->values), X, Y, ld, A->pb_ph_ptr, A->pb_g0, A->pb_list_ptr,   \
@@ -1017,12 +1048,12 @@ void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
 #undef QH_LAUNCH
 }
 
-// false: the handle's phased plan does not fit the compiled shapes
+// false: the handle's phased plan does not fit the compiled shapes.  xcol: X is the caller's column-major block vector.
 template <typename VT, int B>
-bool launch_spmmv_quadph(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+bool launch_spmmv_quadph(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, bool xcol, hipStream_t st) {
     if (!A->pb || A->pb_ngp > 8) return false;
     const int pieces = (A->pb_max_rows * 4 + 255) / 256;
-#define QH_C(CTV) do { if (pieces <= 4) launch_spmmv_quadph_m<VT, B, CTV, 4>(A, X, Y, ld, ycol, st); else if (pieces <= 8) launch_spmmv_quadph_m<VT, B, CTV, 8>(A, X, Y, ld, ycol, st); else return false; } while (0)
+#define QH_C(CTV) do { if (pieces <= 4) launch_spmmv_quadph_m<VT, B, CTV, 4>(A, X, Y, ld, ycol, xcol, st); else if (pieces <= 8) launch_spmmv_quadph_m<VT, B, CTV, 8>(A, X, Y, ld, ycol, xcol, st); else return false; } while (0)
     if (A->C == 32) QH_C(32); else if (A->C == 64) QH_C(64); else if (A->C == 16) QH_C(16); else return false;
 #undef QH_C
     return true;
@@ -1033,7 +1064,7 @@ void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
     constexpr int RB = B * (int)sizeof(VT);          // bytes per X row
     if constexpr (RB == 64) {
         // 64-byte rows, phased plan (variant 8; auto when the handle carries one): eight workgroups per CU
-        if ((g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 8) && !g_tune.ablate && launch_spmmv_quadph<VT, B>(A, X, Y, ld, ycol, st)) return;
+        if ((g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 8) && !g_tune.ablate && launch_spmmv_quadph<VT, B>(A, X, Y, ld, ycol, false, st)) return;
         // 64-byte rows: the four-lanes-per-row kernel over 64-row tiles of the block plan (variant 6; auto when the plan is there)
         if (A->bt && A->bt_tile_rows == 64 && (g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 6 || g_tune.spmmv_variant == 7) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
             // variant 6 (and auto): one tile per workgroup, three workgroups per CU; variant 7: persistent and pipelined over tiles, but 222
@@ -1091,6 +1122,11 @@ int spmmv_fast(const uspmv_dmat *A, const VT *X, VT *Y, long ld, int layout, hip
     if (layout == USPMV_ROWWISE) {
         launch_spmmv_rowmajor<VT, B>(A, X, Y, ld, false, st);
         return USPMV_OK;
+    }
+    if constexpr (B * (int)sizeof(VT) == 64) {
+        // 64-byte rows with a phased plan: the kernel assembles its X rows from the column-major vector itself (no re-layout pass)
+        if ((g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 8) && g_tune.spmmv_xcol && !g_tune.ablate &&
+            launch_spmmv_quadph<VT, B>(A, X, Y, ld, true, true, st)) return USPMV_OK;
     }
     const size_t need = sizeof(VT) * (size_t)B * (size_t)ld;
     if (A->ws_bytes < need) {

@@ -156,6 +156,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_reorder")) g_tune.spmmv_reorder = value != 0;
     else if (!strcmp(key, "spmmv_persist_x")) g_tune.spmmv_persist_x = value < 1 ? 1 : value;
     else if (!strcmp(key, "spmmv_phased")) g_tune.spmmv_phased = value != 0;
+    else if (!strcmp(key, "spmmv_xcol")) g_tune.spmmv_xcol = value != 0;
     else if (!strcmp(key, "spmmv_phase_rows")) g_tune.spmmv_phase_rows = value == 512 ? 512 : 256;
     else if (!strcmp(key, "spmmv_persist_w")) g_tune.spmmv_persist_w = value == 3 ? 3 : 2;
     else if (!strcmp(key, "sweep")) g_tune.sweep = value != 0;
@@ -214,6 +215,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_reorder")) *value = g_tune.spmmv_reorder;
     else if (!strcmp(key, "spmmv_persist_x")) *value = g_tune.spmmv_persist_x;
     else if (!strcmp(key, "spmmv_phased")) *value = g_tune.spmmv_phased;
+    else if (!strcmp(key, "spmmv_xcol")) *value = g_tune.spmmv_xcol;
     else if (!strcmp(key, "spmmv_phase_rows")) *value = g_tune.spmmv_phase_rows;
     else if (!strcmp(key, "spmmv_persist_w")) *value = g_tune.spmmv_persist_w;
     else if (!strcmp(key, "sweep")) *value = g_tune.sweep;
