@@ -162,7 +162,7 @@ def measure_traffic(args):
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", td, "--", sys.executable, os.path.abspath(__file__),
                    "--pmc-child", "--grid", str(args.grid or 253), "-c", str(args.chunk), "-s", str(args.sigma)] + (["--no-tlc"] if args.no_tlc else [])
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=420)
             except (OSError, subprocess.TimeoutExpired) as e:
                 return None, f"rocprofv3 pass {counter} failed: {e}"
             vals = {}
