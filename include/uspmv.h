@@ -173,6 +173,10 @@ int uspmv_dmat_optimize_sweep_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv
  * sweep; tiles of that plan and how many of them it covers (any pointer may be NULL). */
 int uspmv_dmat_plan_info(const uspmv_dmat_t *m, int *kind, int64_t *n_tiles, int64_t *n_planned);
 
+/* The block plan for a handle without a host struct (uspmv_dmat_wrap): the device arrays are copied to the host once and the plan is
+ * built there.  No permutation is known then: ties of the sigma sort are ordered by first column instead of by original row. */
+int uspmv_dmat_optimize_block_device(uspmv_dmat_t *m, int block_vec_size, int64_t *n_tiles, int64_t *n_staged);
+
 /* The same plan built ON THE DEVICE from the handle's own arrays: for handles without a host struct
  * (uspmv_dmat_wrap around the reference's cudaMalloc'ed arrays, uspmv_convert_to_scs_device).  Chunk heights that
  * divide 256; tiles whose line range exceeds 65 536 lines stay on the gather path (the host planner may still

@@ -38,6 +38,7 @@ struct Entry {
     const void *cp2, *cl2, *ci2, *va2;    // second struct of an ap pair (nullptr otherwise)
     uspmv_dmat_t *A, *A2;
     ST C;
+    int b_planned;                        // block width the handle's block plan was built for (0: none yet)
 };
 inline std::vector<Entry> &table() { static std::vector<Entry> t; return t; }
 inline std::mutex &lock() { static std::mutex m; return m; }
@@ -64,7 +65,7 @@ inline Entry one(const ST *C, const ST *n_chunks, const void *cp, const void *cl
     std::lock_guard<std::mutex> g(lock());
     for (const Entry &e : table())
         if (e.cp == cp && e.cl == cl && e.ci == ci && e.va == va && !e.cp2) return e;
-    Entry e{cp, cl, ci, va, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    Entry e{cp, cl, ci, va, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     e.A = wrap(C, n_chunks, cp, cl, ci, va, dtype, &e.C);
     if (crs) ck(uspmv_dmat_set_crs(e.A, 1), "uspmv_dmat_set_crs");
     ck(uspmv_dmat_optimize_device(e.A, 0, nullptr, nullptr), "uspmv_dmat_optimize_device");
@@ -72,12 +73,22 @@ inline Entry one(const ST *C, const ST *n_chunks, const void *cp, const void *cl
     return table().back();
 }
 
+// the LDS block plan for block vectors of width b, built once per (array set, b) from the device arrays
+inline void plan_block(const Entry &e, int b) {
+    std::lock_guard<std::mutex> g(lock());
+    for (Entry &t : table())
+        if (t.A == e.A) {
+            if (t.b_planned != b) { ck(uspmv_dmat_optimize_block_device(t.A, b, nullptr, nullptr), "uspmv_dmat_optimize_block_device"); t.b_planned = b; }
+            return;
+        }
+}
+
 inline Entry pair(const ST *dC, const ST *dn, const void *dcp, const void *dcl, const void *dci, const void *dva,
                          const ST *sC, const ST *sn, const void *scp, const void *scl, const void *sci, const void *sva) {
     std::lock_guard<std::mutex> g(lock());
     for (const Entry &e : table())
         if (e.cp == dcp && e.ci == dci && e.va == dva && e.cp2 == scp && e.ci2 == sci && e.va2 == sva) return e;
-    Entry e{dcp, dcl, dci, dva, scp, scl, sci, sva, nullptr, nullptr, 0};
+    Entry e{dcp, dcl, dci, dva, scp, scl, sci, sva, nullptr, nullptr, 0, 0};
     ST c2 = 0;
     e.A = wrap(dC, dn, dcp, dcl, dci, dva, USPMV_F64, &e.C);
     e.A2 = wrap(sC, sn, scp, scl, sci, sva, USPMV_F32, &c2);
@@ -112,6 +123,7 @@ void spmv_hip_scs_launcher(bool /*warmup_flag*/, const ST *C, const ST *n_chunks
 #else
         const int layout = USPMV_COLWISE;
 #endif
+        if (e.b_planned != b) detail::plan_block(e, b);
         detail::ck(uspmv_spmmv(e.A, x, y, b, vec_length ? *vec_length : 0, layout, nullptr), "uspmv_spmmv");
     } else {
         detail::ck(uspmv_spmv(e.A, x, y, nullptr), "uspmv_spmv");

@@ -421,6 +421,19 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                             assert np.array_equal(got.reshape(b, ld)[:, :n], Yo.reshape(b, ld)[:, :n])
     pkg.set_tuning(spmmv_lds_kb=0, spmmv_tile_rows=0)
     assert seen_partial and seen_full
+    # the plan from device arrays alone (uspmv_dmat_optimize_block_device: ties ordered by first column, no permutation known)
+    for m, C, sigma in ((pkg.read_mtx(mtx_path("bcsstk13")), 32, 512), (pkg.gen_stencil27(20, 20, 20, dof=3), 32, 512), (pkg.gen_stencil27(9, 30, 11, dof=2), 64, 128)):
+        s, a, xp = _prep(pkg, m, C, sigma, pkg.F64, make_x(m.n_rows))
+        A = pkg.DeviceMatrix(s)
+        nt, nst = A.optimize_block_device(8)
+        assert nt == (s.n_rows_padded + 63) // 64 and nst > 0
+        ld = s.n_rows_padded
+        for rowwise in (0, 1):
+            X = block_x(xp, ld, 8, ld, rowwise)
+            Y = t.full((8 * ld,), -3.0, dtype=t.float64, device="cuda")
+            pkg.spmmv(A, _dev(t, X), Y, 8, ld, pkg.ROWWISE if rowwise else pkg.COLWISE)
+            Yo = orc.spmmv_scs(s.C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, 8, ld, rowwise)
+            assert np.array_equal(Y.cpu().numpy(), Yo), (C, sigma, rowwise)
 
 
 def test_crs_spmmv_golden(pkg, torch_cuda):

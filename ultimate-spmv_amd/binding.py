@@ -86,6 +86,7 @@ _SIGS = {
     "uspmv_dmat_optimize_device_ap": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_plan_download": (C.c_int, [_vp, C.POINTER(_i64), _vp, _vp, _vp, _vp]),
     "uspmv_dmat_optimize_block": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
+    "uspmv_dmat_optimize_block_device": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_optimize_ap": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_optimize_sweep": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_optimize_sweep_ap": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
@@ -602,6 +603,13 @@ class DeviceMatrix:
         k, a, b = C.c_int(), _i64(), _i64()
         _ck(lib().uspmv_dmat_plan_info(self.h, C.byref(k), C.byref(a), C.byref(b)))
         return k.value, a.value, b.value
+
+    def optimize_block_device(self, block_vec_size):
+        """The block plan from the handle's device arrays alone (uspmv_dmat_optimize_block_device)."""
+        a, b = _i64(), _i64()
+        _ck(lib().uspmv_dmat_optimize_block_device(self.h, int(block_vec_size), C.byref(a), C.byref(b)))
+        self.block_tiles, self.block_staged = a.value, b.value
+        return a.value, b.value
 
     def optimize(self, scs, max_lines=0):
         """Build the tile-local-column plan (uspmv_dmat_optimize); returns (n_tiles, n_staged_tiles)."""

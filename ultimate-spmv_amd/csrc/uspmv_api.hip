@@ -675,6 +675,34 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
     return USPMV_OK;
 }
 
+// The block plan for a handle whose arrays exist only in HBM (uspmv_dmat_wrap around a harness' own device arrays -- what the
+// function-pointer launchers hold): the arrays are copied to the host once, the plan is built there like in
+// uspmv_dmat_optimize_block and uploaded.  Without the caller's permutation the tie re-ordering orders the rows of equal-length
+// chunks by their first column (uspmv_scs_reorder_ties), which for locally numbered matrices restores the original row order.
+int uspmv_dmat_optimize_block_device(uspmv_dmat_t *A, int block_vec_size, int64_t *n_tiles, int64_t *n_staged) {
+    if (int rc = check_dmat(A, "uspmv_dmat_optimize_block_device")) return rc;
+    if (block_vec_size < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block_device: block_vec_size must be >= 1");
+    if (int rc = require_device()) return rc;
+    uspmv_dmat_t *M = (A->alt && g_tune.rechunk) ? A->alt : A;      // narrow chunks: the internal C = 32 re-chunking is what uspmv_spmmv runs on
+    if (n_tiles) *n_tiles = 0;
+    if (n_staged) *n_staged = 0;
+    if ((M->C != 32 && M->C != 64) || M->n_chunks < 1) return USPMV_OK;
+    uspmv_scs s;
+    s.C = M->C; s.sigma = 0; s.n_chunks = M->n_chunks; s.n_rows = s.n_rows_padded = M->n_chunks * M->C; s.dtype = M->dtype;
+    s.chunk_ptrs.resize((size_t)M->n_chunks + 1); s.chunk_lengths.resize((size_t)M->n_chunks);
+    HIP_TRY(hipMemcpy(s.chunk_ptrs.data(), M->chunk_ptrs, 4 * ((size_t)M->n_chunks + 1), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s.chunk_lengths.data(), M->chunk_lengths, 4 * (size_t)M->n_chunks, hipMemcpyDeviceToHost));
+    s.n_elements = s.chunk_ptrs[(size_t)M->n_chunks]; s.nnz = s.n_elements;
+    s.col_idxs.resize((size_t)s.n_elements);
+    HIP_TRY(hipMemcpy(s.col_idxs.data(), M->col_idxs, 4 * (size_t)s.n_elements, hipMemcpyDeviceToHost));
+    int32_t mc = 0;
+    for (int32_t c : s.col_idxs) mc = std::max(mc, c);
+    s.n_cols = (int64_t)mc + 1;
+    if (s.dtype == USPMV_F64) { s.values_f64.resize((size_t)s.n_elements); HIP_TRY(hipMemcpy(s.values_f64.data(), M->values, 8 * (size_t)s.n_elements, hipMemcpyDeviceToHost)); }
+    else { s.values_f32.resize((size_t)s.n_elements); HIP_TRY(hipMemcpy(s.values_f32.data(), M->values, 4 * (size_t)s.n_elements, hipMemcpyDeviceToHost)); }
+    return uspmv_dmat_optimize_block(M, &s, block_vec_size, n_tiles, n_staged);
+}
+
 int uspmv_dmat_optimize_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t *s_dp, const uspmv_scs_t *s_sp,
                            int max_lines, int64_t *n_tiles, int64_t *n_staged) {
     if (!dp || !sp || !s_dp || !s_sp) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_ap: NULL argument");

@@ -5,7 +5,7 @@
 // the SCS arrays of the caller stay untouched, this is a private re-layout of the same entries.
 //
 // Idea: x is cut into WINDOWS of W = 2^wlog consecutive elements (a global grid: window of column c = c >> wlog).
-// A tile = tile_rows consecutive rows = one workgroup.  If, in every row of the tile, the window index never
+// A tile = tile_rows consecutive rows = one workgroup (above 1 024 rows a lane owns several rows).  If, in every row of the tile, the window index never
 // decreases from one slot to the next (true whenever a row's entries are column-sorted, e.g. a general-pattern
 // MatrixMarket file or the generators of gen_matrix.cpp; sigma-sorting permutes columns only inside aligned
 // sigma blocks, so windows that are multiples of sigma keep the property), the workgroup can SWEEP the windows in
@@ -28,10 +28,6 @@
 #include "uspmv_internal.hpp"
 
 namespace {
-
-struct RowView {
-    int64_t cs, L, i;  // chunk start, chunk length, row-in-chunk
-};
 
 template <typename VT>
 inline bool is_pos_zero(VT v) {
@@ -120,10 +116,8 @@ int uspmv_build_sweep_plan(const uspmv_scs *s, const uspmv_scs *s2, int wlog, in
     // ---- compact list of sweep tiles, offsets
     p->tile_ids.clear(); p->t_smin.clear(); p->t_S.clear(); p->t_cnt_off.clear();
     int64_t cnt_bytes = 0, tot[2] = {0, 0};
-    std::vector<int64_t> slot_of((size_t)n_tiles, -1);
     for (int64_t t = 0; t < n_tiles; ++t) {
         if (!ok[(size_t)t]) continue;
-        slot_of[(size_t)t] = (int64_t)p->tile_ids.size();
         p->tile_ids.push_back((int32_t)t); p->t_smin.push_back(smin[(size_t)t]); p->t_S.push_back(S[(size_t)t]);
         p->t_cnt_off.push_back((uint64_t)cnt_bytes);
         cnt_bytes += (int64_t)S[(size_t)t] * R;

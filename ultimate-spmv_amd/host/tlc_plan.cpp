@@ -201,11 +201,15 @@ int uspmv_scs_reorder_ties(const uspmv_scs *s, uspmv_scs *r, std::vector<int32_t
     const int64_t C = s->C, nc = s->n_chunks, n_pad = nc * C;
     row_map->resize((size_t)n_pad);
     for (int64_t q = 0; q < n_pad; ++q) (*row_map)[(size_t)q] = (int32_t)q;
-    const int64_t W = std::max<int64_t>(s->sigma, C);
     bool changed = false;
-    if (s->sigma > 1 && W % C == 0 && (int64_t)s->new_to_old_idx.size() >= s->n_rows) {
+    const bool have_perm = s->sigma > 1 && std::max<int64_t>(s->sigma, C) % C == 0 && (int64_t)s->new_to_old_idx.size() >= s->n_rows;
+    // with the caller's permutation: original row order inside a sigma window.  Without it (a struct rebuilt from device arrays,
+    // uspmv_dmat_optimize_block_device): rows ordered by their first column inside runs of at most 16 equal-length chunks -- for
+    // locally numbered (banded, stencil-like) matrices that is the original order again.
+    const int64_t W = have_perm ? std::max<int64_t>(s->sigma, C) : 16 * C;
+    {
         const int64_t cpw = W / C;
-        const int32_t *n2o = s->new_to_old_idx.data();
+        const int32_t *n2o = have_perm ? s->new_to_old_idx.data() : nullptr;
         const int64_t n_rows = s->n_rows;
         std::vector<char> ch((size_t)((nc + cpw - 1) / cpw), 0);
 #pragma omp parallel for schedule(dynamic, 64)
@@ -216,9 +220,14 @@ int uspmv_scs_reorder_ties(const uspmv_scs *s, uspmv_scs *r, std::vector<int32_t
                 int64_t c1 = c0 + 1;
                 while (c1 < c_end && s->chunk_lengths[(size_t)c1] == s->chunk_lengths[(size_t)c0]) ++c1;
                 int32_t *b = row_map->data() + c0 * C, *e = row_map->data() + c1 * C;
-                auto key = [&](int32_t q) { return q < n_rows ? (int64_t)n2o[q] : (int64_t)INT32_MAX + q; };
-                if (!std::is_sorted(b, e, [&](int32_t a, int32_t bb) { return key(a) < key(bb); })) {
-                    std::sort(b, e, [&](int32_t a, int32_t bb) { return key(a) < key(bb); });
+                auto key = [&](int32_t q) -> int64_t {
+                    if (n2o) return q < n_rows ? (int64_t)n2o[q] : (int64_t)INT32_MAX + q;
+                    const int64_t cq = q / C;
+                    return s->chunk_lengths[(size_t)cq] > 0 ? (int64_t)s->col_idxs[(size_t)(s->chunk_ptrs[(size_t)cq] + q % C)] : (int64_t)INT32_MAX + q;
+                };
+                auto less = [&](int32_t a, int32_t bb) { const int64_t ka = key(a), kb = key(bb); return ka < kb || (ka == kb && a < bb); };
+                if (!std::is_sorted(b, e, less)) {
+                    std::sort(b, e, less);
                     ch[(size_t)w] = 1;
                 }
                 c0 = c1;
