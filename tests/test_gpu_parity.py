@@ -392,7 +392,7 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                     pkg.spmmv(A0, _dev(t, X), Y0, b, ld, lay)
                     pkg.set_tuning(spmmv_variant=0)
                     for swz in (0, 1):                     # plan kernel for every width it supports, both LDS layouts
-                        for var, pd in ((4, 0), (6, 0), (7, 2), (7, 3), (8, 0), (5, 0)):   # single-wave tiles; four lanes per row (64-byte rows): one tile per workgroup / persistent / phased plan; gather over the re-ordered copy
+                        for var, pd in ((4, 0), (6, 0), (7, 2), (7, 3), (8, 0), (9, 0), (5, 0)):   # single-wave tiles; four lanes per row (64-byte rows): one tile per workgroup / persistent / phased plan / phased plan walked by persistent workgroups; gather over the re-ordered copy
                             if (var, swz) == (5, 1):
                                 continue
                             if var == 7:
@@ -408,6 +408,17 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                     pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
                     assert t.equal(Y, Y0), (name, C, code, b, rowwise, "xcol=1")
                     pkg.set_tuning(spmmv_variant=0, spmmv_swizzle=0, spmmv_xcol=0)
+                    if row_bytes == 64 and C in (32, 64):  # the phased plan with two-byte phase-local indices (one byte is the default when <= 256 rows per phase)
+                        pkg.set_tuning(spmmv_idx8=0)
+                        A16 = pkg.DeviceMatrix(s, block_tlc=b)
+                        pkg.set_tuning(spmmv_idx8=1)
+                        for var in (8, 9):
+                            pkg.set_tuning(spmmv_variant=var)
+                            Y.fill_(-3.0)
+                            pkg.spmmv(A16, _dev(t, X), Y, b, ld, lay)
+                            assert t.equal(Y, Y0), (name, C, code, b, rowwise, "idx16", var)
+                        pkg.set_tuning(spmmv_variant=0)
+                        del A16
                     Y.fill_(-3.0)                          # and whatever auto picks
                     pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
                     assert t.equal(Y, Y0), (name, C, code, b, rowwise, "auto")

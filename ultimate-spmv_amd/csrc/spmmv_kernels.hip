@@ -439,15 +439,6 @@ __global__ void __launch_bounds__(64) scs_spmmv_tlc(const long n_chunks, const i
 // chain still runs over the slots in order: bit-identical to block_spmv_omp_scs_general (code/kernels.hpp:306-398).
 // Four waves share one staged copy of the tile's X rows, ~25 registers each, so a CU holds 12 waves on 3 tiles and the
 // arithmetic of a tile takes a quarter of the time.
-template <int U>
-__device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, U * 0x55, 0xf, 0xf, true); }   // (bound_ctrl + full masks: every lane is written, `old` is dead)
-template <int U>
-__device__ __forceinline__ double quad_bcast(double v) {
-    return __hiloint2double(quad_bcast<U>(__double2hiint(v)), quad_bcast<U>(__double2loint(v)));
-}
-template <int U>
-__device__ __forceinline__ float quad_bcast(float v) { return __int_as_float(quad_bcast<U>(__float_as_int(v))); }
-
 template <typename VT, int B, bool NT, bool YCOL, int C, bool SWZ, int NG, int MAXP>
 __global__ void __launch_bounds__(256) scs_spmmv_quad(const long n_chunks, const int *__restrict__ chunk_ptrs,
         const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const VT *__restrict__ values,
@@ -729,133 +720,6 @@ __global__ void __launch_bounds__(256, WPE) scs_spmmv_quadp(const long n_tiles, 
 #undef QUAD_STEP
 }
 
-// Four lanes per row over the PHASED block plan (uspmv_build_phased_plan): the arithmetic of scs_spmmv_quad, but a tile's slots are
-// processed phase by phase -- at most NGP groups of four slots whose entries touch at most MAXP*64 distinct X rows -- and only the
-// current phase's X rows are staged: 16 KB of LDS and 40 registers per 256-thread workgroup instead of 50 KB and 88, so EIGHT
-// workgroups (the wave limit) instead of three share a CU and one workgroup's round trips (list, X rows + its matrix entries) hide
-// behind the arithmetic of seven others.  Every row still walks its slots in order: bit-identical FMA chains.
-// XCOL: X is the caller's COLUMN-MAJOR block vector (X[col + v*ld]) -- no re-layout pass, no workspace: a phase's X rows are
-// assembled in LDS by the workgroup itself (thread <-> list entry: B coalesced element loads, one per column, written as one
-// row of LDS; rows sit 16 bytes apart from a power-of-two stride so that the column-strided writes spread over the banks).
-template <typename VT, int B, bool NT, bool YCOL, int C, int NGP, int MAXP, bool XCOL>
-__global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, const int *__restrict__ chunk_ptrs,
-        const int *__restrict__ chunk_lengths, const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y, const long ld,
-        const int *__restrict__ ph_ptr, const int *__restrict__ ph_g0, const int *__restrict__ ph_list_ptr, const int *__restrict__ xrows,
-        const unsigned *__restrict__ c16_ptrs, const unsigned short *__restrict__ col16, const int xcd_remap, const long n_store,
-        const int *__restrict__ row_map) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char tlc_smem[];
-    constexpr int VW = 16 / (int)sizeof(VT);
-    static_assert(B == 4 * VW, "four 16-byte pieces per X row");
-    typedef VT vec_t __attribute__((ext_vector_type(VW)));
-    const unsigned tile = remap_block(blockIdx.x, gridDim.x, xcd_remap);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int r = lane >> 2, q = lane & 3;
-    const long row = (long)tile * 64 + wave * 16 + r;
-    const long c = row / C;
-    const int i = (int)(row - c * C);
-    const bool valid = c < n_chunks;
-    int cs = 0, L = 0;
-    unsigned q0 = 0;
-    if (valid) { cs = chunk_ptrs[c]; L = chunk_lengths[c]; q0 = c16_ptrs[c]; }
-    L = __builtin_amdgcn_readfirstlane(L);
-    const int ngf = L >> 2, rem = L & 3;
-    const int p0 = ph_ptr[tile], p1 = ph_ptr[tile + 1];
-    vec_t acc;
-#pragma unroll
-    for (int w = 0; w < VW; ++w) acc[w] = VT(0);
-    const VT *vp = values + (long)cs + i + (long)q * C;
-    const unsigned short *ip = col16 + q0 + (long)i * 4 + q;
-    const vec_t *xs = (const vec_t *)tlc_smem;
-    constexpr unsigned RS = XCOL ? 5u : 4u;                  // 16-byte pieces per staged row (XCOL: 80-byte row stride)
-#define QUAD_STEP(UU, AV, IV)                                                                                 \
-    {                                                                                                         \
-        const VT aa = quad_bcast<UU>(AV);                                                                     \
-        const unsigned li = (unsigned)quad_bcast<UU>((int)(IV));                                              \
-        const vec_t xv = xs[li * RS + (unsigned)q];                                                           \
-        _Pragma("unroll") for (int w = 0; w < VW; ++w) acc[w] = fma_t(aa, xv[w], acc[w]);                     \
-    }
-    int g0 = p0 < p1 ? ph_g0[p0] : 0, lp = p0 < p1 ? ph_list_ptr[p0] : 0;
-    for (int ph = p0; ph < p1; ++ph) {
-        const int g1 = ph + 1 < p1 ? ph_g0[ph + 1] : 0x7fffffff;
-        const int lp1 = ph_list_ptr[ph + 1];
-        const int np = (lp1 - lp) << 2;
-        if constexpr (!XCOL) {
-            // ---- the list entries this lane needs for its DMA pieces (piece p = (wave + 4k)*64 + lane <-> list entry p >> 2)
-            int xr[MAXP];
-#pragma unroll
-            for (int k = 0; k < MAXP; ++k) {
-                const int pp = (wave + 4 * k) * 64 + lane;
-                xr[k] = -1;
-                if (pp < np) xr[k] = xrows[lp + (pp >> 2)];
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (ph > p0) __syncthreads();                    // every wave is through with the previous phase's rows
-            // ---- X rows of the phase -> LDS by DMA, and behind them this wave's matrix entries of the phase
-#pragma unroll
-            for (int k = 0; k < MAXP; ++k)
-                if (xr[k] >= 0)
-                    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(X + (long)xr[k] * B + q * VW), (lds_void_t *)(tlc_smem + (wave + 4 * k) * 1024), 16, 0, 0);
-        } else {
-            // ---- column-major X: thread <-> list entry (MAXP*64/256 entries per thread), its B elements loaded column by column
-            constexpr int EPT = MAXP / 4;                    // list entries per thread (cap rows / 256 threads)
-            int xe[EPT];
-            VT xv_[EPT][B];
-#pragma unroll
-            for (int k = 0; k < EPT; ++k) {
-                const int e = k * 256 + (int)threadIdx.x;
-                xe[k] = -1;
-                if (e < (np >> 2)) xe[k] = xrows[lp + e];
-            }
-#pragma unroll
-            for (int k = 0; k < EPT; ++k)
-                if (xe[k] >= 0) {
-#pragma unroll
-                    for (int v = 0; v < B; ++v) xv_[k][v] = X[(long)xe[k] + (long)v * ld];
-                }
-            if (ph > p0) __syncthreads();                    // every wave is through with the previous phase's rows
-#pragma unroll
-            for (int k = 0; k < EPT; ++k)
-                if (xe[k] >= 0) {
-                    VT *dst = (VT *)(tlc_smem + (size_t)(k * 256 + (int)threadIdx.x) * (RS * 16));
-#pragma unroll
-                    for (int v = 0; v < B; ++v) dst[v] = xv_[k][v];
-                }
-        }
-        const int ge = min(g1, ngf);                         // full groups of this wave's rows in the phase: [g0, ge)
-        VT a[NGP], at = VT(0);
-        unsigned ix[NGP], ixt = 0u;
-#pragma unroll
-        for (int d = 0; d < NGP; ++d) {
-            a[d] = VT(0); ix[d] = 0u;
-            if (g0 + d < ge) { ix[d] = ld_stream<NT>(ip + (long)(g0 + d) * 4 * C); a[d] = ld_stream<NT>(vp + (long)(g0 + d) * 4 * C); }
-        }
-        const bool tail_here = rem && ngf >= g0 && ngf < g1;  // the partial last group of this wave's rows belongs to this phase
-        if (tail_here) { ixt = ld_stream<NT>(ip + (long)ngf * 4 * C); if (q < rem) at = ld_stream<NT>(vp + (long)ngf * 4 * C); }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int d = 0; d < NGP; ++d) {
-            if (g0 + d < ge) { QUAD_STEP(0, a[d], ix[d]) QUAD_STEP(1, a[d], ix[d]) QUAD_STEP(2, a[d], ix[d]) QUAD_STEP(3, a[d], ix[d]) }
-        }
-        if (tail_here) {
-            if (rem > 0) QUAD_STEP(0, at, ixt)
-            if (rem > 1) QUAD_STEP(1, at, ixt)
-            if (rem > 2) QUAD_STEP(2, at, ixt)
-        }
-        g0 = g1; lp = lp1;
-    }
-#undef QUAD_STEP
-    if (!valid) return;
-    const long yrow = row_map ? (long)row_map[row] : row;
-    if (yrow >= n_store) return;
-    if (YCOL) {
-#pragma unroll
-        for (int w = 0; w < VW; ++w) st_y<NT>(Y + (yrow + (long)(q * VW + w) * ld), acc[w]);
-    } else {
-        *((vec_t *)(Y + yrow * B) + q) = acc;
-    }
-}
-
 // Column-major -> row-major re-layout through LDS: 256 rows per workgroup.  Reads are B coalesced element streams (one per column);
 // the rows are assembled in LDS (16 bytes of padding per row against bank conflicts) and written back as 16-byte pieces in linear
 // order, so every store instruction of a wave covers 1 KiB of contiguous output (the lane-per-row form above it replaces wrote
@@ -1062,31 +926,14 @@ bool launch_spmmv_quadp(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool y
     return true;
 }
 
-template <typename VT, int B, int CT, int MAXP>
-void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, bool xcol, hipStream_t st) {
-    const size_t lds = xcol ? (size_t)MAXP * 64 * 80 : (size_t)MAXP * 4 * 1024;   // MAXP*64 rows of 64 (row-major X, DMA pieces) or 80 bytes
-#define QH_LAUNCH(NTV, YC)                                                                                              \
-    do {                                                                                                                \
-        auto kfn = xcol ? scs_spmmv_quadph<VT, B, NTV, YC, CT, 8, MAXP, true> : scs_spmmv_quadph<VT, B, NTV, YC, CT, 8, MAXP, false>; \
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kfn, dim3((unsigned)A->pb_n_tiles), dim3(256), lds, st, (long)A->n_chunks, A->chunk_ptrs, A->chunk_lengths, \
-                           (const VT *)(A->bt_values ? A->bt_values : A->values), X, Y, ld, A->pb_ph_ptr, A->pb_g0, A->pb_list_ptr,   \
-                           A->pb_xrows, A->pb_c16_ptrs, A->pb_col16, g_tune.xcd_remap, (long)A->n_store, (const int *)A->bt_row_map);  \
-    } while (0)
-    if (g_tune.nontemporal) { if (ycol) QH_LAUNCH(true, true); else QH_LAUNCH(true, false); }
-    else { if (ycol) QH_LAUNCH(false, true); else QH_LAUNCH(false, false); }
-#undef QH_LAUNCH
-}
-
-// false: the handle's phased plan does not fit the compiled shapes.  xcol: X is the caller's column-major block vector.
+// the phased-plan kernels live in spmmv_phased.hip (64-byte rows only: dp b = 8, sp b = 16)
 template <typename VT, int B>
 bool launch_spmmv_quadph(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, bool xcol, hipStream_t st) {
-    if (!A->pb || A->pb_ngp > 8) return false;
-    const int pieces = (A->pb_max_rows * 4 + 255) / 256;
-#define QH_C(CTV) do { if (pieces <= 4) launch_spmmv_quadph_m<VT, B, CTV, 4>(A, X, Y, ld, ycol, xcol, st); else if (pieces <= 8) launch_spmmv_quadph_m<VT, B, CTV, 8>(A, X, Y, ld, ycol, xcol, st); else return false; } while (0)
-    if (A->C == 32) QH_C(32); else if (A->C == 64) QH_C(64); else if (A->C == 16) QH_C(16); else return false;
-#undef QH_C
-    return true;
+    return uspmv_dev::spmmv_phased(A, X, Y, ld, ycol, xcol, /*persistent=*/false, st);
+}
+template <typename VT, int B>
+bool launch_spmmv_quadpp(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    return uspmv_dev::spmmv_phased(A, X, Y, ld, ycol, false, /*persistent=*/true, st);
 }
 
 template <typename VT, int B>
@@ -1094,7 +941,9 @@ void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
     constexpr int RB = B * (int)sizeof(VT);          // bytes per X row
     if constexpr (RB == 64) {
         // 64-byte rows, phased plan (variant 8; auto when the handle carries one): eight workgroups per CU
-        if ((g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 8) && !g_tune.ablate && launch_spmmv_quadph<VT, B>(A, X, Y, ld, ycol, false, st)) return;
+        // ... persistent over a per-workgroup schedule of the same phases (variant 9)
+        if (g_tune.spmmv_variant == 9 && launch_spmmv_quadpp<VT, B>(A, X, Y, ld, ycol, st)) return;
+        if ((g_tune.spmmv_variant == 8 || (g_tune.spmmv_variant == 0 && !g_tune.ablate)) && launch_spmmv_quadph<VT, B>(A, X, Y, ld, ycol, false, st)) return;
         // 64-byte rows: the four-lanes-per-row kernel over 64-row tiles of the block plan (variant 6; auto when the plan is there)
         if (A->bt && A->bt_tile_rows == 64 && (g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 6 || g_tune.spmmv_variant == 7) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
             // variant 6 (and auto): one tile per workgroup, three workgroups per CU; variant 7: persistent and pipelined over tiles, but 222

@@ -50,8 +50,13 @@ struct uspmv_dmat {
     int pb_cap_rows = 0, pb_ngp = 0, pb_max_rows = 0;
     int64_t pb_n_tiles = 0, pb_n_phases = 0;
     int32_t *pb_ph_ptr = nullptr, *pb_g0 = nullptr, *pb_list_ptr = nullptr, *pb_xrows = nullptr;
+    // the same phases as one flat schedule per persistent workgroup (variant 9): pb_wg_ptr[w]..pb_wg_ptr[w+1] index pb_sched, whose
+    // entries are 8 ints {tile, g0, g1, list_ptr, list_rows, flags (1: first phase of its tile, 2: last), 0, 0}
+    int32_t *pb_sched = nullptr, *pb_wg_ptr = nullptr;
+    int pb_wgs = 0;
     uint32_t *pb_c16_ptrs = nullptr;
-    uint16_t *pb_col16 = nullptr;
+    uint16_t *pb_col16 = nullptr;       // phase-local indices; ONE BYTE each when pb_idx8 (no phase lists more than 256 rows)
+    bool pb_idx8 = false;
     // column-window sweep plan (host/sweep_plan.cpp, uspmv_dmat_optimize_sweep[_ap]); the _b arrays are the sp part of
     // an ap[dp_sp] pair and live on the dp handle, the sp handle only carries the plan id
     bool sw = false;
@@ -101,6 +106,9 @@ struct Tuning {
                                // the kernel itself from the column-major vector (no workspace, no extra launch, but 1.123 ms: 74 registers, six workgroups per CU)
     int spmmv_phased = 1;      // NEXT uspmv_dmat_optimize_block with 64-byte rows: also build the phased plan (eight workgroups per CU)
     int spmmv_phase_rows = 256;  // ... X rows per phase (256 | 512)
+    int spmmv_idx8 = 1;        // NEXT optimize_block: one-byte phase-local indices when every phase lists <= 256 rows
+    int spmmv_stagger = 0;     // ... start offset between the workgroups of a CU, x 1024 cycles
+    int spmmv_persist_wgs = 8; // phased persistent kernel (variant 9): workgroups per CU the schedule is cut for (NEXT optimize_block)
     int spmmv_persist_w = 2;   // persistent SpMMV kernel: compiled for 3 (168 VGPRs) or 2 (256 VGPRs) waves per SIMD
     int spmmv_persist_x = 1;   // persistent SpMMV kernel: grid = this many times the resident workgroups (1 = exactly resident)
     int spmmv_reorder = 1;  // block plan: rows of equal-length chunks of a sigma window back in original order (private copy of the entries)
@@ -123,6 +131,9 @@ template <typename VT>
 int launch_csr(long n_rows, long nnz_hint, const int *rp, const int *ci, const VT *va, const VT *x, VT *y, hipStream_t st);  // spmv_kernels.hip
 template <typename VT>
 int launch_spmmv(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int layout, hipStream_t st);            // spmmv_kernels.hip
+// phased block plan, 64-byte X rows (spmmv_phased.hip); false: no plan / schedule on the handle or it does not fit the compiled shapes
+bool spmmv_phased(const uspmv_dmat *A, const double *X, double *Y, long ld, bool ycol, bool xcol, bool persistent, hipStream_t st);
+bool spmmv_phased(const uspmv_dmat *A, const float *X, float *Y, long ld, bool ycol, bool xcol, bool persistent, hipStream_t st);
 int launch_spmv_ap(const uspmv_dmat *dp, const uspmv_dmat *sp, const double *d_x, const float *d_x_sp, double *d_y,
                    hipStream_t stream);                                                                           // ap_kernels.hip
 template <typename VT>
@@ -168,6 +179,16 @@ __device__ __forceinline__ void st_y(T *p, T v) {
 }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// DPP quad broadcast: every lane of a quad gets lane U's value (the four-lanes-per-row SpMMV kernels)
+template <int U>
+__device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, U * 0x55, 0xf, 0xf, true); }   // (bound_ctrl + full masks: every lane is written, `old` is dead)
+template <int U>
+__device__ __forceinline__ double quad_bcast(double v) {
+    return __hiloint2double(quad_bcast<U>(__double2hiint(v)), quad_bcast<U>(__double2loint(v)));
+}
+template <int U>
+__device__ __forceinline__ float quad_bcast(float v) { return __int_as_float(quad_bcast<U>(__float_as_int(v))); }
 
 // logical block id.  Hardware deals blocks round-robin over the 8 XCDs (b, b+8, b+16, ... share
 // one).  mode 0: identity.  mode 1: every XCD walks one contiguous eighth of the grid.
