@@ -392,7 +392,7 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                     pkg.spmmv(A0, _dev(t, X), Y0, b, ld, lay)
                     pkg.set_tuning(spmmv_variant=0)
                     for swz in (0, 1):                     # plan kernel for every width it supports, both LDS layouts
-                        for var, pd in ((4, 0), (6, 0), (7, 2), (7, 3), (8, 0), (9, 0), (5, 0)):   # single-wave tiles; four lanes per row (64-byte rows): one tile per workgroup / persistent / phased plan / phased plan walked by persistent workgroups; gather over the re-ordered copy
+                        for var, pd in ((4, 0), (6, 0), (7, 2), (7, 3), (8, 0), (5, 0)):   # single-wave tiles; four lanes per row (64-byte rows): one tile per workgroup / persistent / phased plan; gather over the re-ordered copy
                             if (var, swz) == (5, 1):
                                 continue
                             if var == 7:
@@ -412,13 +412,20 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                         pkg.set_tuning(spmmv_idx8=0)
                         A16 = pkg.DeviceMatrix(s, block_tlc=b)
                         pkg.set_tuning(spmmv_idx8=1)
-                        for var in (8, 9):
+                        pkg.set_tuning(spmmv_variant=8)
+                        Y.fill_(-3.0)
+                        pkg.spmmv(A16, _dev(t, X), Y, b, ld, lay)
+                        assert t.equal(Y, Y0), (name, C, code, b, rowwise, "idx16")
+                        pkg.set_tuning(spmmv_reorder=2)                  # ... and over clustered rows (breadth-first balls per tile)
+                        Acl = pkg.DeviceMatrix(s, block_tlc=b)
+                        pkg.set_tuning(spmmv_reorder=1)
+                        for var in (8, 6, 4):
                             pkg.set_tuning(spmmv_variant=var)
                             Y.fill_(-3.0)
-                            pkg.spmmv(A16, _dev(t, X), Y, b, ld, lay)
-                            assert t.equal(Y, Y0), (name, C, code, b, rowwise, "idx16", var)
+                            pkg.spmmv(Acl, _dev(t, X), Y, b, ld, lay)
+                            assert t.equal(Y, Y0), (name, C, code, b, rowwise, "clustered rows", var)
                         pkg.set_tuning(spmmv_variant=0)
-                        del A16
+                        del A16, Acl
                     Y.fill_(-3.0)                          # and whatever auto picks
                     pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
                     assert t.equal(Y, Y0), (name, C, code, b, rowwise, "auto")

@@ -17,23 +17,11 @@ for dt, tdt, vs, b in ((pkg.F64, torch.float64, 8, 8), (pkg.F32, torch.float32, 
     X = torch.rand(b * ld, dtype=tdt, device="cuda"); Y = torch.zeros_like(X)
     A0 = pkg.DeviceMatrix(s)
     byts = s.n_elements * (vs + 4) + 8 * s.n_chunks + 2 * b * vs * ld
-    pkg.set_tuning(spmmv_idx8=0)
-    A = pkg.DeviceMatrix(s, block_tlc=b)
-    pkg.set_tuning(spmmv_idx8=1)
-    for lay, nm in ((pkg.ROWWISE, "rowwise"), (pkg.COLWISE, "colwise")):
-        for var in (8, 9):
-            pkg.set_tuning(spmmv_variant=var)
-            B.time_launches(5, 5, A=A, x=X, y=Y, b=b, ld=ld, layout=lay)
-            ms = min(B.time_launches(5, 40, A=A, x=X, y=Y, b=b, ld=ld, layout=lay) for _ in range(3))
-            print(json.dumps(dict(dtype=vs, b=b, layout=nm, variant=var, index_bytes=2, ms=round(ms, 4), frac=round(byts / ms / 1e6 / 8000, 3))), flush=True)
-    pkg.set_tuning(spmmv_variant=0)
-    del A
     for wgs in (8,):
-        pkg.set_tuning(spmmv_persist_wgs=wgs)
         A = pkg.DeviceMatrix(s, block_tlc=b)
         for lay, nm in ((pkg.ROWWISE, "rowwise"), (pkg.COLWISE, "colwise")):
             pkg.set_tuning(spmmv_variant=3); Y0 = torch.zeros_like(X); pkg.spmmv(A0, X, Y0, b, ld, lay)
-            for var in ((8, 9) if wgs == 8 else (9,)):
+            for var in (8,):
                 pkg.set_tuning(spmmv_variant=var)
                 Y.fill_(-1.0); pkg.spmmv(A, X, Y, b, ld, lay)
                 same = bool(torch.equal(Y, Y0))
@@ -42,4 +30,3 @@ for dt, tdt, vs, b in ((pkg.F64, torch.float64, 8, 8), (pkg.F32, torch.float32, 
                 print(json.dumps(dict(dtype=vs, b=b, layout=nm, variant=var, index_bytes=1, wgs_per_cu=wgs, bitexact=same, ms=round(ms, 4), TF=round(2 * s.nnz * b / ms / 1e9, 2), frac=round(byts / ms / 1e6 / 8000, 3))), flush=True)
         pkg.set_tuning(spmmv_variant=0)
         del A
-pkg.set_tuning(spmmv_persist_wgs=8)

@@ -929,20 +929,13 @@ bool launch_spmmv_quadp(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool y
 // the phased-plan kernels live in spmmv_phased.hip (64-byte rows only: dp b = 8, sp b = 16)
 template <typename VT, int B>
 bool launch_spmmv_quadph(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, bool xcol, hipStream_t st) {
-    return uspmv_dev::spmmv_phased(A, X, Y, ld, ycol, xcol, /*persistent=*/false, st);
+    return uspmv_dev::spmmv_phased(A, X, Y, ld, ycol, xcol, st);
 }
-template <typename VT, int B>
-bool launch_spmmv_quadpp(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
-    return uspmv_dev::spmmv_phased(A, X, Y, ld, ycol, false, /*persistent=*/true, st);
-}
-
 template <typename VT, int B>
 void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
     constexpr int RB = B * (int)sizeof(VT);          // bytes per X row
     if constexpr (RB == 64) {
         // 64-byte rows, phased plan (variant 8; auto when the handle carries one): eight workgroups per CU
-        // ... persistent over a per-workgroup schedule of the same phases (variant 9)
-        if (g_tune.spmmv_variant == 9 && launch_spmmv_quadpp<VT, B>(A, X, Y, ld, ycol, st)) return;
         if ((g_tune.spmmv_variant == 8 || (g_tune.spmmv_variant == 0 && !g_tune.ablate)) && launch_spmmv_quadph<VT, B>(A, X, Y, ld, ycol, false, st)) return;
         // 64-byte rows: the four-lanes-per-row kernel over 64-row tiles of the block plan (variant 6; auto when the plan is there)
         if (A->bt && A->bt_tile_rows == 64 && (g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 6 || g_tune.spmmv_variant == 7) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {

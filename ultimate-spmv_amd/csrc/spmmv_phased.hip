@@ -2,6 +2,10 @@
 // (scs_spmmv_quadph) or persistent workgroups walking a flat schedule of the same phases (scs_spmmv_quadpp).
 // Reference loop: code/kernels.hpp:277-333 (block_colwise / block_rowwise SELL-C-sigma SpMMV); same slot order per row.
 #include "uspmv_device.hpp"
+#include <vector>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 using namespace uspmv_dev;
 
@@ -45,7 +49,10 @@ __global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, con
     vec_t acc;
 #pragma unroll
     for (int w = 0; w < VW; ++w) acc[w] = VT(0);
-    const VT *vp = values + (long)cs + i + (long)q * C;
+    // the plan's own copy of the entries is GROUP-major like the indices ([chunk][group of four slots][row][slot % 4]): the four
+    // lanes of a row read 32 contiguous bytes and a wave 512 -- four cache lines per load instead of the sixteen (one per lane
+    // quad and slot) a column-major chunk costs, which is what the L1 tag rate could not take (profiles/r02/spmmv_phase_ablation.txt)
+    const VT *vp = values + q0 + (long)i * 4 + q;
     const IT *ip = col16 + q0 + (long)i * 4 + q;             // (IT: phase-local index type, 8 bits when no phase lists more than 256 rows)
     const vec_t *xs = (const vec_t *)tlc_smem;
     constexpr unsigned RS = XCOL ? 5u : 4u;                  // 16-byte pieces per staged row (XCOL: 80-byte row stride)
@@ -142,156 +149,6 @@ __global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, con
     }
 }
 
-// The phased plan again, PERSISTENT: the grid is as many workgroups as the chip holds at once (8 per CU) and every workgroup walks
-// its own flat schedule of phases (uspmv_dmat::pb_sched, cut on the host in the launch order of scs_spmmv_quadph).  What this buys
-// is the dependent round trips of a one-tile workgroup: there, a tile starts with ph_ptr -> (g0, list_ptr) -> list -> X rows, and
-// every later phase with list -> X rows, each a full memory latency with nothing of this workgroup in flight.  Here the descriptor
-// of phase i+2, the list of phase i+1 and (when phase i+1 opens a tile) that tile's chunk data are requested together with the X
-// rows and matrix entries of phase i, so a phase costs ONE round trip plus its arithmetic.  Same entries, same slot order per row:
-// bit-identical to scs_spmmv_quadph.
-template <typename VT, typename IT, int B, bool NT, bool YCOL, int C, int NGP, int MAXP, int ABL = 0>
-__global__ void __launch_bounds__(256) scs_spmmv_quadpp(const long n_chunks, const int *__restrict__ chunk_ptrs,
-        const int *__restrict__ chunk_lengths, const VT *__restrict__ values, const VT *__restrict__ X, VT *__restrict__ Y, const long ld,
-        const int *__restrict__ wg_ptr, const int4 *__restrict__ sched, const int *__restrict__ xrows,
-        const unsigned *__restrict__ c16_ptrs, const IT *__restrict__ col16, const long n_store,
-        const int *__restrict__ row_map, const int stagger) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char tlc_smem[];
-    constexpr int VW = 16 / (int)sizeof(VT);
-    static_assert(B == 4 * VW, "four 16-byte pieces per X row");
-    typedef VT vec_t __attribute__((ext_vector_type(VW)));
-    // the workgroups of a CU start `stagger` x 1024 cycles apart (all of them start a phase at once otherwise, and stay in step)
-    for (int z = (int)((blockIdx.x >> 3) & 7u) * stagger; z > 0; --z) __builtin_amdgcn_s_sleep(16);
-    int it = wg_ptr[blockIdx.x];
-    const int it_end = wg_ptr[blockIdx.x + 1];
-    if (it >= it_end) return;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int r = lane >> 2, q = lane & 3;
-    const vec_t *xs = (const vec_t *)tlc_smem;
-#define QUAD_STEP(UU, AV, IV)                                                                                 \
-    {                                                                                                         \
-        const VT aa = quad_bcast<UU>(AV);                                                                     \
-        const unsigned li = (unsigned)quad_bcast<UU>((int)(IV));                                              \
-        const vec_t xv = xs[li * 4u + (unsigned)q];                                                           \
-        _Pragma("unroll") for (int w = 0; w < VW; ++w) acc[w] = fma_t(aa, xv[w], acc[w]);                     \
-    }
-    // list entries this lane needs for its DMA pieces (piece p = (wave + 4k)*64 + lane <-> list entry p >> 2 = lrow + 64k)
-#define LOAD_LIST(LP, NROWS)                                                                                  \
-    {                                                                                                         \
-        const int *lb_ = xrows + (LP);                                                                        \
-        _Pragma("unroll") for (int k = 0; k < MAXP; ++k) {                                                    \
-            xr[k] = -1;                                                                                       \
-            if (lrow + 64 * k < (NROWS)) xr[k] = lb_[(unsigned)(lrow + 64 * k)];                              \
-        }                                                                                                     \
-    }
-    // chunk data of this wave's sixteen rows in tile T (one chunk: wave-uniform, scalar loads)
-#define LOAD_META(T, CS, LL, Q0, VALID)                                                                       \
-    {                                                                                                         \
-        const long c_ = ((long)(T) * 64 + wave * 16) / C;                                                     \
-        VALID = c_ < n_chunks;                                                                                \
-        CS = 0; LL = 0; Q0 = 0u;                                                                              \
-        if (VALID) { CS = chunk_ptrs[c_]; LL = chunk_lengths[c_]; Q0 = c16_ptrs[c_]; }                        \
-    }
-    const int lrow = wave * 16 + r;                            // this lane's row within a tile
-    const unsigned lo_v = (unsigned)(r + q * C) * (unsigned)sizeof(VT), lo_i = (unsigned)(r * 4 + q) * (unsigned)sizeof(IT);   // lane byte offsets
-    int4 da = sched[2 * it], db = sched[2 * it + 1];          // {tile, g0, g1, list_ptr}, {list_rows, flags, -, -}
-    int4 na = da, nb = db;
-    if (it + 1 < it_end) { na = sched[2 * it + 2]; nb = sched[2 * it + 3]; }
-    int xr[MAXP];
-    LOAD_LIST(da.w, db.x)
-    int cs, L, cs_n = 0, L_n = 0;
-    unsigned q0, q0_n = 0u;
-    bool valid, valid_n = false;
-    LOAD_META(da.x, cs, L, q0, valid)
-    vec_t acc;
-#pragma unroll
-    for (int w = 0; w < VW; ++w) acc[w] = VT(0);
-#define STORE_Y(ROW0, VALID)                                                                                  \
-    {                                                                                                         \
-        if (VALID) {                                                                                          \
-            const long row_ = (ROW0) + r;                                                                     \
-            const long yrow = row_map ? (long)row_map[row_] : row_;                                           \
-            if (yrow < n_store) {                                                                             \
-                if (YCOL) {                                                                                   \
-                    _Pragma("unroll") for (int w = 0; w < VW; ++w) st_y<NT>(Y + (yrow + (long)(q * VW + w) * ld), acc[w]); \
-                } else {                                                                                      \
-                    *((vec_t *)(Y + yrow * B) + q) = acc;                                                     \
-                }                                                                                             \
-            }                                                                                                 \
-        }                                                                                                     \
-        _Pragma("unroll") for (int w = 0; w < VW; ++w) acc[w] = VT(0);                                        \
-    }
-    bool store_pending = false, valid_s = false;
-    long row0_s = 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the first phase's list
-    for (;;) {
-        const bool has_next = it + 1 < it_end;
-        const int ngf = L >> 2, rem = L & 3;
-        const long row0 = (long)da.x * 64 + wave * 16;
-        const int i0 = (int)(row0 % C);
-        const int g0 = da.y, g1 = da.z;
-        // wave-uniform bases of the phase's first group; a lane adds lo_v / lo_i and d * (one group of the chunk)
-        const char *vb = (const char *)(values + ((long)cs + i0 + (long)g0 * 4 * C));
-        const char *ib = (const char *)(col16 + ((long)q0 + (long)i0 * 4 + (long)g0 * 4 * C));
-        constexpr unsigned GV = 4u * C * (unsigned)sizeof(VT), GI = 4u * C * (unsigned)sizeof(IT);
-        // (this phase's list, requested during the previous phase, arrived with that phase's entries; the very first one: below)
-        __syncthreads();                                       // every wave is through with the previous phase's rows
-        if (store_pending) {                                   // the rows of the tile that ended with the previous phase: stored HERE, ahead
-            STORE_Y(row0_s, valid_s)                           // of this phase's requests, so that no wait ever covers just a store
-            store_pending = false;
-        }
-#pragma unroll
-        for (int k = 0; k < MAXP; ++k)
-            if (!(ABL & 1) && xr[k] >= 0)
-                __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(X + (long)xr[k] * B + q * VW), (lds_void_t *)(tlc_smem + (wave + 4 * k) * 1024), 16, 0, 0);
-        const int ng = min(g1, ngf) - g0;                      // full groups of this wave's rows in the phase
-        VT a[NGP], at = VT(0);
-        unsigned ix[NGP], ixt = 0u;
-#pragma unroll
-        for (int d = 0; d < NGP; ++d) {
-            a[d] = VT(0); ix[d] = 0u;
-            if (d < ng) {
-                if (!(ABL & 8)) ix[d] = ld_stream<NT>((const IT *)(ib + (lo_i + d * GI)));
-                if (!(ABL & 4)) a[d] = ld_stream<NT>((const VT *)(vb + (lo_v + d * GV)));
-            }
-        }
-        const bool tail_here = rem && ngf >= g0 && ngf < g1;   // the partial last group of this wave's rows belongs to this phase
-        if (tail_here) {
-            const int dt = ngf - g0;
-            ixt = ld_stream<NT>((const IT *)(ib + (lo_i + dt * GI)));
-            if (q < rem) at = ld_stream<NT>((const VT *)(vb + (lo_v + dt * GV)));
-        }
-        // ---- behind them: what the NEXT phase needs before it can issue anything
-        int4 nna = na, nnb = nb;
-        if (has_next) {
-            LOAD_LIST(na.w, nb.x)
-            if (nb.y & 1) LOAD_META(na.x, cs_n, L_n, q0_n, valid_n)
-            if (it + 2 < it_end) { nna = sched[2 * it + 4]; nnb = sched[2 * it + 5]; }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int d = 0; d < NGP; ++d) {
-            if (ABL & 2) { if (ix[d] == 0xdeadbeefu) acc[0] += a[d]; continue; }
-            if (d < ng) { QUAD_STEP(0, a[d], ix[d]) QUAD_STEP(1, a[d], ix[d]) QUAD_STEP(2, a[d], ix[d]) QUAD_STEP(3, a[d], ix[d]) }
-        }
-        if (tail_here) {
-            if (rem > 0) QUAD_STEP(0, at, ixt)
-            if (rem > 1) QUAD_STEP(1, at, ixt)
-            if (rem > 2) QUAD_STEP(2, at, ixt)
-        }
-        if (db.y & 2) { store_pending = true; row0_s = row0; valid_s = valid; }   // last phase of the tile: its rows are complete
-        if (!has_next) break;
-        if (nb.y & 1) { cs = cs_n; L = L_n; q0 = q0_n; valid = valid_n; }
-        da = na; db = nb; na = nna; nb = nnb;
-        ++it;
-    }
-    if (store_pending) STORE_Y(row0_s, valid_s)
-#undef STORE_Y
-#undef LOAD_META
-#undef LOAD_LIST
-#undef QUAD_STEP
-}
-
 template <typename VT, typename IT, int B, int CT, int MAXP>
 void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, bool xcol, hipStream_t st) {
     const size_t lds = xcol ? (size_t)MAXP * 64 * 80 : (size_t)MAXP * 4 * 1024;   // MAXP*64 rows of 64 (row-major X, DMA pieces) or 80 bytes
@@ -300,13 +157,13 @@ void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
         auto kfn = xcol ? scs_spmmv_quadph<VT, IT, B, NTV, YC, CT, 8, MAXP, true> : scs_spmmv_quadph<VT, IT, B, NTV, YC, CT, 8, MAXP, false>; \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)A->pb_n_tiles), dim3(256), lds, st, (long)A->n_chunks, A->chunk_ptrs, A->chunk_lengths, \
-                           (const VT *)(A->bt_values ? A->bt_values : A->values), X, Y, ld, A->pb_ph_ptr, A->pb_g0, A->pb_list_ptr,   \
+                           (const VT *)A->pb_values, X, Y, ld, A->pb_ph_ptr, A->pb_g0, A->pb_list_ptr,   \
                            A->pb_xrows, A->pb_c16_ptrs, (const IT *)A->pb_col16, g_tune.xcd_remap, (long)A->n_store, (const int *)A->bt_row_map);  \
     } while (0)
     if constexpr (sizeof(VT) == 8 && CT == 32 && MAXP == 4 && sizeof(IT) == 1) {
         if (g_tune.ablate >= 1 && !xcol && !ycol) {   // measurement only
 #define QH_ABL(N) case N: hipLaunchKernelGGL((scs_spmmv_quadph<VT, IT, B, true, false, CT, 8, MAXP, false, N>), dim3((unsigned)A->pb_n_tiles), dim3(256), lds, st, \
-                           (long)A->n_chunks, A->chunk_ptrs, A->chunk_lengths, (const VT *)(A->bt_values ? A->bt_values : A->values), X, Y, ld, A->pb_ph_ptr, \
+                           (long)A->n_chunks, A->chunk_ptrs, A->chunk_lengths, (const VT *)A->pb_values, X, Y, ld, A->pb_ph_ptr, \
                            A->pb_g0, A->pb_list_ptr, A->pb_xrows, A->pb_c16_ptrs, (const IT *)A->pb_col16, g_tune.xcd_remap, (long)A->n_store, (const int *)A->bt_row_map); break;
             switch (g_tune.ablate) { QH_ABL(1) QH_ABL(2) QH_ABL(4) QH_ABL(8) QH_ABL(17) QH_ABL(14) QH_ABL(3) QH_ABL(19) default: break; }
 #undef QH_ABL
@@ -318,48 +175,10 @@ void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
 #undef QH_LAUNCH
 }
 
-template <typename VT, typename IT, int B, int CT, int MAXP>
-void launch_spmmv_quadpp_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
-    const size_t lds = (size_t)MAXP * 4 * 1024;
-#define QPP_LAUNCH(NTV, YC)                                                                                             \
-    do {                                                                                                                \
-        auto kfn = scs_spmmv_quadpp<VT, IT, B, NTV, YC, CT, 8, MAXP>;                                                       \
-        hipLaunchKernelGGL(kfn, dim3((unsigned)A->pb_wgs), dim3(256), lds, st, (long)A->n_chunks, A->chunk_ptrs, A->chunk_lengths, \
-                           (const VT *)(A->bt_values ? A->bt_values : A->values), X, Y, ld, A->pb_wg_ptr, (const int4 *)A->pb_sched, \
-                           A->pb_xrows, A->pb_c16_ptrs, (const IT *)A->pb_col16, (long)A->n_store, (const int *)A->bt_row_map, g_tune.spmmv_stagger); \
-    } while (0)
-    if constexpr (sizeof(VT) == 8 && CT == 32 && MAXP == 4 && sizeof(IT) == 1) {
-        if (g_tune.ablate >= 1 && !ycol) {   // measurement only
-#define QPP_ABL(N) case N: hipLaunchKernelGGL((scs_spmmv_quadpp<VT, IT, B, true, false, CT, 8, MAXP, N>), dim3((unsigned)A->pb_wgs), dim3(256), lds, st, \
-                           (long)A->n_chunks, A->chunk_ptrs, A->chunk_lengths, (const VT *)(A->bt_values ? A->bt_values : A->values), X, Y, ld, A->pb_wg_ptr, \
-                           (const int4 *)A->pb_sched, A->pb_xrows, A->pb_c16_ptrs, (const IT *)A->pb_col16, (long)A->n_store, (const int *)A->bt_row_map, g_tune.spmmv_stagger); break;
-            switch (g_tune.ablate) { QPP_ABL(1) QPP_ABL(2) QPP_ABL(4) QPP_ABL(8) QPP_ABL(14) QPP_ABL(3) default: break; }
-#undef QPP_ABL
-            return;
-        }
-    }
-    if (g_tune.nontemporal) { if (ycol) QPP_LAUNCH(true, true); else QPP_LAUNCH(true, false); }
-    else { if (ycol) QPP_LAUNCH(false, true); else QPP_LAUNCH(false, false); }
-#undef QPP_LAUNCH
-}
-
-// false: no schedule on the handle or the plan does not fit the compiled shapes
-template <typename VT, int B>
-bool launch_spmmv_quadpp(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
-    if (!A->pb || !A->pb_sched || A->pb_wgs < 1 || A->pb_ngp > 8) return false;
-    const int pieces = (A->pb_max_rows * 4 + 255) / 256;
-#define QPP_C(CTV) do { if (pieces <= 4 && A->pb_idx8) launch_spmmv_quadpp_m<VT, unsigned char, B, CTV, 4>(A, X, Y, ld, ycol, st); \
-        else if (pieces <= 4) launch_spmmv_quadpp_m<VT, unsigned short, B, CTV, 4>(A, X, Y, ld, ycol, st); \
-        else if (pieces <= 8) launch_spmmv_quadpp_m<VT, unsigned short, B, CTV, 8>(A, X, Y, ld, ycol, st); else return false; } while (0)
-    if (A->C == 32) QPP_C(32); else if (A->C == 64) QPP_C(64); else return false;
-#undef QPP_C
-    return true;
-}
-
 // false: the handle's phased plan does not fit the compiled shapes.  xcol: X is the caller's column-major block vector.
 template <typename VT, int B>
 bool launch_spmmv_quadph(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, bool xcol, hipStream_t st) {
-    if (!A->pb || A->pb_ngp > 8) return false;
+    if (!A->pb || !A->pb_values || A->pb_ngp > 8) return false;
     const int pieces = (A->pb_max_rows * 4 + 255) / 256;
 #define QH_C(CTV) do { if (pieces <= 4 && A->pb_idx8) launch_spmmv_quadph_m<VT, unsigned char, B, CTV, 4>(A, X, Y, ld, ycol, xcol, st); \
         else if (pieces <= 4) launch_spmmv_quadph_m<VT, unsigned short, B, CTV, 4>(A, X, Y, ld, ycol, xcol, st); \
@@ -373,11 +192,11 @@ bool launch_spmmv_quadph(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool 
 
 namespace uspmv_dev {
 
-bool spmmv_phased(const uspmv_dmat *A, const double *X, double *Y, long ld, bool ycol, bool xcol, bool persistent, hipStream_t st) {
-    return persistent ? launch_spmmv_quadpp<double, 8>(A, X, Y, ld, ycol, st) : launch_spmmv_quadph<double, 8>(A, X, Y, ld, ycol, xcol, st);
+bool spmmv_phased(const uspmv_dmat *A, const double *X, double *Y, long ld, bool ycol, bool xcol, hipStream_t st) {
+    return launch_spmmv_quadph<double, 8>(A, X, Y, ld, ycol, xcol, st);
 }
-bool spmmv_phased(const uspmv_dmat *A, const float *X, float *Y, long ld, bool ycol, bool xcol, bool persistent, hipStream_t st) {
-    return persistent ? launch_spmmv_quadpp<float, 16>(A, X, Y, ld, ycol, st) : launch_spmmv_quadph<float, 16>(A, X, Y, ld, ycol, xcol, st);
+bool spmmv_phased(const uspmv_dmat *A, const float *X, float *Y, long ld, bool ycol, bool xcol, hipStream_t st) {
+    return launch_spmmv_quadph<float, 16>(A, X, Y, ld, ycol, xcol, st);
 }
 
 }  // namespace uspmv_dev

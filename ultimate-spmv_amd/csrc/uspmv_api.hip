@@ -153,15 +153,13 @@ int uspmv_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "ablate")) g_tune.ablate = value;
     else if (!strcmp(key, "spmmv_prefetch")) g_tune.spmmv_prefetch = value != 0;
     else if (!strcmp(key, "spmmv_swizzle")) g_tune.spmmv_swizzle = value != 0;
-    else if (!strcmp(key, "spmmv_reorder")) g_tune.spmmv_reorder = value != 0;
+    else if (!strcmp(key, "spmmv_reorder")) g_tune.spmmv_reorder = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (!strcmp(key, "spmmv_persist_x")) g_tune.spmmv_persist_x = value < 1 ? 1 : value;
     else if (!strcmp(key, "spmmv_phased")) g_tune.spmmv_phased = value != 0;
     else if (!strcmp(key, "spmmv_xcol")) g_tune.spmmv_xcol = value != 0;
     else if (!strcmp(key, "spmmv_phase_rows")) g_tune.spmmv_phase_rows = value == 512 ? 512 : 256;
     else if (!strcmp(key, "spmmv_persist_w")) g_tune.spmmv_persist_w = value == 3 ? 3 : 2;
     else if (!strcmp(key, "spmmv_idx8")) g_tune.spmmv_idx8 = value != 0;
-    else if (!strcmp(key, "spmmv_stagger")) g_tune.spmmv_stagger = value < 0 ? 0 : value > 64 ? 64 : (int)value;
-    else if (!strcmp(key, "spmmv_persist_wgs")) g_tune.spmmv_persist_wgs = value < 1 ? 1 : value > 16 ? 16 : (int)value;
     else if (!strcmp(key, "sweep")) g_tune.sweep = value != 0;
     else if (!strcmp(key, "sweep_nbuf")) g_tune.sweep_nbuf = value == 1 ? 1 : 2;
     else if (!strcmp(key, "sweep_unroll")) g_tune.sweep_unroll = value >= 8 ? 8 : value >= 4 ? 4 : 2;
@@ -179,7 +177,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_tile_rows")) g_tune.spmmv_tile_rows = value == 64 ? 64 : value == 32 ? 32 : 0;
     else if (!strcmp(key, "spmmv_lds_kb")) g_tune.spmmv_lds_kb = value < 0 ? 0 : value;
     else if (!strcmp(key, "spmmv_variant")) {
-        if (value < 0 || value > 10) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0..10");
+        if (value < 0 || value > 8) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0..8");
         g_tune.spmmv_variant = value;
     }
     else if (!strcmp(key, "tail_batch")) g_tune.tail_batch = value != 0;
@@ -222,8 +220,6 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_phase_rows")) *value = g_tune.spmmv_phase_rows;
     else if (!strcmp(key, "spmmv_persist_w")) *value = g_tune.spmmv_persist_w;
     else if (!strcmp(key, "spmmv_idx8")) *value = g_tune.spmmv_idx8;
-    else if (!strcmp(key, "spmmv_stagger")) *value = g_tune.spmmv_stagger;
-    else if (!strcmp(key, "spmmv_persist_wgs")) *value = g_tune.spmmv_persist_wgs;
     else if (!strcmp(key, "sweep")) *value = g_tune.sweep;
     else if (!strcmp(key, "sweep_nbuf")) *value = g_tune.sweep_nbuf;
     else if (!strcmp(key, "sweep_unroll")) *value = g_tune.sweep_unroll;
@@ -611,7 +607,7 @@ static void bt_release(uspmv_dmat_t *A) {
     (void)hipFree(A->bt_values); (void)hipFree(A->bt_cols); (void)hipFree(A->bt_row_map);
     A->bt_values = nullptr; A->bt_cols = A->bt_row_map = nullptr;
     (void)hipFree(A->pb_ph_ptr); (void)hipFree(A->pb_g0); (void)hipFree(A->pb_list_ptr); (void)hipFree(A->pb_xrows); (void)hipFree(A->pb_c16_ptrs); (void)hipFree(A->pb_col16);
-    (void)hipFree(A->pb_sched); (void)hipFree(A->pb_wg_ptr); A->pb_sched = A->pb_wg_ptr = nullptr; A->pb_wgs = 0; A->pb_idx8 = false;
+    (void)hipFree(A->pb_values); A->pb_values = nullptr; A->pb_idx8 = false;
     A->pb_ph_ptr = A->pb_g0 = A->pb_list_ptr = A->pb_xrows = nullptr; A->pb_c16_ptrs = nullptr; A->pb_col16 = nullptr; A->pb = false;
     A->bt_line_ptr = A->bt_xrows = nullptr; A->bt_c16_ptrs = nullptr; A->bt_col16 = nullptr;
     A->bt = false;
@@ -637,7 +633,7 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
     uspmv_tlc_plan p;
     uspmv_scs r;                       // private copy with the sigma sort's ties undone (only kept when rows moved)
     std::vector<int32_t> row_map;
-    const bool moved = g_tune.spmmv_reorder && uspmv_scs_reorder_ties(s, &r, &row_map) == 1;
+    const bool moved = g_tune.spmmv_reorder && uspmv_scs_reorder_rows(s, g_tune.spmmv_reorder == 2 ? 2 : 1, &r, &row_map) == 1;
     if (int rc = uspmv_build_tlc_plan(moved ? &r : s, nullptr, max_rows, tile_rows, &p, /*line_shift=*/0)) return rc;
     if (n_tiles) *n_tiles = p.n_tiles;
     if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
@@ -675,34 +671,22 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
                 e = up(c8.data(), c8.size(), (void **)&A->pb_col16);
             } else if (e == hipSuccess) e = up(pp.col16.data(), pp.col16.size() * 2, (void **)&A->pb_col16);
             if (e == hipSuccess) {
-                // the flat schedule of the persistent kernel: workgroup w = (XCD w % 8, slot w / 8) takes, in round k, the tile the
-                // one-tile-per-workgroup launch gives block k*G + w under xcd_remap = G/8 (remap_block) -- the same sweep order
-                int cus = 256;
-                hipDeviceProp_t prop;
-                int dev = 0;
-                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-                const int64_t G = std::max<int64_t>(8, ((int64_t)cus * g_tune.spmmv_persist_wgs) / 8 * 8), S = G / 8;
-                const int64_t full = pp.n_tiles / G * G;
-                std::vector<int32_t> wg_ptr((size_t)G + 1, 0), sched;
-                sched.reserve((size_t)pp.n_phases * 8);
-                for (int64_t w = 0; w < G; ++w) {
-                    const int64_t in_group = (w % 8) * S + w / 8;
-                    for (int64_t k = 0;; ++k) {
-                        const int64_t t = k * G < full ? k * G + in_group : full + w;
-                        if (t >= pp.n_tiles) break;
-                        for (int32_t ph = pp.ph_ptr[(size_t)t]; ph < pp.ph_ptr[(size_t)t + 1]; ++ph) {
-                            const bool first = ph == pp.ph_ptr[(size_t)t], last = ph + 1 == pp.ph_ptr[(size_t)t + 1];
-                            const int32_t ent[8] = {(int32_t)t, pp.ph_g0[(size_t)ph], last ? 0x7fffffff : pp.ph_g0[(size_t)ph + 1], pp.ph_list_ptr[(size_t)ph],
-                                                    pp.ph_list_ptr[(size_t)ph + 1] - pp.ph_list_ptr[(size_t)ph], (first ? 1 : 0) | (last ? 2 : 0), 0, 0};
-                            sched.insert(sched.end(), ent, ent + 8);
+                // the entries once more, group-major like the indices (what scs_spmmv_quadph streams)
+                const uspmv_scs *src = moved ? &r : s;
+                const size_t vs = src->dtype == USPMV_F64 ? 8 : 4;
+                std::vector<unsigned char> gv(pp.col16.size() * vs, 0);
+                const int64_t C_ = src->C;
+#pragma omp parallel for schedule(static)
+                for (int64_t c = 0; c < src->n_chunks; ++c) {
+                    const int64_t cs = src->chunk_ptrs[(size_t)c], L = src->chunk_lengths[(size_t)c];
+                    const size_t base = pp.c16_ptrs[(size_t)c];
+                    for (int64_t j = 0; j < L; ++j)
+                        for (int64_t i = 0; i < C_; ++i) {
+                            const size_t dst = base + (size_t)((j / 4) * 4 * C_ + i * 4 + (j % 4)), from = (size_t)(cs + j * C_ + i);
+                            if (vs == 8) ((double *)gv.data())[dst] = src->values_f64[from]; else ((float *)gv.data())[dst] = src->values_f32[from];
                         }
-                        if (k * G >= full) break;
-                    }
-                    wg_ptr[(size_t)w + 1] = (int32_t)(sched.size() / 8);
                 }
-                e = up(sched.data(), sched.size() * 4, (void **)&A->pb_sched);
-                if (e == hipSuccess) e = up(wg_ptr.data(), wg_ptr.size() * 4, (void **)&A->pb_wg_ptr);
-                if (e == hipSuccess) A->pb_wgs = (int)G;
+                e = up(gv.data(), gv.size(), &A->pb_values);
             }
             if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] phased block plan: tiles=%lld phases=%lld rows_total=%zu max_rows=%d (cap %d)\n",
                                                  (long long)pp.n_tiles, (long long)pp.n_phases, pp.xrows.size(), pp.max_rows_used, pp.cap_rows);

@@ -50,10 +50,7 @@ struct uspmv_dmat {
     int pb_cap_rows = 0, pb_ngp = 0, pb_max_rows = 0;
     int64_t pb_n_tiles = 0, pb_n_phases = 0;
     int32_t *pb_ph_ptr = nullptr, *pb_g0 = nullptr, *pb_list_ptr = nullptr, *pb_xrows = nullptr;
-    // the same phases as one flat schedule per persistent workgroup (variant 9): pb_wg_ptr[w]..pb_wg_ptr[w+1] index pb_sched, whose
-    // entries are 8 ints {tile, g0, g1, list_ptr, list_rows, flags (1: first phase of its tile, 2: last), 0, 0}
-    int32_t *pb_sched = nullptr, *pb_wg_ptr = nullptr;
-    int pb_wgs = 0;
+    void *pb_values = nullptr;          // the entries again, GROUP-major like pb_col16 ([chunk][group of four slots][row][slot % 4])
     uint32_t *pb_c16_ptrs = nullptr;
     uint16_t *pb_col16 = nullptr;       // phase-local indices; ONE BYTE each when pb_idx8 (no phase lists more than 256 rows)
     bool pb_idx8 = false;
@@ -107,11 +104,10 @@ struct Tuning {
     int spmmv_phased = 1;      // NEXT uspmv_dmat_optimize_block with 64-byte rows: also build the phased plan (eight workgroups per CU)
     int spmmv_phase_rows = 256;  // ... X rows per phase (256 | 512)
     int spmmv_idx8 = 1;        // NEXT optimize_block: one-byte phase-local indices when every phase lists <= 256 rows
-    int spmmv_stagger = 0;     // ... start offset between the workgroups of a CU, x 1024 cycles
-    int spmmv_persist_wgs = 8; // phased persistent kernel (variant 9): workgroups per CU the schedule is cut for (NEXT optimize_block)
     int spmmv_persist_w = 2;   // persistent SpMMV kernel: compiled for 3 (168 VGPRs) or 2 (256 VGPRs) waves per SIMD
     int spmmv_persist_x = 1;   // persistent SpMMV kernel: grid = this many times the resident workgroups (1 = exactly resident)
-    int spmmv_reorder = 1;  // block plan: rows of equal-length chunks of a sigma window back in original order (private copy of the entries)
+    int spmmv_reorder = 1;  // block plan's private copy of the entries: 1 = rows of equal-length chunks of a sigma window back in original order,
+                            // 2 = rows re-dealt to the tiles as breadth-first balls of the matrix graph (fewer X rows per tile, scattered y rows), 0 = as is
     int spmmv_variant = 0;  // 0 = auto (= 3 where a B-specialised kernel exists); 1 = generic kernel; 2 = row-major with transposing X phase; 3 = row-major, lane per row
 };
 extern Tuning g_tune;   // uspmv_api.hip
@@ -132,8 +128,8 @@ int launch_csr(long n_rows, long nnz_hint, const int *rp, const int *ci, const V
 template <typename VT>
 int launch_spmmv(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int layout, hipStream_t st);            // spmmv_kernels.hip
 // phased block plan, 64-byte X rows (spmmv_phased.hip); false: no plan / schedule on the handle or it does not fit the compiled shapes
-bool spmmv_phased(const uspmv_dmat *A, const double *X, double *Y, long ld, bool ycol, bool xcol, bool persistent, hipStream_t st);
-bool spmmv_phased(const uspmv_dmat *A, const float *X, float *Y, long ld, bool ycol, bool xcol, bool persistent, hipStream_t st);
+bool spmmv_phased(const uspmv_dmat *A, const double *X, double *Y, long ld, bool ycol, bool xcol, hipStream_t st);
+bool spmmv_phased(const uspmv_dmat *A, const float *X, float *Y, long ld, bool ycol, bool xcol, hipStream_t st);
 int launch_spmv_ap(const uspmv_dmat *dp, const uspmv_dmat *sp, const double *d_x, const float *d_x_sp, double *d_y,
                    hipStream_t stream);                                                                           // ap_kernels.hip
 template <typename VT>

@@ -197,11 +197,92 @@ int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *o) {
 // chunk length or pointer, so the plan's private copy of the entries puts them back in original-row order
 // inside every run of equal-length chunks of a window; row_map[new position] = position in the caller's
 // struct (= where y goes).  Per-row slot order is untouched, hence the same FMA chain per (row, column).
-int uspmv_scs_reorder_ties(const uspmv_scs *s, uspmv_scs *r, std::vector<int32_t> *row_map) {
+// Row CLUSTERING for the block plan (mode 2 of uspmv_scs_reorder_rows).  The X rows a 64-row tile stages are the union of its
+// rows' columns; for a matrix from a 2-D / 3-D mesh a tile of 64 CONSECUTIVE rows is a line segment of the mesh and touches
+// ~10 X rows per row, a compact patch of the mesh about 6.  Rows may be exchanged freely between positions that sit in chunks of
+// equal length (nothing about the chunk structure changes, every row keeps its own padded slot sequence -> same FMA chain), so the
+// tiles are re-filled greedily: a tile takes the next unassigned row of its chunk-length class and grows a breadth-first ball
+// around it over rows of the same class (the matrix' own column indices are the graph).  row_map[new position] = position in the
+// caller's struct.  Serial, O(elements).
+static void cluster_row_map(const uspmv_scs *s, std::vector<int32_t> *row_map) {
     const int64_t C = s->C, nc = s->n_chunks, n_pad = nc * C;
+    int32_t max_len = 0;
+    for (int64_t c = 0; c < nc; ++c) max_len = std::max(max_len, s->chunk_lengths[(size_t)c]);
+    // rows of every class in position order, and a cursor to the first one that may still be unassigned
+    std::vector<int64_t> cls_begin((size_t)max_len + 2, 0);
+    for (int64_t c = 0; c < nc; ++c) cls_begin[(size_t)s->chunk_lengths[(size_t)c] + 1] += C;
+    for (size_t l = 0; l + 1 < cls_begin.size(); ++l) cls_begin[l + 1] += cls_begin[l];
+    std::vector<int32_t> cls_rows((size_t)n_pad);
+    {
+        std::vector<int64_t> fill(cls_begin.begin(), cls_begin.end() - 1);
+        for (int64_t c = 0; c < nc; ++c) {
+            const int32_t l = s->chunk_lengths[(size_t)c];
+            for (int64_t i = 0; i < C; ++i) cls_rows[(size_t)fill[(size_t)l]++] = (int32_t)(c * C + i);
+        }
+    }
+    std::vector<int64_t> cursor(cls_begin.begin(), cls_begin.end() - 1);
+    std::vector<char> assigned((size_t)n_pad, 0);
+    std::vector<int32_t> stamp((size_t)n_pad, -1), queue;
+    const int64_t T = std::max<int64_t>(1, 64 / C);
+    int32_t blob = 0;
+    for (int64_t c0 = 0; c0 < nc;) {
+        const int64_t tile_end = std::min(nc, (c0 / T + 1) * T);
+        int64_t c1 = c0 + 1;
+        const int32_t l = s->chunk_lengths[(size_t)c0];
+        while (c1 < tile_end && s->chunk_lengths[(size_t)c1] == l) ++c1;
+        const int64_t need = (c1 - c0) * C;
+        int32_t *out = row_map->data() + c0 * C;
+        if (l == 0) {                                        // empty chunks: rows stay where they are
+            for (int64_t k = 0; k < need; ++k) { out[k] = (int32_t)(c0 * C + k); assigned[(size_t)out[k]] = 1; }
+            c0 = c1;
+            continue;
+        }
+        int64_t got = 0;
+        size_t head = 0;
+        queue.clear();
+        ++blob;
+        while (got < need) {
+            if (head == queue.size()) {                      // (re)seed: the next unassigned row of the class in position order
+                int64_t &cu = cursor[(size_t)l];
+                while (cu < cls_begin[(size_t)l + 1] && assigned[(size_t)cls_rows[(size_t)cu]]) ++cu;
+                if (cu >= cls_begin[(size_t)l + 1]) break;   // (cannot happen: the class has exactly as many rows as positions)
+                const int32_t seed = cls_rows[(size_t)cu];
+                stamp[(size_t)seed] = blob;
+                queue.push_back(seed);
+            }
+            const int32_t v = queue[head++];
+            if (assigned[(size_t)v]) continue;
+            assigned[(size_t)v] = 1;
+            out[got++] = v;
+            const int64_t vc = v / C, vi = v % C, vcs = s->chunk_ptrs[(size_t)vc];
+            for (int64_t j = 0; j < l; ++j) {
+                const int32_t u = s->col_idxs[(size_t)(vcs + j * C + vi)];
+                if ((int64_t)u < n_pad && !assigned[(size_t)u] && stamp[(size_t)u] != blob && s->chunk_lengths[(size_t)(u / C)] == l) {
+                    stamp[(size_t)u] = blob;
+                    queue.push_back(u);
+                }
+            }
+        }
+        std::sort(out, out + got);                           // inside the run: position order (neighbouring lanes <-> neighbouring y rows)
+        c0 = c1;
+    }
+}
+
+int uspmv_scs_reorder_ties(const uspmv_scs *s, uspmv_scs *r, std::vector<int32_t> *row_map) { return uspmv_scs_reorder_rows(s, 1, r, row_map); }
+
+// mode 1: tie re-ordering (below); mode 2: row clustering (above); mode -1: copy under the caller's row_map
+int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vector<int32_t> *row_map) {
+    if (mode == 2) {                                         // (on the caller's struct: there a column index IS a row position)
+        row_map->resize((size_t)(s->n_chunks * s->C));
+        cluster_row_map(s, row_map);
+        return uspmv_scs_reorder_rows(s, -1, r, row_map);
+    }
+    const int64_t C = s->C, nc = s->n_chunks, n_pad = nc * C;
+    bool changed = false;
+    if (mode == -1) changed = true;                          // row_map given by the caller: only the copy below
+    else {
     row_map->resize((size_t)n_pad);
     for (int64_t q = 0; q < n_pad; ++q) (*row_map)[(size_t)q] = (int32_t)q;
-    bool changed = false;
     const bool have_perm = s->sigma > 1 && std::max<int64_t>(s->sigma, C) % C == 0 && (int64_t)s->new_to_old_idx.size() >= s->n_rows;
     // with the caller's permutation: original row order inside a sigma window.  Without it (a struct rebuilt from device arrays,
     // uspmv_dmat_optimize_block_device): rows ordered by their first column inside runs of at most 16 equal-length chunks -- for
@@ -234,6 +315,7 @@ int uspmv_scs_reorder_ties(const uspmv_scs *s, uspmv_scs *r, std::vector<int32_t
             }
         }
         for (char v : ch) changed = changed || v;
+    }
     }
     r->C = C; r->sigma = s->sigma; r->n_rows = s->n_rows; r->n_cols = s->n_cols; r->nnz = s->nnz; r->dtype = s->dtype;
     r->n_chunks = nc; r->n_rows_padded = s->n_rows_padded; r->n_elements = s->n_elements;

@@ -89,6 +89,9 @@ int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *out);   // host/tlc_plan.
 // private copy of the entries with the rows of equal-length chunks of a sigma window back in original order;
 // returns 1 when anything moved, 0 when the copy is identical (row_map = identity)
 int uspmv_scs_reorder_ties(const uspmv_scs *s, uspmv_scs *r, std::vector<int32_t> *row_map);   // host/tlc_plan.cpp
+// mode 1 = the above; mode 2 = rows re-dealt to the 64-row tiles as breadth-first balls of the matrix graph (per chunk-length
+// class, so the chunk structure is still untouched); mode -1 = copy under the caller's row_map
+int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vector<int32_t> *row_map);   // host/tlc_plan.cpp
 
 int uspmv_scs_layout(const uspmv_coo *m, int64_t C, int64_t sigma, int dtype, const int32_t *fixed_permutation,
                      uspmv_scs *s, std::vector<int64_t> *row_start, const char *who);   // host/scs_convert.cpp
