@@ -260,7 +260,10 @@ int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_
  *   "spmmv_phased" 1|0 and "spmmv_phase_rows" 256|512: NEXT uspmv_dmat_optimize_block with 64-byte rows also builds the phased plan,
  *   "spmmv_xcol" 0|1: phased kernel on column-major X behind a re-layout pass (0) or assembling its X rows from the caller's vector itself (1),
  *   "spmmv_swizzle" 0|1 bank-swizzled LDS rows in the block-plan kernel,
- *   "spmmv_reorder" 1|0 NEXT uspmv_dmat_optimize_block: undo the sigma sort's tie scrambling in the plan's private copy of the entries,
+ *   "spmmv_reorder" 1|2|0 NEXT uspmv_dmat_optimize_block, row order of the plan's private copy of the entries: 1 = the sigma sort's tie
+ *   scrambling undone, 2 = rows re-dealt to the 64-row tiles as breadth-first balls of the matrix graph (fewer X rows per tile, but
+ *   scattered y rows: measured slower on config 3, kept as an option), 0 = the caller's order;
+ *   "spmmv_idx8" 1|0 NEXT uspmv_dmat_optimize_block: one-byte phase-local indices when no phase lists more than 256 X rows,
  *   "sweep" 1|0 use a handle's column-window sweep plan, "sweep_nbuf" 1|2 LDS buffers, "sweep_unroll" 2|4|8, "sweep_remap" tiles per XCD group,
  *   "sweep_wlog" / "sweep_tile_rows" / "sweep_max_stage" defaults of the NEXT sweep plan (window = 2^wlog elements; rows per tile;
  *   largest staging cost in bytes per non-zero for a tile to qualify, 0 = 24),
