@@ -55,7 +55,7 @@ __device__ __forceinline__ void sweep_window(const XT *__restrict__ xs, const in
             v[u] = AT(0); ix[u] = 0u;
             if (k0 + u < c) {
                 const unsigned off = first[u] + lanes_below(m[u]);
-                v[u] = ld_stream<NT>(vp + off); ix[u] = ld_stream<NT>(ip + off);
+                v[u] = ld_stream_g<NT>(vp + off); ix[u] = ld_stream_g<NT>(ip + off);
             }
         }
 #pragma unroll
@@ -178,7 +178,10 @@ int launch_sweep(const uspmv_dmat *A, const VT *x, VT *y, hipStream_t st) {
     const int nbuf = g_tune.sweep_nbuf == 2 ? 2 : 1;
     const size_t lds = (size_t)nbuf * (size_t)W * sizeof(VT);
     const int remap = g_tune.sweep_remap;
-    const int rpl = A->sw_tile_rows > 1024 ? A->sw_tile_rows / 1024 : 1, threads = A->sw_tile_rows / rpl;
+    // threads per workgroup: 1 024 (or the tile, if smaller) unless "sweep_threads" asks for fewer -- a lane then owns more rows
+    int threads = std::min<int>(A->sw_tile_rows, g_tune.sweep_threads > 0 ? g_tune.sweep_threads : 1024);
+    if (A->sw_tile_rows / threads > 4) threads = A->sw_tile_rows / 4;
+    const int rpl = A->sw_tile_rows / threads;
 #define SW_LAUNCH(NTV, NB, UU, RP)                                                                                          \
     do {                                                                                                                    \
         auto kfn = scs_spmv_sweep<VT, AP, NTV, NB, UU, RP>;                                                                 \

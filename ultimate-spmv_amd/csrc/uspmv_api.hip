@@ -172,6 +172,7 @@ int uspmv_set_tuning(const char *key, int value) {
         if (value != 0 && value != 256 && value != 512 && value != 1024 && value != 2048 && value != 4096) return uspmv::fail(USPMV_ERR_INVALID, "sweep_tile_rows must be 0|256|512|1024|2048|4096");
         g_tune.sweep_tile_rows = value;
     }
+    else if (!strcmp(key, "sweep_threads")) g_tune.sweep_threads = (value == 256 || value == 512 || value == 1024) ? (int)value : 0;
     else if (!strcmp(key, "sweep_max_stage")) g_tune.sweep_max_stage = value < 0 ? 0 : value;
     else if (!strcmp(key, "raw_plan_cache")) g_tune.raw_plan_cache = value != 0;
     else if (!strcmp(key, "spmmv_tile_rows")) g_tune.spmmv_tile_rows = value == 64 ? 64 : value == 32 ? 32 : 0;
@@ -226,6 +227,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "sweep_remap")) *value = g_tune.sweep_remap;
     else if (!strcmp(key, "sweep_wlog")) *value = g_tune.sweep_wlog;
     else if (!strcmp(key, "sweep_tile_rows")) *value = g_tune.sweep_tile_rows;
+    else if (!strcmp(key, "sweep_threads")) *value = g_tune.sweep_threads;
     else if (!strcmp(key, "sweep_max_stage")) *value = g_tune.sweep_max_stage;
     else if (!strcmp(key, "raw_plan_cache")) *value = g_tune.raw_plan_cache;
     else if (!strcmp(key, "spmmv_tile_rows")) *value = g_tune.spmmv_tile_rows;

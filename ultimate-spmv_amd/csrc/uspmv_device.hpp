@@ -92,6 +92,7 @@ struct Tuning {
                             // needs ~10 fewer address instructions per non-zero and measures 5-7 % faster (spmmv_probe16.txt)
     int spmmv_prefetch = 1; // row-major lane-per-row kernel: request batch k+1's matrix entries behind batch k's X rows
     int sweep = 1;          // use the column-window sweep kernel when the handle carries a sweep plan
+    int sweep_threads = 0;     // threads per sweep workgroup (0 = min(tile rows, 1024); 256 | 512: a lane owns tile rows / threads rows, at most 4)
     int sweep_nbuf = 1;     // LDS buffers per workgroup: 1 = two 1024-thread workgroups per CU cover each other's staging (0.63 vs 0.72 ms on
                             // config 4b); 2 = one workgroup, window s+1 lands while window s is consumed
     int sweep_unroll = 8;   // rounds per batch
@@ -162,6 +163,14 @@ template <bool NT, typename T>
 __device__ __forceinline__ T ld_stream(const T *p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
+}
+// the same through an explicitly GLOBAL pointer: where the address reaches the load through a reference or a local pointer array
+// the compiler no longer knows the address space and emits flat_load (which also ties up the LDS counter) instead of global_load
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_stream_g(const T *p) {
+    typedef const T __attribute__((address_space(1))) *gp_t;
+    if constexpr (NT) return __builtin_nontemporal_load((gp_t)p);
+    else return *(gp_t)p;
 }
 // y store.  A y vector is ~2 % of the bytes of an SpMV, but its HBM write stream costs 15-18 % of the
 // kernel when it goes through the write-back L2 (profiles/r01_microbench.txt: 0.74 ms without the
