@@ -251,6 +251,14 @@ def test_convert_to_scs_device_bitexact(pkg, torch_cuda):
         pkg.convert_to_scs_device(unsorted, 2, 2)
 
 
+def C_tile_rows(pkg, A):
+    import ctypes
+    from ultimate_spmv_amd import binding
+    tr = ctypes.c_int()
+    assert binding.lib().uspmv_dmat_tile_rows(A.h, ctypes.byref(tr)) == 0
+    return tr.value
+
+
 def test_device_plan_builder_matches_host_planner(pkg, orc, torch_cuda):
     """uspmv_dmat_optimize_device: the plan built on the GPU from the handle's arrays equals the host planner's
     (line lists, 16-bit indices) and the SpMV on it is bit-exact; also on handles made by convert_to_scs_device and
@@ -284,6 +292,40 @@ def test_device_plan_builder_matches_host_planner(pkg, orc, torch_cuda):
             y = t.full((s.n_rows_padded,), 3.0, dtype=Ad.torch_dtype, device="cuda")
             pkg.spmv(Ad, _dev(t, xp), y)
             assert np.array_equal(y.cpu().numpy(), yo), (name, C, code)
+    # tiles of 512 / 1024 rows (a lane of the builder owns 2 / 4 rows), and the shared plan of an ap[dp_sp] pair (512 rows by default)
+    m = pkg.read_mtx(mtx_path("bcsstk13"))
+    for C, sigma in ((32, 512), (64, 64), (16, 16)):
+        s, a, xp = _prep(pkg, m, C, sigma, pkg.F64, make_x(m.n_rows))
+        yo = orc.spmv_scs(s.C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+        for tile_rows in (512, 1024):
+            pkg.set_tuning(tlc_tile_rows=tile_rows, rechunk=0)
+            Ah = pkg.DeviceMatrix(s); Ah.optimize(s)
+            Ad = pkg.DeviceMatrix(s); Ad.optimize_device()
+            pkg.set_tuning(tlc_tile_rows=0, rechunk=1)
+            assert Ah.tile_rows == tile_rows and Ad.tile_rows == tile_rows
+            assert (Ad.tlc_tiles, Ad.tlc_staged) == (Ah.tlc_tiles, Ah.tlc_staged), (C, tile_rows)
+            ph, pd = Ah.plan_download(), Ad.plan_download()
+            for k in ("tile_line_ptr", "tile_lines", "c16_ptrs", "col16"):
+                assert np.array_equal(ph[k], pd[k]), (C, tile_rows, k)
+            y = t.full((s.n_rows_padded,), 3.0, dtype=t.float64, device="cuda")
+            pkg.spmv(Ad, _dev(t, xp), y)
+            assert np.array_equal(y.cpu().numpy(), yo), (C, tile_rows)
+    dp, sp = pkg.partition_precisions(m, 1e-1)
+    assert dp.nnz > 0 and sp.nnz > 0
+    ds = pkg.convert_to_scs(dp, 32, 512, pkg.F64)
+    perm = ds.arrays()["old_to_new_idx"].copy()
+    ss = pkg.convert_to_scs(sp, 32, 512, pkg.F32, fixed_permutation=perm)
+    pkg.permute_scs_cols(ds, perm); pkg.permute_scs_cols(ss, perm)
+    Ahd, Ahs = pkg.DeviceMatrix(ds), pkg.DeviceMatrix(ss)
+    Add, Ads = pkg.DeviceMatrix(ds), pkg.DeviceMatrix(ss)
+    pkg.optimize_ap(Ahd, Ahs, ds, ss)
+    pkg.optimize_device_ap(Add, Ads)
+    for Ah, Ad in ((Ahd, Add), (Ahs, Ads)):
+        th, td = C_tile_rows(pkg, Ah), C_tile_rows(pkg, Ad)
+        assert th == td == 512
+    ph, pd = Ahd.plan_download(), Add.plan_download()
+    for k in ("tile_line_ptr", "tile_lines", "c16_ptrs", "col16"):
+        assert np.array_equal(ph[k], pd[k]), ("ap pair", k)
     m = pkg.read_mtx(mtx_path("bcsstk13"))                    # device-converted handle, no host entries at all
     lay, A = pkg.convert_to_scs_device(m, 32, 512, pkg.F64)
     nt, ns = A.optimize_device()
@@ -513,7 +555,7 @@ def test_ap_golden_bitexact(pkg, torch_cuda, name):
     for max_lines, tile_rows in ((0, 256), (2, 256), (0, 1024)):
         pkg.set_tuning(tlc_tile_rows=tile_rows)
         nt_, ns_ = pkg.optimize_ap(Ad, As, ds, ss, max_lines)
-        pkg.set_tuning(tlc_tile_rows=256)
+        pkg.set_tuning(tlc_tile_rows=0)
         y.fill_(7.0)
         pkg.spmv_ap(Ad, As, _dev(t, a[p + "x_perm"]), y)
         if Cc in ADV_CS:
@@ -587,7 +629,7 @@ def test_tile_local_column_kernel_bitexact(pkg, orc, torch_cuda, name):
             for max_lines, tile_rows in ((0, 256), (3, 256), (1, 512), (0, 512), (0, 1024), (5, 1024)):
                 pkg.set_tuning(tlc_tile_rows=tile_rows)
                 A = pkg.DeviceMatrix(s, tlc=True, tlc_max_lines=max_lines)
-                pkg.set_tuning(tlc_tile_rows=256)
+                pkg.set_tuning(tlc_tile_rows=0)
                 if Cc < 32:      # narrow chunks are re-chunked to C = 32 internally (same row order)
                     nc32 = (s.n_chunks * Cc + 31) // 32
                     assert A.tlc_tiles in (0, (nc32 + tile_rows // 32 - 1) // (tile_rows // 32))

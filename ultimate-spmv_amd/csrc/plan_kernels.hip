@@ -34,42 +34,55 @@ __device__ __forceinline__ int bit_to_line(int b, int lo, int hi) {
 __device__ void tile_bitmap(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
                             const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const long tile,
                             unsigned *bits, int *s_lo, int *s_hi, int *s_maxcol, int *s_bad,
-                            const int *__restrict__ chunk_ptrs2 = nullptr, const int *__restrict__ chunk_lengths2 = nullptr,
+                            const int rpt, const int *__restrict__ chunk_ptrs2 = nullptr, const int *__restrict__ chunk_lengths2 = nullptr,
                             const int *__restrict__ col_idxs2 = nullptr) {
-    const long row = tile * 256 + threadIdx.x;
-    const long c = row / C;
-    const int i = (int)(row - c * C);
-    int cs = 0, L = 0, cs2 = 0, L2 = 0;
-    if (c < n_chunks) {
-        cs = chunk_ptrs[c]; L = chunk_lengths[c];
-        if (chunk_ptrs2) { cs2 = chunk_ptrs2[c]; L2 = chunk_lengths2[c]; }
-    }
+    // a tile is rpt * 256 rows: thread <-> rows tile*rpt*256 + h*256 + threadIdx.x, h < rpt
     if (threadIdx.x == 0) { *s_lo = INT32_MAX; *s_hi = -1; *s_bad = 0; }
     for (int w = threadIdx.x; w < PLAN_WORDS; w += 256) bits[w] = 0u;
     __syncthreads();
     int lo = INT32_MAX, hi = -1;
-    for (int j = 0; j < L; ++j) {
-        const int col = col_idxs[(long)cs + (long)j * C + i];
-        lo = min(lo, col); hi = max(hi, col);
-    }
-    for (int j = 0; j < L2; ++j) {
-        const int col = col_idxs2[(long)cs2 + (long)j * C + i];
-        lo = min(lo, col); hi = max(hi, col);
+    for (int h = 0; h < rpt; ++h) {
+        const long row = (tile * rpt + h) * 256 + threadIdx.x;
+        const long c = row / C;
+        const int i = (int)(row - c * C);
+        if (c >= n_chunks) continue;
+        const int cs = chunk_ptrs[c], L = chunk_lengths[c];
+        for (int j = 0; j < L; ++j) {
+            const int col = col_idxs[(long)cs + (long)j * C + i];
+            lo = min(lo, col); hi = max(hi, col);
+        }
+        if (chunk_ptrs2) {
+            const int cs2 = chunk_ptrs2[c], L2 = chunk_lengths2[c];
+            for (int j = 0; j < L2; ++j) {
+                const int col = col_idxs2[(long)cs2 + (long)j * C + i];
+                lo = min(lo, col); hi = max(hi, col);
+            }
+        }
     }
     if (hi >= 0) { atomicMin(s_lo, lo >> 4); atomicMax(s_hi, hi >> 4); atomicMax(s_maxcol, hi); }
     __syncthreads();
     const int tlo = *s_lo, thi = *s_hi;
     if (thi < 0) return;
     bool bad = false;
-    for (int j = 0; j < L; ++j) {
-        const int b = line_to_bit(col_idxs[(long)cs + (long)j * C + i] >> 4, tlo, thi);
-        if (b < 0) bad = true;
-        else atomicOr(&bits[b >> 5], 1u << (b & 31));
-    }
-    for (int j = 0; j < L2; ++j) {
-        const int b = line_to_bit(col_idxs2[(long)cs2 + (long)j * C + i] >> 4, tlo, thi);
-        if (b < 0) bad = true;
-        else atomicOr(&bits[b >> 5], 1u << (b & 31));
+    for (int h = 0; h < rpt; ++h) {
+        const long row = (tile * rpt + h) * 256 + threadIdx.x;
+        const long c = row / C;
+        const int i = (int)(row - c * C);
+        if (c >= n_chunks) continue;
+        const int cs = chunk_ptrs[c], L = chunk_lengths[c];
+        for (int j = 0; j < L; ++j) {
+            const int b = line_to_bit(col_idxs[(long)cs + (long)j * C + i] >> 4, tlo, thi);
+            if (b < 0) bad = true;
+            else atomicOr(&bits[b >> 5], 1u << (b & 31));
+        }
+        if (chunk_ptrs2) {
+            const int cs2 = chunk_ptrs2[c], L2 = chunk_lengths2[c];
+            for (int j = 0; j < L2; ++j) {
+                const int b = line_to_bit(col_idxs2[(long)cs2 + (long)j * C + i] >> 4, tlo, thi);
+                if (b < 0) bad = true;
+                else atomicOr(&bits[b >> 5], 1u << (b & 31));
+            }
+        }
     }
     if (bad) *s_bad = 1;
     __syncthreads();
@@ -78,12 +91,12 @@ __device__ void tile_bitmap(const long n_chunks, const int C, const int *__restr
 __global__ void __launch_bounds__(256) plan_count_lines(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
         const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const int max_lines,
         int *__restrict__ n_lines, int *__restrict__ max_col, const int *__restrict__ chunk_ptrs2, const int *__restrict__ chunk_lengths2,
-        const int *__restrict__ col_idxs2) {
+        const int *__restrict__ col_idxs2, const int rpt) {
     __shared__ unsigned bits[PLAN_WORDS];
     __shared__ int s_lo, s_hi, s_cnt, s_maxcol, s_bad;
     if (threadIdx.x == 0) { s_cnt = 0; s_maxcol = 0; }
     const long tile = blockIdx.x;
-    tile_bitmap(n_chunks, C, chunk_ptrs, chunk_lengths, col_idxs, tile, bits, &s_lo, &s_hi, &s_maxcol, &s_bad, chunk_ptrs2, chunk_lengths2, col_idxs2);
+    tile_bitmap(n_chunks, C, chunk_ptrs, chunk_lengths, col_idxs, tile, bits, &s_lo, &s_hi, &s_maxcol, &s_bad, rpt, chunk_ptrs2, chunk_lengths2, col_idxs2);
     int n = 0;
     if (s_hi >= 0 && !s_bad) {
         int cnt = 0;
@@ -102,7 +115,7 @@ __global__ void __launch_bounds__(256) plan_write(const long n_chunks, const int
         const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const int *__restrict__ tile_line_ptr,
         const unsigned *__restrict__ c16_ptrs, int *__restrict__ tile_lines, unsigned short *__restrict__ col16,
         const int *__restrict__ chunk_ptrs2, const int *__restrict__ chunk_lengths2, const int *__restrict__ col_idxs2,
-        const unsigned *__restrict__ c16_ptrs2, unsigned short *__restrict__ col16_2) {
+        const unsigned *__restrict__ c16_ptrs2, unsigned short *__restrict__ col16_2, const int rpt) {
     __shared__ unsigned bits[PLAN_WORDS];
     __shared__ unsigned short rank0[PLAN_WORDS];   // set bits in the words before this one (< 4096)
     __shared__ int s_lo, s_hi, s_dummy, s_bad;
@@ -111,7 +124,7 @@ __global__ void __launch_bounds__(256) plan_write(const long n_chunks, const int
     const int lp0 = tile_line_ptr[tile];
     if (tile_line_ptr[tile + 1] == lp0) return;   // unstaged or empty tile: col16 stays zero, the kernel gathers
     if (threadIdx.x == 0) s_dummy = 0;
-    tile_bitmap(n_chunks, C, chunk_ptrs, chunk_lengths, col_idxs, tile, bits, &s_lo, &s_hi, &s_dummy, &s_bad, chunk_ptrs2, chunk_lengths2, col_idxs2);
+    tile_bitmap(n_chunks, C, chunk_ptrs, chunk_lengths, col_idxs, tile, bits, &s_lo, &s_hi, &s_dummy, &s_bad, rpt, chunk_ptrs2, chunk_lengths2, col_idxs2);
     // exclusive prefix of the popcounts: 8 consecutive words per thread, then a block scan of the 256 partial sums
     constexpr int WPT = PLAN_WORDS / 256;
     int part = 0;
@@ -138,29 +151,31 @@ __global__ void __launch_bounds__(256) plan_write(const long n_chunks, const int
         run += __popc(bits[w]);
     }
     __syncthreads();
-    const long row = tile * 256 + threadIdx.x;
-    const long c = row / C;
-    const int i = (int)(row - c * C);
-    if (c >= n_chunks) return;
-    const int cs = chunk_ptrs[c], L = chunk_lengths[c];
-    unsigned short *q = col16 + c16_ptrs[c];
     const int tlo = s_lo, thi = s_hi;
-    for (int j = 0; j < L; ++j) {
-        const int col = col_idxs[(long)cs + (long)j * C + i];
-        const int l = line_to_bit(col >> 4, tlo, thi);
-        const unsigned below = bits[l >> 5] & ((1u << (l & 31)) - 1u);
-        const int pos = rank0[l >> 5] + __popc(below);
-        q[(long)(j >> 2) * 4 * C + i * 4 + (j & 3)] = (unsigned short)((pos << 4) | (col & 15));
-    }
-    if (chunk_ptrs2) {
-        const int cs2 = chunk_ptrs2[c], L2 = chunk_lengths2[c];
-        unsigned short *q2 = col16_2 + c16_ptrs2[c];
-        for (int j = 0; j < L2; ++j) {
-            const int col = col_idxs2[(long)cs2 + (long)j * C + i];
+    for (int h = 0; h < rpt; ++h) {
+        const long row = (tile * rpt + h) * 256 + threadIdx.x;
+        const long c = row / C;
+        const int i = (int)(row - c * C);
+        if (c >= n_chunks) continue;
+        const int cs = chunk_ptrs[c], L = chunk_lengths[c];
+        unsigned short *q = col16 + c16_ptrs[c];
+        for (int j = 0; j < L; ++j) {
+            const int col = col_idxs[(long)cs + (long)j * C + i];
             const int l = line_to_bit(col >> 4, tlo, thi);
             const unsigned below = bits[l >> 5] & ((1u << (l & 31)) - 1u);
             const int pos = rank0[l >> 5] + __popc(below);
-            q2[(long)(j >> 2) * 4 * C + i * 4 + (j & 3)] = (unsigned short)((pos << 4) | (col & 15));
+            q[(long)(j >> 2) * 4 * C + i * 4 + (j & 3)] = (unsigned short)((pos << 4) | (col & 15));
+        }
+        if (chunk_ptrs2) {
+            const int cs2 = chunk_ptrs2[c], L2 = chunk_lengths2[c];
+            unsigned short *q2 = col16_2 + c16_ptrs2[c];
+            for (int j = 0; j < L2; ++j) {
+                const int col = col_idxs2[(long)cs2 + (long)j * C + i];
+                const int l = line_to_bit(col >> 4, tlo, thi);
+                const unsigned below = bits[l >> 5] & ((1u << (l & 31)) - 1u);
+                const int pos = rank0[l >> 5] + __popc(below);
+                q2[(long)(j >> 2) * 4 * C + i * 4 + (j & 3)] = (unsigned short)((pos << 4) | (col & 15));
+            }
         }
     }
 }
@@ -187,19 +202,19 @@ __global__ void rechunk32_kernel(const long n_rows_old, const int C, const int *
 
 namespace uspmv_dev {
 
-int launch_plan_count(const uspmv_dmat *A, long n_tiles, int max_lines, int *d_n_lines, int *d_max_col, hipStream_t st, const uspmv_dmat *A2) {
+int launch_plan_count(const uspmv_dmat *A, long n_tiles, int max_lines, int *d_n_lines, int *d_max_col, hipStream_t st, const uspmv_dmat *A2, int tile_rows) {
     hipLaunchKernelGGL(plan_count_lines, dim3((unsigned)n_tiles), dim3(256), 0, st, (long)A->n_chunks, (int)A->C, A->chunk_ptrs,
                        A->chunk_lengths, A->col_idxs, max_lines, d_n_lines, d_max_col, A2 ? A2->chunk_ptrs : nullptr,
-                       A2 ? A2->chunk_lengths : nullptr, A2 ? A2->col_idxs : nullptr);
+                       A2 ? A2->chunk_lengths : nullptr, A2 ? A2->col_idxs : nullptr, tile_rows / 256);
     HIP_TRY(hipGetLastError());
     return USPMV_OK;
 }
 
 int launch_plan_write(const uspmv_dmat *A, long n_tiles, const int *d_tile_line_ptr, const unsigned *d_c16_ptrs, int *d_tile_lines,
-                      unsigned short *d_col16, hipStream_t st, const uspmv_dmat *A2, const unsigned *d_c16_ptrs2, unsigned short *d_col16_2) {
+                      unsigned short *d_col16, hipStream_t st, const uspmv_dmat *A2, const unsigned *d_c16_ptrs2, unsigned short *d_col16_2, int tile_rows) {
     hipLaunchKernelGGL(plan_write, dim3((unsigned)n_tiles), dim3(256), 0, st, (long)A->n_chunks, (int)A->C, A->chunk_ptrs,
                        A->chunk_lengths, A->col_idxs, d_tile_line_ptr, d_c16_ptrs, d_tile_lines, d_col16, A2 ? A2->chunk_ptrs : nullptr,
-                       A2 ? A2->chunk_lengths : nullptr, A2 ? A2->col_idxs : nullptr, d_c16_ptrs2, d_col16_2);
+                       A2 ? A2->chunk_lengths : nullptr, A2 ? A2->col_idxs : nullptr, d_c16_ptrs2, d_col16_2, tile_rows / 256);
     HIP_TRY(hipGetLastError());
     return USPMV_OK;
 }

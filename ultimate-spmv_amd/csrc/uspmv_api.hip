@@ -186,7 +186,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "tlc")) g_tune.tlc = value != 0;
     else if (!strcmp(key, "rechunk")) g_tune.rechunk = value != 0;
     else if (!strcmp(key, "tlc_tile_rows")) {
-        if (value != 256 && value != 512 && value != 1024) return uspmv::fail(USPMV_ERR_INVALID, "tlc_tile_rows must be 256|512|1024");
+        if (value != 0 && value != 256 && value != 512 && value != 1024) return uspmv::fail(USPMV_ERR_INVALID, "tlc_tile_rows must be 0|256|512|1024");
         g_tune.tlc_tile_rows = value;
     }
     else if (!strcmp(key, "block")) {
@@ -375,6 +375,9 @@ static void tlc_release(uspmv_dmat_t *A) {
     A->tlc = false; A->tlc_plan_id = 0;
 }
 
+// rows per tile of the next tile-local-column plan (g_tune.tlc_tile_rows = 0: by kind)
+static int plan_tile_rows(bool ap) { return g_tune.tlc_tile_rows ? g_tune.tlc_tile_rows : (ap ? 512 : 256); }
+
 int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
     if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: NULL argument");
     if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: layout-only struct; the plan builder needs the host column indices");
@@ -401,7 +404,7 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     const int cap = (int)(160 * 1024 / (16 * (s->dtype == USPMV_F64 ? 8 : 4)));
     if (max_lines > cap) max_lines = cap;
     uspmv_tlc_plan p;
-    if (int rc = uspmv_build_tlc_plan(s, nullptr, max_lines, g_tune.tlc_tile_rows, &p)) return rc;
+    if (int rc = uspmv_build_tlc_plan(s, nullptr, max_lines, plan_tile_rows(false), &p)) return rc;
     if (n_tiles) *n_tiles = p.n_tiles;
     if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
     if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] tlc plan: tile_rows=%d tiles=%lld staged=%lld max_lines=%d lines_total=%zu col16=%zu\n",
@@ -460,7 +463,8 @@ static int device_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, 
     if (max_lines <= 0) max_lines = 512;
     max_lines = std::min(max_lines, (int)(160 * 1024 / (16 * (A->dtype == USPMV_F64 ? 8 : 4))));
     max_lines = std::min(max_lines, B ? 1280 : 4096);
-    const int64_t T = 256 / C, nt = (nc + T - 1) / T;
+    const int R = plan_tile_rows(B != nullptr);
+    const int64_t T = R / C, nt = (nc + T - 1) / T;
     std::vector<int32_t> cl((size_t)nc);
     std::vector<uint32_t> c16p, c16p_b;
     int64_t tot16 = 0, tot16_b = 0;
@@ -475,7 +479,7 @@ static int device_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, 
     if (e == hipSuccess) e = hipMalloc((void **)&d_max, 4);
     if (e == hipSuccess) e = hipMemset(d_max, 0, 4);
     if (e != hipSuccess) { (void)hipFree(d_n); (void)hipFree(d_max); return uspmv::fail(USPMV_ERR_ALLOC, "%s: %s", who, hipGetErrorString(e)); }
-    int rc = launch_plan_count(A, (long)nt, max_lines, d_n, d_max, nullptr, B);
+    int rc = launch_plan_count(A, (long)nt, max_lines, d_n, d_max, nullptr, B, R);
     std::vector<int32_t> lp((size_t)nt + 1, 0);
     int max_col = 0;
     if (!rc) {
@@ -511,7 +515,7 @@ static int device_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, 
         if (e == hipSuccess) e = hipMemcpy(B->tlc_c16_ptrs, c16p_b.data(), 4 * ((size_t)nc + 1), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess && launch_plan_write(A, (long)nt, A->tlc_line_ptr, A->tlc_c16_ptrs, A->tlc_lines, A->tlc_col16, nullptr, B,
-                                             B ? B->tlc_c16_ptrs : nullptr, B ? B->tlc_col16 : nullptr) != USPMV_OK)
+                                             B ? B->tlc_c16_ptrs : nullptr, B ? B->tlc_col16 : nullptr, R) != USPMV_OK)
         e = hipErrorUnknown;
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
@@ -523,7 +527,7 @@ static int device_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, 
     const uint64_t id = B ? next_dev_plan_id++ : 0;
     for (uspmv_dmat_t *M : {A, B}) {
         if (!M) continue;
-        M->tlc = true; M->tlc_tile_rows = 256; M->tlc_max_lines = used; M->tlc_x_len = (int64_t)max_col + 1; M->tlc_n_tiles = nt;
+        M->tlc = true; M->tlc_tile_rows = R; M->tlc_max_lines = used; M->tlc_x_len = (int64_t)max_col + 1; M->tlc_n_tiles = nt;
         M->tlc_staged = staged; M->tlc_plan_id = id;
     }
     return USPMV_OK;
@@ -746,7 +750,7 @@ int uspmv_dmat_optimize_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t
     if (max_lines <= 0) max_lines = 512;
     if (max_lines > 1280) max_lines = 1280;
     uspmv_tlc_plan p;
-    if (int rc = uspmv_build_tlc_plan(s_dp, s_sp, max_lines, g_tune.tlc_tile_rows, &p)) return rc;
+    if (int rc = uspmv_build_tlc_plan(s_dp, s_sp, max_lines, plan_tile_rows(true), &p)) return rc;
     if (n_tiles) *n_tiles = p.n_tiles;
     if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
     if (dp->sw) sw_release(dp);

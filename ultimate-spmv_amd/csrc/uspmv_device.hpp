@@ -82,7 +82,8 @@ struct Tuning {
     int ablate = 0;     // measurement only
     int tlc = 1;            // use the tile-local-column kernel when the handle carries a plan
     int rechunk = 1;        // uspmv_dmat_optimize may re-chunk C < 32 structs to C = 32 internally
-    int tlc_tile_rows = 256;  // rows (= threads) per tile used by the NEXT uspmv_dmat_optimize
+    int tlc_tile_rows = 0;    // rows (= threads) per tile used by the NEXT uspmv_dmat_optimize[_ap / _device]: 256 | 512 | 1024, 0 = 256 for one
+                              // struct and 512 for an ap[dp_sp] pair (two streams: the x window of 256 rows left 20 waves per CU, profiles/r02/ap_tile_rows.txt)
     int tail_batch = 0;     // ragged tail of a chunk as one predicated batch
     int spmmv_unroll = 0;   // 0 = auto (256 bytes of X rows per lane and batch)
     int spmmv_lds_kb = 0;    // block plan: LDS budget per tile in KiB for the NEXT uspmv_dmat_optimize_block (0 = 80)
@@ -141,10 +142,10 @@ int launch_spmv_ap_chunks(const uspmv_dmat *dp, const uspmv_dmat *sp, const int 
 
 // (A2 / the *_2 arrays: optional second struct sharing the plan -- the sp part of an ap[dp_sp] pair)
 int launch_plan_count(const uspmv_dmat *A, long n_tiles, int max_lines, int *d_n_lines, int *d_max_col, hipStream_t st,
-                      const uspmv_dmat *A2 = nullptr);                                                                     // plan_kernels.hip
+                      const uspmv_dmat *A2 = nullptr, int tile_rows = 256);                                               // plan_kernels.hip
 int launch_plan_write(const uspmv_dmat *A, long n_tiles, const int *d_tile_line_ptr, const unsigned *d_c16_ptrs, int *d_tile_lines,
                       unsigned short *d_col16, hipStream_t st, const uspmv_dmat *A2 = nullptr, const unsigned *d_c16_ptrs2 = nullptr,
-                      unsigned short *d_col16_2 = nullptr);                                                                // plan_kernels.hip
+                      unsigned short *d_col16_2 = nullptr, int tile_rows = 256);                                           // plan_kernels.hip
 int launch_rechunk32(const uspmv_dmat *A, const int *d_cp_new, int *d_ci_new, void *d_va_new, hipStream_t st);             // plan_kernels.hip
 
 }  // namespace uspmv_dev
