@@ -258,7 +258,7 @@ int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_
  *   (0 = 256 for one struct, 512 for an ap[dp_sp] pair),
  *   "spmmv_variant" 0 (auto) | 1 (generic) | 2 (row-major, transposing X phase) | 3 (row-major, lane per row)
  *                   | 4 (single-wave block-plan tiles) | 5 (3 over the plan's tie-re-ordered copy) | 6 (four lanes per row, 64-byte rows)
- *                   | 7 (6, persistent) | 8 (four lanes per row over the phased plan; what auto picks for 64-byte rows),
+ *                   | 8 (four lanes per row over the phased plan; what auto picks for 64-byte rows),
  *   "spmmv_phased" 1|0 and "spmmv_phase_rows" 256|512: NEXT uspmv_dmat_optimize_block with 64-byte rows also builds the phased plan,
  *   "spmmv_xcol" 0|1: phased kernel on column-major X behind a re-layout pass (0) or assembling its X rows from the caller's vector itself (1),
  *   "spmmv_swizzle" 0|1 bank-swizzled LDS rows in the block-plan kernel,

@@ -434,17 +434,14 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                     pkg.spmmv(A0, _dev(t, X), Y0, b, ld, lay)
                     pkg.set_tuning(spmmv_variant=0)
                     for swz in (0, 1):                     # plan kernel for every width it supports, both LDS layouts
-                        for var, pd in ((4, 0), (6, 0), (7, 2), (7, 3), (8, 0), (5, 0)):   # single-wave tiles; four lanes per row (64-byte rows): one tile per workgroup / persistent / phased plan; gather over the re-ordered copy
+                        for var, pd in ((4, 0), (6, 0), (8, 0), (5, 0)):   # single-wave tiles; four lanes per row (64-byte rows): one tile per workgroup / phased plan; gather over the re-ordered copy
                             if (var, swz) == (5, 1):
                                 continue
-                            if var == 7:
-                                pkg.set_tuning(spmmv_variant=7, spmmv_swizzle=0, spmmv_unroll=0, spmmv_persist_w=pd, spmmv_persist_x=1 + swz)
-                            else:
-                                pkg.set_tuning(spmmv_variant=var, spmmv_swizzle=swz, spmmv_unroll=pd)
+                            pkg.set_tuning(spmmv_variant=var, spmmv_swizzle=swz, spmmv_unroll=pd)
                             Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
                             pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
                             assert t.equal(Y, Y0), (name, C, code, b, rowwise, swz, var, pd)
-                    pkg.set_tuning(spmmv_unroll=0, spmmv_persist_w=2, spmmv_persist_x=1)
+                    pkg.set_tuning(spmmv_unroll=0)
                     pkg.set_tuning(spmmv_variant=8, spmmv_swizzle=0, spmmv_xcol=1)   # phased kernel assembling its X rows from the column-major vector itself
                     Y.fill_(-3.0)
                     pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)

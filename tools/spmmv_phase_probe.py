@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Config 3 (Queen_4147-class, dp, b = 8): the phased-plan kernels side by side -- one tile per workgroup (variant 8) and the
-persistent schedule (variant 9, `spmmv_persist_wgs` workgroups per CU), both layouts; every line checked against variant 3."""
+"""Config 3 (Queen_4147-class, dp b = 8 and sp b = 16): the phased-plan kernel (variant 8), both layouts; every line checked
+against the gather kernel (variant 3)."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -566,160 +566,6 @@ __global__ void __launch_bounds__(256) scs_spmmv_quad(const long n_chunks, const
     }
 }
 
-// The same four-lanes-per-row arithmetic as scs_spmmv_quad, PERSISTENT and software-pipelined over tiles.  Measured on the
-// one-tile-per-workgroup form (profiles/r02/spmmv_quad_ablation.txt): with the arithmetic removed it still takes 0.85 of
-// 0.95 ms -- a workgroup's life is a chain of dependent round trips (tile meta data, chunk pointers, the burst of matrix
-// entries, the row list, the X rows) during most of which it moves nothing.  Here a workgroup walks tiles t, t+G, t+2G, ...
-// and every round trip of tile t+G is in flight while tile t is being staged and computed: its meta data are requested two
-// tiles ahead, its matrix entries (the wave's whole share, NG groups of four slots per lane, in a second register set) and
-// its X-row list (MAXP list entries per lane, registers too -- no LDS list, no extra barrier) one tile ahead.  Per tile the
-// workgroup waits once (X rows of t landed; the prefetches for t+G ride along) and passes two barriers.
-template <typename VT, int B, bool NT, bool YCOL, int C, int NG, int MAXP, int WPE>
-__global__ void __launch_bounds__(256, WPE) scs_spmmv_quadp(const long n_tiles, const long n_chunks, const int *__restrict__ chunk_ptrs,
-        const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const VT *__restrict__ values,
-        const VT *__restrict__ X, VT *__restrict__ Y, const long ld, const int *__restrict__ tile_line_ptr,
-        const int *__restrict__ tile_xrows, const unsigned *__restrict__ c16_ptrs, const unsigned short *__restrict__ col16,
-        const long n_store, const int *__restrict__ row_map) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char tlc_smem[];
-    constexpr int VW = 16 / (int)sizeof(VT);
-    static_assert(B == 4 * VW, "four 16-byte pieces per X row");
-    static_assert(64 % C == 0 && C % 16 == 0, "a wave's 16 rows sit in one chunk, a tile holds whole chunks");
-    typedef VT vec_t __attribute__((ext_vector_type(VW)));
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int r = lane >> 2, q = lane & 3;
-    const int iw = wave * 16 + r;            // row within the tile
-    const int i = iw % C, cw = iw / C;       // row within its chunk, chunk within the tile (a tile starts at a chunk boundary)
-    struct Meta { int lp0, nl, cs, L; unsigned q0; };
-    auto load_meta = [&](const long t) {
-        Meta m{0, 0, 0, 0, 0u};
-        if (t < n_tiles) {
-            m.lp0 = tile_line_ptr[t]; m.nl = tile_line_ptr[t + 1] - m.lp0;
-            const long c = t * (64 / C) + cw;
-            if (c < n_chunks) { m.cs = chunk_ptrs[c]; m.L = chunk_lengths[c]; m.q0 = c16_ptrs[c]; }
-        }
-        return m;
-    };
-    // the wave's share of a tile's matrix entries: NG full groups + the partial last group (nothing is touched after the load)
-    auto issue_matrix = [&](const Meta &m, VT (&a)[NG], unsigned (&ix)[NG], VT &at, unsigned &ixt) {
-        const int ngf = m.L >> 2, rem = m.L & 3;
-        const VT *vp = values + (long)m.cs + i + (long)q * C;
-        const unsigned short *ip = col16 + m.q0 + (long)i * 4 + q;
-#pragma unroll
-        for (int d = 0; d < NG; ++d) {
-            a[d] = VT(0); ix[d] = 0u;
-            if (d < ngf && m.nl > 0) { ix[d] = ld_stream<NT>(ip + (long)d * 4 * C); a[d] = ld_stream<NT>(vp + (long)d * 4 * C); }
-        }
-        at = VT(0); ixt = 0u;
-        if (rem && m.nl > 0) { ixt = ld_stream<NT>(ip + (long)ngf * 4 * C); if (q < rem) at = ld_stream<NT>(vp + (long)ngf * 4 * C); }
-    };
-    // the tile's X-row list entries this lane will need for its DMA pieces: piece p = (wave + 4k)*64 + lane <-> list entry p >> 2
-    auto load_xlist = [&](const Meta &m, int (&xr)[MAXP]) {
-        const int np = m.nl << 2;
-#pragma unroll
-        for (int k = 0; k < MAXP; ++k) {
-            const int p = (wave + 4 * k) * 64 + lane;
-            xr[k] = -1;
-            if (p < np) xr[k] = tile_xrows[m.lp0 + (p >> 2)];
-        }
-    };
-#define QUAD_STEP(UU, AV, IV, XOF)                                                                            \
-    {                                                                                                         \
-        const VT aa = quad_bcast<UU>(AV);                                                                     \
-        const unsigned li = (unsigned)quad_bcast<UU>((int)(IV));                                              \
-        const vec_t xv = XOF(li);                                                                             \
-        _Pragma("unroll") for (int w = 0; w < VW; ++w) acc[w] = fma_t(aa, xv[w], acc[w]);                     \
-    }
-    const vec_t *xs = (const vec_t *)tlc_smem;
-#define X_LDS(li) xs[(li) * 4 + (unsigned)q]
-#define X_GLB(col) (*((const vec_t *)(X + (long)(col) * B) + q))
-    const long G = gridDim.x;
-    long t = blockIdx.x;
-    Meta mc = load_meta(t), mn = load_meta(t + G);
-    VT a0[NG], a1[NG], at0, at1;
-    unsigned ix0[NG], ix1[NG], ixt0, ixt1;
-    int xr0[MAXP];
-    issue_matrix(mc, a0, ix0, at0, ixt0);
-    load_xlist(mc, xr0);
-    while (t < n_tiles) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's list entries (and matrix entries) are in registers
-        // ---- X rows of tile t -> LDS by DMA, 64 pieces of 16 bytes per wave-instruction
-#pragma unroll
-        for (int k = 0; k < MAXP; ++k)
-            if (xr0[k] >= 0)
-                __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(X + (long)xr0[k] * B + q * VW), (lds_void_t *)(tlc_smem + (wave + 4 * k) * 1024), 16, 0, 0);
-        // ---- everything tile t+G needs, behind them
-        const Meta mn2 = load_meta(t + 2 * G);
-        issue_matrix(mn, a1, ix1, at1, ixt1);
-        load_xlist(mn, xr0);                                  // (the DMA instructions above have read their addresses at issue)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // ---- arithmetic of tile t from registers and LDS
-        const int L = __builtin_amdgcn_readfirstlane(mc.L), nl = __builtin_amdgcn_readfirstlane(mc.nl);
-        const int ngf = L >> 2, rem = L & 3;
-        vec_t acc;
-#pragma unroll
-        for (int w = 0; w < VW; ++w) acc[w] = VT(0);
-        if (nl > 0) {
-#pragma unroll
-            for (int d = 0; d < NG; ++d) {
-                if (d < ngf) {
-                    QUAD_STEP(0, a0[d], ix0[d], X_LDS) QUAD_STEP(1, a0[d], ix0[d], X_LDS) QUAD_STEP(2, a0[d], ix0[d], X_LDS) QUAD_STEP(3, a0[d], ix0[d], X_LDS)
-                }
-            }
-            if (ngf > NG) {                                   // rows longer than 4*NG slots: the rest straight from memory
-                const VT *vp = values + (long)mc.cs + i + (long)q * C;
-                const unsigned short *ip = col16 + mc.q0 + (long)i * 4 + q;
-                for (int g = NG; g < ngf; ++g) {
-                    const VT av = ld_stream<NT>(vp + (long)g * 4 * C);
-                    const unsigned iv = ld_stream<NT>(ip + (long)g * 4 * C);
-                    QUAD_STEP(0, av, iv, X_LDS) QUAD_STEP(1, av, iv, X_LDS) QUAD_STEP(2, av, iv, X_LDS) QUAD_STEP(3, av, iv, X_LDS)
-                }
-            }
-            if (rem > 0) QUAD_STEP(0, at0, ixt0, X_LDS)
-            if (rem > 1) QUAD_STEP(1, at0, ixt0, X_LDS)
-            if (rem > 2) QUAD_STEP(2, at0, ixt0, X_LDS)
-        } else if (L > 0) {                                   // wide-footprint tile: 32-bit columns, X pieces gathered from global memory
-            const VT *vp = values + (long)mc.cs + i + (long)q * C;
-            const int *cp = col_idxs + (long)mc.cs + i + (long)q * C;
-            for (int g = 0; g < ngf; ++g) {
-                const VT av = ld_stream<NT>(vp + (long)g * 4 * C);
-                const int cv = ld_stream<NT>(cp + (long)g * 4 * C);
-                QUAD_STEP(0, av, cv, X_GLB) QUAD_STEP(1, av, cv, X_GLB) QUAD_STEP(2, av, cv, X_GLB) QUAD_STEP(3, av, cv, X_GLB)
-            }
-            if (rem) {
-                VT av = VT(0);
-                int cv = 0;
-                if (q < rem) { av = ld_stream<NT>(vp + (long)ngf * 4 * C); cv = ld_stream<NT>(cp + (long)ngf * 4 * C); }
-                if (rem > 0) QUAD_STEP(0, av, cv, X_GLB)
-                if (rem > 1) QUAD_STEP(1, av, cv, X_GLB)
-                if (rem > 2) QUAD_STEP(2, av, cv, X_GLB)
-            }
-        }
-        const long row = t * 64 + iw;
-        if (row < n_chunks * C) {
-            const long yrow = row_map ? (long)row_map[row] : row;
-            if (yrow < n_store) {
-                if (YCOL) {
-#pragma unroll
-                    for (int w = 0; w < VW; ++w) st_y<NT>(Y + (yrow + (long)(q * VW + w) * ld), acc[w]);
-                } else {
-                    *((vec_t *)(Y + yrow * B) + q) = acc;
-                }
-            }
-        }
-        __syncthreads();                                      // every wave is through with the staged rows
-        // ---- rotate: t+G becomes the current tile
-#pragma unroll
-        for (int d = 0; d < NG; ++d) { a0[d] = a1[d]; ix0[d] = ix1[d]; }
-        at0 = at1; ixt0 = ixt1;
-        mc = mn; mn = mn2;
-        t += G;
-    }
-#undef X_GLB
-#undef X_LDS
-#undef QUAD_STEP
-}
-
 // Column-major -> row-major re-layout through LDS: 256 rows per workgroup.  Reads are B coalesced element streams (one per column);
 // the rows are assembled in LDS (16 bytes of padding per row against bank conflicts) and written back as 16-byte pieces in linear
 // order, so every store instruction of a wave covers 1 KiB of contiguous output (the lane-per-row form above it replaces wrote
@@ -886,46 +732,6 @@ void launch_spmmv_quad(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool yc
 #undef QD_PD
 }
 
-template <typename VT, int B, int CT, int MAXP>
-void launch_spmmv_quadp_g(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
-    const size_t lds = (size_t)MAXP * 4 * 1024;              // whole DMA pieces: MAXP per wave, four waves
-    static int n_cu = 0;
-    if (!n_cu) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); n_cu = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
-    const int wpe = g_tune.spmmv_persist_w == 3 ? 3 : 2;     // waves per SIMD the kernel is compiled for (= workgroups per CU)
-    const long per_cu = std::max<long>(1, std::min<long>(wpe, (long)(160 * 1024 / lds)));
-    const long grid = std::min<long>((long)A->bt_n_tiles, (long)n_cu * per_cu * (g_tune.spmmv_persist_x > 0 ? g_tune.spmmv_persist_x : 1));
-#define QP_LAUNCH(NTV, YC)                                                                                              \
-    do {                                                                                                                \
-        auto kfn = wpe == 2 ? scs_spmmv_quadp<VT, B, NTV, YC, CT, 20, MAXP, 2> : scs_spmmv_quadp<VT, B, NTV, YC, CT, 20, MAXP, 3>; \
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), lds, st, (long)A->bt_n_tiles, (long)A->n_chunks,        \
-                           A->chunk_ptrs, A->chunk_lengths, A->bt_cols ? A->bt_cols : A->col_idxs,                       \
-                           (const VT *)(A->bt_values ? A->bt_values : A->values), X, Y, ld, A->bt_line_ptr,                \
-                           A->bt_xrows, A->bt_c16_ptrs, A->bt_col16, (long)A->n_store, (const int *)A->bt_row_map);       \
-    } while (0)
-    if (g_tune.nontemporal) { if (ycol) QP_LAUNCH(true, true); else QP_LAUNCH(true, false); }
-    else { if (ycol) QP_LAUNCH(false, true); else QP_LAUNCH(false, false); }
-#undef QP_LAUNCH
-}
-
-// false: the plan's tiles do not fit this kernel
-template <typename VT, int B>
-bool launch_spmmv_quadp(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
-    const int pieces = (A->bt_max_rows * 4 + 255) / 256;     // DMA pieces per wave for the largest tile
-    if (A->C == 32) {
-        if (pieces <= 8) launch_spmmv_quadp_g<VT, B, 32, 8>(A, X, Y, ld, ycol, st);
-        else if (pieces <= 13) launch_spmmv_quadp_g<VT, B, 32, 13>(A, X, Y, ld, ycol, st);
-        else if (pieces <= 20) launch_spmmv_quadp_g<VT, B, 32, 20>(A, X, Y, ld, ycol, st);
-        else return false;
-    } else {
-        if (pieces <= 8) launch_spmmv_quadp_g<VT, B, 64, 8>(A, X, Y, ld, ycol, st);
-        else if (pieces <= 13) launch_spmmv_quadp_g<VT, B, 64, 13>(A, X, Y, ld, ycol, st);
-        else if (pieces <= 20) launch_spmmv_quadp_g<VT, B, 64, 20>(A, X, Y, ld, ycol, st);
-        else return false;
-    }
-    return true;
-}
-
 // the phased-plan kernels live in spmmv_phased.hip (64-byte rows only: dp b = 8, sp b = 16)
 template <typename VT, int B>
 bool launch_spmmv_quadph(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, bool xcol, hipStream_t st) {
@@ -938,10 +744,9 @@ void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
         // 64-byte rows, phased plan (variant 8; auto when the handle carries one): eight workgroups per CU
         if ((g_tune.spmmv_variant == 8 || (g_tune.spmmv_variant == 0 && !g_tune.ablate)) && launch_spmmv_quadph<VT, B>(A, X, Y, ld, ycol, false, st)) return;
         // 64-byte rows: the four-lanes-per-row kernel over 64-row tiles of the block plan (variant 6; auto when the plan is there)
-        if (A->bt && A->bt_tile_rows == 64 && (g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 6 || g_tune.spmmv_variant == 7) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
-            // variant 6 (and auto): one tile per workgroup, three workgroups per CU; variant 7: persistent and pipelined over tiles, but 222
-            // registers -> two workgroups per CU, which measures 5-7 % slower (profiles/r02/spmmv_variants.txt)
-            if (g_tune.spmmv_variant == 7 && !g_tune.spmmv_swizzle && !g_tune.ablate && launch_spmmv_quadp<VT, B>(A, X, Y, ld, ycol, st)) return;
+        if (A->bt && A->bt_tile_rows == 64 && (g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 6) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
+            // one tile per workgroup, three workgroups per CU (a persistent, software-pipelined form of it -- 222 registers, two workgroups
+            // per CU -- measured 5-7 % slower and was removed: profiles/r02/spmmv_variants.txt)
             launch_spmmv_quad<VT, B>(A, X, Y, ld, ycol, st);
             return;
         }

@@ -154,11 +154,9 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_prefetch")) g_tune.spmmv_prefetch = value != 0;
     else if (!strcmp(key, "spmmv_swizzle")) g_tune.spmmv_swizzle = value != 0;
     else if (!strcmp(key, "spmmv_reorder")) g_tune.spmmv_reorder = value < 0 ? 0 : value > 2 ? 2 : (int)value;
-    else if (!strcmp(key, "spmmv_persist_x")) g_tune.spmmv_persist_x = value < 1 ? 1 : value;
     else if (!strcmp(key, "spmmv_phased")) g_tune.spmmv_phased = value != 0;
     else if (!strcmp(key, "spmmv_xcol")) g_tune.spmmv_xcol = value != 0;
     else if (!strcmp(key, "spmmv_phase_rows")) g_tune.spmmv_phase_rows = value == 512 ? 512 : 256;
-    else if (!strcmp(key, "spmmv_persist_w")) g_tune.spmmv_persist_w = value == 3 ? 3 : 2;
     else if (!strcmp(key, "spmmv_idx8")) g_tune.spmmv_idx8 = value != 0;
     else if (!strcmp(key, "sweep")) g_tune.sweep = value != 0;
     else if (!strcmp(key, "sweep_nbuf")) g_tune.sweep_nbuf = value == 1 ? 1 : 2;
@@ -178,7 +176,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_tile_rows")) g_tune.spmmv_tile_rows = value == 64 ? 64 : value == 32 ? 32 : 0;
     else if (!strcmp(key, "spmmv_lds_kb")) g_tune.spmmv_lds_kb = value < 0 ? 0 : value;
     else if (!strcmp(key, "spmmv_variant")) {
-        if (value < 0 || value > 8) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0..8");
+        if (value < 0 || value > 8 || value == 7) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0..6 or 8");
         g_tune.spmmv_variant = value;
     }
     else if (!strcmp(key, "tail_batch")) g_tune.tail_batch = value != 0;
@@ -215,11 +213,9 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_prefetch")) *value = g_tune.spmmv_prefetch;
     else if (!strcmp(key, "spmmv_swizzle")) *value = g_tune.spmmv_swizzle;
     else if (!strcmp(key, "spmmv_reorder")) *value = g_tune.spmmv_reorder;
-    else if (!strcmp(key, "spmmv_persist_x")) *value = g_tune.spmmv_persist_x;
     else if (!strcmp(key, "spmmv_phased")) *value = g_tune.spmmv_phased;
     else if (!strcmp(key, "spmmv_xcol")) *value = g_tune.spmmv_xcol;
     else if (!strcmp(key, "spmmv_phase_rows")) *value = g_tune.spmmv_phase_rows;
-    else if (!strcmp(key, "spmmv_persist_w")) *value = g_tune.spmmv_persist_w;
     else if (!strcmp(key, "spmmv_idx8")) *value = g_tune.spmmv_idx8;
     else if (!strcmp(key, "sweep")) *value = g_tune.sweep;
     else if (!strcmp(key, "sweep_nbuf")) *value = g_tune.sweep_nbuf;

@@ -106,8 +106,6 @@ struct Tuning {
     int spmmv_phased = 1;      // NEXT uspmv_dmat_optimize_block with 64-byte rows: also build the phased plan (eight workgroups per CU)
     int spmmv_phase_rows = 256;  // ... X rows per phase (256 | 512)
     int spmmv_idx8 = 1;        // NEXT optimize_block: one-byte phase-local indices when every phase lists <= 256 rows
-    int spmmv_persist_w = 2;   // persistent SpMMV kernel: compiled for 3 (168 VGPRs) or 2 (256 VGPRs) waves per SIMD
-    int spmmv_persist_x = 1;   // persistent SpMMV kernel: grid = this many times the resident workgroups (1 = exactly resident)
     int spmmv_reorder = 1;  // block plan's private copy of the entries: 1 = rows of equal-length chunks of a sigma window back in original order,
                             // 2 = rows re-dealt to the tiles as breadth-first balls of the matrix graph (fewer X rows per tile, scattered y rows), 0 = as is
     int spmmv_variant = 0;  // 0 = auto (= 3 where a B-specialised kernel exists); 1 = generic kernel; 2 = row-major with transposing X phase; 3 = row-major, lane per row
