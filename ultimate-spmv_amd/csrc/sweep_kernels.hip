@@ -38,6 +38,12 @@ __device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
 template <typename AT, typename XT, int U, bool NT>
 __device__ __forceinline__ void sweep_window(const XT *__restrict__ xs, const int c, const AT *__restrict__ &vp,
                                              const unsigned short *__restrict__ &ip, XT &acc) {
+    // (entry registers of lanes that sit a round out keep what an earlier round left there -- a valid window index and a value whose
+    //  product is discarded -- instead of being zeroed every round: three moves less per round)
+    AT v[U];
+    unsigned ix[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { v[u] = AT(0); ix[u] = 0u; }
     for (int k0 = 0;; k0 += U) {
         unsigned long long m[U];
         unsigned first[U + 1];
@@ -48,11 +54,8 @@ __device__ __forceinline__ void sweep_window(const XT *__restrict__ xs, const in
             first[u + 1] = first[u] + (unsigned)__popcll(m[u]);
         }
         if (m[0] == 0ull) break;                             // wave-uniform: every row of the wave is through this window
-        AT v[U];
-        unsigned ix[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            v[u] = AT(0); ix[u] = 0u;
             if (k0 + u < c) {
                 const unsigned off = first[u] + lanes_below(m[u]);
                 v[u] = ld_stream_g<NT>(vp + off); ix[u] = ld_stream_g<NT>(ip + off);
