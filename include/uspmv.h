@@ -266,6 +266,8 @@ int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_
  *   scrambling undone, 2 = rows re-dealt to the 64-row tiles as breadth-first balls of the matrix graph (fewer X rows per tile, but
  *   scattered y rows: measured slower on config 3, kept as an option), 0 = the caller's order;
  *   "spmmv_idx8" 1|0 NEXT uspmv_dmat_optimize_block: one-byte phase-local indices when no phase lists more than 256 X rows,
+ *   "spmmv_list_plan" 0|1 NEXT uspmv_dmat_optimize_block: also build the one-list-per-tile plan of variants 4-6 (and its column-major copy
+ *   of the entries) when the phased kernel can take the matrix,
  *   "sweep" 1|0 use a handle's column-window sweep plan, "sweep_nbuf" 1|2 LDS buffers, "sweep_unroll" 2|4|8, "sweep_remap" tiles per XCD group,
  *   "sweep_threads" 0|256|512|1024 threads per sweep workgroup (0 = min(tile rows, 1024); fewer threads = more rows per lane, at most 4),
  *   "sweep_wlog" / "sweep_tile_rows" / "sweep_max_stage" defaults of the NEXT sweep plan (window = 2^wlog elements; rows per tile;

@@ -410,7 +410,7 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                                            ("impcol_e", 64, 64, 0, 0), ("matrix1", 1, 1, 0, 0), ("bcsstk13", 128, 128, 0, 0),
                                            ("bcsstk13", 32, 1, 8, 0), ("bcsstk13", 64, 512, 12, 0), ("bcsstk13", 32, 512, 0, 64),
                                            ("impcol_e", 32, 1, 0, 0)):
-        pkg.set_tuning(spmmv_lds_kb=lds_kb, spmmv_tile_rows=tile64)     # (apply to the plans built below)
+        pkg.set_tuning(spmmv_lds_kb=lds_kb, spmmv_tile_rows=tile64, spmmv_list_plan=1)     # (apply to the plans built below; list plan: the older kernels too)
         m = pkg.read_mtx(mtx_path(name))
         for code in (pkg.F64, pkg.F32):
             s, a, xp = _prep(pkg, m, C, sigma, code, make_x(m.n_rows))
@@ -468,6 +468,13 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                     Y.fill_(-3.0)                          # and whatever auto picks
                     pkg.spmmv(A, _dev(t, X), Y, b, ld, lay)
                     assert t.equal(Y, Y0), (name, C, code, b, rowwise, "auto")
+                    pkg.set_tuning(spmmv_list_plan=0)      # ... on the default plan (no one-list-per-tile plan where the phased kernel takes the matrix)
+                    Adef = pkg.DeviceMatrix(s, block_tlc=b)
+                    pkg.set_tuning(spmmv_list_plan=1)
+                    Y.fill_(-3.0)
+                    pkg.spmmv(Adef, _dev(t, X), Y, b, ld, lay)
+                    assert t.equal(Y, Y0), (name, C, code, b, rowwise, "auto, default plan")
+                    del Adef
                     if b == 8:
                         Yo = orc.spmmv_scs(s.C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, b, ld, rowwise)
                         got = Y.cpu().numpy()
@@ -476,7 +483,7 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                             assert np.array_equal(got[:n * b], Yo[:n * b])
                         else:
                             assert np.array_equal(got.reshape(b, ld)[:, :n], Yo.reshape(b, ld)[:, :n])
-    pkg.set_tuning(spmmv_lds_kb=0, spmmv_tile_rows=0)
+    pkg.set_tuning(spmmv_lds_kb=0, spmmv_tile_rows=0, spmmv_list_plan=0)
     assert seen_partial and seen_full
     # the plan from device arrays alone (uspmv_dmat_optimize_block_device: ties ordered by first column, no permutation known)
     for m, C, sigma in ((pkg.read_mtx(mtx_path("bcsstk13")), 32, 512), (pkg.gen_stencil27(20, 20, 20, dof=3), 32, 512), (pkg.gen_stencil27(9, 30, 11, dof=2), 64, 128)):

@@ -9,6 +9,7 @@ import __graft_entry__ as ge
 pkg = ge.load_package()
 from ultimate_spmv_amd import binding as B
 torch.cuda.set_device(0)
+pkg.set_tuning(spmmv_list_plan=1)      # these probes time the older block-plan kernels too
 g = int(sys.argv[1]) if len(sys.argv) > 1 else 111
 coo = pkg.gen_stencil27(g, g, g, dof=3)
 s = pkg.convert_to_scs(coo, 32, 512, pkg.F64); a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"])

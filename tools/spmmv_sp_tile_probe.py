@@ -5,6 +5,7 @@ import __graft_entry__ as ge
 pkg = ge.load_package()
 from ultimate_spmv_amd import binding as B
 torch.cuda.set_device(0)
+pkg.set_tuning(spmmv_list_plan=1)      # these probes time the older block-plan kernels too
 coo = pkg.gen_stencil27(111, 111, 111, dof=3)
 s = pkg.convert_to_scs(coo, 32, 512, pkg.F32); pkg.permute_scs_cols(s, s.arrays()["old_to_new_idx"])
 b, ld = 8, s.n_rows_padded

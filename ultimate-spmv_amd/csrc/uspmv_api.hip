@@ -158,6 +158,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_xcol")) g_tune.spmmv_xcol = value != 0;
     else if (!strcmp(key, "spmmv_phase_rows")) g_tune.spmmv_phase_rows = value == 512 ? 512 : 256;
     else if (!strcmp(key, "spmmv_idx8")) g_tune.spmmv_idx8 = value != 0;
+    else if (!strcmp(key, "spmmv_list_plan")) g_tune.spmmv_list_plan = value != 0;
     else if (!strcmp(key, "sweep")) g_tune.sweep = value != 0;
     else if (!strcmp(key, "sweep_nbuf")) g_tune.sweep_nbuf = value == 1 ? 1 : 2;
     else if (!strcmp(key, "sweep_unroll")) g_tune.sweep_unroll = value >= 8 ? 8 : value >= 4 ? 4 : 2;
@@ -217,6 +218,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_xcol")) *value = g_tune.spmmv_xcol;
     else if (!strcmp(key, "spmmv_phase_rows")) *value = g_tune.spmmv_phase_rows;
     else if (!strcmp(key, "spmmv_idx8")) *value = g_tune.spmmv_idx8;
+    else if (!strcmp(key, "spmmv_list_plan")) *value = g_tune.spmmv_list_plan;
     else if (!strcmp(key, "sweep")) *value = g_tune.sweep;
     else if (!strcmp(key, "sweep_nbuf")) *value = g_tune.sweep_nbuf;
     else if (!strcmp(key, "sweep_unroll")) *value = g_tune.sweep_unroll;
@@ -622,7 +624,7 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
         return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: handle and host struct do not describe the same matrix");
     if (block_vec_size < 1) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: block_vec_size must be >= 1");
     if (int rc = require_device()) return rc;
-    if (A->bt) bt_release(A);
+    if (A->bt || A->pb) bt_release(A);
     if (n_tiles) *n_tiles = 0;
     if (n_staged) *n_staged = 0;
     const size_t row_bytes = (size_t)block_vec_size * (s->dtype == USPMV_F64 ? 8 : 4);
@@ -636,31 +638,44 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
     uspmv_scs r;                       // private copy with the sigma sort's ties undone (only kept when rows moved)
     std::vector<int32_t> row_map;
     const bool moved = g_tune.spmmv_reorder && uspmv_scs_reorder_rows(s, g_tune.spmmv_reorder == 2 ? 2 : 1, &r, &row_map) == 1;
-    if (int rc = uspmv_build_tlc_plan(moved ? &r : s, nullptr, max_rows, tile_rows, &p, /*line_shift=*/0)) return rc;
-    if (n_tiles) *n_tiles = p.n_tiles;
-    if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
-    if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] block plan: b=%d tile_rows=%d tiles=%lld staged=%lld max_rows=%d (cap %d) rows_total=%zu\n",
-                                         block_vec_size, p.tile_rows, (long long)p.n_tiles, (long long)p.n_staged_tiles, p.max_lines_used, max_rows, p.tile_lines.size());
-    if (!p.valid) return USPMV_OK;
+    // 64-byte rows: the phased plan over the same (tie-re-ordered) entries -- what uspmv_spmmv runs by default.  When the phased kernel
+    // can take it (at most 512 rows per phase), the one-list-per-tile plan of the older kernels and its column-major copy of the entries
+    // (8 + 6 bytes per non-zero of HBM, a second or two of planning) are only built on request ("spmmv_list_plan" 1).
+    uspmv_phased_plan pp;
+    if (row_bytes == 64 && tile_rows == 64 && g_tune.spmmv_phased)
+        if (int rc = uspmv_build_phased_plan(moved ? &r : s, g_tune.spmmv_phase_rows, 8, &pp)) return rc;
+    const bool phased_ok = pp.valid && pp.ngp <= 8 && (pp.max_rows_used * 4 + 255) / 256 <= 8;
+    const bool list_plan = !phased_ok || g_tune.spmmv_list_plan;
+    if (list_plan) {
+        if (int rc = uspmv_build_tlc_plan(moved ? &r : s, nullptr, max_rows, tile_rows, &p, /*line_shift=*/0)) return rc;
+        if (n_tiles) *n_tiles = p.n_tiles;
+        if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
+        if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] block plan: b=%d tile_rows=%d tiles=%lld staged=%lld max_rows=%d (cap %d) rows_total=%zu\n",
+                                             block_vec_size, p.tile_rows, (long long)p.n_tiles, (long long)p.n_staged_tiles, p.max_lines_used, max_rows, p.tile_lines.size());
+        if (!p.valid && !pp.valid) return USPMV_OK;
+    } else {
+        if (n_tiles) *n_tiles = pp.n_tiles;
+        if (n_staged) *n_staged = pp.n_tiles;
+    }
     auto up = [&](const void *h, size_t bytes, void **d) -> hipError_t {
         hipError_t e = hipMalloc(d, bytes ? bytes : 4);
         if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
         return e;
     };
-    hipError_t e = up(p.tile_line_ptr.data(), p.tile_line_ptr.size() * 4, (void **)&A->bt_line_ptr);
-    if (e == hipSuccess) e = up(p.tile_lines.data(), p.tile_lines.size() * 4, (void **)&A->bt_xrows);
-    if (e == hipSuccess) e = up(p.c16_ptrs.data(), p.c16_ptrs.size() * 4, (void **)&A->bt_c16_ptrs);
-    if (e == hipSuccess) e = up(p.col16.data(), p.col16.size() * 2, (void **)&A->bt_col16);
-    if (e == hipSuccess && moved) {
-        e = up(r.values_ptr(), (size_t)r.n_elements * (r.dtype == USPMV_F64 ? 8 : 4), &A->bt_values);
-        if (e == hipSuccess) e = up(row_map.data(), row_map.size() * 4, (void **)&A->bt_row_map);
-        if (e == hipSuccess && (p.n_staged_tiles < p.n_tiles || g_tune.spmmv_variant == 5)) e = up(r.col_idxs.data(), (size_t)r.n_elements * 4, (void **)&A->bt_cols);
+    hipError_t e = hipSuccess;
+    if (moved) e = up(row_map.data(), row_map.size() * 4, (void **)&A->bt_row_map);
+    if (list_plan && p.valid) {
+        if (e == hipSuccess) e = up(p.tile_line_ptr.data(), p.tile_line_ptr.size() * 4, (void **)&A->bt_line_ptr);
+        if (e == hipSuccess) e = up(p.tile_lines.data(), p.tile_lines.size() * 4, (void **)&A->bt_xrows);
+        if (e == hipSuccess) e = up(p.c16_ptrs.data(), p.c16_ptrs.size() * 4, (void **)&A->bt_c16_ptrs);
+        if (e == hipSuccess) e = up(p.col16.data(), p.col16.size() * 2, (void **)&A->bt_col16);
+        if (e == hipSuccess && moved) {
+            e = up(r.values_ptr(), (size_t)r.n_elements * (r.dtype == USPMV_F64 ? 8 : 4), &A->bt_values);
+            if (e == hipSuccess && (p.n_staged_tiles < p.n_tiles || g_tune.spmmv_variant == 5)) e = up(r.col_idxs.data(), (size_t)r.n_elements * 4, (void **)&A->bt_cols);
+        }
     }
-    uspmv_phased_plan pp;
-    if (e == hipSuccess && row_bytes == 64 && tile_rows == 64 && g_tune.spmmv_phased) {
-        // 64-byte rows: the phased plan over the same (tie-re-ordered) entries -- what uspmv_spmmv runs by default
-        if (int rc = uspmv_build_phased_plan(moved ? &r : s, g_tune.spmmv_phase_rows, 8, &pp)) { bt_release(A); return rc; }
-        if (pp.valid) {
+    if (e == hipSuccess && pp.valid) {
+        {
             e = up(pp.ph_ptr.data(), pp.ph_ptr.size() * 4, (void **)&A->pb_ph_ptr);
             if (e == hipSuccess) e = up(pp.ph_g0.data(), pp.ph_g0.size() * 4, (void **)&A->pb_g0);
             if (e == hipSuccess) e = up(pp.ph_list_ptr.data(), pp.ph_list_ptr.size() * 4, (void **)&A->pb_list_ptr);
@@ -699,7 +714,7 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
         return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_block: device copy failed: %s", hipGetErrorString(e));
     }
     if (pp.valid) { A->pb = true; A->pb_cap_rows = pp.cap_rows; A->pb_ngp = pp.ngp; A->pb_max_rows = pp.max_rows_used; A->pb_n_tiles = pp.n_tiles; A->pb_n_phases = pp.n_phases; }
-    A->bt = true; A->bt_tile_rows = p.tile_rows; A->bt_max_rows = p.max_lines_used; A->bt_n_tiles = p.n_tiles; A->bt_staged = p.n_staged_tiles;
+    if (list_plan && p.valid) { A->bt = true; A->bt_tile_rows = p.tile_rows; A->bt_max_rows = p.max_lines_used; A->bt_n_tiles = p.n_tiles; A->bt_staged = p.n_staged_tiles; }
     return USPMV_OK;
 }
 
@@ -878,7 +893,7 @@ void uspmv_dmat_free(uspmv_dmat_t *A) {
     if (A->sw) sw_release(A);
     if (A->alt) { uspmv_dmat_free(A->alt); A->alt = nullptr; }
     if (A->tlc) tlc_release(A);
-    if (A->bt) bt_release(A);
+    if (A->bt || A->pb) bt_release(A);
     if (A->ws) (void)hipFree(A->ws);
     if (A->owns) {
         (void)hipFree((void *)A->chunk_ptrs); (void)hipFree((void *)A->chunk_lengths);

@@ -105,6 +105,7 @@ struct Tuning {
                                // the kernel itself from the column-major vector (no workspace, no extra launch, but 1.123 ms: 74 registers, six workgroups per CU)
     int spmmv_phased = 1;      // NEXT uspmv_dmat_optimize_block with 64-byte rows: also build the phased plan (eight workgroups per CU)
     int spmmv_phase_rows = 256;  // ... X rows per phase (256 | 512)
+    int spmmv_list_plan = 0;   // NEXT optimize_block: also build the one-list-per-tile plan (variants 4 / 5 / 6) when the phased kernel can take the matrix
     int spmmv_idx8 = 1;        // NEXT optimize_block: one-byte phase-local indices when every phase lists <= 256 rows
     int spmmv_reorder = 1;  // block plan's private copy of the entries: 1 = rows of equal-length chunks of a sigma window back in original order,
                             // 2 = rows re-dealt to the tiles as breadth-first balls of the matrix graph (fewer X rows per tile, scattered y rows), 0 = as is
