@@ -15,7 +15,7 @@ def torch_cuda(pkg):
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     torch.cuda.set_device(0)
     yield torch
-    pkg.set_tuning(sweep=1, sweep_nbuf=2, sweep_unroll=8, sweep_remap=8, sweep_wlog=0, sweep_tile_rows=0, sweep_max_stage=0, tlc=1)
+    pkg.set_tuning(sweep=1, sweep_nbuf=1, sweep_unroll=8, sweep_remap=8, sweep_wlog=0, sweep_tile_rows=0, sweep_max_stage=0, tlc=1)
 
 
 def _prep(pkg, coo, C, sigma, dtype, fixed=None, perm=None):
@@ -55,7 +55,7 @@ def test_sweep_banded_random_bitexact(pkg, orc, torch_cuda, dt):
                     y = t.full((s.n_rows_padded,), -7.0, dtype=A.torch_dtype, device="cuda")
                     pkg.spmv(A, x, y)
                     assert np.array_equal(y.cpu().numpy(), y_or), (C, sigma, wlog, rows, nbuf, un)
-        pkg.set_tuning(sweep_nbuf=2, sweep_unroll=8)
+        pkg.set_tuning(sweep_nbuf=1, sweep_unroll=8)
 
 
 def test_sweep_ap_banded_random_bitexact(pkg, orc, torch_cuda):

@@ -178,7 +178,8 @@ __global__ void __launch_bounds__(1024) scs_spmv_sweep(const int wlog, const int
 template <typename VT, bool AP>
 int launch_sweep(const uspmv_dmat *A, const VT *x, VT *y, hipStream_t st) {
     const long W = 1L << A->sw_wlog;
-    const int nbuf = g_tune.sweep_nbuf == 2 ? 2 : 1;
+    // (two buffers only where the plan's window leaves room for them)
+    const int nbuf = (g_tune.sweep_nbuf == 2 && 2 * (size_t)W * sizeof(VT) <= 160 * 1024) ? 2 : 1;
     const size_t lds = (size_t)nbuf * (size_t)W * sizeof(VT);
     const int remap = g_tune.sweep_remap;
     // threads per workgroup: 1 024 (or the tile, if smaller) unless "sweep_threads" asks for fewer -- a lane then owns more rows

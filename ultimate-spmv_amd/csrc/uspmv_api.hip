@@ -817,12 +817,21 @@ static int sweep_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, const uspmv_scs_
     if (n_sweep) *n_sweep = 0;
     const size_t vsz = s->dtype == USPMV_F64 ? 8 : 4;
     if (wlog <= 0) wlog = g_tune.sweep_wlog;
-    if (wlog <= 0) wlog = vsz == 8 ? 13 : 14;                         // 64 KiB windows
-    if (((size_t)1 << wlog) * vsz > 80 * 1024) return uspmv::fail(USPMV_ERR_INVALID, "%s: a window of 2^%d elements does not fit two LDS buffers", who, wlog);
+    const int nbuf = g_tune.sweep_nbuf == 2 ? 2 : 1;
+    // window: as much of the LDS as one buffer per workgroup allows (128 KiB; 64 KiB each when double-buffered) -- on config 4b every
+    // doubling from 8 KiB up paid (1.51 / 0.97 / 0.74 / 0.61 ms for the ap kernel at 2^10 .. 2^13 elements, 0.55 at 2^14 with 4 096-row
+    // tiles; profiles/r02/config4b_sweep_variants.txt): fewer, longer rounds per wave and fewer barriers
+    if (wlog <= 0) wlog = (vsz == 8 ? 13 : 14) + (nbuf == 1 ? 1 : 0);
+    if (((size_t)1 << wlog) * vsz * (size_t)nbuf > 160 * 1024)
+        return uspmv::fail(USPMV_ERR_INVALID, "%s: %d window buffer(s) of 2^%d elements do not fit the 160 KB of LDS", who, nbuf, wlog);
     if (tile_rows <= 0) tile_rows = g_tune.sweep_tile_rows;
-    // one precision: two rows per lane (the windows are staged once per 2 048 rows: 0.611 vs 0.650 ms on config 4b); ap[dp_sp]: one
-    // row per lane (four dependent chains per window and lane measured slower: 0.70 vs 0.63 ms)
-    if (tile_rows <= 0) tile_rows = B ? 1024 : 2048;
+    // rows per tile: the windows are staged once per tile, so more rows = fewer staged bytes per non-zero (a lane owns up to four rows);
+    // but at least ~1.5 tiles per CU
+    if (tile_rows <= 0) {
+        const int64_t n_pad = s->n_chunks * s->C;
+        tile_rows = 4096;
+        while (tile_rows > 1024 && n_pad / tile_rows < 384) tile_rows /= 2;
+    }
     uspmv_sweep_plan p;
     const double max_stage = g_tune.sweep_max_stage > 0 ? (double)g_tune.sweep_max_stage : 24.0;
     if (int rc = uspmv_build_sweep_plan(s, sB, wlog, tile_rows, max_stage, &p)) return rc;
