@@ -228,6 +228,23 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
             if d is not None:
                 d.close()
             native = False
+    if native:                                    # one step of the C++ object before anything is timed: if it fails on ANY rank, every rank takes the python step
+        try:
+            x = d.new_x(np.full(d.n_local, 5.0))
+            y = d.new_y()
+            d.run(x, y, 1, use_graph=False)
+            torch.cuda.synchronize(dev)
+        except Exception as e:
+            native_error = f"first C++ step failed: {type(e).__name__}: {e}"
+        bad = torch.tensor([1 if native_error else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            native_error = native_error or "the first C++ step failed on another rank"
+            try:
+                d.close()
+            except Exception:
+                pass
+            native = False
     if not native:
         d = DistSpmv(loc, wsa, args.chunk, args.sigma, B.F64, device=dev, overlap=not args.no_overlap, tlc=not args.no_tlc)
     del loc
@@ -314,15 +331,17 @@ def main():
     from ultimate_spmv_amd import binding as B
 
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
+        if world == 1 and args.gpus > 1 and not os.environ.get("USPMV_BENCH_WORLD1"):
             raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    dist_path = world > 1 or bool(os.environ.get("USPMV_BENCH_WORLD1"))   # USPMV_BENCH_WORLD1: the N > 1 code path (C++ RCCL step object and all) rehearsed with ONE rank
     if os.environ.get("USPMV_BENCH_ONE_DEVICE"):   # rehearsal only: several ranks share GPU 0
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if os.environ.get("USPMV_BENCH_ONE_DEVICE"):
             dist.init_process_group("gloo", rank=rank, world_size=world)      # rehearsal: RCCL refuses duplicate GPUs
         else:
@@ -336,7 +355,7 @@ def main():
     tuning = {k: pkg.get_tuning(k) for k in ("unroll", "nontemporal", "xcd_remap", "block", "spmv_variant", "tlc")}
 
     # ================================================================== N > 1: BASELINE config 5 (strong) + the weak line
-    if world > 1:
+    if dist_path:
         first = args.scaling or "strong"
         grid1 = args.grid or (304 if first == "strong" else 253)
         res = run_distributed(args, pkg, B, torch, dist, dev, world, rank, first, grid1)

@@ -13,3 +13,5 @@ bash tools/pmc_sq.sh $OUT/pmc_cfg3 3 ""
 bash tools/pmc_sq.sh $OUT/pmc_cfg4b 4b ""
 # two ranks on the one GPU (gloo; the C++ RCCL object refuses duplicate devices, so this rehearses bench.py's N > 1 control flow on the Python step)
 ( export USPMV_BENCH_ONE_DEVICE=1; timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --grid 96 --grid2 64 > $OUT/bench_2rank_1gpu_rehearsal.json 2> $OUT/bench_2rank_1gpu_rehearsal.err ); cut -c1-400 $OUT/bench_2rank_1gpu_rehearsal.json
+# the same code path with ONE rank and the real thing (torch's nccl = RCCL process group, the C++ RCCL step object, the guarded first step)
+( export USPMV_BENCH_WORLD1=1; timeout -k 10 600 python bench.py --gpus 2 --steps 20 --warmup 5 --grid 96 --grid2 64 > $OUT/bench_dist_path_1rank.json 2> $OUT/bench_dist_path_1rank.err ); cut -c1-400 $OUT/bench_dist_path_1rank.json
