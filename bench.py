@@ -196,6 +196,22 @@ def stream_rates(B, torch, dev):
     return {"copy": round(copy, 1), "triad": round(triad, 1), "read": round(read, 1)}
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; the contract is ONE JSON line there, so file descriptor 1
+    points at stderr while communicators come up."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
     """One N > 1 measurement: the C++ step (uspmv_dist_run) on one RCCL communicator, K timed steps between barriers."""
     from ultimate_spmv_amd.distributed import DistSpmv
@@ -213,9 +229,11 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
         idt = torch.zeros(128, dtype=torch.uint8, device=dev)
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
+        with stdout_to_stderr():
+            dist.broadcast(idt, 0)                # (the first collective creates torch's communicator)
         try:
-            d = pkg.DistNative(loc, wsa, args.chunk, args.sigma, rank, world, bytes(idt.cpu().numpy().tobytes()), tlc=not args.no_tlc)
+            with stdout_to_stderr():
+                d = pkg.DistNative(loc, wsa, args.chunk, args.sigma, rank, world, bytes(idt.cpu().numpy().tobytes()), tlc=not args.no_tlc)
             if args.no_overlap:
                 d.set_overlap(False)
         except Exception as e:          # e.g. ncclCommInitRank refused: every rank must take the same road, and the line must say so
@@ -345,7 +363,8 @@ def main():
         if os.environ.get("USPMV_BENCH_ONE_DEVICE"):
             dist.init_process_group("gloo", rank=rank, world_size=world)      # rehearsal: RCCL refuses duplicate GPUs
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            with stdout_to_stderr():
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     # torchrun exports OMP_NUM_THREADS=1; the host set-up (generation, conversion, planning) is OpenMP code,
     # so give every rank its share of the usable cores instead
     set_omp_threads(max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
