@@ -11,11 +11,16 @@ given with --mtx.
 Workload at N > 1 (BASELINE.json configs[4]): ONE nlpkkt240-class matrix (27-point stencil on 304^3,
 n = 28 094 464, nnz = 7.5e8) split over the N GPUs by the reference's -seg_nnz rule -- STRONG scaling --
 with the halo x-vector exchange (-comm_halos 1) on RCCL every step.  The step runs in C++ behind the C ABI
-(uspmv_dist_run: pack kernel, grouped ncclSend/ncclRecv on a side stream, interior tiles, boundary tiles)
--- one C-ABI call per batch of steps, no Python in the loop (the uspmv CLI additionally replays it from one captured
-hipGraph).  A weak-scaling run (every GPU owns an nlpkkt200-class block,
-grid 253 x 253 x 253*N) is measured after it and reported inside the same JSON line under "weak_scaling";
---scaling weak makes that the headline instead.
+(uspmv_dist_run: pack kernel, grouped ncclSend/ncclRecv on a side stream, interior tiles, boundary tiles, replayed from ONE
+captured hipGraph).  Every torchrun rank starts the `uspmv` harness as a CHILD PROCESS before it touches the GPU
+(`uspmv gen:... scs -c 32 -s 512 -dp -seg_nnz -comm_halos 1 -bench_steps K -bench_warmup W -check_y 1 -json ...`): the
+children bind to the system's RCCL / HIP runtime, where graph capture of the step works (inside a torch process the library
+binds to torch's older bundled RCCL), time exactly K steps between barriers, take the slowest rank's clock, and then check
+y of every local row bitwise against the rows' entry-ordered FMA chains ("y_checked").  If the children fail, all ranks fall
+back to the same C++ step inside this process (eager under torch's RCCL, also y-checked) and "config.step" / "fallback_reason"
+say so; if that fails too, the torch.distributed twin of round 1 runs, "value" is null and its number sits in "fallback_value".
+A weak-scaling run (every GPU owns an nlpkkt200-class block, grid 253 x 253 x 253*N) is measured after it and reported
+inside the same JSON line under "weak_scaling"; --scaling weak makes that the headline instead.
 
 GF/s = 2 * nnz_total / t_step / 1e9 (code/main.cpp:521-526).  Algorithmic bytes per SpMV per GPU
 = n_elements*(8+4) + 8*n_chunks + 8*(n_local + n_halo) + 8*n_rows_padded (code/main.cpp:655-663).
@@ -47,9 +52,13 @@ def parse():
     ap.add_argument("--grid2", type=int, default=0, help="N > 1: grid edge of the second (other scaling mode) measurement (default 253 weak / 304 strong)")
     ap.add_argument("--graph", action="store_true", help="N > 1: replay the C++ step from a hipGraph (crashes in hipStreamEndCapture under torch's bundled RCCL on this image; the uspmv CLI, on the system RCCL, replays graphs)")
     ap.add_argument("--no-second-line", action="store_true", help="N > 1: skip the other scaling mode's measurement")
+    ap.add_argument("--in-process", action="store_true", help="N > 1: skip the uspmv child processes, run the C++ step inside this (torch) process")
+    ap.add_argument("--ba-synch", type=int, default=0, choices=[0, 1], help="N > 1: per-step barrier of the headline protocol (the reference's default is 1; the other setting is timed too and reported)")
+    ap.add_argument("--child-timeout", type=float, default=1500.0, help="N > 1: seconds a uspmv child may take")
     ap.add_argument("--python-step", action="store_true", help="N > 1: round-1 path (torch.distributed all_to_all per step) instead of the C++ step")
     ap.add_argument("--seg", choices=["seg-nnz", "seg-rows"], default="seg-nnz")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="N > 1: eager C++ steps in the uspmv children")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--tune", default="", help="key=value,... forwarded to uspmv_set_tuning")
@@ -212,6 +221,67 @@ class stdout_to_stderr:
         return False
 
 
+def cli_measure(args, world, rank, scaling, grid, parents):
+    """One N > 1 measurement by the `uspmv` harness: every rank starts it as a child process (this process has not touched the GPU),
+    rank 0's child writes the JSON report.  Returns (report dict | None, reason)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "ultimate-spmv_amd", "uspmv")
+    g = grid
+    nz = g * world if scaling == "weak" else g
+    cores = max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
+    tmp = tempfile.mkdtemp(prefix=f"uspmv_bench_r{rank}_")
+    js = os.path.join(tmp, "report.json")
+    cmd = [exe, f"gen:{g}x{g}x{nz}", "scs", "-c", str(args.chunk), "-s", str(args.sigma), "-dp", "-" + args.seg.replace("-", "_"), "-comm_halos", "1",
+           "-ba_synch", str(args.ba_synch), "-bench_steps", str(args.steps), "-bench_warmup", str(args.warmup), "-check_y", "1", "-json", js,
+           "-tlc", "0" if args.no_tlc else "1", "-graph", "0" if args.no_graph else "1"]
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), USPMV_JOB_ID=f"bench{os.environ.get('MASTER_PORT', '0')}_{scaling}_{g}")
+    if args.no_overlap:
+        env["USPMV_NO_OVERLAP"] = "1"
+    rc, out = -1, ""
+    try:
+        r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=args.child_timeout)
+        rc, out = r.returncode, (r.stdout + r.stderr)[-2000:]
+    except subprocess.TimeoutExpired:
+        rc, out = -9, "timed out"
+    except OSError as e:
+        rc, out = -2, str(e)
+    rcs = parents.allgather(np.array([rc], np.int64)).ravel().tolist()
+    if any(rcs):
+        sys.stderr.write(f"[bench rank {rank}] uspmv child exit codes {rcs}; rank {rank}: {out}\n")
+        return None, f"uspmv child processes failed (exit codes {rcs})"
+    rep = None
+    if rank == 0:
+        try:
+            rep = json.load(open(js))
+            rep["cmd"] = " ".join(cmd[1:])
+        except (OSError, ValueError) as e:
+            return None, f"rank 0's report is unreadable: {e}"
+    return rep, ""
+
+
+def cli_result(args, rep, scaling, grid, world):
+    g = grid
+    nz = g * world if scaling == "weak" else g
+    klass = "nlpkkt240-class" if g == 304 else "nlpkkt200-class" if g == 253 else "stencil"
+    r0 = rep["rank0"]
+    k_ms = r0["local_kernel_ms"]
+    return {
+        "value": round(rep["gflops"], 2), "ms_per_step": round(rep["ms_per_step"], 5), "scaling": scaling,
+        "workload": (f"{klass} synthetic (27-pt stencil {g}x{g}x{nz}, n={rep['n_rows']}, nnz={rep['nnz']}) scs -c {args.chunk} -s {args.sigma} -dp "
+                     f"-{args.seg.replace('-', '_')} -comm_halos 1"),
+        "n_rows": rep["n_rows"], "nnz": rep["nnz"], "beta": None,
+        "step": "uspmv child processes on the system RCCL: C++ uspmv_dist_run, " + ("hipGraph replay" if rep["graph_replay"] else "eager C++ steps"),
+        "protocol": f"exactly {rep['steps']} steps between barriers after {rep['warmup']} warm-ups, slowest rank's clock; -ba_synch {rep['ba_synch']} "
+                    f"(with -ba_synch {1 - rep['ba_synch']}: {rep['other_ba_synch_ms_per_step']:.5f} ms per step; 1 = the reference's default, a barrier behind every step, code/main.cpp:467)",
+        "y_checked": rep["y_checked"], "y_mismatches": rep["y_mismatches"],
+        "rank0": {"n_local": r0["n_local"], "n_halo": r0["n_halo"], "n_send": r0["n_send"], "interior": r0["interior"], "boundary": r0["boundary"],
+                  "tiles": r0["tiles"], "plan_kind": 1 if r0["tiles"] else 0, "local_kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(r0["algorithmic_bytes"]),
+                  "local_kernel_GBs": round(r0["algorithmic_bytes"] / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None},
+        "versions": rep["versions"], "cmd": "uspmv " + rep["cmd"],
+    }
+
+
 def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
     """One N > 1 measurement: the C++ step (uspmv_dist_run) on one RCCL communicator, K timed steps between barriers."""
     from ultimate_spmv_amd.distributed import DistSpmv
@@ -265,7 +335,8 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
             native = False
     if not native:
         d = DistSpmv(loc, wsa, args.chunk, args.sigma, B.F64, device=dev, overlap=not args.no_overlap, tlc=not args.no_tlc)
-    del loc
+        del loc
+        loc = None
     x = d.new_x(np.full(d.n_local, 5.0))          # DefaultValues::x (code/classes_structs.hpp:1799-1800)
     y = d.new_y()
     s = d.scs
@@ -294,8 +365,17 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
     ms = elapsed / args.steps * 1e3
+    y_checked, y_bad = None, None
     if native:
         d._refresh()
+        # one checked step: x_global[j] = 1 + 1e-3 (j mod 1000), y of the local rows bitwise against the entry-ordered FMA chains
+        bad, _ = d.check(loc, x, y, use_graph=args.graph)
+        del loc
+        tb = torch.tensor([bad], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tb)
+        y_bad = int(tb.item())
+        y_checked = y_bad == 0
+        x = d.new_x(np.full(d.n_local, 5.0))
         # the local kernel alone (interior + boundary tiles without the exchange), HIP events on the object's stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(d.stream):
@@ -322,7 +402,8 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
                   "boundary": int(d.n_boundary) if native else int(len(d.boundary_ids)), "tiles": bool(d.use_tiles), "plan_kind": kind,
                   "local_kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(bytes_local),
                   "local_kernel_GBs": round(bytes_local / (k_ms * 1e-3) / 1e9, 1)},
-        "setup_s": round(t_setup, 1),
+        "setup_s": round(t_setup, 1), "y_checked": y_checked, "y_mismatches": y_bad, "native": bool(native),
+        "protocol": f"exactly {args.steps} steps between barriers after {args.warmup} warm-ups, slowest rank's clock; -ba_synch 0",
     }
     if native:
         d.close()
@@ -355,16 +436,9 @@ def main():
     dist_path = world > 1 or bool(os.environ.get("USPMV_BENCH_WORLD1"))   # USPMV_BENCH_WORLD1: the N > 1 code path (C++ RCCL step object and all) rehearsed with ONE rank
     if os.environ.get("USPMV_BENCH_ONE_DEVICE"):   # rehearsal only: several ranks share GPU 0
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    if not dist_path:      # (N > 1: the GPU is touched only after the uspmv child processes are done, and only as a fall-back)
+        torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if dist_path:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        if os.environ.get("USPMV_BENCH_ONE_DEVICE"):
-            dist.init_process_group("gloo", rank=rank, world_size=world)      # rehearsal: RCCL refuses duplicate GPUs
-        else:
-            with stdout_to_stderr():
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     # torchrun exports OMP_NUM_THREADS=1; the host set-up (generation, conversion, planning) is OpenMP code,
     # so give every rank its share of the usable cores instead
     set_omp_threads(max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
@@ -372,39 +446,81 @@ def main():
         k, v = kv.split("=")
         pkg.set_tuning(**{k: int(v)})
     tuning = {k: pkg.get_tuning(k) for k in ("unroll", "nontemporal", "xcd_remap", "block", "spmv_variant", "tlc")}
+    if args.tune and dist_path and not (args.in_process or args.python_step):
+        sys.stderr.write("bench.py: --tune applies to in-process measurements only (the uspmv children run the library defaults)\n")
 
     # ================================================================== N > 1: BASELINE config 5 (strong) + the weak line
     if dist_path:
         first = args.scaling or "strong"
+        second = "weak" if first == "strong" else "strong"
         grid1 = args.grid or (304 if first == "strong" else 253)
-        res = run_distributed(args, pkg, B, torch, dist, dev, world, rank, first, grid1)
-        other = None
-        if not args.no_second_line:
-            second = "weak" if first == "strong" else "strong"
-            other = run_distributed(args, pkg, B, torch, dist, dev, world, rank, second, args.grid2 or (253 if second == "weak" else 304))
-        r0 = res["rank0"]
-        out = {
-            "metric": "SpMV GFLOP/s (SELL-32-512 dp; achieved HBM GB/s in roofline)",
-            "value": res["value"], "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": first, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": res["workload"], "C": args.chunk, "sigma": args.sigma, "n_rows": res["n_rows"], "nnz": res["nnz"], "beta": res["beta"],
-                       "x": "5.0 (DefaultValues)", "partition": args.seg, "halo_overlap": not args.no_overlap, "step": res["step"],
-                       "rank0": r0, "tuning": tuning},
-            "roofline": {"bound": "hbm", "achieved": r0["local_kernel_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(r0["local_kernel_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "rank 0's local SpMV (interior + boundary tiles, no exchange): " + ("scs_spmv_tlc<double,32>" if r0["plan_kind"] == 1 else "scs_spmv_rows<double,32,8>"),
-                         "kernel_ms": r0["local_kernel_ms"], "algorithmic_bytes_per_launch": r0["algorithmic_bytes"],
-                         "rank0_step_frac": round(r0["algorithmic_bytes"] / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "setup_s": res["setup_s"],
-        }
-        if other is not None:
-            out[("weak" if first == "strong" else "strong") + "_scaling"] = {k: other[k] for k in ("value", "ms_per_step", "scaling", "workload", "step", "rank0", "setup_s")}
-            out[("weak" if first == "strong" else "strong") + "_scaling"]["unit"] = "GFLOP/s"
+        grid2 = args.grid2 or (253 if second == "weak" else 304)
+        use_cli = not (args.in_process or args.python_step or args.graph or os.environ.get("USPMV_BENCH_WORLD1") or os.environ.get("USPMV_BENCH_ONE_DEVICE"))
+        res = other = None
+        reason = ""
+        if use_cli:   # the uspmv harness as child processes, BEFORE this process touches the GPU
+            parents = pkg.HostComm(f"benchparents{os.environ.get('MASTER_PORT', '0')}", rank, world, timeout_s=args.child_timeout + 600)
+            rep, reason = cli_measure(args, world, rank, first, grid1, parents)
+            good = int(parents.allgather(np.array([0 if (reason or (rank == 0 and rep is None)) else 1], np.int64)).min())
+            if good:
+                if rank == 0:
+                    res = cli_result(args, rep, first, grid1, world)
+                if not args.no_second_line:
+                    rep2, reason2 = cli_measure(args, world, rank, second, grid2, parents)
+                    good2 = int(parents.allgather(np.array([0 if (reason2 or (rank == 0 and rep2 is None)) else 1], np.int64)).min())
+                    if good2 and rank == 0:
+                        other = cli_result(args, rep2, second, grid2, world)
+                    elif rank == 0:
+                        other = {"value": None, "scaling": second, "error": reason2 or "failed on another rank"}
+            else:
+                reason = reason or "the uspmv child processes failed on another rank"
+            parents.barrier()
+            parents.close()
+            use_cli = bool(good)
+        if not use_cli:   # in-process: the same C++ step under torch's RCCL (eager), then the torch.distributed twin
+            torch.cuda.set_device(local_rank)
+            dev = torch.device("cuda", local_rank)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            if os.environ.get("USPMV_BENCH_ONE_DEVICE"):
+                dist.init_process_group("gloo", rank=rank, world_size=world)      # rehearsal: RCCL refuses duplicate GPUs
+            else:
+                with stdout_to_stderr():
+                    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            res = run_distributed(args, pkg, B, torch, dist, dev, world, rank, first, grid1)
+            if not args.no_second_line:
+                other = run_distributed(args, pkg, B, torch, dist, dev, world, rank, second, grid2)
         if rank == 0:
+            r0 = res["rank0"]
+            twin = not use_cli and not res.get("native", True)
+            out = {
+                "metric": "SpMV GFLOP/s (SELL-32-512 dp; achieved HBM GB/s in roofline)",
+                "value": None if twin else res["value"], "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": first, "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic",
+                "y_checked": res.get("y_checked"), "y_mismatches": res.get("y_mismatches"),
+                "config": {"workload": res["workload"], "C": args.chunk, "sigma": args.sigma, "n_rows": res["n_rows"], "nnz": res["nnz"], "beta": res["beta"],
+                           "x": "5.0 (DefaultValues) in the timed steps; x_global[j] = 1 + 1e-3 (j mod 1000) in the checked step", "partition": args.seg,
+                           "halo_overlap": not args.no_overlap, "step": res["step"], "protocol": res.get("protocol"),
+                           "rank0": r0, "tuning": tuning, "versions": res.get("versions"), "cmd": res.get("cmd")},
+                "roofline": {"bound": "hbm", "achieved": r0["local_kernel_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(r0["local_kernel_GBs"] / HBM_PEAK_GBS, 4) if r0["local_kernel_GBs"] else None, "traffic": None,
+                             "kernel": "rank 0's local SpMV (interior + boundary tiles, no exchange): " + ("scs_spmv_tlc<double,32>" if r0["plan_kind"] == 1 else "scs_spmv_rows<double,32,8>"),
+                             "kernel_ms": r0["local_kernel_ms"], "algorithmic_bytes_per_launch": r0["algorithmic_bytes"],
+                             "rank0_step_frac": round(r0["algorithmic_bytes"] / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "setup_s": res.get("setup_s"),
+            }
+            if twin:
+                out["fallback_value"] = res["value"]
+            if reason:
+                out["fallback_reason"] = reason
+            if other is not None:
+                out[second + "_scaling"] = {k: other.get(k) for k in ("value", "ms_per_step", "scaling", "workload", "step", "protocol", "y_checked", "y_mismatches", "rank0", "setup_s", "error") if k in other}
+                out[second + "_scaling"]["unit"] = "GFLOP/s"
             print(json.dumps(out), flush=True)
-        dist.barrier()
-        dist.destroy_process_group()
+        if not use_cli:
+            dist.barrier()
+            dist.destroy_process_group()
         return
 
     # ================================================================== N = 1: BASELINE config 2
@@ -458,7 +574,7 @@ def main():
     out = {
         "metric": "SpMV GFLOP/s (SELL-32-512 dp; achieved HBM GB/s in roofline)",
         "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": None, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic" if not args.mtx else "file",
         "config": {"workload": workload, "C": args.chunk, "sigma": args.sigma, "n_rows": n_global, "nnz": total_nnz,
                    "beta": round(s.nnz / s.n_elements, 6), "x": "5.0 (DefaultValues)", "partition": "none", "halo_overlap": False,

@@ -37,7 +37,8 @@ typedef enum {
     USPMV_ERR_OVERFLOW = 4,    /* a 32-bit index would overflow (code/utilities.hpp:1959-1962) */
     USPMV_ERR_NO_DEVICE = 5,   /* no HIP device visible                                        */
     USPMV_ERR_HIP = 6,         /* a HIP runtime call failed                                    */
-    USPMV_ERR_ALLOC = 7
+    USPMV_ERR_ALLOC = 7,
+    USPMV_ERR_COMM = 8         /* a peer rank failed, never arrived or disagrees (host communicator / transport) */
 } uspmv_status;
 
 typedef enum { USPMV_F64 = 0, USPMV_F32 = 1 } uspmv_dtype;            /* -dp / -sp              */
@@ -54,6 +55,8 @@ typedef struct uspmv_halo uspmv_halo_t;   /* per-rank halo description (ContextD
 const char *uspmv_status_string(int status);
 const char *uspmv_last_error(void);
 const char *uspmv_version(void);
+/* debugging aid: SIGSEGV / SIGBUS / SIGABRT print the native call stack (module+offset) to stderr before the default action */
+int uspmv_debug_backtrace_on_crash(int on);
 
 /* ------------------------------------------------------------------ L1: COO / MatrixMarket */
 /* read_mtx (code/utilities.hpp:2148-2309) + mm_read_unsymmetric_sparse (code/mmio.h:132-263):
@@ -312,6 +315,50 @@ void uspmv_free(void *p);
 int uspmv_pack_send_buf(const void *d_x, const int32_t *d_perm, const int32_t *d_send_idxs, int64_t n,
                         int64_t block_offset, void *d_send, int dtype, void *stream);
 
+/* ------------------------------------------------------------------ L4a: set-up transport, host communicator, exchange plan */
+/* collect_comm_info (code/mpi_funcs.hpp:1061-1124) needs two exchanges between the ranks: every rank tells every owner HOW MANY
+ * of the owner's rows it needs (the reference all-gathers the cumsums, :190-196) and WHICH (the MPI_INT index all-to-all,
+ * :143-171).  Both run over this small transport, so the SAME C++ set-up is driven by RCCL (device staging, the default of
+ * uspmv_dist_create), by the host communicator below (real processes, no GPU: tests/test_dist_setup_mp.py) and in loopback.
+ * All buffers are HOST memory; offsets are in bytes with size+1 entries:
+ *   alltoallv: recv[recv_off[q] .. recv_off[q+1]) <- rank q's send[send_off_q[me] .. send_off_q[me+1])
+ *   allgather: recv[q*bytes .. (q+1)*bytes) <- rank q's send[0 .. bytes) */
+typedef struct uspmv_transport {
+    void *ctx;
+    int rank, size;
+    int (*alltoallv)(void *ctx, const void *send, const int64_t *send_off, void *recv, const int64_t *recv_off);
+    int (*allgather)(void *ctx, const void *send, void *recv, int64_t bytes_per_rank);
+    int (*barrier)(void *ctx);
+} uspmv_transport_t;
+
+/* Host communicator of ONE node: the ranks of a job meet in a memory-mapped segment (<USPMV_HC_DIR or /dev/shm>/uspmv_hc_<job>,
+ * published by rank 0 with an atomic rename and unlinked as soon as every rank has attached; leftovers of a crashed job are
+ * recognised by their dead creator and ignored).  Stands where the reference has MPI_Bcast / MPI_Allgather / the index exchange
+ * during set-up (code/mpi_funcs.hpp:143-171, :190-196, :732-736); every wait has a deadline (timeout_s, <= 0: 300 s) and fails
+ * on all ranks with USPMV_ERR_COMM when a peer dies. */
+typedef struct uspmv_hostcomm uspmv_hostcomm_t;
+int uspmv_hostcomm_create(const char *job, int rank, int size, double timeout_s, uspmv_hostcomm_t **out);
+int uspmv_hostcomm_info(const uspmv_hostcomm_t *h, int *rank, int *size, uint64_t *nonce /* random per segment, same on all ranks */);
+int uspmv_hostcomm_barrier(uspmv_hostcomm_t *h);
+int uspmv_hostcomm_abort(uspmv_hostcomm_t *h);   /* tell the peers this rank cannot go on: their next wait fails at once */
+int uspmv_hostcomm_bcast(uspmv_hostcomm_t *h, void *buf, int64_t bytes, int root);
+int uspmv_hostcomm_allgather(uspmv_hostcomm_t *h, const void *send, void *recv, int64_t bytes_per_rank);
+int uspmv_hostcomm_alltoallv(uspmv_hostcomm_t *h, const void *send, const int64_t *send_off, void *recv, const int64_t *recv_off);
+int uspmv_hostcomm_allreduce_max_f64(uspmv_hostcomm_t *h, double *value);
+int uspmv_hostcomm_transport(uspmv_hostcomm_t *h, uspmv_transport_t *t);   /* the transport view (h must outlive its users) */
+void uspmv_hostcomm_free(uspmv_hostcomm_t *h);
+
+/* organize_cumsums + collect_comm_idxs (code/mpi_funcs.hpp:117-232): from what this rank NEEDS from whom (its halo description)
+ * to what it must SEND to whom -- collective over the transport, no GPU involved.  send_off[P+1] / recv_off[P+1] count elements;
+ * send_idxs[send_off[p] .. send_off[p+1]) are THIS rank's local rows (original order) rank p asked for, i.e. the reference's
+ * comm_send_idxs[p].  Every id is checked against [0, n_local): a peer asking for a row this rank does not own is an error on
+ * this rank (USPMV_ERR_INVALID), never an out-of-bounds gather. */
+typedef struct uspmv_comm_plan uspmv_comm_plan_t;
+int uspmv_comm_plan_create(const uspmv_transport_t *t, const uspmv_halo_t *halo, uspmv_comm_plan_t **out);
+int uspmv_comm_plan_meta(const uspmv_comm_plan_t *p, int64_t *n_send, const int64_t **send_off, const int32_t **send_idxs,
+                         const int64_t **recv_off);
+void uspmv_comm_plan_free(uspmv_comm_plan_t *p);
+
 /* ------------------------------------------------------------------ L4b: the distributed step on RCCL */
 /* One process per GPU.  Replaces the per-iteration MPI flow of the reference -- init_local_structs (code/main.cpp:1075-1334),
  * collect_comm_info (code/mpi_funcs.hpp:1061-1124), init/finalize_halo_exchange (code/classes_structs.hpp:857-995) and the
@@ -335,6 +382,41 @@ int uspmv_dist_create(const void *comm_id, int comm_rank, int comm_size, int ran
  * column ids (uspmv_seg_local_coo or a generator's row range).  The object owns everything it built. */
 int uspmv_dist_create_from_coo(const void *comm_id, int comm_rank, int comm_size, int rank, int P, const uspmv_coo_t *local,
                                const int32_t *wsa, int64_t C, int64_t sigma, int dtype, int tlc, uspmv_dist_t **out);
+/* The same two with options.  transport: who carries the set-up exchanges (NULL = the RCCL communicator, device-staged; loopback
+ * uses an identity transport).  exchange: USPMV_EXCHANGE_RCCL (default) or USPMV_EXCHANGE_HOST -- the per-step halo exchange
+ * staged through host memory over `transport` (pack kernel -> D2H -> all-to-all-v -> H2D into the tail of x), which lets P real
+ * processes share ONE GPU: it is how a single-GPU box runs the C++ step with unequal seg-nnz blocks and asymmetric send / recv
+ * lists (tests/test_dist_native_gpu.py).  With USPMV_EXCHANGE_HOST no RCCL communicator is created (comm_id may be NULL);
+ * transport->size must equal P and transport->rank the block.  The transport must outlive the object. */
+typedef enum { USPMV_EXCHANGE_RCCL = 0, USPMV_EXCHANGE_HOST = 1 } uspmv_exchange;
+typedef struct uspmv_dist_options {
+    const uspmv_transport_t *transport;
+    int exchange;
+} uspmv_dist_options_t;
+int uspmv_dist_create_ex(const void *comm_id, int comm_rank, int comm_size, int rank, int P, uspmv_dmat_t *A, const uspmv_halo_t *halo,
+                         const int32_t *old_to_new_idx, const int32_t *interior_ids, int64_t n_interior, const int32_t *boundary_ids,
+                         int64_t n_boundary, int ids_are_tiles, const uspmv_dist_options_t *opt, uspmv_dist_t **out);
+int uspmv_dist_create_from_coo_ex(const void *comm_id, int comm_rank, int comm_size, int rank, int P, const uspmv_coo_t *local,
+                                  const int32_t *wsa, int64_t C, int64_t sigma, int dtype, int tlc, const uspmv_dist_options_t *opt,
+                                  uspmv_dist_t **out);
+/* the exchange plan of the object (borrowed): n_send, send_off[P+1], send_idxs[n_send], recv_off[P+1] as in uspmv_comm_plan_meta */
+int uspmv_dist_comm_plan(const uspmv_dist_t *d, int64_t *n_send, const int64_t **send_off, const int32_t **send_idxs,
+                         const int64_t **recv_off);
+/* Options by name: "overlap" 1|0, "no_pack" 0|1, "ba_synch" 0|1 (a stream-ordered one-element all-reduce after every step: the
+ * MPI_Barrier the reference issues per iteration by default, code/main.cpp:467, :417; part of the captured graph),
+ * "capture_mode" 0 global | 1 thread-local | 2 relaxed (hipStreamCaptureMode of uspmv_dist_run's capture),
+ * "diag_skip_exchange" 0|1 (diagnosis only: the step skips the RCCL group, results are wrong). */
+int uspmv_dist_set_option(uspmv_dist_t *d, const char *key, int value);
+/* Self-check of the whole distributed path (partition, halo discovery, exchange plan, exchange, kernels) on the object's own
+ * matrix: one step with x_global[j] = 1 + 1e-3 * (j mod 1000) -- every halo element differs from its neighbours, unlike the
+ * benchmark's constant 5.0 -- and y of the local rows compared BITWISE with the rows' entry-ordered FMA chains evaluated on the
+ * host straight from `local` (global column ids; the role of the reference's MKL validation, code/write_results.hpp:442-556).
+ * mismatches = rows that differ on this rank, checksum = sum of the local y in original order (both optional). */
+int uspmv_dist_check(uspmv_dist_t *d, const uspmv_coo_t *local, const int32_t *wsa, void *d_x, void *d_y, int use_graph,
+                     void *stream, int64_t *mismatches, double *checksum);
+/* HIP / RCCL versions this library was COMPILED against and the ones it RUNS on in this process:
+ * v[0] HIP_VERSION (build), v[1] hipRuntimeGetVersion, v[2] NCCL_VERSION_CODE (build), v[3] ncclGetVersion. */
+int uspmv_runtime_versions(int v[4]);
 /* meta[12] = n_local, n_halo, padded_vec_size, n_send, n_interior, n_boundary, ids_are_tiles, n_rows_padded, loopback,
  *            graph captured, graph launches so far, eager steps so far */
 int uspmv_dist_info(const uspmv_dist_t *d, int64_t meta[12]);

@@ -59,13 +59,23 @@ def test_native_step_loopback_bitexact(pkg, orc, P, shape, C, sigma):
         assert torch.equal(y, y2) and torch.equal(x[d.n_local:d.n_local + d.n_halo], x_tail)
         d.set_overlap(True)
         x[d.n_local:].zero_()
-        # uspmv_dist_run, eager form.  (The hipGraph replay of the step is exercised by the CLI test below, on the system's RCCL:
-        # inside a Python process the library binds to the RCCL / HIP runtime that torch ships, whose hipStreamEndCapture crashes
-        # on a captured RCCL group -- profiles/r02/dist_graph_capture.txt -- so Python callers keep use_graph = False.)
+        # uspmv_dist_run: eager, then replayed from ONE captured hipGraph -- also inside this torch process (round 2 crashed here:
+        # under torch's bundled HIP 7.0 / RCCL 2.26 an RCCL group captured on a JOINED stream kills hipStreamEndCapture; the step
+        # now keeps the group on the capture's origin stream, profiles/r03/graph_capture_diag.txt)
         y3 = d.new_y(); d.run(x, y3, 5, use_graph=False); d.synchronize()
         d._refresh()
         assert torch.equal(y, y3), (P, rank, "run")
         assert not d.graph_captured and d.eager_steps >= 5
+        x[d.n_local:].zero_()
+        y5 = d.new_y(); d.run(x, y5, 7, use_graph=True); d.synchronize()
+        d._refresh()
+        assert d.graph_captured and d.graph_launches == 7, (d.graph_captured, d.graph_launches)
+        assert torch.equal(y, y5) and torch.equal(x[d.n_local:d.n_local + d.n_halo], x_tail), (P, rank, "graph")
+        d.set_option("ba_synch", 1)            # the per-step barrier is part of the captured step
+        y6 = d.new_y(); d.run(x, y6, 3, use_graph=True); d.synchronize()
+        d._refresh()
+        assert d.graph_captured and torch.equal(y, y6)
+        d.set_option("ba_synch", 0)
         # without the exchange the boundary rows differ (the halo really is what makes y right)
         x[d.n_local:].zero_()
         y4 = d.new_y(); d.spmv(x, y4, comm_halos=False); d.synchronize()
@@ -134,3 +144,176 @@ def test_cli_distributed_loopback_dumps_the_right_y(pkg, orc, tmp_path):
         yv, _ = _global_reference(pkg, orc, shape, P, 32, 512, scale=1.0 + v / 8.0)
         assert np.array_equal(Y[v], yv[nl:2 * nl]), v
     assert "block_vec_size: 2" in open(tmp_path / "spmv_bench.txt").read() and "MPI_mode: multivec" in open(tmp_path / "spmv_bench.txt").read()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Round 3: unequal seg-nnz blocks with REAL ranks.  RCCL refuses several ranks on one GPU, so on a single-GPU box the ranks are
+# real processes sharing the card and the per-step exchange is staged through the host communicator (USPMV_EXCHANGE_HOST): the
+# same C++ object, set-up, pack kernel, interior / boundary split and kernels as a production run -- only ncclSend / ncclRecv are
+# replaced by D2H + all-to-all-v + H2D.  The RCCL calls themselves are what the loopback tests above execute.
+import multiprocessing as mp
+import sys
+import time
+
+from conftest import GOLDEN, mtx_path
+
+
+def _hx_worker(rank, world, q, job, case):
+    try:
+        sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import torch
+        import __graft_entry__ as ge
+        pkg = ge.load_package()
+        from ultimate_spmv_amd import binding as B
+        torch.cuda.set_device(0)
+        name, Cc, sg, method = case
+        key = f"{name}_C{Cc}_s{sg}_{method}_P{world}"
+        h = np.load(os.path.join(GOLDEN, "halo.npz"))
+        hc = pkg.HostComm(job, rank, world, timeout_s=120)
+        tot = pkg.read_mtx(mtx_path(name))
+        wsa = pkg.seg_work_sharing_arr(tot, method, world)
+        assert np.array_equal(wsa, h[key + "_wsa"])
+        loc = B.seg_local_coo(tot, wsa, rank)
+        d = pkg.DistNative(loc, wsa, Cc, sg, rank, world, hostcomm=hc, host_exchange=True)
+        nl = int(wsa[rank + 1] - wsa[rank])
+        assert d.n_local == nl and not d.loopback
+        # exchange plan == the reference's (what p's recv list asks this rank for)
+        n_send, send_off, send_idxs, recv_off = d.comm_plan()
+        for p in range(world):
+            cnt = np.diff(h[f"{key}_r{p}_recv_cumsum"].astype(np.int64))
+            off = np.concatenate([[0], np.cumsum(cnt)])
+            assert np.array_equal(send_idxs[send_off[p]:send_off[p + 1]], h[f"{key}_r{p}_recv_idxs"][off[rank]:off[rank + 1]]), p
+        assert recv_off[-1] == d.n_halo == len(h[f"{key}_r{rank}_recv_idxs"])
+        xg = 1.0 + 1e-3 * (np.arange(tot.n_rows) % 1000)
+        want = h[key + "_y_global"][wsa[rank]:wsa[rank + 1]]
+        gx = h[f"{key}_r{rank}_x_local"]
+        for overlap in (True, False):
+            d.set_option("overlap", int(overlap))
+            for ba in (0, 1):
+                d.set_option("ba_synch", ba)
+                x = d.new_x(xg[wsa[rank]:wsa[rank + 1]])
+                y = d.new_y()
+                d.run(x, y, 2, use_graph=True)          # (host-staged exchange: runs eagerly, the flag must not break it)
+                d.synchronize()
+                assert np.array_equal(x.cpu().numpy()[:len(gx)], gx), "x_local (halo tail) differs from the reference's"
+                assert np.array_equal(d.y_to_original_order(y)[:nl], want), (overlap, ba)
+        # the product's own self-check agrees (same x as the golden: x_global[j] = 1 + 1e-3 (j mod 1000))
+        x, y = d.new_x(np.zeros(nl)), d.new_y()
+        bad, cs = d.check(loc, x, y)
+        assert bad == 0, bad
+        assert np.array_equal(d.y_to_original_order(y)[:nl], want)
+        d.barrier()
+        assert d.allreduce_max(float(rank)) == float(world - 1)
+        d.close(); hc.close()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_native_step_real_ranks_unequal_seg_nnz_blocks(pkg, world):
+    """bcsstk13 split by -seg_nnz (block heights 724 / 459 / 417 / 403 at P = 4, asymmetric send / recv counts): the C++ step object
+    in `world` real processes on one GPU, against the reference's x_local and y (tests/golden/halo.npz)."""
+    case = ("bcsstk13", 32, 512, "seg-nnz")
+    if f"bcsstk13_C32_s512_seg-nnz_P{world}_wsa" not in np.load(os.path.join(GOLDEN, "halo.npz")):
+        pytest.skip("no golden for this world size")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    job = f"hx{os.getpid()}_{time.monotonic_ns()}"
+    procs = [ctx.Process(target=_hx_worker, args=(r, world, q, job, case)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in procs:
+            res.append(q.get(timeout=300))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for rank, msg in sorted(res):
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_loopback_refuses_unequal_blocks_cleanly(pkg):
+    """seg-nnz blocks of different heights in LOOPBACK: the ids a rank asks block p for index p's rows, not its own -- the set-up
+    must say so (USPMV_ERR_INVALID) instead of letting the pack kernel gather out of bounds."""
+    import torch
+    torch.cuda.set_device(0)
+    shape, P = (12, 12, 30), 3
+    counts = pkg.gen_stencil27_row_counts(*shape)
+    wsa = pkg.seg_from_row_counts(counts, "seg-nnz", P)
+    assert len(set(np.diff(wsa).tolist())) > 1, "the case needs unequal blocks"
+    small = int(np.argmin(np.diff(wsa)))
+    loc = pkg.gen_stencil27(*shape, row_begin=int(wsa[small]), row_end=int(wsa[small + 1]))
+    with pytest.raises(pkg.UspmvError) as e:
+        pkg.DistNative(loc, wsa, 32, 512, small, P, pkg.comm_unique_id(), comm_rank=0, comm_size=1)
+    assert e.value.status == 1 and "equal block heights" in str(e.value)
+
+
+def test_self_check_passes_in_loopback_and_catches_a_missing_exchange(pkg):
+    import torch
+    torch.cuda.set_device(0)
+    shape, P, rank = (16, 16, 40), 4, 2
+    counts = pkg.gen_stencil27_row_counts(*shape)
+    wsa = pkg.seg_from_row_counts(counts, "seg-rows", P)
+    loc = pkg.gen_stencil27(*shape, row_begin=int(wsa[rank]), row_end=int(wsa[rank + 1]))
+    d = pkg.DistNative(loc, wsa, 32, 512, rank, P, pkg.comm_unique_id(), comm_rank=0, comm_size=1)
+    x, y = d.new_x(np.zeros(d.n_local)), d.new_y()
+    for ba in (0, 1):
+        d.set_option("ba_synch", ba)
+        bad, _ = d.check(loc, x, y)
+        assert bad == 0
+    d.set_option("diag_skip_exchange", 1)      # the halo tail stays zero: every boundary row must be reported
+    bad, _ = d.check(loc, x, y)
+    assert bad > 0
+    d.set_option("diag_skip_exchange", 0)
+    bad, _ = d.check(loc, x, y)
+    assert bad == 0
+    d.close()
+
+
+def test_cli_real_ranks_host_exchange_mtx_scatter_and_check(pkg, tmp_path):
+    """`uspmv bcsstk13.mtx scs -c 32 -s 512 -seg_nnz -comm_halos 1` as FOUR real rank processes (rank 0 reads and scatters the .mtx,
+    the ranks meet in the host communicator), fixed-step protocol, -ba_synch 1, -check_y 1, JSON report."""
+    h = np.load(os.path.join(GOLDEN, "halo.npz"))
+    key = "bcsstk13_C32_s512_seg-nnz_P4"
+    wsa = h[key + "_wsa"]
+    js = str(tmp_path / "out.json")
+    procs = []
+    for rank in range(4):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="4", LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
+                   USPMV_JOB_ID=f"c{os.getpid()}", USPMV_HC_TIMEOUT="120")
+        env.pop("USPMV_LOOPBACK", None)
+        procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-seg_nnz", "-comm_halos", "1", "-bench_steps", "5",
+                                       "-bench_warmup", "2", "-check_y", "1", "-json", js, "-print_comm_vol", "1"], cwd=tmp_path, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    import json
+    rep = json.load(open(js))
+    assert rep["y_checked"] is True and rep["y_mismatches"] == 0 and rep["steps"] == 5 and rep["warmup"] == 2
+    assert rep["ba_synch"] == 1 and rep["exchange"] == "host" and rep["ranks"] == 4 and rep["nnz"] == 83883
+    assert rep["rank0"]["n_local"] == int(wsa[1] - wsa[0]) == 724 and rep["rank0"]["n_halo"] == 220
+    assert "y checked bitwise on every rank: ok" in outs[0]
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".uspmvcoo")], "block files must be gone"
+    txt = open(tmp_path / "spmv_bench.txt").read()
+    assert "seg_method: seg-nnz" in txt and "ba_synch: 1" in txt and "Per rank Elems Recvd" in txt
+
+
+def test_cli_loopback_graph_replay_with_ba_synch_and_check(pkg, tmp_path):
+    """the captured step now also carries the per-step barrier (-ba_synch 1, the reference's default) and the self-check runs
+    through the replayed graph"""
+    env = dict(os.environ, USPMV_LOOPBACK="2", USPMV_LOOPBACK_RANK="1", USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID=f"g{os.getpid()}")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    for ba in ("1", "0"):
+        r = subprocess.run([EXE, "gen:24x24x24", "scs", "-c", "32", "-s", "512", "-seg_rows", "-comm_halos", "1", "-bench_time", "0.05", "-ba_synch", ba,
+                            "-check_y", "1", "-json", "-"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        import json
+        rep = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert rep["graph_replay"] is True and rep["y_checked"] is True and rep["ba_synch"] == int(ba) and rep["loopback"] is True
+        assert rep["versions"]["rccl_runtime"] >= rep["versions"]["rccl_build"] > 0

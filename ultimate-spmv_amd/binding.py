@@ -129,6 +129,26 @@ _SIGS = {
     "uspmv_dist_allreduce_max": (C.c_int, [_vp, C.POINTER(C.c_double), _vp]),
     "uspmv_dist_allgather_i64": (C.c_int, [_vp, _i64, C.POINTER(_i64), _vp]),
     "uspmv_dist_free": (None, [_vp]),
+    "uspmv_dist_create_ex": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp, _i64, C.c_int, _vp, C.POINTER(_vp)]),
+    "uspmv_dist_create_from_coo_ex": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "uspmv_dist_comm_plan": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.POINTER(_i64)), C.POINTER(_i32p), C.POINTER(C.POINTER(_i64))]),
+    "uspmv_dist_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "uspmv_dist_check": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "uspmv_runtime_versions": (C.c_int, [C.POINTER(C.c_int)]),
+    "uspmv_debug_backtrace_on_crash": (C.c_int, [C.c_int]),
+    "uspmv_hostcomm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_double, C.POINTER(_vp)]),
+    "uspmv_hostcomm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "uspmv_hostcomm_barrier": (C.c_int, [_vp]),
+    "uspmv_hostcomm_abort": (C.c_int, [_vp]),
+    "uspmv_hostcomm_bcast": (C.c_int, [_vp, _vp, _i64, C.c_int]),
+    "uspmv_hostcomm_allgather": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "uspmv_hostcomm_alltoallv": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "uspmv_hostcomm_allreduce_max_f64": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "uspmv_hostcomm_transport": (C.c_int, [_vp, _vp]),
+    "uspmv_hostcomm_free": (None, [_vp]),
+    "uspmv_comm_plan_create": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
+    "uspmv_comm_plan_meta": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.POINTER(_i64)), C.POINTER(_i32p), C.POINTER(C.POINTER(_i64))]),
+    "uspmv_comm_plan_free": (None, [_vp]),
     "uspmv_stream_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
     "uspmv_stream_triad": (C.c_int, [_vp, _vp, _vp, C.c_double, _i64, _vp]),
     "uspmv_stream_read": (C.c_int, [_vp, _i64, _vp, _vp]),
@@ -145,10 +165,11 @@ def lib():
         # own HIP/HSA runtime and publishes it RTLD_GLOBAL; loaded first, it is the one runtime the
         # whole process (torch + libuspmv kernels + RCCL) shares.  Loaded second, the process ends up
         # with two HSA runtimes and the later one finds no device.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        if not os.environ.get("USPMV_NO_TORCH"):   # (USPMV_NO_TORCH=1: a torch-free process binds to the system's /opt/rocm runtime)
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         path = library_path()
         if not os.path.exists(path):
             raise UspmvError(-1, f"{path} is missing: build it with __graft_entry__.build() "
@@ -158,6 +179,8 @@ def lib():
             f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             f.restype, f.argtypes = res, args
         _LIB = L
+        if os.environ.get("USPMV_BACKTRACE"):
+            L.uspmv_debug_backtrace_on_crash(1)
     return _LIB
 
 
@@ -370,20 +393,138 @@ class _BorrowedScs(Scs):
         self.h = None
 
 
+class Transport(C.Structure):
+    """uspmv_transport_t (include/uspmv.h, L4a)"""
+    _fields_ = [("ctx", _vp), ("rank", C.c_int), ("size", C.c_int), ("alltoallv", _vp), ("allgather", _vp), ("barrier", _vp)]
+
+
+class DistOptions(C.Structure):
+    """uspmv_dist_options_t"""
+    _fields_ = [("transport", C.POINTER(Transport)), ("exchange", C.c_int)]
+
+
+EXCHANGE_RCCL, EXCHANGE_HOST = 0, 1
+
+
+class HostComm:
+    """Host communicator of one node (uspmv_hostcomm_*, host/hostcomm.cpp): barrier / broadcast / all-gather / all-to-all-v between
+    the ranks of a job through a memory-mapped segment.  No GPU involved."""
+
+    def __init__(self, job, rank, size, timeout_s=120.0):
+        h = _vp()
+        _ck(lib().uspmv_hostcomm_create(str(job).encode(), rank, size, float(timeout_s), C.byref(h)))
+        self.h, self.rank, self.size = h, rank, size
+        self.transport = Transport()
+        _ck(lib().uspmv_hostcomm_transport(h, C.byref(self.transport)))
+
+    @property
+    def nonce(self):
+        n = C.c_uint64()
+        _ck(lib().uspmv_hostcomm_info(self.h, None, None, C.byref(n)))
+        return n.value
+
+    def barrier(self):
+        _ck(lib().uspmv_hostcomm_barrier(self.h))
+
+    def abort(self):
+        lib().uspmv_hostcomm_abort(self.h)
+
+    def bcast(self, arr, root=0):
+        """in place on a contiguous numpy array (same shape and dtype on every rank)"""
+        assert arr.flags["C_CONTIGUOUS"]
+        _ck(lib().uspmv_hostcomm_bcast(self.h, _np_ptr(arr), arr.nbytes, root))
+        return arr
+
+    def allgather(self, arr):
+        arr = np.ascontiguousarray(arr)
+        out = np.empty((self.size,) + arr.shape, arr.dtype)
+        _ck(lib().uspmv_hostcomm_allgather(self.h, _np_ptr(arr), _np_ptr(out), arr.nbytes))
+        return out
+
+    def alltoallv(self, send, send_counts, recv_counts):
+        """element counts per peer; returns the received array"""
+        send = np.ascontiguousarray(send)
+        isz = send.dtype.itemsize
+        so = np.zeros(self.size + 1, np.int64); so[1:] = np.cumsum(send_counts) * isz
+        ro = np.zeros(self.size + 1, np.int64); ro[1:] = np.cumsum(recv_counts) * isz
+        recv = np.empty(int(ro[-1] // isz), send.dtype)
+        _ck(lib().uspmv_hostcomm_alltoallv(self.h, _np_ptr(send) if send.size else None, _np_ptr(so), _np_ptr(recv) if recv.size else None, _np_ptr(ro)))
+        return recv
+
+    def allreduce_max(self, v):
+        d = C.c_double(float(v))
+        _ck(lib().uspmv_hostcomm_allreduce_max_f64(self.h, C.byref(d)))
+        return d.value
+
+    def close(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.uspmv_hostcomm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def _plan_meta(fn, handle, P):
+    n = _i64()
+    so, ro = C.POINTER(_i64)(), C.POINTER(_i64)()
+    si = _i32p()
+    _ck(fn(handle, C.byref(n), C.byref(so), C.byref(si), C.byref(ro)))
+    send_off = np.ctypeslib.as_array(so, shape=(P + 1,)).copy()
+    recv_off = np.ctypeslib.as_array(ro, shape=(P + 1,)).copy()
+    send_idxs = np.ctypeslib.as_array(si, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int32)
+    return n.value, send_off, send_idxs, recv_off
+
+
+class CommPlan:
+    """uspmv_comm_plan_create: what this rank must send to whom (the reference's comm_send_idxs / send cumsums,
+    code/mpi_funcs.hpp:117-232), derived collectively over a transport.  No GPU involved."""
+
+    def __init__(self, transport, halo):
+        h = _vp()
+        _ck(lib().uspmv_comm_plan_create(C.byref(transport), halo.h, C.byref(h)))
+        self.h = h
+        self.n_send, self.send_off, self.send_idxs, self.recv_off = _plan_meta(lib().uspmv_comm_plan_meta, h, halo.P)
+
+    def __del__(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.uspmv_comm_plan_free(self.h)
+            self.h = None
+
+
+def runtime_versions():
+    """(HIP build, HIP runtime, RCCL build, RCCL runtime) version codes of libuspmv.so in this process"""
+    v = (C.c_int * 4)()
+    _ck(lib().uspmv_runtime_versions(v))
+    return tuple(int(a) for a in v)
+
+
 class DistNative:
     """The distributed SpMV object of the C ABI (uspmv_dist_*, csrc/uspmv_dist_api.hip): partition block `rank` of P on an RCCL
     communicator of comm_size ranks (comm_size == P, or 1 = loopback).  Everything per step happens in C++.  use_graph (one
     hipGraphLaunch per step) works in processes bound to the system's RCCL (the uspmv CLI); under torch's bundled RCCL / HIP runtime
     the capture of an RCCL group crashes in hipStreamEndCapture, so it is off by default here."""
 
-    def __init__(self, local_coo, wsa, C_, sigma, rank, P, comm_id, comm_rank=None, comm_size=None, dtype=F64, tlc=True):
+    def __init__(self, local_coo, wsa, C_, sigma, rank, P, comm_id=None, comm_rank=None, comm_size=None, dtype=F64, tlc=True,
+                 hostcomm=None, host_exchange=False):
+        """hostcomm: a HostComm that carries the set-up exchanges (default: the RCCL communicator made from comm_id);
+        host_exchange=True additionally stages the per-step halo exchange through it (USPMV_EXCHANGE_HOST: no RCCL communicator,
+        P processes may share one GPU)."""
         import torch
         self.rank, self.P = rank, P
         wsa = np.ascontiguousarray(wsa, np.int32)
+        self._wsa = wsa
         h = _vp()
-        idbuf = (C.c_ubyte * 128).from_buffer_copy(comm_id)
-        _ck(lib().uspmv_dist_create_from_coo(idbuf, rank if comm_rank is None else comm_rank, P if comm_size is None else comm_size,
-                                             rank, P, local_coo.h, _np_ptr(wsa), C_, sigma, dtype, int(bool(tlc)), C.byref(h)))
+        idbuf = (C.c_ubyte * 128).from_buffer_copy(comm_id) if comm_id is not None else None
+        self._hostcomm = hostcomm
+        opt = None
+        if hostcomm is not None:
+            self._opt = DistOptions(C.pointer(hostcomm.transport), EXCHANGE_HOST if host_exchange else EXCHANGE_RCCL)
+            opt = C.byref(self._opt)
+        elif host_exchange:
+            raise ValueError("host_exchange needs a HostComm")
+        _ck(lib().uspmv_dist_create_from_coo_ex(idbuf, rank if comm_rank is None else comm_rank, P if comm_size is None else comm_size,
+                                                rank, P, local_coo.h, _np_ptr(wsa), C_, sigma, dtype, int(bool(tlc)), opt, C.byref(h)))
         self.h = h
         s, a, hl = _vp(), _vp(), _vp()
         _ck(lib().uspmv_dist_parts(h, C.byref(s), C.byref(a), C.byref(hl)))
@@ -425,13 +566,39 @@ class DistNative:
     def set_overlap(self, on):
         _ck(lib().uspmv_dist_set_overlap(self.h, int(bool(on))))
 
+    def set_option(self, key, value):
+        _ck(lib().uspmv_dist_set_option(self.h, key.encode(), int(value)))
+
+    def comm_plan(self):
+        """(n_send, send_off[P+1], send_idxs, recv_off[P+1]) of the object's exchange plan"""
+        return _plan_meta(lib().uspmv_dist_comm_plan, self.h, self.P)
+
+    def check(self, local_coo, x, y, use_graph=False):
+        """uspmv_dist_check: one step with x_global[j] = 1 + 1e-3 (j mod 1000), y of the local rows compared bitwise with the
+        entry-ordered FMA chains of the block's COO.  Overwrites x and y.  Returns (mismatching rows, checksum of the local y)."""
+        bad, cs = _i64(), C.c_double()
+        self._order(x, y)
+        _ck(lib().uspmv_dist_check(self.h, local_coo.h, _np_ptr(self._wsa), _dp(x), _dp(y), int(bool(use_graph)), self.stream.cuda_stream,
+                                   C.byref(bad), C.byref(cs)))
+        return bad.value, cs.value
+
+    def _order(self, *tensors):
+        """the object's stream is non-blocking: make it wait for whatever torch's current stream still does to the tensors
+        (zero fills, copies of new_x / new_y), and tell the caching allocator the tensors are used on it"""
+        import torch
+        self.stream.wait_stream(torch.cuda.current_stream())
+        for t in tensors:
+            t.record_stream(self.stream)
+
     def spmv(self, x, y, comm_halos=True):
         """one eager step on the object's stream"""
+        self._order(x, y)
         _ck(lib().uspmv_dist_spmv(self.h, _dp(x), _dp(y), int(bool(comm_halos)), self.stream.cuda_stream))
         return y
 
     def spmmv(self, X, Y, b, layout=COLWISE, mode=0, comm_halos=True):
         """Y = A X for b vectors of leading dimension padded_vec_size; mode 0 bulkvec | 1 multivec | 2 singlevec (uspmv_dist_spmmv)."""
+        self._order(X, Y)
         _ck(lib().uspmv_dist_spmmv(self.h, _dp(X), _dp(Y), int(b), int(layout), int(mode), int(bool(comm_halos)), self.stream.cuda_stream))
         return Y
 
@@ -448,6 +615,7 @@ class DistNative:
         return X
 
     def run(self, x, y, n_steps, use_graph=False):
+        self._order(x, y)
         _ck(lib().uspmv_dist_run(self.h, _dp(x), _dp(y), int(n_steps), int(bool(use_graph)), self.stream.cuda_stream))
         return y
 

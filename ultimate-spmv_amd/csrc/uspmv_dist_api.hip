@@ -1,21 +1,27 @@
-// Distributed SpMV step on RCCL (xGMI), in C++ behind the C ABI (include/uspmv.h, section L4b).
+// Distributed SpMV step on RCCL (xGMI), in C++ behind the C ABI (include/uspmv.h, sections L4a / L4b).
 //
 // Replaces the per-iteration part of the reference's MPI flow for the single-vector one-precision path:
 //   init_local_structs            code/main.cpp:1075-1334      (partition block -> SELL-C-sigma, halo discovery)
 //   collect_comm_info             code/mpi_funcs.hpp:1061-1124 (who sends what to whom)
 //   init/finalize_halo_exchange   code/classes_structs.hpp:857-995
-//   the iteration of bench_spmv   code/main.cpp:458-474        (exchange, then kernel)
+//   the iteration of bench_spmv   code/main.cpp:458-474        (exchange, then kernel, then the -ba_synch barrier)
 // One process per GPU.  Per SpMV: ONE pack kernel over the concatenated send list, ONE grouped ncclSend/ncclRecv with every
 // receive landing directly in x[n_local + recv_cumsum[p]] (the reference's halo numbering) on a side stream, the tiles /
 // chunks that touch no halo column meanwhile on the caller's stream, the boundary ones after the exchange.  The whole step
-// (two streams, two events, three kernels, the RCCL group) can be captured once into a hipGraph and replayed: per step the
-// host then pays one hipGraphLaunch instead of ~12 runtime calls (the strong-scaling regime of BASELINE config 5, where a
-// rank's kernel takes < 0.2 ms).
+// (two streams, two events, three kernels, the RCCL group, the optional barrier) can be captured once into a hipGraph and
+// replayed: per step the host then pays one hipGraphLaunch instead of ~12 runtime calls (the strong-scaling regime of
+// BASELINE config 5, where a rank's kernel takes < 0.2 ms).
+//
+// Set-up ("who sends what to whom") runs over a uspmv_transport (host/comm_plan.cpp): RCCL with device staging by default,
+// the host communicator when the caller passes one (real processes on a CPU box test exactly this code), identity in loopback.
 //
 // Loopback (comm_size == 1 and P > 1): this process plays logical rank `rank` of a P-way partition and every neighbour is
 // itself -- sends and receives become RCCL self send/recv pairs of the ids it asked for.  With an x that repeats with the
 // block height this reproduces the true multi-rank result for the rank's rows; it is how a single-GPU box exercises the
-// RCCL path end to end (tests/test_dist_native_gpu.py).
+// RCCL calls end to end (tests/test_dist_native_gpu.py).  It needs equal block heights (seg-rows on a divisible size): the
+// ids a rank asks block p for index p's rows, and the set-up refuses ids outside this block.
+// USPMV_EXCHANGE_HOST: the per-step exchange staged through host memory over the transport -- P real processes may then share
+// ONE GPU, which is how the step runs with unequal seg-nnz blocks and asymmetric lists on a single-GPU box.
 #include <rccl/rccl.h>
 
 #include <string>
@@ -24,19 +30,24 @@
 
 struct uspmv_dist {
     int rank = 0, P = 1, comm_rank = 0, comm_size = 1;
-    bool loopback = false, overlap = true, tiles = false, owns_setup = false, no_pack = false;
+    bool loopback = false, overlap = true, tiles = false, owns_setup = false, no_pack = false, ba_synch = false, host_exchange = false;
+    bool diag_skip_exchange = false;
+    int capture_mode = hipStreamCaptureModeRelaxed;
     ncclComm_t comm = nullptr;
-    hipStream_t comm_stream = nullptr;
+    uspmv_transport_t tr{};           // set-up transport (and the per-step one of USPMV_EXCHANGE_HOST)
+    hipStream_t side_stream = nullptr;
     hipEvent_t ev_main = nullptr, ev_comm = nullptr;
     uspmv_dmat_t *A = nullptr;
     uspmv_scs_t *scs = nullptr;       // owned when built by uspmv_dist_create_from_coo
     uspmv_halo_t *halo = nullptr;
+    uspmv_comm_plan_t *plan = nullptr;
     int dtype = USPMV_F64;
     int64_t n_local = 0, n_halo = 0, n_send = 0, n_int = 0, n_bnd = 0, vec_len = 0, n_rows_padded = 0;
     std::vector<int64_t> send_off, recv_off;
     std::vector<int32_t> recv_counts;
     int32_t *d_send_idxs = nullptr, *d_perm = nullptr, *d_int = nullptr, *d_bnd = nullptr;
     void *d_send = nullptr;
+    void *h_send = nullptr, *h_recv = nullptr;   // pinned staging of USPMV_EXCHANGE_HOST
     int *d_scratch = nullptr;
     // captured step
     hipGraphExec_t gexec = nullptr;
@@ -65,11 +76,75 @@ namespace {
 
 inline int peer(const uspmv_dist *D, int p) { return D->loopback ? 0 : p; }
 inline ncclDataType_t nccl_vt(const uspmv_dist *D) { return D->dtype == USPMV_F64 ? ncclDouble : ncclFloat; }
+inline size_t vsize(const uspmv_dist *D) { return D->dtype == USPMV_F64 ? 8 : 4; }
 
-int exchange(uspmv_dist *D, void *d_x, hipStream_t st) {
-    const size_t vsz = D->dtype == USPMV_F64 ? 8 : 4;
+// ---- set-up transports that live in this file: RCCL with device staging, identity for loopback
+struct DevBuf {   // scoped device allocation: freed on every return path
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 16)); }
+};
+
+int rccl_alltoallv(void *ctx, const void *send, const int64_t *so, void *recv, const int64_t *ro) {
+    auto *D = (uspmv_dist *)ctx;
+    const int P = D->comm_size;
+    const int64_t sb = so[P] - so[0], rb = ro[P] - ro[0];
+    DevBuf ds, dr;
+    HIP_TRY(ds.alloc((size_t)sb));
+    HIP_TRY(dr.alloc((size_t)rb));
+    if (sb) HIP_TRY(hipMemcpy(ds.p, (const char *)send + so[0], (size_t)sb, hipMemcpyHostToDevice));
+    hipStream_t st = D->side_stream;
+    NCCL_TRY(ncclGroupStart());
+    for (int q = 0; q < P; ++q) {
+        const int64_t ns = so[q + 1] - so[q], nr = ro[q + 1] - ro[q];
+        if (nr) NCCL_TRY(ncclRecv((char *)dr.p + (ro[q] - ro[0]), (size_t)nr, ncclInt8, q, D->comm, st));
+        if (ns) NCCL_TRY(ncclSend((const char *)ds.p + (so[q] - so[0]), (size_t)ns, ncclInt8, q, D->comm, st));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    HIP_TRY(hipStreamSynchronize(st));
+    if (rb) HIP_TRY(hipMemcpy((char *)recv + ro[0], dr.p, (size_t)rb, hipMemcpyDeviceToHost));
+    return USPMV_OK;
+}
+int rccl_allgather(void *ctx, const void *send, void *recv, int64_t bytes) {
+    auto *D = (uspmv_dist *)ctx;
+    if (bytes == 0) return USPMV_OK;
+    DevBuf ds, dr;
+    HIP_TRY(ds.alloc((size_t)bytes));
+    HIP_TRY(dr.alloc((size_t)bytes * (size_t)D->comm_size));
+    HIP_TRY(hipMemcpy(ds.p, send, (size_t)bytes, hipMemcpyHostToDevice));
+    NCCL_TRY(ncclAllGather(ds.p, dr.p, (size_t)bytes, ncclInt8, D->comm, D->side_stream));
+    HIP_TRY(hipStreamSynchronize(D->side_stream));
+    HIP_TRY(hipMemcpy(recv, dr.p, (size_t)bytes * (size_t)D->comm_size, hipMemcpyDeviceToHost));
+    return USPMV_OK;
+}
+int rccl_barrier(void *ctx) {
+    auto *D = (uspmv_dist *)ctx;
+    NCCL_TRY(ncclAllReduce(D->d_scratch, D->d_scratch, 1, ncclInt32, ncclSum, D->comm, D->side_stream));
+    HIP_TRY(hipStreamSynchronize(D->side_stream));
+    return USPMV_OK;
+}
+// loopback: "rank p needs from me" := what I asked p for -- every exchange is the identity on this process
+int self_alltoallv(void *ctx, const void *send, const int64_t *so, void *recv, const int64_t *ro) {
+    const int P = ((uspmv_dist *)ctx)->P;
+    for (int q = 0; q < P; ++q) {
+        if (so[q + 1] - so[q] != ro[q + 1] - ro[q]) return uspmv::fail(USPMV_ERR_INVALID, "loopback all-to-all-v: segment lengths differ");
+        if (so[q + 1] > so[q]) memmove((char *)recv + ro[q], (const char *)send + so[q], (size_t)(so[q + 1] - so[q]));
+    }
+    return USPMV_OK;
+}
+int self_allgather(void *ctx, const void *send, void *recv, int64_t bytes) {
+    const int P = ((uspmv_dist *)ctx)->P;
+    for (int q = 0; q < P; ++q) memcpy((char *)recv + (size_t)q * (size_t)bytes, send, (size_t)bytes);
+    return USPMV_OK;
+}
+int self_barrier(void *) { return USPMV_OK; }
+
+// ---- the per-step exchange
+int exchange_rccl(uspmv_dist *D, void *d_x, hipStream_t st) {
+    const size_t vsz = vsize(D);
     if (!D->no_pack)
         if (int rc = uspmv_pack_send_buf(d_x, D->d_perm, D->d_send_idxs, D->n_send, 0, D->d_send, D->dtype, st)) return rc;
+    if (D->diag_skip_exchange) return USPMV_OK;
     NCCL_TRY(ncclGroupStart());
     for (int p = 0; p < D->P; ++p) {
         const int64_t ns = D->send_off[(size_t)p + 1] - D->send_off[(size_t)p], nr = D->recv_counts[(size_t)p];
@@ -80,25 +155,62 @@ int exchange(uspmv_dist *D, void *d_x, hipStream_t st) {
     return USPMV_OK;
 }
 
+// USPMV_EXCHANGE_HOST: pack -> pinned host buffer -> all-to-all-v over the transport -> tail of x.  The host waits for the
+// pack (and returns with the upload queued on `st`), so the caller may queue independent device work on another stream first.
+int exchange_host(uspmv_dist *D, void *d_x, hipStream_t st) {
+    const size_t vsz = vsize(D);
+    if (!D->no_pack)
+        if (int rc = uspmv_pack_send_buf(d_x, D->d_perm, D->d_send_idxs, D->n_send, 0, D->d_send, D->dtype, st)) return rc;
+    if (D->n_send) HIP_TRY(hipMemcpyAsync(D->h_send, D->d_send, (size_t)D->n_send * vsz, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<int64_t> so((size_t)D->P + 1), ro((size_t)D->P + 1);
+    for (int p = 0; p <= D->P; ++p) { so[(size_t)p] = D->send_off[(size_t)p] * (int64_t)vsz; ro[(size_t)p] = D->recv_off[(size_t)p] * (int64_t)vsz; }
+    if (int rc = D->tr.alltoallv(D->tr.ctx, D->h_send, so.data(), D->h_recv, ro.data())) return rc;
+    if (D->n_halo) HIP_TRY(hipMemcpyAsync((char *)d_x + (size_t)D->n_local * vsz, D->h_recv, (size_t)D->n_halo * vsz, hipMemcpyHostToDevice, st));
+    return USPMV_OK;
+}
+
+inline int exchange(uspmv_dist *D, void *d_x, hipStream_t st) { return D->host_exchange ? exchange_host(D, d_x, st) : exchange_rccl(D, d_x, st); }
+
 int part(uspmv_dist *D, const int32_t *ids, int64_t n, const void *x, void *y, hipStream_t st) {
     if (n == 0) return USPMV_OK;
     return D->tiles ? uspmv_spmv_tiles(D->A, ids, n, x, y, st) : uspmv_spmv_chunks(D->A, ids, n, x, y, st);
 }
 
-// one SpMV: exchange on the side stream, interior meanwhile, boundary after it
+// -ba_synch 1: the barrier the reference issues after every iteration (code/main.cpp:467, :417; default on,
+// code/classes_structs.hpp:90) as a stream-ordered one-element all-reduce -- no rank's next step starts before every rank has
+// finished this one, and the host is not involved (so it is part of the captured graph)
+int step_barrier(uspmv_dist *D, hipStream_t main) {
+    if (!D->ba_synch || D->P == 1) return USPMV_OK;
+    if (D->host_exchange) {
+        HIP_TRY(hipStreamSynchronize(main));
+        return D->tr.barrier ? D->tr.barrier(D->tr.ctx) : USPMV_OK;
+    }
+    if (D->diag_skip_exchange) return USPMV_OK;
+    NCCL_TRY(ncclAllReduce(D->d_scratch, D->d_scratch + 1, 1, ncclInt32, ncclSum, D->comm, main));
+    return USPMV_OK;
+}
+
+// One SpMV: the interior tiles on the side stream, the exchange meanwhile on the caller's stream, the boundary tiles after both.
+// The RCCL group stays on the CALLER's stream on purpose: when the step is captured, that is the capture's origin stream.  Under
+// the HIP 7.0 / RCCL 2.26 pair that torch bundles, hipStreamEndCapture crashes if an RCCL p2p group was captured on a stream that
+// JOINED the capture through an event, while the same group on the origin stream, and kernels on joined streams, capture fine
+// (profiles/r03/graph_capture_diag.txt; the system's HIP 7.2 / RCCL 2.27 takes either form).  Same DAG, same overlap.
 int step(uspmv_dist *D, void *d_x, void *d_y, hipStream_t main, bool comm_halos) {
     if (D->P == 1 || !comm_halos) return uspmv_spmv(D->A, d_x, d_y, main);
     if (!D->overlap) {
         if (int rc = exchange(D, d_x, main)) return rc;
-        return uspmv_spmv(D->A, d_x, d_y, main);
+        if (int rc = uspmv_spmv(D->A, d_x, d_y, main)) return rc;
+        return step_barrier(D, main);
     }
-    HIP_TRY(hipEventRecord(D->ev_main, main));
-    HIP_TRY(hipStreamWaitEvent(D->comm_stream, D->ev_main, 0));
-    if (int rc = exchange(D, d_x, D->comm_stream)) return rc;
-    HIP_TRY(hipEventRecord(D->ev_comm, D->comm_stream));
-    if (int rc = part(D, D->d_int, D->n_int, d_x, d_y, main)) return rc;
-    HIP_TRY(hipStreamWaitEvent(main, D->ev_comm, 0));
-    return part(D, D->d_bnd, D->n_bnd, d_x, d_y, main);
+    HIP_TRY(hipEventRecord(D->ev_main, main));                       // fork: everything queued on `main` so far precedes the interior tiles
+    HIP_TRY(hipStreamWaitEvent(D->side_stream, D->ev_main, 0));
+    if (int rc = part(D, D->d_int, D->n_int, d_x, d_y, D->side_stream)) return rc;
+    HIP_TRY(hipEventRecord(D->ev_comm, D->side_stream));
+    if (int rc = exchange(D, d_x, main)) return rc;                  // pack kernel + grouped send / recv into the tail of x (host mode: blocks the host)
+    HIP_TRY(hipStreamWaitEvent(main, D->ev_comm, 0));                // join
+    if (int rc = part(D, D->d_bnd, D->n_bnd, d_x, d_y, main)) return rc;
+    return step_barrier(D, main);
 }
 
 void drop_graph(uspmv_dist *D) {
@@ -112,7 +224,7 @@ int capture(uspmv_dist *D, void *d_x, void *d_y, hipStream_t main) {
     drop_graph(D);
     hipGraph_t g = nullptr;
     DBG("begin");
-    hipError_t e = hipStreamBeginCapture(main, hipStreamCaptureModeRelaxed);
+    hipError_t e = hipStreamBeginCapture(main, (hipStreamCaptureMode)D->capture_mode);
     if (e != hipSuccess) { (void)hipGetLastError(); return uspmv::fail(USPMV_ERR_HIP, "uspmv_dist_run: hipStreamBeginCapture: %s", hipGetErrorString(e)); }
     const int rc = step(D, d_x, d_y, main, true);
     DBG("step issued");
@@ -144,6 +256,14 @@ int uspmv_comm_unique_id(void *id128) {
     return USPMV_OK;
 }
 
+int uspmv_runtime_versions(int v[4]) {
+    if (!v) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_runtime_versions: NULL argument");
+    v[0] = HIP_VERSION; v[1] = 0; v[2] = NCCL_VERSION_CODE; v[3] = 0;
+    (void)hipRuntimeGetVersion(&v[1]);
+    (void)ncclGetVersion(&v[3]);
+    return USPMV_OK;
+}
+
 void uspmv_dist_free(uspmv_dist_t *D) {
     if (!D) return;
     drop_graph(D);
@@ -152,82 +272,78 @@ void uspmv_dist_free(uspmv_dist_t *D) {
         for (int32_t *u : bp.d_unpack) (void)hipFree(u);
     }
     (void)hipFree(D->d_send_idxs); (void)hipFree(D->d_perm); (void)hipFree(D->d_int); (void)hipFree(D->d_bnd); (void)hipFree(D->d_send); (void)hipFree(D->d_scratch);
+    if (D->h_send) (void)hipHostFree(D->h_send);
+    if (D->h_recv) (void)hipHostFree(D->h_recv);
     if (D->ev_main) (void)hipEventDestroy(D->ev_main);
     if (D->ev_comm) (void)hipEventDestroy(D->ev_comm);
-    if (D->comm_stream) (void)hipStreamDestroy(D->comm_stream);
+    if (D->side_stream) (void)hipStreamDestroy(D->side_stream);
     if (D->comm) (void)ncclCommDestroy(D->comm);
+    uspmv_comm_plan_free(D->plan);
     if (D->owns_setup) { uspmv_dmat_free(D->A); uspmv_halo_free(D->halo); uspmv_scs_free(D->scs); }
     delete D;
 }
 
-int uspmv_dist_create(const void *comm_id, int comm_rank, int comm_size, int rank, int P, uspmv_dmat_t *A, const uspmv_halo_t *halo,
-                      const int32_t *old_to_new_idx, const int32_t *interior_ids, int64_t n_interior, const int32_t *boundary_ids,
-                      int64_t n_boundary, int ids_are_tiles, uspmv_dist_t **out) {
-    if (!comm_id || !A || !halo || !out || P < 1 || rank < 0 || rank >= P || comm_size < 1 || comm_rank < 0 || comm_rank >= comm_size ||
-        n_interior < 0 || n_boundary < 0 || (n_interior > 0 && !interior_ids) || (n_boundary > 0 && !boundary_ids))
+int uspmv_dist_create_ex(const void *comm_id, int comm_rank, int comm_size, int rank, int P, uspmv_dmat_t *A, const uspmv_halo_t *halo,
+                         const int32_t *old_to_new_idx, const int32_t *interior_ids, int64_t n_interior, const int32_t *boundary_ids,
+                         int64_t n_boundary, int ids_are_tiles, const uspmv_dist_options_t *opt, uspmv_dist_t **out) {
+    const bool host_ex = opt && opt->exchange == USPMV_EXCHANGE_HOST;
+    if (opt && opt->exchange != USPMV_EXCHANGE_RCCL && opt->exchange != USPMV_EXCHANGE_HOST)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: unknown exchange %d", opt->exchange);
+    if (!A || !halo || !out || P < 1 || rank < 0 || rank >= P || n_interior < 0 || n_boundary < 0 || (n_interior > 0 && !interior_ids) ||
+        (n_boundary > 0 && !boundary_ids))
         return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: bad argument");
-    if (!(comm_size == P && comm_rank == rank) && !(comm_size == 1 && comm_rank == 0))
-        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: the communicator must have one rank per partition block (comm_size == P) or a single rank (loopback)");
+    if (host_ex) {
+        if (!opt->transport || !opt->transport->alltoallv) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: USPMV_EXCHANGE_HOST needs a transport");
+        comm_rank = rank; comm_size = P;
+    } else {
+        if (!comm_id || comm_size < 1 || comm_rank < 0 || comm_rank >= comm_size) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: bad communicator argument");
+        if (!(comm_size == P && comm_rank == rank) && !(comm_size == 1 && comm_rank == 0))
+            return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: the communicator must have one rank per partition block (comm_size == P) or a single rank (loopback)");
+    }
+    if (opt && opt->transport && (opt->transport->size != P || opt->transport->rank != rank))
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: the transport is rank %d of %d, the block is %d of %d", opt->transport->rank, opt->transport->size, rank, P);
     if (halo->P != P || halo->rank != rank) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: halo description belongs to another partition");
     if (halo->n_local > 0 && !old_to_new_idx) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: NULL permutation");
     if (int rc = uspmv_dev::check_dmat(A, "uspmv_dist_create")) return rc;
     if (int rc = uspmv_dev::require_device()) return rc;
     auto *D = new uspmv_dist;
-    D->rank = rank; D->P = P; D->comm_rank = comm_rank; D->comm_size = comm_size; D->loopback = comm_size == 1 && P > 1;
+    D->rank = rank; D->P = P; D->comm_rank = comm_rank; D->comm_size = comm_size; D->loopback = !host_ex && comm_size == 1 && P > 1;
+    D->host_exchange = host_ex;
     D->A = A; D->dtype = A->dtype; D->tiles = ids_are_tiles != 0;
     D->n_local = halo->n_local; D->n_halo = halo->n_halo; D->n_int = n_interior; D->n_bnd = n_boundary;
     D->recv_counts = halo->recv_counts;
-    D->recv_off.assign((size_t)P + 1, 0); D->send_off.assign((size_t)P + 1, 0);
-    for (int p = 0; p < P; ++p) D->recv_off[(size_t)p + 1] = D->recv_off[(size_t)p] + D->recv_counts[(size_t)p];
-    int rc = USPMV_OK;
     auto bail = [&](int code) { uspmv_dist_free(D); return code; };
 #define D_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bail(uspmv::fail(USPMV_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__)); } while (0)
 #define D_NCCL(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return bail(uspmv::fail(USPMV_ERR_HIP, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__)); } while (0)
-    ncclUniqueId id;
-    memcpy(&id, comm_id, sizeof id);
-    D_NCCL(ncclCommInitRank(&D->comm, comm_size, id, comm_rank));
-    D_HIP(hipStreamCreateWithFlags(&D->comm_stream, hipStreamNonBlocking));
+    if (!host_ex) {
+        ncclUniqueId id;
+        memcpy(&id, comm_id, sizeof id);
+        D_NCCL(ncclCommInitRank(&D->comm, comm_size, id, comm_rank));
+    }
+    D_HIP(hipStreamCreateWithFlags(&D->side_stream, hipStreamNonBlocking));
     D_HIP(hipEventCreateWithFlags(&D->ev_main, hipEventDisableTiming));
     D_HIP(hipEventCreateWithFlags(&D->ev_comm, hipEventDisableTiming));
     D_HIP(hipMalloc((void **)&D->d_scratch, 256));
     D_HIP(hipMemset(D->d_scratch, 0, 256));
-    hipStream_t st = D->comm_stream;
-    // ---- who sends what to whom (collect_comm_info): all-gather of the recv counts, then the requested ids travel to their owners
-    std::vector<int32_t> counts_all((size_t)P * P, 0);
-    if (D->loopback) {
-        for (int p = 0; p < P; ++p) counts_all[(size_t)p * P + rank] = D->recv_counts[(size_t)p];   // "p needs from me" := what I asked p for
-    } else {
-        int32_t *d_c = nullptr, *d_all = nullptr;
-        D_HIP(hipMalloc((void **)&d_c, 4 * (size_t)P));
-        D_HIP(hipMalloc((void **)&d_all, 4 * (size_t)P * P));
-        D_HIP(hipMemcpy(d_c, D->recv_counts.data(), 4 * (size_t)P, hipMemcpyHostToDevice));
-        D_NCCL(ncclAllGather(d_c, d_all, (size_t)P, ncclInt32, D->comm, st));
-        D_HIP(hipStreamSynchronize(st));
-        D_HIP(hipMemcpy(counts_all.data(), d_all, 4 * counts_all.size(), hipMemcpyDeviceToHost));
-        (void)hipFree(d_c); (void)hipFree(d_all);
-    }
-    for (int p = 0; p < P; ++p) D->send_off[(size_t)p + 1] = D->send_off[(size_t)p] + counts_all[(size_t)p * P + rank];
-    D->n_send = D->send_off[(size_t)P];
-    int32_t *d_recv_idxs = nullptr;
-    D_HIP(hipMalloc((void **)&d_recv_idxs, 4 * (size_t)std::max<int64_t>(D->n_halo, 1)));
-    D_HIP(hipMalloc((void **)&D->d_send_idxs, 4 * (size_t)std::max<int64_t>(D->n_send, 1)));
-    if (D->n_halo) D_HIP(hipMemcpy(d_recv_idxs, halo->recv_idxs.data(), 4 * (size_t)D->n_halo, hipMemcpyHostToDevice));
-    if (P > 1) {
-        D_NCCL(ncclGroupStart());
-        for (int p = 0; p < P; ++p) {
-            const int64_t ns = D->send_off[(size_t)p + 1] - D->send_off[(size_t)p], nr = D->recv_counts[(size_t)p];
-            if (nr) D_NCCL(ncclSend(d_recv_idxs + D->recv_off[(size_t)p], (size_t)nr, ncclInt32, peer(D, p), D->comm, st));
-            if (ns) D_NCCL(ncclRecv(D->d_send_idxs + D->send_off[(size_t)p], (size_t)ns, ncclInt32, peer(D, p), D->comm, st));
+    // ---- who sends what to whom (collect_comm_info, code/mpi_funcs.hpp:1061-1124) over the set-up transport
+    if (opt && opt->transport) D->tr = *opt->transport;
+    else if (D->loopback) { D->tr.ctx = D; D->tr.rank = rank; D->tr.size = P; D->tr.alltoallv = self_alltoallv; D->tr.allgather = self_allgather; D->tr.barrier = self_barrier; }
+    else { D->tr.ctx = D; D->tr.rank = comm_rank; D->tr.size = comm_size; D->tr.alltoallv = rccl_alltoallv; D->tr.allgather = rccl_allgather; D->tr.barrier = rccl_barrier; }
+    if (int rc = uspmv_comm_plan_create(&D->tr, halo, &D->plan)) {
+        if (D->loopback && rc == USPMV_ERR_INVALID) {
+            const std::string why = uspmv_last_error();
+            rc = uspmv::fail(USPMV_ERR_INVALID, "%s -- loopback needs equal block heights (seg-rows on a size divisible by P); unequal blocks run with real "
+                             "ranks (USPMV_EXCHANGE_HOST on one GPU, RCCL on several)", why.c_str());
         }
-        D_NCCL(ncclGroupEnd());
-        D_HIP(hipStreamSynchronize(st));
+        return bail(rc);
     }
-    (void)hipFree(d_recv_idxs);
-    D->h_send_idxs.resize((size_t)D->n_send);
-    if (D->n_send) D_HIP(hipMemcpy(D->h_send_idxs.data(), D->d_send_idxs, 4 * (size_t)D->n_send, hipMemcpyDeviceToHost));
+    D->send_off = D->plan->send_off; D->recv_off = D->plan->recv_off; D->n_send = D->plan->n_send;
+    D->h_send_idxs = D->plan->send_idxs;
     D->h_perm.assign(old_to_new_idx, old_to_new_idx + D->n_local);
     // ---- device state of the step
-    const size_t vsz = D->dtype == USPMV_F64 ? 8 : 4;
+    const size_t vsz = vsize(D);
+    D_HIP(hipMalloc((void **)&D->d_send_idxs, 4 * (size_t)std::max<int64_t>(D->n_send, 1)));
+    if (D->n_send) D_HIP(hipMemcpy(D->d_send_idxs, D->h_send_idxs.data(), 4 * (size_t)D->n_send, hipMemcpyHostToDevice));
     D_HIP(hipMalloc((void **)&D->d_perm, 4 * (size_t)std::max<int64_t>(D->n_local, 1)));
     if (D->n_local) D_HIP(hipMemcpy(D->d_perm, old_to_new_idx, 4 * (size_t)D->n_local, hipMemcpyHostToDevice));
     D_HIP(hipMalloc((void **)&D->d_int, 4 * (size_t)std::max<int64_t>(n_interior, 1)));
@@ -235,17 +351,28 @@ int uspmv_dist_create(const void *comm_id, int comm_rank, int comm_size, int ran
     if (n_interior) D_HIP(hipMemcpy(D->d_int, interior_ids, 4 * (size_t)n_interior, hipMemcpyHostToDevice));
     if (n_boundary) D_HIP(hipMemcpy(D->d_bnd, boundary_ids, 4 * (size_t)n_boundary, hipMemcpyHostToDevice));
     D_HIP(hipMalloc(&D->d_send, vsz * (size_t)std::max<int64_t>(D->n_send, 1)));
+    if (host_ex) {
+        D_HIP(hipHostMalloc(&D->h_send, vsz * (size_t)std::max<int64_t>(D->n_send, 1), hipHostMallocDefault));
+        D_HIP(hipHostMalloc(&D->h_recv, vsz * (size_t)std::max<int64_t>(D->n_halo, 1), hipHostMallocDefault));
+    }
     D->n_rows_padded = A->n_chunks * A->C;
     D->vec_len = D->n_local + std::max(D->n_rows_padded - D->n_local, D->n_halo);       // padded_vec_size (code/main.cpp:1406-1412)
 #undef D_HIP
 #undef D_NCCL
-    (void)rc;
     *out = D;
     return USPMV_OK;
 }
 
-int uspmv_dist_create_from_coo(const void *comm_id, int comm_rank, int comm_size, int rank, int P, const uspmv_coo_t *local,
-                               const int32_t *wsa, int64_t C, int64_t sigma, int dtype, int tlc, uspmv_dist_t **out) {
+int uspmv_dist_create(const void *comm_id, int comm_rank, int comm_size, int rank, int P, uspmv_dmat_t *A, const uspmv_halo_t *halo,
+                      const int32_t *old_to_new_idx, const int32_t *interior_ids, int64_t n_interior, const int32_t *boundary_ids,
+                      int64_t n_boundary, int ids_are_tiles, uspmv_dist_t **out) {
+    return uspmv_dist_create_ex(comm_id, comm_rank, comm_size, rank, P, A, halo, old_to_new_idx, interior_ids, n_interior, boundary_ids, n_boundary,
+                                ids_are_tiles, nullptr, out);
+}
+
+int uspmv_dist_create_from_coo_ex(const void *comm_id, int comm_rank, int comm_size, int rank, int P, const uspmv_coo_t *local,
+                                  const int32_t *wsa, int64_t C, int64_t sigma, int dtype, int tlc, const uspmv_dist_options_t *opt,
+                                  uspmv_dist_t **out) {
     if (!local || !wsa || !out) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create_from_coo: NULL argument");
     if (P < 1 || rank < 0 || rank >= P) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create_from_coo: bad rank / P");
     if (int rc = uspmv_dev::require_device()) return rc;
@@ -282,11 +409,37 @@ int uspmv_dist_create_from_coo(const void *comm_id, int comm_rank, int comm_size
     }
     uspmv_free(interior); uspmv_free(boundary); interior = boundary = nullptr;
     uspmv_dist_t *D = nullptr;
-    rc = uspmv_dist_create(comm_id, comm_rank, comm_size, rank, P, A, halo, o2n, ids_int.data(), (int64_t)ids_int.size(), ids_bnd.data(),
-                           (int64_t)ids_bnd.size(), use_tiles ? 1 : 0, &D);
+    rc = uspmv_dist_create_ex(comm_id, comm_rank, comm_size, rank, P, A, halo, o2n, ids_int.data(), (int64_t)ids_int.size(), ids_bnd.data(),
+                              (int64_t)ids_bnd.size(), use_tiles ? 1 : 0, opt, &D);
     if (rc) { cleanup(); return rc; }
     D->owns_setup = true; D->scs = scs; D->halo = halo;
     *out = D;
+    return USPMV_OK;
+}
+
+int uspmv_dist_create_from_coo(const void *comm_id, int comm_rank, int comm_size, int rank, int P, const uspmv_coo_t *local,
+                               const int32_t *wsa, int64_t C, int64_t sigma, int dtype, int tlc, uspmv_dist_t **out) {
+    return uspmv_dist_create_from_coo_ex(comm_id, comm_rank, comm_size, rank, P, local, wsa, C, sigma, dtype, tlc, nullptr, out);
+}
+
+int uspmv_dist_comm_plan(const uspmv_dist_t *D, int64_t *n_send, const int64_t **send_off, const int32_t **send_idxs, const int64_t **recv_off) {
+    if (!D || !D->plan) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_comm_plan: NULL argument");
+    return uspmv_comm_plan_meta(D->plan, n_send, send_off, send_idxs, recv_off);
+}
+
+int uspmv_dist_set_option(uspmv_dist_t *D, const char *key, int value) {
+    if (!D || !key) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_option: NULL argument");
+    const std::string k(key);
+    if (k == "overlap") { if ((value != 0) != D->overlap) drop_graph(D); D->overlap = value != 0; }
+    else if (k == "no_pack") { if ((value != 0) != D->no_pack) drop_graph(D); D->no_pack = value != 0; }
+    else if (k == "ba_synch") { if ((value != 0) != D->ba_synch) drop_graph(D); D->ba_synch = value != 0; }
+    else if (k == "capture_mode") {
+        if (value < 0 || value > 2) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_option: capture_mode is 0 (global), 1 (thread-local) or 2 (relaxed)");
+        D->capture_mode = value == 0 ? hipStreamCaptureModeGlobal : value == 1 ? hipStreamCaptureModeThreadLocal : hipStreamCaptureModeRelaxed;
+        drop_graph(D); D->graph_failed = false;
+    }
+    else if (k == "diag_skip_exchange") { drop_graph(D); D->diag_skip_exchange = value != 0; }
+    else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_option: unknown key '%s'", key);
     return USPMV_OK;
 }
 
@@ -329,7 +482,7 @@ int uspmv_dist_spmv(uspmv_dist_t *D, void *d_x, void *d_y, int comm_halos, void 
 int uspmv_dist_run(uspmv_dist_t *D, void *d_x, void *d_y, int n_steps, int use_graph, void *stream) {
     if (!D || !d_x || !d_y || n_steps < 0) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_run: bad argument");
     hipStream_t main = (hipStream_t)stream;
-    if (use_graph && D->P > 1 && !D->graph_failed) {
+    if (use_graph && D->P > 1 && !D->graph_failed && !D->host_exchange) {   // (the host-staged exchange blocks the host: nothing to capture)
         if (!main) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_run: graph replay needs an explicit (non-default) stream");
         if (!D->gexec || D->g_x != d_x || D->g_y != d_y || D->g_stream != main) {
             // RCCL sets up its p2p channels at the first use of a pair: one eager step before the capture
@@ -356,13 +509,24 @@ int uspmv_dist_run(uspmv_dist_t *D, void *d_x, void *d_y, int n_steps, int use_g
 
 int uspmv_dist_barrier(uspmv_dist_t *D, void *stream) {
     if (!D) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_barrier: NULL argument");
-    NCCL_TRY(ncclAllReduce(D->d_scratch, D->d_scratch, 1, ncclInt32, ncclSum, D->comm, (hipStream_t)stream));
+    if (D->host_exchange) {
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        return D->tr.barrier ? D->tr.barrier(D->tr.ctx) : USPMV_OK;
+    }
+    NCCL_TRY(ncclAllReduce(D->d_scratch, D->d_scratch + 1, 1, ncclInt32, ncclSum, D->comm, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return USPMV_OK;
 }
 
 int uspmv_dist_allreduce_max(uspmv_dist_t *D, double *value, void *stream) {
     if (!D || !value) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_allreduce_max: NULL argument");
+    if (D->host_exchange) {
+        if (!D->tr.allgather) return uspmv::fail(USPMV_ERR_UNSUPPORTED, "uspmv_dist_allreduce_max: the transport has no all-gather");
+        std::vector<double> all((size_t)D->P, *value);
+        if (int rc = D->tr.allgather(D->tr.ctx, value, all.data(), 8)) return rc;
+        for (double v : all) *value = std::max(*value, v);
+        return USPMV_OK;
+    }
     double *d_t = (double *)(D->d_scratch + 16);
     HIP_TRY(hipMemcpy(d_t, value, 8, hipMemcpyHostToDevice));
     NCCL_TRY(ncclAllReduce(d_t, d_t, 1, ncclDouble, ncclMax, D->comm, (hipStream_t)stream));
@@ -374,16 +538,55 @@ int uspmv_dist_allreduce_max(uspmv_dist_t *D, double *value, void *stream) {
 int uspmv_dist_allgather_i64(uspmv_dist_t *D, int64_t value, int64_t *all, void *stream) {
     if (!D || !all) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_allgather_i64: NULL argument");
     if (D->loopback) { for (int p = 0; p < D->P; ++p) all[p] = value; return USPMV_OK; }
-    int64_t *d_v = nullptr, *d_all = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_v, 8));
-    HIP_TRY(hipMalloc((void **)&d_all, 8 * (size_t)D->comm_size));
-    HIP_TRY(hipMemcpy(d_v, &value, 8, hipMemcpyHostToDevice));
-    ncclResult_t r = ncclAllGather(d_v, d_all, 1, ncclInt64, D->comm, (hipStream_t)stream);
-    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
-    if (r == ncclSuccess && e == hipSuccess) e = hipMemcpy(all, d_all, 8 * (size_t)D->comm_size, hipMemcpyDeviceToHost);
-    (void)hipFree(d_v); (void)hipFree(d_all);
-    if (r != ncclSuccess) return uspmv::fail(USPMV_ERR_HIP, "uspmv_dist_allgather_i64: %s", ncclGetErrorString(r));
-    if (e != hipSuccess) return uspmv::fail(USPMV_ERR_HIP, "uspmv_dist_allgather_i64: %s", hipGetErrorString(e));
+    if (D->host_exchange) {
+        if (!D->tr.allgather) return uspmv::fail(USPMV_ERR_UNSUPPORTED, "uspmv_dist_allgather_i64: the transport has no all-gather");
+        return D->tr.allgather(D->tr.ctx, &value, all, 8);
+    }
+    DevBuf d_v, d_all;
+    HIP_TRY(d_v.alloc(8));
+    HIP_TRY(d_all.alloc(8 * (size_t)D->comm_size));
+    HIP_TRY(hipMemcpy(d_v.p, &value, 8, hipMemcpyHostToDevice));
+    NCCL_TRY(ncclAllGather(d_v.p, d_all.p, 1, ncclInt64, D->comm, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(all, d_all.p, 8 * (size_t)D->comm_size, hipMemcpyDeviceToHost));
+    return USPMV_OK;
+}
+
+// Self-check of the distributed path on the object's own matrix (include/uspmv.h): x_global[j] = 1 + 1e-3 * (j mod 1000), one
+// step, y of the local rows compared bitwise with the entry-ordered FMA chains of the block's COO (host/dist_check.cpp).
+int uspmv_dist_check(uspmv_dist_t *D, const uspmv_coo_t *local, const int32_t *wsa, void *d_x, void *d_y, int use_graph, void *stream,
+                     int64_t *mismatches, double *checksum) {
+    if (!D || !local || !wsa || !d_x || !d_y) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_check: NULL argument");
+    if (!D->scs) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_check: needs an object made by uspmv_dist_create_from_coo (it owns the row permutation)");
+    if (local->n_rows != D->n_local || wsa[D->rank + 1] - wsa[D->rank] != D->n_local)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_check: the COO block has %ld rows, the object %ld", (long)local->n_rows, (long)D->n_local);
+    const size_t vsz = vsize(D);
+    const int64_t nl = D->n_local;
+    hipStream_t st = (hipStream_t)stream;
+    // x in the kernel's (permuted) order: x_perm[k] = x_global[wsa[rank] + new_to_old[k]]; halo tail and padding zero
+    std::vector<char> hx((size_t)D->vec_len * vsz, 0), hy((size_t)D->vec_len * vsz);
+    const int32_t *n2o = D->scs->new_to_old_idx.data(), *o2n = D->scs->old_to_new_idx.data();
+    for (int64_t k = 0; k < nl; ++k) {
+        const double v = uspmv::check_x((int64_t)wsa[D->rank] + n2o[k]);
+        if (D->dtype == USPMV_F64) ((double *)hx.data())[k] = v; else ((float *)hx.data())[k] = (float)v;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(d_x, hx.data(), hx.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_y, 0xff, (size_t)D->n_rows_padded * vsz));            // NaN pattern: a row nobody writes cannot pass
+    if (int rc = uspmv_dist_run(D, d_x, d_y, 1, use_graph, stream)) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(hy.data(), d_y, (size_t)D->n_rows_padded * vsz, hipMemcpyDeviceToHost));
+    std::vector<char> ref((size_t)std::max<int64_t>(nl, 1) * vsz);
+    if (int rc = uspmv::dist_reference_rows(local, wsa, D->P, D->rank, D->loopback, D->dtype, ref.data())) return rc;
+    int64_t bad = 0;
+    double sum = 0.0;
+    for (int64_t i = 0; i < nl; ++i) {   // copy_back_result: y_orig[i] = y[old_to_new[i]] (code/utilities.hpp:3862)
+        const char *got = hy.data() + (size_t)o2n[i] * vsz, *want = ref.data() + (size_t)i * vsz;
+        if (memcmp(got, want, vsz) != 0) ++bad;
+        sum += D->dtype == USPMV_F64 ? *(const double *)got : (double)*(const float *)got;
+    }
+    if (mismatches) *mismatches = bad;
+    if (checksum) *checksum = sum;
     return USPMV_OK;
 }
 
@@ -490,7 +693,10 @@ extern "C" int uspmv_dist_spmmv(uspmv_dist_t *D, void *d_X, void *d_Y, int b, in
     if (mode != USPMV_BULKVEC && mode != USPMV_MULTIVEC && mode != USPMV_SINGLEVEC) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_spmmv: unknown mode %d", mode);
     if (layout == USPMV_ROWWISE && mode != USPMV_BULKVEC)
         return uspmv::fail(USPMV_ERR_UNSUPPORTED, "uspmv_dist_spmmv: row-wise block vectors travel in one message per neighbour (bulkvec) only");
-    if (D->P > 1 && comm_halos)
+    if (D->P > 1 && comm_halos) {
+        if (D->host_exchange) return uspmv::fail(USPMV_ERR_UNSUPPORTED, "uspmv_dist_spmmv: block vectors are exchanged on RCCL only (USPMV_EXCHANGE_HOST is the single-vector test transport)");
         if (int rc = exchange_block(D, d_X, b, layout, mode, (hipStream_t)stream)) return rc;
-    return uspmv_spmmv(D->A, d_X, d_Y, b, D->vec_len, layout, stream);
+    }
+    if (int rc = uspmv_spmmv(D->A, d_X, d_Y, b, D->vec_len, layout, stream)) return rc;
+    return D->P > 1 && comm_halos ? step_barrier(D, (hipStream_t)stream) : USPMV_OK;   // -ba_synch
 }

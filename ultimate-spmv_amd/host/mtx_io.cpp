@@ -84,6 +84,7 @@ const char *uspmv_status_string(int s) {
         case USPMV_ERR_NO_DEVICE: return "no HIP device";
         case USPMV_ERR_HIP: return "HIP runtime error";
         case USPMV_ERR_ALLOC: return "allocation failed";
+        case USPMV_ERR_COMM: return "communication failure (peer rank)";
     }
     return "unknown status";
 }

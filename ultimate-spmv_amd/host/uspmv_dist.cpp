@@ -9,15 +9,24 @@
 // rank discovery, the RCCL id hand-off, the per-rank matrix block, the bench protocol and the report.
 //
 // Launch: any launcher that exports RANK / WORLD_SIZE / LOCAL_RANK (torchrun, srun with a wrapper,
-// `for r in ...; do RANK=$r WORLD_SIZE=$N LOCAL_RANK=$r uspmv ... & done`).  The RCCL unique id travels
-// through a file under $USPMV_ID_DIR (default /tmp) keyed by $MASTER_PORT / $USPMV_JOB_ID.
+// `for r in ...; do RANK=$r WORLD_SIZE=$N LOCAL_RANK=$r uspmv ... & done`).  The ranks of one node meet in a host communicator
+// (uspmv_hostcomm_*, host/hostcomm.cpp) keyed by $USPMV_JOB_ID / $MASTER_PORT: the RCCL unique id, the partition and the set-up
+// exchanges of collect_comm_info travel through it (USPMV_SETUP_TRANSPORT=rccl moves the latter onto the RCCL communicator); the
+// per-step halo exchange is RCCL.  A leftover of a crashed job cannot be picked up (dead creator / fresh nonce per segment).
 //
 // Every rank holds ONLY its row block: generated matrices (gen:...) are generated per block (the partition comes from the
-// analytic row counts); a .mtx file is read by rank 0 alone, which writes one binary block per rank next to the id file --
-// the reference's root-reads-and-scatters (code/mpi_funcs.hpp:739-860) without MPI.
+// analytic row counts); a .mtx file is read by rank 0 alone, which writes one binary block per rank (file names carry the
+// segment's nonce) -- the reference's root-reads-and-scatters (code/mpi_funcs.hpp:739-860) without MPI.
+//
+// Protocols: the reference's (100 warm-ups, doubling batches until -bench_time, code/main.cpp:408-474) by default;
+// `-bench_steps K [-bench_warmup W]` times EXACTLY K steps between barriers (what bench.py --gpus N asks for).  -ba_synch 1
+// (default, as in the reference) puts a barrier behind every step (a stream-ordered all-reduce, part of the captured graph);
+// `-json <file|->` adds one JSON line with everything measured, `-check_y 1` the bitwise self-check of uspmv_dist_check.
 //
 // Single-GPU rehearsal of the whole path: USPMV_LOOPBACK=P (with WORLD_SIZE unset) makes this process block
-// $USPMV_LOOPBACK_RANK (default 0) of a P-way partition whose neighbours are itself (RCCL self send/recv).
+// $USPMV_LOOPBACK_RANK (default 0) of a P-way partition whose neighbours are itself (RCCL self send/recv); USPMV_EXCHANGE=host
+// with WORLD_SIZE = P real processes stages the halo exchange through the host communicator instead of RCCL, so that the
+// ranks may share one GPU (unequal seg-nnz blocks included).
 // USPMV_DIST_X=ramp sets x_local[i] = 1 + 1e-3 * (i mod 1000) in ORIGINAL local row order on every rank (the default is the
 // reference's constant 5.0); USPMV_DUMP_Y=<prefix> writes y of the local rows in original order to <prefix>.<rank> (raw
 // doubles) after one step.  tests/test_dist_native_gpu.py checks that output against the oracle.
@@ -39,11 +48,12 @@
 
 namespace {
 
-struct Ctx { int rank = 0; };
+struct Ctx { int rank = 0; uspmv_hostcomm_t *hc = nullptr; };
 Ctx g;
 
 [[noreturn]] void die(const std::string &msg) {
     fprintf(stderr, "[rank %d] ERROR: %s\n", g.rank, msg.c_str());
+    if (g.hc) uspmv_hostcomm_abort(g.hc);     // the peers fail at their next wait instead of sitting in it
     exit(1);
 }
 #define CK(call) do { int rc_ = (call); if (rc_ != USPMV_OK) die(std::string(#call) + ": " + uspmv_last_error()); } while (0)
@@ -55,18 +65,16 @@ int env_int(const char *a, const char *b, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-std::string side_path(const std::string &what) {
-    const char *dir = getenv("USPMV_ID_DIR");
+std::string job_key() {
     const char *job = getenv("USPMV_JOB_ID") ? getenv("USPMV_JOB_ID") : getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0";
-    return std::string(dir ? dir : "/tmp") + "/uspmv_" + job + "_" + what;
+    return std::string("cli_") + job;
 }
 
-bool wait_for(const std::string &path, int seconds) {
-    for (int tries = 0; tries < seconds * 100; ++tries) {
-        if (access(path.c_str(), R_OK) == 0) return true;
-        std::this_thread::sleep_for(std::chrono::milliseconds(10));
-    }
-    return false;
+std::string block_path(uint64_t nonce, int r) {
+    const char *dir = getenv("USPMV_ID_DIR");
+    char buf[64];
+    snprintf(buf, sizeof buf, "/uspmv_%016llx_block%d.uspmvcoo", (unsigned long long)nonce, r);
+    return std::string(dir ? dir : "/tmp") + buf;
 }
 
 void publish(const std::string &path, const void *data, size_t bytes) {
@@ -90,21 +98,23 @@ int uspmv_run_distributed(const DistConfig &c) {
     const int rank = loop_P > 1 ? env_int("USPMV_LOOPBACK_RANK", nullptr, 0) : comm_rank;
     if (rank < 0 || rank >= P) die("bad rank");
     g.rank = rank;
+    const char *exk = getenv("USPMV_EXCHANGE");
+    const bool host_exchange = exk && !strcmp(exk, "host");
+    if (host_exchange && loop_P > 1) die("USPMV_EXCHANGE=host needs real ranks (WORLD_SIZE = P), not USPMV_LOOPBACK");
+    if (getenv("USPMV_BACKTRACE")) uspmv_debug_backtrace_on_crash(1);
     int ndev = 0;
     CK(uspmv_device_count(&ndev));
     if (ndev < 1) die("no HIP device visible");
     CK(uspmv_set_device(local_rank % ndev));  // device = my_rank % num_devices (code/main.cpp:1838-1842)
 
-    // ---- RCCL id through a file
-    unsigned char id[USPMV_COMM_ID_BYTES];
-    const std::string id_path = side_path("rccl.id");
-    if (comm_rank == 0) {
-        CK(uspmv_comm_unique_id(id));
-        publish(id_path, id, sizeof id);
-    } else {
-        if (!wait_for(id_path, 120)) die("timed out waiting for " + id_path);
-        std::ifstream f(id_path, std::ios::binary);
-        if (!f.read((char *)id, sizeof id)) die("cannot read " + id_path);
+    // ---- the ranks meet (MPI_Init's part); the RCCL id travels through the host communicator
+    CK(uspmv_hostcomm_create(job_key().c_str(), comm_rank, comm_size, (double)env_int("USPMV_HC_TIMEOUT", nullptr, 3600), &g.hc));
+    uint64_t nonce = 0;
+    CK(uspmv_hostcomm_info(g.hc, nullptr, nullptr, &nonce));
+    unsigned char id[USPMV_COMM_ID_BYTES] = {0};
+    if (!host_exchange) {
+        if (comm_rank == 0) CK(uspmv_comm_unique_id(id));
+        CK(uspmv_hostcomm_bcast(g.hc, id, sizeof id, 0));
     }
 
     // ---- this rank's row block (and nothing else)
@@ -124,8 +134,7 @@ int uspmv_run_distributed(const DistConfig &c) {
         }
         CK(uspmv_gen_stencil27(nx, ny, nz, dof, 0x5EED, dec, wsa[(size_t)rank], wsa[(size_t)rank + 1], &local));
     } else {
-        const std::string meta_path = side_path("blocks.meta");
-        auto block_path = [&](int r) { return side_path("block" + std::to_string(r) + ".uspmvcoo"); };
+        std::vector<int64_t> meta((size_t)P + 3, 0);
         if (comm_rank == 0) {
             uspmv_coo_t *total = nullptr;
             CK(uspmv_read_mtx(c.matrix_name.c_str(), &total));
@@ -137,37 +146,38 @@ int uspmv_run_distributed(const DistConfig &c) {
                 CK(uspmv_seg_local_coo(total, wsa.data(), r, &blk));
                 if (r == rank) local = blk;
                 else {
-                    if (comm_size > 1) CK(uspmv_coo_save(blk, block_path(r).c_str()));
+                    if (comm_size > 1) CK(uspmv_coo_save(blk, block_path(nonce, r).c_str()));
                     uspmv_coo_free(blk);
                 }
             }
             uspmv_coo_free(total);
-            std::vector<int64_t> meta((size_t)P + 3);
             meta[0] = n_rows_g; meta[1] = nnz_g;
             for (int r = 0; r <= P; ++r) meta[(size_t)r + 2] = wsa[(size_t)r];
-            if (comm_size > 1) publish(meta_path, meta.data(), meta.size() * 8);
-        } else {
-            if (!wait_for(meta_path, 3600)) die("timed out waiting for " + meta_path);
-            std::vector<int64_t> meta((size_t)P + 3);
-            std::ifstream f(meta_path, std::ios::binary);
-            if (!f.read((char *)meta.data(), (std::streamsize)(meta.size() * 8))) die("cannot read " + meta_path);
+        }
+        CK(uspmv_hostcomm_bcast(g.hc, meta.data(), (int64_t)(meta.size() * 8), 0));   // (also: the blocks are on disk now)
+        if (comm_rank != 0) {
             n_rows_g = meta[0]; nnz_g = meta[1];
             for (int r = 0; r <= P; ++r) wsa[(size_t)r] = (int32_t)meta[(size_t)r + 2];
-            CK(uspmv_coo_load(block_path(rank).c_str(), &local));
-            unlink(block_path(rank).c_str());
+            CK(uspmv_coo_load(block_path(nonce, rank).c_str(), &local));
+            unlink(block_path(nonce, rank).c_str());
         }
     }
 
-    // ---- the distributed object: convert, halo discovery, upload, plan, communicator (init_local_structs + collect_comm_info)
+    // ---- the distributed object: convert, halo discovery, upload, plan, exchange plan, communicator (init_local_structs + collect_comm_info)
     uspmv_dist_t *D = nullptr;
-    CK(uspmv_dist_create_from_coo(id, comm_rank, comm_size, rank, P, local, wsa.data(), c.C, c.sigma, USPMV_F64, c.tlc ? 1 : 0, &D));
-    uspmv_coo_free(local);
+    uspmv_transport_t tr{};
+    uspmv_dist_options_t opt{nullptr, host_exchange ? USPMV_EXCHANGE_HOST : USPMV_EXCHANGE_RCCL};
+    const char *stk = getenv("USPMV_SETUP_TRANSPORT");
+    const bool setup_on_rccl = stk && !strcmp(stk, "rccl") && !host_exchange;
+    if (comm_size == P && P > 1 && !setup_on_rccl) { CK(uspmv_hostcomm_transport(g.hc, &tr)); opt.transport = &tr; }
+    CK(uspmv_dist_create_from_coo_ex(host_exchange ? nullptr : id, comm_rank, comm_size, rank, P, local, wsa.data(), c.C, c.sigma, USPMV_F64, c.tlc ? 1 : 0, &opt, &D));
+    if (!c.check_y) { uspmv_coo_free(local); local = nullptr; }
     hipStream_t st = nullptr;
     HK(hipStreamCreate(&st));
     CK(uspmv_dist_barrier(D, st));
-    if (comm_rank == 0) { unlink(id_path.c_str()); unlink(side_path("blocks.meta").c_str()); }
-    if (c.no_overlap) CK(uspmv_dist_set_overlap(D, 0));
-    if (c.no_pack) CK(uspmv_dist_set_no_pack(D, 1));   // -no_pack 1: the exchange sends a stale buffer (code/classes_structs.hpp:941)
+    if (c.no_overlap) CK(uspmv_dist_set_option(D, "overlap", 0));
+    if (c.no_pack) CK(uspmv_dist_set_option(D, "no_pack", 1));   // -no_pack 1: the exchange sends a stale buffer (code/classes_structs.hpp:941)
+    CK(uspmv_dist_set_option(D, "ba_synch", c.ba_synch && c.comm_halos ? 1 : 0));   // -ba_synch (code/main.cpp:467; default 1, code/classes_structs.hpp:90)
     int64_t meta[12];
     CK(uspmv_dist_info(D, meta));
     const int64_t n_local = meta[0], n_halo = meta[1], vec_len = meta[2], n_send = meta[3];
@@ -186,8 +196,9 @@ int uspmv_run_distributed(const DistConfig &c) {
     HK(hipMalloc((void **)&d_x, sizeof(double) * (size_t)vec_len * b));
     HK(hipMalloc((void **)&d_y, sizeof(double) * (size_t)vec_len * b));
     HK(hipMemset(d_y, 0, sizeof(double) * (size_t)vec_len * b));
+    std::vector<double> hx((size_t)vec_len * b, 0.0);
     {
-        std::vector<double> xo((size_t)n_local), xp((size_t)n_local), hx((size_t)vec_len * b, 0.0);
+        std::vector<double> xo((size_t)n_local), xp((size_t)n_local);
         const char *xk = getenv("USPMV_DIST_X");
         const bool ramp = xk && !strcmp(xk, "ramp");
         for (int v = 0; v < b; ++v) {
@@ -216,34 +227,95 @@ int uspmv_run_distributed(const DistConfig &c) {
         publish(std::string(dump) + "." + std::to_string(rank), yo.data(), yo.size() * 8);
     }
 
-    // ---- bench loop (code/main.cpp:408-474): 100 warm-ups, doubling batches, barriers around each batch
-    steps(100);
-    CK(uspmv_dist_barrier(D, st));
+    // ---- timed region
     int n_iter = 2;
-    double runtime = 0;
-    do {
+    double runtime = 0, runtime_other = 0;
+    const int warm = c.bench_warmup >= 0 ? c.bench_warmup : 100;
+    steps(warm);                                       // WARM_UP_REPS (code/main.cpp:22, :408-419)
+    HK(hipStreamSynchronize(st));
+    CK(uspmv_dist_barrier(D, st));
+    if (c.bench_steps > 0) {   // exactly K steps between barriers, the slowest rank's clock
+        n_iter = c.bench_steps;
+        HK(hipDeviceSynchronize());
         CK(uspmv_dist_barrier(D, st));
         auto t0 = std::chrono::steady_clock::now();
         steps(n_iter);
+        HK(hipStreamSynchronize(st));
         CK(uspmv_dist_barrier(D, st));
         runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        n_iter *= 2;
-        CK(uspmv_dist_allreduce_max(D, &runtime, st));   // every rank must take the same decision: the slowest rank's clock
-    } while (runtime < c.bench_time);
-    n_iter /= 2;
+        CK(uspmv_dist_allreduce_max(D, &runtime, st));
+        if (comm_halos && P > 1) {   // the same K steps under the OTHER per-step barrier setting (reported next to the headline)
+            CK(uspmv_dist_set_option(D, "ba_synch", c.ba_synch ? 0 : 1));
+            steps(std::min(warm, 10) + 1);
+            HK(hipDeviceSynchronize());
+            CK(uspmv_dist_barrier(D, st));
+            auto t1 = std::chrono::steady_clock::now();
+            steps(n_iter);
+            HK(hipStreamSynchronize(st));
+            CK(uspmv_dist_barrier(D, st));
+            runtime_other = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+            CK(uspmv_dist_allreduce_max(D, &runtime_other, st));
+            CK(uspmv_dist_set_option(D, "ba_synch", c.ba_synch ? 1 : 0));
+        }
+    } else {                   // bench loop of the reference (code/main.cpp:449-523): doubling batches, barriers around each batch
+        do {
+            CK(uspmv_dist_barrier(D, st));
+            auto t0 = std::chrono::steady_clock::now();
+            steps(n_iter);
+            CK(uspmv_dist_barrier(D, st));
+            runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            n_iter *= 2;
+            CK(uspmv_dist_allreduce_max(D, &runtime, st));   // every rank must take the same decision: the slowest rank's clock
+        } while (runtime < c.bench_time);
+        n_iter /= 2;
+    }
     const double perf = (double)nnz_g * 2.0 * b / (runtime / n_iter) / 1e9;
+
+    // ---- this rank's kernel alone (interior + boundary without the exchange), HIP events on the step's stream
+    double kernel_ms = 0;
+    if (b == 1) {
+        hipEvent_t e0, e1;
+        HK(hipEventCreate(&e0)); HK(hipEventCreate(&e1));
+        CK(uspmv_dist_spmv(D, d_x, d_y, 0, st));
+        HK(hipEventRecord(e0, st));
+        for (int k = 0; k < 20; ++k) CK(uspmv_dist_spmv(D, d_x, d_y, 0, st));
+        HK(hipEventRecord(e1, st));
+        HK(hipEventSynchronize(e1));
+        float ms = 0;
+        HK(hipEventElapsedTime(&ms, e0, e1));
+        kernel_ms = ms / 20.0;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+
+    // ---- self-check (-check_y 1): one step on x_global[j] = 1 + 1e-3 (j mod 1000), bitwise against the block's entry-ordered FMA chains
+    int64_t mism = -1, mism_total = -1;
+    double checksum = 0;
+    if (c.check_y && b == 1 && comm_halos) {
+        CK(uspmv_dist_check(D, local, wsa.data(), d_x, d_y, c.use_graph ? 1 : 0, st, &mism, &checksum));
+        std::vector<int64_t> all((size_t)std::max(P, comm_size), 0);
+        CK(uspmv_dist_allgather_i64(D, mism, all.data(), st));
+        mism_total = 0;
+        for (int p = 0; p < (meta[8] ? 1 : comm_size); ++p) mism_total += all[(size_t)p];
+        HK(hipMemcpy(d_x, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
+        if (mism) fprintf(stderr, "[rank %d] CHECK FAILED: %ld of %ld local rows differ from the entry-ordered FMA chains\n", rank, (long)mism, (long)n_local);
+    }
+    uspmv_coo_free(local);
 
     // ---- report
     std::vector<int64_t> halos((size_t)std::max(P, comm_size), 0), sends((size_t)std::max(P, comm_size), 0);
     CK(uspmv_dist_allgather_i64(D, n_halo, halos.data(), st));
     CK(uspmv_dist_allgather_i64(D, n_send, sends.data(), st));
     CK(uspmv_dist_info(D, meta));
+    int ver[4] = {0, 0, 0, 0};
+    CK(uspmv_runtime_versions(ver));
+    const char *protocol = c.bench_steps > 0 ? "fixed steps between barriers" : "reference bench loop (doubling batches)";
     if (comm_rank == 0) {
         const double bytes = n_el * 12.0 + 8.0 * n_chunks + 8.0 * b * (n_local + n_halo) + 8.0 * b * n_pad;  // this rank's share
         std::ofstream f("spmv_bench.txt", std::ios::app);
         f << c.matrix_name << " with " << P << " RCCL ranks (one per GPU), halo exchange " << (c.comm_halos ? "on" : "off") << std::endl;
         f << "kernel: scs, block_vec_size: " << b << ", C: " << c.C << " sigma: " << c.sigma << ", data_type: double, revisions: " << n_iter
-          << ", seg_method: " << (c.seg_nnz ? "seg-nnz" : "seg-rows") << ", MPI_mode: " << (b == 1 || c.vec_mode == USPMV_SINGLEVEC ? "singlevec" : c.vec_mode == USPMV_MULTIVEC ? "multivec" : "bulkvec") << std::endl << std::endl;
+          << ", seg_method: " << (c.seg_nnz ? "seg-nnz" : "seg-rows") << ", MPI_mode: " << (b == 1 || c.vec_mode == USPMV_SINGLEVEC ? "singlevec" : c.vec_mode == USPMV_MULTIVEC ? "multivec" : "bulkvec")
+          << ", ba_synch: " << (c.ba_synch && c.comm_halos ? 1 : 0) << std::endl << std::endl;
         char buf[256];
         snprintf(buf, sizeof buf, "%-32s%-32s\n%-32s%-32s\n%-32.16g%-32.16g\n\n", "Total Gflops:", "Total Walltime:", "-------------",
                  "-------------", perf, runtime);
@@ -257,13 +329,34 @@ int uspmv_run_distributed(const DistConfig &c) {
             f << std::endl;
         }
         printf("%d ranks%s, n = %ld, nnz = %ld: Total Gflops: %.4f (%d iterations in %.4f s, %.6f ms per SpMV); rank %d: %.1f GB/s algorithmic, "
-               "%ld halo elements, %ld interior + %ld boundary %s, %s\n", P, meta[8] ? " (loopback)" : "", (long)n_rows_g, (long)nnz_g, perf, n_iter, runtime,
+               "%ld halo elements, %ld interior + %ld boundary %s, %s, ba_synch %d%s\n", P, meta[8] ? " (loopback)" : host_exchange ? " (host-staged exchange)" : "", (long)n_rows_g, (long)nnz_g, perf, n_iter, runtime,
                runtime / n_iter * 1e3, rank, bytes / (runtime / n_iter) / 1e9, (long)n_halo, (long)meta[4], (long)meta[5], meta[6] ? "tiles" : "chunks",
-               meta[9] ? "hipGraph replay" : "eager steps");
+               meta[9] ? "hipGraph replay" : "eager steps", c.ba_synch && c.comm_halos ? 1 : 0,
+               mism_total < 0 ? "" : mism_total == 0 ? ", y checked bitwise on every rank: ok" : ", y CHECK FAILED");
+        if (!c.json.empty()) {
+            char js[2048];
+            snprintf(js, sizeof js,
+                     "{\"gflops\": %.4f, \"ms_per_step\": %.6f, \"steps\": %d, \"warmup\": %d, \"runtime_s\": %.6f, \"ranks\": %d, \"loopback\": %s, "
+                     "\"exchange\": \"%s\", \"n_rows\": %ld, \"nnz\": %ld, \"protocol\": \"%s\", \"ba_synch\": %d, \"graph_replay\": %s, \"graph_launches\": %ld, "
+                     "\"eager_steps\": %ld, \"overlap\": %s, \"other_ba_synch_ms_per_step\": %.6f, \"y_checked\": %s, \"y_mismatches\": %ld, \"y_checksum_rank0\": %.17g, "
+                     "\"rank0\": {\"n_local\": %ld, \"n_halo\": %ld, \"n_send\": %ld, \"interior\": %ld, \"boundary\": %ld, \"tiles\": %s, \"n_elements\": %ld, "
+                     "\"n_chunks\": %ld, \"n_rows_padded\": %ld, \"algorithmic_bytes\": %.0f, \"local_kernel_ms\": %.6f}, "
+                     "\"versions\": {\"hip_build\": %d, \"hip_runtime\": %d, \"rccl_build\": %d, \"rccl_runtime\": %d}}",
+                     perf, runtime / n_iter * 1e3, n_iter, warm, runtime, P, meta[8] ? "true" : "false", host_exchange ? "host" : "rccl", (long)n_rows_g, (long)nnz_g,
+                     protocol, c.ba_synch && c.comm_halos ? 1 : 0, meta[9] ? "true" : "false", (long)meta[10], (long)meta[11], c.no_overlap ? "false" : "true", runtime_other / n_iter * 1e3,
+                     mism_total < 0 ? "null" : mism_total == 0 ? "true" : "false", (long)mism_total, checksum, (long)n_local, (long)n_halo, (long)n_send,
+                     (long)meta[4], (long)meta[5], meta[6] ? "true" : "false", (long)n_el, (long)n_chunks, (long)n_pad, bytes, kernel_ms,
+                     ver[0], ver[1], ver[2], ver[3]);
+            if (c.json == "-") printf("%s\n", js);
+            else { std::ofstream jf(c.json); jf << js << std::endl; }
+        }
     }
     CK(uspmv_dist_barrier(D, st));
     (void)hipFree(d_x); (void)hipFree(d_y);
     uspmv_dist_free(D);
     (void)hipStreamDestroy(st);
-    return 0;
+    uspmv_hostcomm_t *hc = g.hc;
+    g.hc = nullptr;
+    uspmv_hostcomm_free(hc);
+    return mism_total > 0 ? 3 : 0;
 }

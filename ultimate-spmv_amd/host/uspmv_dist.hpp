@@ -10,6 +10,9 @@ struct DistConfig {
     bool no_overlap = false, use_graph = true, print_comm_vol = false, no_pack = false;
     int block_vec_size = 1, layout = USPMV_COLWISE, vec_mode = USPMV_BULKVEC;   // -block_vec_size, -block_vec_layout, -mpi_mode
     double bench_time = 5.0;
+    int bench_steps = 0, bench_warmup = -1;   // -bench_steps K: time exactly K steps between barriers (0 = the reference's doubling loop); -bench_warmup W (-1 = 100)
+    bool check_y = false;                      // -check_y 1: bitwise self-check of one distributed step (uspmv_dist_check)
+    std::string json;                          // -json <file|->: one JSON line with everything measured (rank 0)
     std::string matrix_name;
 };
 

@@ -39,6 +39,15 @@ struct uspmv_halo {
     std::vector<int32_t> recv_idxs;           // grouped by owner ascending, owner-local row ids
 };
 
+// Exchange plan of one rank (host/comm_plan.cpp): what to send to whom, derived from the peers' halo descriptions
+// (role of comm_send_idxs / send_counts_cumsum, code/mpi_funcs.hpp:117-232)
+struct uspmv_comm_plan {
+    int P = 0, rank = 0;
+    int64_t n_local = 0, n_send = 0;
+    std::vector<int64_t> send_off, recv_off;   // P+1, elements
+    std::vector<int32_t> send_idxs;            // this rank's local rows (original order), grouped by receiver
+};
+
 // Tile-local-column plan (host copy), see host/tlc_plan.cpp
 struct uspmv_tlc_plan {
     bool valid = false;
@@ -100,4 +109,8 @@ namespace uspmv {
 int fail(int status, const char *fmt, ...);  // records the thread-local error text, returns status
 // false for the layout-only structs uspmv_convert_to_scs_device hands back (entries live on the device only)
 inline bool scs_has_entries(const uspmv_scs *s) { return (int64_t)s->col_idxs.size() == s->n_elements; }
+// host side of uspmv_dist_check (host/dist_check.cpp)
+double check_x(int64_t global_col);
+int64_t check_col(int64_t j, const int32_t *wsa, int P, int rank, bool loopback);
+int dist_reference_rows(const uspmv_coo *local, const int32_t *wsa, int P, int rank, bool loopback, int dtype, void *y_ref);
 }
