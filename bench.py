@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--tune", default="", help="key=value,... forwarded to uspmv_set_tuning")
     ap.add_argument("--no-tlc", action="store_true", help="skip the tile-local-column plan (plain gather kernel)")
     ap.add_argument("--no-traffic", action="store_true", help="N = 1: do not run the two rocprofv3 PMC child passes (roofline.traffic then comes from profiles/traffic.json)")
+    ap.add_argument("--other-configs", default="3,4b", help="N = 1: further BASELINE configurations measured after the headline and reported under \"other_configs\" (3 = Queen_4147-class SpMMV b = 8, both layouts; 4b = HV15R-class ap[dp_sp] and dp); \"\" = none")
+    ap.add_argument("--grid3", type=int, default=111, help="config 3: nodes per edge (3 dof per node)")
+    ap.add_argument("--n4b", type=int, default=2017169, help="config 4b: rows")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -127,6 +130,140 @@ def cpu_baseline(scs_arrays, C, n_chunks, nnz, x, seconds):
     return {"value": round(2.0 * nnz * reps / el / 1e9, 3), "unit": "GFLOP/s", "cores": cores, "kind": kind,
             "sample": f"whole matrix, {reps} SpMVs of spmv_omp_scs_adv<C=32,double> in {el:.1f} s, "
                       f"OMP threads = {cores}"}
+
+
+def _cpu_leg(flops, fn_ref, fn_port, y_cpu, y_gpu, seconds, name):
+    """cpu_baseline leg of one configuration: the reference CPU kernel (oracle/_ref when present, else the oracle's C port) timed
+    for about `seconds` on the usable host cores; its y doubles as the checker of the GPU's y (bitwise)."""
+    from oracle import refshim
+    cores = usable_cores()
+    set_omp_threads(cores)
+    ref = refshim.available("colwise")
+    run = fn_ref if ref else fn_port
+    out = run()
+    if isinstance(out, np.ndarray):       # (the port returns y, the reference writes into y_cpu)
+        y_cpu = out
+    same = bool(np.array_equal(np.asarray(y_cpu), y_gpu))
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        run(); reps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or reps >= 200:
+            break
+    return ({"value": round(flops * reps / el / 1e9, 2), "unit": "GFLOP/s", "cores": cores, "kind": "reference" if ref else "port",
+             "sample": f"whole matrix, {reps} calls of {name} in {el:.1f} s, OMP threads = {cores}"}, same)
+
+
+def other_configs(pkg, B, torch, args, which):
+    """BASELINE configs 3 (Queen_4147-class, -block_vec_size 8, both block-vector layouts) and 4b (HV15R-class banded-random matrix of
+    SURVEY 8(d), ap[dp_sp] and plain dp) under the driver's clock: set-up, the timed kernel (HIP events on its stream, whole
+    uspmv_spmmv / uspmv_spmv_ap / uspmv_spmv call), the algorithmic-byte roofline of SURVEY 8(d) and the reference CPU kernel of the
+    same configuration, whose result is compared bitwise with the GPU's."""
+    from oracle import refshim
+    from oracle import oracle as orc       # cpu_baseline leg: the port stands in when oracle/_ref did not travel
+    t = torch
+    reps = max(10, min(args.steps, 50))
+    res = []
+
+    def line(config, workload, kernel, ms, byts, flops, same, cpu, setup, extra=None):
+        d = {"config": config, "workload": workload, "kernel": kernel, "kernel_ms": round(ms, 5), "ms_per_step": round(ms, 5),
+             "value": round(flops / ms / 1e6, 1), "unit": "GFLOP/s",
+             "roofline": {"bound": "hbm", "achieved": round(byts / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(byts / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(byts)},
+             "bitexact_vs_reference_cpu": same, "cpu_baseline": cpu, "setup_s": round(setup, 1)}
+        if extra:
+            d.update(extra)
+        res.append(d)
+
+    if "3" in which:
+        t0 = time.time()
+        g = args.grid3
+        coo = pkg.gen_stencil27(g, g, g, dof=3)
+        s = pkg.convert_to_scs(coo, 32, 512, B.F64)
+        a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
+        nnz = s.nnz
+        del coo
+        b, ld = 8, s.n_rows_padded
+        A = pkg.DeviceMatrix(s, block_tlc=b)
+        xp = np.zeros(ld); xp[:s.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(s.n_rows) % 1000), a["new_to_old_idx"])
+        byts = s.n_elements * 12 + 8 * s.n_chunks + b * 8 * s.n_rows + b * 8 * s.n_rows_padded
+        setup = time.time() - t0
+        for lay, nm in ((B.COLWISE, "colwise"), (B.ROWWISE, "rowwise")):
+            X = np.zeros(b * ld)
+            for v in range(b):
+                col = xp * (1.0 + v / 8.0)
+                if lay == B.ROWWISE:
+                    X[v::b] = col
+                else:
+                    X[v * ld:(v + 1) * ld] = col
+            dX = t.from_numpy(X).cuda(); dY = t.zeros(b * ld, dtype=t.float64, device="cuda")
+            pkg.spmmv(A, dX, dY, b, ld, lay)
+            t.cuda.synchronize()
+            ms = B.time_launches(5, reps, A=A, x=dX, y=dY, b=b, ld=ld, layout=lay)
+            Yc = np.zeros(b * ld)
+            var = "rowwise" if lay == B.ROWWISE else "colwise"
+            fr = (lambda: refshim.lib(var).ref_block_spmv_omp_scs_general_f64(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, Yc, b, ld)) if refshim.available(var) else None
+            fp = lambda: orc.spmmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, b, ld, lay == B.ROWWISE)
+            cpu, same = _cpu_leg(2.0 * nnz * b, fr or fp, fp, Yc, dY.cpu().numpy(), args.cpu_seconds / 3, "block_spmv_omp_scs_general (" + nm + ")")
+            kind = A.plan_info()[0]
+            line(f"3 ({nm})", f"Queen_4147-class synthetic (27-pt stencil {g}^3 x 3 dof, n={s.n_rows}, nnz={nnz}) scs -c 32 -s 512 -dp -block_vec_size 8, {nm} X / Y",
+                 "uspmv_spmmv: scs_spmmv_quadph<double,8> (phased block plan)" + (" behind block_vector_to_rowmajor" if lay == B.COLWISE else ""),
+                 ms, byts, 2.0 * nnz * b, same, cpu, setup, {"block_plan_tiles": [A.block_staged, A.block_tiles], "plan_kind": kind})
+            del dX, dY
+        del A, s, a
+        t.cuda.empty_cache()
+    if "4b" in which:
+        t0 = time.time()
+        coo = pkg.gen_banded_random(args.n4b, 140, 50000, magnitude_decades=10.0)
+        dp, sp = pkg.partition_precisions(coo, 1e-3)
+        ds = pkg.convert_to_scs(dp, 32, 512, B.F64)
+        perm = ds.arrays()["old_to_new_idx"].copy()
+        ss = pkg.convert_to_scs(sp, 32, 512, B.F32, fixed_permutation=perm)
+        pkg.permute_scs_cols(ds, perm); pkg.permute_scs_cols(ss, perm)
+        da, sa = ds.arrays(), ss.arrays()
+        Ad, As = pkg.DeviceMatrix(ds), pkg.DeviceMatrix(ss)
+        nt_, ns_ = pkg.optimize_ap(Ad, As, ds, ss)
+        xp = np.zeros(ds.n_rows_padded); xp[:ds.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(ds.n_rows) % 1000), da["new_to_old_idx"])
+        x = t.from_numpy(xp).cuda(); y = t.zeros(ds.n_rows_padded, dtype=t.float64, device="cuda")
+        pkg.spmv_ap(Ad, As, x, y)
+        t.cuda.synchronize()
+        setup = time.time() - t0
+        ms = B.time_launches(4, reps, A=Ad, B=As, x=x, y=y)
+        byts = 12 * ds.n_elements + 8 * ss.n_elements + 16 * ds.n_chunks + 8 * (ds.n_rows + ds.n_rows_padded)
+        ycpu = np.zeros(ds.n_rows_padded); yspc = np.zeros(ds.n_rows_padded, np.float32); xspc = xp.astype(np.float32)
+        fr = (lambda: refshim.lib("colwise").ref_spmv_omp_scs_ap_adv(32, ds.n_chunks, da["chunk_ptrs"], da["chunk_lengths"], da["col_idxs"], da["values"], xp, ycpu,
+                                                                     sa["chunk_ptrs"], sa["chunk_lengths"], sa["col_idxs"], sa["values"], xspc, yspc)) if refshim.available("colwise") else None
+        fp = lambda: orc.spmv_scs_ap_adv(32, ds.n_chunks, (da["chunk_ptrs"], da["chunk_lengths"], da["col_idxs"], da["values"]),
+                                         (sa["chunk_ptrs"], sa["chunk_lengths"], sa["col_idxs"], sa["values"]), xp)
+        cpu, same = _cpu_leg(2.0 * coo.nnz, fr or fp, fp, ycpu, y.cpu().numpy(), args.cpu_seconds / 3, "spmv_omp_scs_ap_adv<C=32>")
+        kind, ntile, nplan = Ad.plan_info()
+        wl = f"HV15R-class synthetic (banded-random n={coo.n_rows}, 140 entries per row within +-50000, |a_ij| log-uniform over 10 decades, nnz={coo.nnz})"
+        line("4b (ap[dp_sp])", wl + " scs -c 32 -s 512 -ap[dp_sp] -ap_threshold_1 1e-3",
+             {2: "scs_spmv_sweep<double,AP> (column-window sweep)", 1: "scs_spmv_ap_tlc", 0: "scs_spmv_ap_rows"}[kind], ms, byts, 2.0 * coo.nnz, same, cpu, setup,
+             {"dp_nnz": dp.nnz, "sp_nnz": sp.nnz, "dp_elements": ds.n_elements, "sp_elements": ss.n_elements, "plan_kind": kind, "plan_tiles_planned": [nplan, ntile]})
+        del Ad, As, ds, ss, da, sa, dp, sp
+        t.cuda.empty_cache()
+        t0 = time.time()
+        s = pkg.convert_to_scs(coo, 32, 512, B.F64)
+        a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
+        A = pkg.DeviceMatrix(s, tlc=True)
+        xp = np.zeros(s.n_rows_padded); xp[:s.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(s.n_rows) % 1000), a["new_to_old_idx"])
+        x = t.from_numpy(xp).cuda(); y = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
+        pkg.spmv(A, x, y)
+        t.cuda.synchronize()
+        setup = time.time() - t0
+        ms = B.time_launches(0, reps, A=A, x=x, y=y)
+        byts = s.n_elements * 12 + 8 * s.n_chunks + 8 * (s.n_rows + s.n_rows_padded)
+        yc = np.zeros(s.n_rows_padded)
+        fr = (lambda: refshim.lib("colwise").ref_spmv_omp_scs_adv_f64(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp, yc)) if refshim.available("colwise") else None
+        fp = lambda: orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+        cpu, same = _cpu_leg(2.0 * s.nnz, fr or fp, fp, yc, y.cpu().numpy(), args.cpu_seconds / 3, "spmv_omp_scs_adv<C=32,double>")
+        kind, ntile, nplan = A.plan_info()
+        line("4b (dp)", wl + " scs -c 32 -s 512 -dp", {2: "scs_spmv_sweep<double> (column-window sweep)", 1: "scs_spmv_tlc<double,32>", 0: "scs_spmv_rows<double,32,8>"}[kind],
+             ms, byts, 2.0 * s.nnz, same, cpu, setup, {"plan_kind": kind, "plan_tiles_planned": [nplan, ntile]})
+        del A, s, a, coo
+        t.cuda.empty_cache()
+    return res
 
 
 def pmc_child(args):
@@ -597,6 +734,14 @@ def main():
     if not args.no_cpu_baseline:
         a = s.arrays()
         out["cpu_baseline"] = cpu_baseline(a, s.C, s.n_chunks, s.nnz, x.cpu().numpy(), args.cpu_seconds)
+    which = [w for w in args.other_configs.split(",") if w]
+    if which and not args.mtx:
+        del A, x, y, s
+        torch.cuda.empty_cache()
+        try:
+            out["other_configs"] = other_configs(pkg, B, torch, args, which)
+        except Exception as e:      # the headline line must survive a failure down here
+            out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out), flush=True)
 
 

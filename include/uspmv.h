@@ -94,6 +94,12 @@ int uspmv_gen_stencil27_row_counts(int64_t nx, int64_t ny, int64_t nz, int dof, 
  * pattern, columns ascending inside a row; the irregular counterpart of the stencil generator. */
 int uspmv_gen_banded_random(int64_t n, int nnz_per_row, int64_t band, uint64_t seed, double magnitude_decades,
                             int64_t row_begin, int64_t row_end, uspmv_coo_t **out);
+/* KKT-structured matrix of the nlpkkt class ([H A^T; A 0], PDE-constrained optimisation on an N^3 grid with boundary control;
+ * n = 2 N^3 + 6 N^2 as in SuiteSparse nlpkkt200 / nlpkkt240): unknowns = states, multipliers, boundary controls; interior state
+ * rows 28 entries, multiplier rows 25, control rows 5-7; a row's columns live in two index ranges N^3 apart.  Symmetric pattern
+ * and values, columns ascending inside a row; rows [row_begin, row_end) with local row ids and global column ids. */
+int uspmv_gen_kkt(int64_t N, uint64_t seed, int64_t row_begin, int64_t row_end, uspmv_coo_t **out);
+int uspmv_gen_kkt_row_counts(int64_t N, int64_t row_begin, int64_t row_end, int32_t *out);
 
 /* ------------------------------------------------------------------ L2: format conversion */
 /* convert_to_scs (code/utilities.hpp:1842-2104; library twin code/interface.hpp:401-656).
@@ -175,6 +181,10 @@ int uspmv_dmat_optimize_sweep_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv
 /* Which single-vector plan uspmv_spmv / uspmv_spmv_ap will use: kind 0 none (gather kernel), 1 tile-local-column, 2 column-window
  * sweep; tiles of that plan and how many of them it covers (any pointer may be NULL). */
 int uspmv_dmat_plan_info(const uspmv_dmat_t *m, int *kind, int64_t *n_tiles, int64_t *n_planned);
+/* block-vector plans of the handle: meta[8] = one-list-per-tile plan present, phased plan present, line plan present (column-major
+ * block vectors staged by 128-byte lines, no re-layout pass), tiles, phases of the phased plan, phases of the line plan, X rows the
+ * line plan stages, one-byte indices */
+int uspmv_dmat_block_plan_info(const uspmv_dmat_t *m, int64_t meta[8]);
 
 /* The block plan for a handle without a host struct (uspmv_dmat_wrap): the device arrays are copied to the host once and the plan is
  * built there.  No permutation is known then: ties of the sigma sort are ordered by first column instead of by original row. */

@@ -211,13 +211,11 @@ def _hx_worker(rank, world, q, job, case):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_native_step_real_ranks_unequal_seg_nnz_blocks(pkg, world):
-    """bcsstk13 split by -seg_nnz (block heights 724 / 459 / 417 / 403 at P = 4, asymmetric send / recv counts): the C++ step object
-    in `world` real processes on one GPU, against the reference's x_local and y (tests/golden/halo.npz)."""
-    case = ("bcsstk13", 32, 512, "seg-nnz")
-    if f"bcsstk13_C32_s512_seg-nnz_P{world}_wsa" not in np.load(os.path.join(GOLDEN, "halo.npz")):
-        pytest.skip("no golden for this world size")
+@pytest.mark.parametrize("case,world", [(("impcol_e", 8, 16, "seg-nnz"), 2), (("FDM-2d-16", 16, 512, "seg-nnz"), 3), (("bcsstk13", 32, 512, "seg-nnz"), 4)])
+def test_native_step_real_ranks_unequal_seg_nnz_blocks(pkg, case, world):
+    """-seg_nnz partitions with unequal blocks (bcsstk13 at P = 4: heights 724 / 459 / 417 / 403, asymmetric send / recv counts): the C++
+    step object in `world` real processes on one GPU, against the reference's x_local and y (tests/golden/halo.npz)."""
+    assert f"{case[0]}_C{case[1]}_s{case[2]}_{case[3]}_P{world}_wsa" in np.load(os.path.join(GOLDEN, "halo.npz"))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     job = f"hx{os.getpid()}_{time.monotonic_ns()}"

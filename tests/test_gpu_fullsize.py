@@ -108,3 +108,39 @@ def test_full_size_config4b_plain_dp_sweep(pkg, orc, torch_cuda):
     y = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
     pkg.spmv(A, t.from_numpy(xp).cuda(), y)
     assert np.array_equal(y.cpu().numpy(), orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp))
+
+
+def test_full_size_kkt_nlpkkt200_class(pkg, orc, torch_cuda):
+    """The KKT-structured member of the nlpkkt class (uspmv_gen_kkt, N = 200: n = 16 240 000 = nlpkkt200's size, nnz = 4.3e8, rows of
+    5-28 entries, every state / multiplier row reaching into two index ranges N^3 apart): SELL-32-512 dp through the plan uspmv_dmat_optimize
+    picks, bit for bit against scs_impl_cpu<32>'s restatement, plus linearity.  Shows the headline kernel off the friendly end of its class."""
+    t = torch_cuda
+    from ultimate_spmv_amd import binding as B
+    N = max(6, int(200 * SCALE))
+    t0 = time.time()
+    coo = pkg.gen_kkt(N)
+    assert coo.n_rows == 2 * N ** 3 + 6 * N ** 2
+    s = pkg.convert_to_scs(coo, 32, 512, pkg.F64)
+    a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
+    nnz = coo.nnz
+    del coo
+    A = pkg.DeviceMatrix(s, tlc=True)
+    kind, nt, npl = A.plan_info()
+    xp = np.zeros(s.n_rows_padded); xp[:s.n_rows] = pkg.apply_permutation(make_x(s.n_rows), a["new_to_old_idx"])
+    x = t.from_numpy(xp).cuda(); y = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
+    pkg.spmv(A, x, y)
+    t.cuda.synchronize()
+    ms = B.time_launches(0, 30, A=A, x=x, y=y)
+    byts = s.n_elements * 12 + 8 * s.n_chunks + 8 * (s.n_rows + s.n_rows_padded)
+    print(f"\n[kkt] N={N} n={s.n_rows} nnz={nnz} beta={nnz / s.n_elements:.4f} set-up {time.time() - t0:.1f}s plan kind {kind}: {npl}/{nt} tiles; "
+          f"{ms:.4f} ms = {2.0 * nnz / ms / 1e6:.0f} GF/s, {byts / ms / 1e6:.0f} GB/s algorithmic = {byts / ms / 1e6 / 8000:.3f} of 8 TB/s", flush=True)
+    yo = orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+    assert np.array_equal(y.cpu().numpy(), yo)
+    y2 = t.zeros_like(y)
+    pkg.spmv(A, 2.0 * x, y2)
+    assert t.equal(y2, 2.0 * y)
+    A0 = pkg.DeviceMatrix(s)            # the plain gather kernel on the same arrays
+    y3 = t.zeros_like(y)
+    pkg.spmv(A0, x, y3)
+    assert t.equal(y3, y)
+    print(f"[kkt] bit-exact vs oracle; gather kernel {B.time_launches(0, 30, A=A0, x=x, y=y3):.4f} ms", flush=True)

@@ -830,3 +830,38 @@ def test_full_size_nlpkkt200_class(pkg, orc, torch_cuda):
         for k in range(b, e):
             acc = float(np.float64(V[k]) * np.float64(x0[J[k]]) + acc)   # not fused: tolerance
         assert abs(acc - yo[r]) <= 1e-13 * float(np.abs(V[b:e] * x0[J[b:e]]).sum())
+
+
+def test_spmmv_line_plan_column_major_without_relayout(pkg, orc, torch_cuda):
+    """Column-major block vectors with 64-byte rows staged by 128-byte LINES straight from the caller's X (scs_spmmv_quadph, XM = 2:
+    no re-layout pass, no workspace) -- the path uspmv_spmmv takes when the handle's line plan qualifies (X rows that come in runs:
+    sigma = 1 here; under sigma = 512 the column numbering is scrambled inside the windows and the planner turns the line plan
+    down).  Same bits as the gather kernel, the re-layout path and the oracle (block_spmv_omp_scs_general, code/kernels.hpp:306-398)."""
+    t = torch_cuda
+    used = 0
+    for shape, dof, C, sigma, code, b in (((14, 12, 11), 3, 32, 1, pkg.F64, 8), ((12, 9, 10), 1, 64, 1, pkg.F64, 8), ((10, 12, 13), 2, 32, 1, pkg.F32, 16),
+                                          ((14, 12, 11), 3, 32, 512, pkg.F64, 8)):
+        coo = pkg.gen_stencil27(*shape, dof=dof)
+        s, a, xp = _prep(pkg, coo, C, sigma, code, make_x(coo.n_rows))
+        ld = s.n_rows_padded + 8                     # (a multiple of the 16-byte piece: what the line path needs)
+        A = pkg.DeviceMatrix(s, block_tlc=b)
+        info = A.block_plan_info()
+        assert info["phased_plan"] == 1
+        if sigma == 1:
+            assert info["line_plan"] == 1 and info["line_rows_staged"] > 0, info
+        X = block_x(xp, s.n_rows_padded, b, ld, 0)
+        Yo = orc.spmmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, b, ld, False)
+        res = {}
+        for xline in (1, 0):
+            pkg.set_tuning(spmmv_xline=xline)
+            Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
+            pkg.spmmv(A, _dev(t, X), Y, b, ld, pkg.COLWISE)
+            res[xline] = Y.cpu().numpy()
+        pkg.set_tuning(spmmv_xline=1)
+        n = s.n_rows_padded
+        for v in range(b):                           # (the guard zone between the columns keeps its fill value)
+            assert np.array_equal(res[1][v * ld:v * ld + n], Yo[v * ld:v * ld + n]), (shape, C, sigma, v)
+            assert np.all(res[1][v * ld + n:(v + 1) * ld] == -3.0)
+        assert np.array_equal(res[1], res[0])
+        used += info["line_plan"]
+    assert used >= 3

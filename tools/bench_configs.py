@@ -57,6 +57,26 @@ def main():
             ycpu = np.zeros(s.n_rows_padded)
             cpu_fn = lambda R: R.lib("colwise").ref_spmv_omp_scs_adv_f64(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp, ycpu)
             cpu_name = "spmv_omp_scs_adv<C=32,double>"
+        elif cfg == "2k":   # the KKT-structured member of the nlpkkt class (uspmv_gen_kkt): rows of 5-28 entries, two index ranges N^3 apart
+            N = int(200 * args.scale)
+            coo = pkg.gen_kkt(N)
+            s = prep(coo, pkg.F64)
+            a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
+            A = pkg.DeviceMatrix(s, tlc=True)
+            xp = np.zeros(s.n_rows_padded); xp[:s.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(s.n_rows) % 1000), a["new_to_old_idx"])
+            x = t.from_numpy(xp).cuda(); y = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
+            pkg.spmv(A, x, y)
+            ok = None if args.no_check else bool(np.array_equal(y.cpu().numpy(), orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)))
+            ms = B.time_launches(0, args.reps, A=A, x=x, y=y)
+            byts = s.n_elements * 12 + 8 * s.n_chunks + 8 * s.n_rows + 8 * s.n_rows_padded
+            A0 = pkg.DeviceMatrix(s)
+            out = dict(config="2k", workload=f"nlpkkt200-class KKT [H A^T; A 0] N={N} (n = 2N^3 + 6N^2) scs -c 32 -s 512 -dp", n=s.n_rows, nnz=s.nnz, b=1,
+                       beta=round(s.nnz / s.n_elements, 5), plan_kind_tiles_planned=list(A.plan_info()), tlc_tiles_staged=[A.tlc_staged, A.tlc_tiles],
+                       gather_kernel_ms=round(B.time_launches(0, args.reps, A=A0, x=x, y=y), 5))
+            flops = 2.0 * s.nnz
+            ycpu = np.zeros(s.n_rows_padded)
+            cpu_fn = lambda R: R.lib("colwise").ref_spmv_omp_scs_adv_f64(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp, ycpu)
+            cpu_name = "spmv_omp_scs_adv<C=32,double>"
         elif cfg == "3":
             g = int(111 * args.scale)
             coo = pkg.gen_stencil27(g, g, g, dof=3)

@@ -58,6 +58,8 @@ _SIGS = {
     "uspmv_coo_free": (None, [_vp]),
     "uspmv_gen_stencil27": (C.c_int, [_i64, _i64, _i64, C.c_int, C.c_uint64, C.c_double, _i64, _i64, C.POINTER(_vp)]),
     "uspmv_gen_banded_random": (C.c_int, [_i64, C.c_int, _i64, C.c_uint64, C.c_double, _i64, _i64, C.POINTER(_vp)]),
+    "uspmv_gen_kkt": (C.c_int, [_i64, C.c_uint64, _i64, _i64, C.POINTER(_vp)]),
+    "uspmv_gen_kkt_row_counts": (C.c_int, [_i64, _i64, _i64, _vp]),
     "uspmv_convert_to_scs": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, C.POINTER(_vp)]),
     "uspmv_scs_meta": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_scs_dtype": (C.c_int, [_vp, C.POINTER(C.c_int)]),
@@ -91,6 +93,7 @@ _SIGS = {
     "uspmv_dmat_optimize_sweep": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_optimize_sweep_ap": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_plan_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(_i64)]),
+    "uspmv_dmat_block_plan_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp]),
     "uspmv_spmv_ap": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "uspmv_spmv_ap_generic": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
@@ -265,6 +268,22 @@ def gen_banded_random(n, nnz_per_row, band, seed=0x5EED, magnitude_decades=0.0, 
     h = _vp()
     _ck(lib().uspmv_gen_banded_random(n, nnz_per_row, band, seed, magnitude_decades, row_begin, n if row_end is None else row_end, C.byref(h)))
     return Coo(h)
+
+
+def gen_kkt(N, seed=0x5EED, row_begin=0, row_end=None):
+    """nlpkkt-class KKT matrix [H A^T; A 0] on an N^3 grid with boundary controls (n = 2 N^3 + 6 N^2), uspmv_gen_kkt."""
+    n = 2 * N ** 3 + 6 * N ** 2
+    h = _vp()
+    _ck(lib().uspmv_gen_kkt(N, seed, row_begin, n if row_end is None else row_end, C.byref(h)))
+    return Coo(h)
+
+
+def gen_kkt_row_counts(N, row_begin=0, row_end=None):
+    n = 2 * N ** 3 + 6 * N ** 2
+    row_end = n if row_end is None else row_end
+    out = np.empty(row_end - row_begin, np.int32)
+    _ck(lib().uspmv_gen_kkt_row_counts(N, row_begin, row_end, _np_ptr(out)))
+    return out
 
 
 # ---------------------------------------------------------------------------------------- SCS
@@ -771,6 +790,13 @@ class DeviceMatrix:
         k, a, b = C.c_int(), _i64(), _i64()
         _ck(lib().uspmv_dmat_plan_info(self.h, C.byref(k), C.byref(a), C.byref(b)))
         return k.value, a.value, b.value
+
+    def block_plan_info(self):
+        """dict of the handle's block-vector plans (uspmv_dmat_block_plan_info)"""
+        m = (_i64 * 8)()
+        _ck(lib().uspmv_dmat_block_plan_info(self.h, m))
+        keys = ("list_plan", "phased_plan", "line_plan", "tiles", "phases", "line_phases", "line_rows_staged", "idx8")
+        return dict(zip(keys, [int(v) for v in m]))
 
     def optimize_block_device(self, block_vec_size):
         """The block plan from the handle's device arrays alone (uspmv_dmat_optimize_block_device)."""

@@ -734,15 +734,15 @@ void launch_spmmv_quad(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool yc
 
 // the phased-plan kernels live in spmmv_phased.hip (64-byte rows only: dp b = 8, sp b = 16)
 template <typename VT, int B>
-bool launch_spmmv_quadph(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, bool xcol, hipStream_t st) {
-    return uspmv_dev::spmmv_phased(A, X, Y, ld, ycol, xcol, st);
+bool launch_spmmv_quadph(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, int xmode, hipStream_t st) {
+    return uspmv_dev::spmmv_phased(A, X, Y, ld, ycol, xmode, st);
 }
 template <typename VT, int B>
 void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
     constexpr int RB = B * (int)sizeof(VT);          // bytes per X row
     if constexpr (RB == 64) {
         // 64-byte rows, phased plan (variant 8; auto when the handle carries one): eight workgroups per CU
-        if ((g_tune.spmmv_variant == 8 || (g_tune.spmmv_variant == 0 && !g_tune.ablate)) && launch_spmmv_quadph<VT, B>(A, X, Y, ld, ycol, false, st)) return;
+        if ((g_tune.spmmv_variant == 8 || (g_tune.spmmv_variant == 0 && !g_tune.ablate)) && launch_spmmv_quadph<VT, B>(A, X, Y, ld, ycol, 0, st)) return;
         // 64-byte rows: the four-lanes-per-row kernel over 64-row tiles of the block plan (variant 6; auto when the plan is there)
         if (A->bt && A->bt_tile_rows == 64 && (g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 6) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
             // one tile per workgroup, three workgroups per CU (a persistent, software-pipelined form of it -- 222 registers, two workgroups
@@ -801,9 +801,12 @@ int spmmv_fast(const uspmv_dmat *A, const VT *X, VT *Y, long ld, int layout, hip
         return USPMV_OK;
     }
     if constexpr (B * (int)sizeof(VT) == 64) {
-        // 64-byte rows with a phased plan: the kernel assembles its X rows from the column-major vector itself (no re-layout pass)
-        if ((g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 8) && g_tune.spmmv_xcol && !g_tune.ablate &&
-            launch_spmmv_quadph<VT, B>(A, X, Y, ld, true, true, st)) return USPMV_OK;
+        // 64-byte rows with a phased plan: the kernel stages X straight from the column-major vector -- by 128-byte lines when the
+        // handle carries the line plan (default), through registers with "spmmv_xcol" 1 -- no re-layout pass, no workspace
+        if ((g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 8) && !g_tune.ablate) {
+            if (g_tune.spmmv_xcol && launch_spmmv_quadph<VT, B>(A, X, Y, ld, true, 1, st)) return USPMV_OK;
+            if (g_tune.spmmv_xline && launch_spmmv_quadph<VT, B>(A, X, Y, ld, true, 2, st)) return USPMV_OK;
+        }
     }
     const size_t need = sizeof(VT) * (size_t)B * (size_t)ld;
     if (A->ws_bytes < need) {

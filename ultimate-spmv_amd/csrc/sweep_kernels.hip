@@ -71,9 +71,64 @@ __device__ __forceinline__ void sweep_window(const XT *__restrict__ xs, const in
     }
 }
 
+// TWO independent chains of one lane through the same window in one loop -- two of the lane's rows (dp / sp kernels with several rows
+// per lane) or the dp and the sp part of one row (ap[dp_sp]: their accumulators only meet after the last window).  Per batch both
+// chains' ballots are taken, then BOTH batches of loads are issued before the first wait: twice the entries in flight per wave
+// and half as many dependent HBM round trips per window (a wave walks ~4 batches per window and chain; with 16 waves per CU and
+// one workgroup per CU -- the window takes the LDS -- those round trips are what the kernel waits for, profiles/r02/pmc_cfg4b.txt:
+// 51 % of the wave cycles).  Each chain still sees its entries in slot order: the FMA chains of the reference, bit for bit.
+// Pointers travel by value and come back through the struct (by-reference pointer arrays made the compiler shuffle 64-bit
+// scalar pairs on every batch).
+template <typename A0, typename A1>
+struct SweepPtrs { const A0 *v0; const unsigned short *i0; const A1 *v1; const unsigned short *i1; };
+
+template <typename A0, typename A1, typename X0, typename X1, int U, bool NT>
+__device__ __forceinline__ SweepPtrs<A0, A1> sweep_window2(const X0 *__restrict__ xs0, const X1 *__restrict__ xs1, const int c0, const int c1,
+                                                            SweepPtrs<A0, A1> p, X0 &acc0, X1 &acc1) {
+    A0 v0[U];
+    A1 v1[U];
+    unsigned ix0[U], ix1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { v0[u] = A0(0); v1[u] = A1(0); ix0[u] = 0u; ix1[u] = 0u; }
+    for (int k0 = 0;; k0 += U) {
+        unsigned long long m0[U], m1[U];
+        unsigned f0[U + 1], f1[U + 1];
+        f0[0] = 0u; f1[0] = 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            m0[u] = __ballot(k0 + u < c0);
+            m1[u] = __ballot(k0 + u < c1);
+            f0[u + 1] = f0[u] + (unsigned)__popcll(m0[u]);
+            f1[u + 1] = f1[u] + (unsigned)__popcll(m1[u]);
+        }
+        if ((m0[0] | m1[0]) == 0ull) break;                  // wave-uniform: both chains of every lane are through this window
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (k0 + u < c0) {
+                const unsigned off = f0[u] + lanes_below(m0[u]);
+                v0[u] = ld_stream_g<NT>(p.v0 + off); ix0[u] = ld_stream_g<NT>(p.i0 + off);
+            }
+            if (k0 + u < c1) {
+                const unsigned off = f1[u] + lanes_below(m1[u]);
+                v1[u] = ld_stream_g<NT>(p.v1 + off); ix1[u] = ld_stream_g<NT>(p.i1 + off);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const X0 t0 = fma_t((X0)v0[u], xs0[ix0[u]], acc0);
+            acc0 = (k0 + u < c0) ? t0 : acc0;
+            const X1 t1 = fma_t((X1)v1[u], xs1[ix1[u]], acc1);
+            acc1 = (k0 + u < c1) ? t1 : acc1;
+        }
+        p.v0 += f0[U]; p.i0 += f0[U];
+        p.v1 += f1[U]; p.i1 += f1[U];
+    }
+    return p;
+}
+
 // RPL rows per lane: a tile is RPL * blockDim.x rows, lane <-> rows tid, tid + blockDim.x, ...  The windows of x are staged once per
 // tile, so RPL = 2 halves the staging traffic per non-zero (the workgroup is already 1 024 threads).
-template <typename VT, bool AP, bool NT, int NBUF, int U, int RPL>
+template <typename VT, bool AP, bool NT, int NBUF, int U, int RPL, bool PAIR = false>
 __global__ void __launch_bounds__(1024) scs_spmv_sweep(const int wlog, const int *__restrict__ tile_ids, const int *__restrict__ t_smin,
         const int *__restrict__ t_S, const unsigned long long *__restrict__ t_cnt_off,
         const unsigned *__restrict__ wave_off, const unsigned char *__restrict__ cnt, const VT *__restrict__ vals, const unsigned short *__restrict__ idx,
@@ -153,11 +208,31 @@ __global__ void __launch_bounds__(1024) scs_spmv_sweep(const int wlog, const int
                 if (AP) cb_next[h] = cpb[(long)(s + 1) * R + h * T];
             }
         }
+        if constexpr (PAIR && AP) {            // the dp and the sp chain of a row side by side
 #pragma unroll
-        for (int h = 0; h < RPL; ++h) {
-            sweep_window<VT, VT, U, NT>(cur, c_cur[h], vp[h], ip[h], acc[h]);
-            if constexpr (AP) sweep_window<float, double, U, NT>((const double *)cur, cb_cur[h], vpb[h], ipb[h], acc_b[h]);
-            c_cur[h] = c_next[h]; cb_cur[h] = cb_next[h];
+            for (int h = 0; h < RPL; ++h) {
+                SweepPtrs<double, float> pr{(const double *)vp[h], ip[h], vpb[h], ipb[h]};
+                double a0 = (double)acc[h];
+                pr = sweep_window2<double, float, double, double, U, NT>((const double *)cur, (const double *)cur, c_cur[h], cb_cur[h], pr, a0, acc_b[h]);
+                acc[h] = (VT)a0;
+                vp[h] = (const VT *)pr.v0; ip[h] = pr.i0; vpb[h] = pr.v1; ipb[h] = pr.i1;
+                c_cur[h] = c_next[h]; cb_cur[h] = cb_next[h];
+            }
+        } else if constexpr (PAIR && RPL >= 2) {   // two of the lane's rows side by side
+#pragma unroll
+            for (int h = 0; h < RPL; h += 2) {
+                SweepPtrs<VT, VT> pr{vp[h], ip[h], vp[h + 1], ip[h + 1]};
+                pr = sweep_window2<VT, VT, VT, VT, U, NT>(cur, cur, c_cur[h], c_cur[h + 1], pr, acc[h], acc[h + 1]);
+                vp[h] = pr.v0; ip[h] = pr.i0; vp[h + 1] = pr.v1; ip[h + 1] = pr.i1;
+                c_cur[h] = c_next[h]; c_cur[h + 1] = c_next[h + 1];
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < RPL; ++h) {
+                sweep_window<VT, VT, U, NT>(cur, c_cur[h], vp[h], ip[h], acc[h]);
+                if constexpr (AP) sweep_window<float, double, U, NT>((const double *)cur, cb_cur[h], vpb[h], ipb[h], acc_b[h]);
+                c_cur[h] = c_next[h]; cb_cur[h] = cb_next[h];
+            }
         }
     }
     // trailing padding of the row, applied once (see sweep_plan.cpp)
@@ -186,9 +261,11 @@ int launch_sweep(const uspmv_dmat *A, const VT *x, VT *y, hipStream_t st) {
     int threads = std::min<int>(A->sw_tile_rows, g_tune.sweep_threads > 0 ? g_tune.sweep_threads : 1024);
     if (A->sw_tile_rows / threads > 4) threads = A->sw_tile_rows / 4;
     const int rpl = A->sw_tile_rows / threads;
+    const bool pair = g_tune.sweep_pair != 0 && (AP || rpl >= 2);
 #define SW_LAUNCH(NTV, NB, UU, RP)                                                                                          \
     do {                                                                                                                    \
         auto kfn = scs_spmv_sweep<VT, AP, NTV, NB, UU, RP>;                                                                 \
+        if (pair) kfn = scs_spmv_sweep<VT, AP, NTV, NB, UU, RP, true>;                                                      \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)A->sw_n_tiles), dim3(threads), lds, st, A->sw_wlog, A->sw_tile_ids,           \
                            A->sw_smin, A->sw_S, (const unsigned long long *)A->sw_cnt_off, A->sw_wave_off, A->sw_cnt,        \

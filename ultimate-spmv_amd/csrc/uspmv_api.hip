@@ -156,12 +156,15 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_reorder")) g_tune.spmmv_reorder = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (!strcmp(key, "spmmv_phased")) g_tune.spmmv_phased = value != 0;
     else if (!strcmp(key, "spmmv_xcol")) g_tune.spmmv_xcol = value != 0;
+    else if (!strcmp(key, "spmmv_ycol_nt")) g_tune.spmmv_ycol_nt = value != 0;
+    else if (!strcmp(key, "spmmv_xline")) g_tune.spmmv_xline = value != 0;
     else if (!strcmp(key, "spmmv_phase_rows")) g_tune.spmmv_phase_rows = value == 512 ? 512 : 256;
     else if (!strcmp(key, "spmmv_idx8")) g_tune.spmmv_idx8 = value != 0;
     else if (!strcmp(key, "spmmv_list_plan")) g_tune.spmmv_list_plan = value != 0;
     else if (!strcmp(key, "sweep")) g_tune.sweep = value != 0;
     else if (!strcmp(key, "sweep_nbuf")) g_tune.sweep_nbuf = value == 1 ? 1 : 2;
     else if (!strcmp(key, "sweep_unroll")) g_tune.sweep_unroll = value >= 8 ? 8 : value >= 4 ? 4 : 2;
+    else if (!strcmp(key, "sweep_pair")) g_tune.sweep_pair = value != 0;
     else if (!strcmp(key, "sweep_remap")) g_tune.sweep_remap = value < 0 ? 0 : value;
     else if (!strcmp(key, "sweep_wlog")) {
         if (value != 0 && (value < 8 || value > 16)) return uspmv::fail(USPMV_ERR_INVALID, "sweep_wlog must be 0 or 8..16");
@@ -216,12 +219,15 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_reorder")) *value = g_tune.spmmv_reorder;
     else if (!strcmp(key, "spmmv_phased")) *value = g_tune.spmmv_phased;
     else if (!strcmp(key, "spmmv_xcol")) *value = g_tune.spmmv_xcol;
+    else if (!strcmp(key, "spmmv_ycol_nt")) *value = g_tune.spmmv_ycol_nt;
+    else if (!strcmp(key, "spmmv_xline")) *value = g_tune.spmmv_xline;
     else if (!strcmp(key, "spmmv_phase_rows")) *value = g_tune.spmmv_phase_rows;
     else if (!strcmp(key, "spmmv_idx8")) *value = g_tune.spmmv_idx8;
     else if (!strcmp(key, "spmmv_list_plan")) *value = g_tune.spmmv_list_plan;
     else if (!strcmp(key, "sweep")) *value = g_tune.sweep;
     else if (!strcmp(key, "sweep_nbuf")) *value = g_tune.sweep_nbuf;
     else if (!strcmp(key, "sweep_unroll")) *value = g_tune.sweep_unroll;
+    else if (!strcmp(key, "sweep_pair")) *value = g_tune.sweep_pair;
     else if (!strcmp(key, "sweep_remap")) *value = g_tune.sweep_remap;
     else if (!strcmp(key, "sweep_wlog")) *value = g_tune.sweep_wlog;
     else if (!strcmp(key, "sweep_tile_rows")) *value = g_tune.sweep_tile_rows;
@@ -615,6 +621,8 @@ static void bt_release(uspmv_dmat_t *A) {
     A->pb_ph_ptr = A->pb_g0 = A->pb_list_ptr = A->pb_xrows = nullptr; A->pb_c16_ptrs = nullptr; A->pb_col16 = nullptr; A->pb = false;
     A->bt_line_ptr = A->bt_xrows = nullptr; A->bt_c16_ptrs = nullptr; A->bt_col16 = nullptr;
     A->bt = false;
+    (void)hipFree(A->pl_ph_ptr); (void)hipFree(A->pl_g0); (void)hipFree(A->pl_list_ptr); (void)hipFree(A->pl_lines); (void)hipFree(A->pl_col8);
+    A->pl_ph_ptr = A->pl_g0 = A->pl_list_ptr = A->pl_lines = nullptr; A->pl_col8 = nullptr; A->pl = false;
 }
 
 int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_vec_size, int64_t *n_tiles, int64_t *n_staged) {
@@ -645,6 +653,20 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
     if (row_bytes == 64 && tile_rows == 64 && g_tune.spmmv_phased)
         if (int rc = uspmv_build_phased_plan(moved ? &r : s, g_tune.spmmv_phase_rows, 8, &pp)) return rc;
     const bool phased_ok = pp.valid && pp.ngp <= 8 && (pp.max_rows_used * 4 + 255) / 256 <= 8;
+    // ... and once more with LINE lists for column-major block vectors (no re-layout pass over X): kept when no phase needs more
+    // than 256 rows' worth of lines and the lines staged stay below twice the rows the row plan stages
+    uspmv_phased_plan pl;
+    if (phased_ok && g_tune.spmmv_xline && g_tune.spmmv_phase_rows == 256) {
+        const int shift = s->dtype == USPMV_F64 ? 4 : 5;
+        if (int rc = uspmv_build_phased_plan(moved ? &r : s, 256, 8, &pl, shift)) return rc;
+        if (getenv("USPMV_VERBOSE")) {
+            int64_t over = 0;
+            for (int64_t ph = 0; ph < pl.n_phases; ++ph) over += (pl.ph_list_ptr[(size_t)ph + 1] - pl.ph_list_ptr[(size_t)ph]) > (256 >> shift);
+            fprintf(stderr, "[uspmv] line plan candidate: valid=%d phases=%lld lines_total=%zu (= %zu rows; row plan stages %zu) max_rows=%d phases over the cap: %lld\n",
+                    (int)pl.valid, (long long)pl.n_phases, pl.xrows.size(), pl.xrows.size() << shift, pp.xrows.size(), pl.max_rows_used, (long long)over);
+        }
+        if (pl.valid && (pl.max_rows_used > 256 || pl.ngp > 8 || ((int64_t)pl.xrows.size() << shift) > 2 * (int64_t)pp.xrows.size())) pl.valid = false;
+    }
     const bool list_plan = !phased_ok || g_tune.spmmv_list_plan;
     if (list_plan) {
         if (int rc = uspmv_build_tlc_plan(moved ? &r : s, nullptr, max_rows, tile_rows, &p, /*line_shift=*/0)) return rc;
@@ -707,12 +729,26 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
             }
             if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] phased block plan: tiles=%lld phases=%lld rows_total=%zu max_rows=%d (cap %d)\n",
                                                  (long long)pp.n_tiles, (long long)pp.n_phases, pp.xrows.size(), pp.max_rows_used, pp.cap_rows);
+            if (e == hipSuccess && pl.valid) {
+                e = up(pl.ph_ptr.data(), pl.ph_ptr.size() * 4, (void **)&A->pl_ph_ptr);
+                if (e == hipSuccess) e = up(pl.ph_g0.data(), pl.ph_g0.size() * 4, (void **)&A->pl_g0);
+                if (e == hipSuccess) e = up(pl.ph_list_ptr.data(), pl.ph_list_ptr.size() * 4, (void **)&A->pl_list_ptr);
+                if (e == hipSuccess) e = up(pl.xrows.data(), pl.xrows.size() * 4, (void **)&A->pl_lines);
+                if (e == hipSuccess) {
+                    std::vector<uint8_t> c8(pl.col16.size());
+                    for (size_t k = 0; k < c8.size(); ++k) c8[k] = (uint8_t)pl.col16[k];
+                    e = up(c8.data(), c8.size(), (void **)&A->pl_col8);
+                }
+                if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] line plan (column-major X): phases=%lld lines_total=%zu (= %zu rows) max_rows=%d\n",
+                                                     (long long)pl.n_phases, pl.xrows.size(), pl.xrows.size() << pl.line_shift, pl.max_rows_used);
+            }
         }
     }
     if (e != hipSuccess) {
         bt_release(A);
         return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_block: device copy failed: %s", hipGetErrorString(e));
     }
+    if (pp.valid && pl.valid) { A->pl = true; A->pl_shift = pl.line_shift; A->pl_max_rows = pl.max_rows_used; A->pl_n_phases = pl.n_phases; A->pl_rows_staged = (int64_t)pl.xrows.size() << pl.line_shift; }
     if (pp.valid) { A->pb = true; A->pb_cap_rows = pp.cap_rows; A->pb_ngp = pp.ngp; A->pb_max_rows = pp.max_rows_used; A->pb_n_tiles = pp.n_tiles; A->pb_n_phases = pp.n_phases; }
     if (list_plan && p.valid) { A->bt = true; A->bt_tile_rows = p.tile_rows; A->bt_max_rows = p.max_lines_used; A->bt_n_tiles = p.n_tiles; A->bt_staged = p.n_staged_tiles; }
     return USPMV_OK;
@@ -969,6 +1005,14 @@ int uspmv_dmat_plan_info(const uspmv_dmat_t *A, int *kind, int64_t *n_tiles, int
     if (kind) *kind = k;
     if (n_tiles) *n_tiles = nt;
     if (n_planned) *n_planned = np;
+    return USPMV_OK;
+}
+
+int uspmv_dmat_block_plan_info(const uspmv_dmat_t *A, int64_t meta[8]) {
+    if (!A || !meta) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_block_plan_info: NULL argument");
+    const uspmv_dmat_t *M = (A->alt && g_tune.rechunk) ? A->alt : A;
+    meta[0] = M->bt; meta[1] = M->pb; meta[2] = M->pl; meta[3] = M->pb_n_tiles; meta[4] = M->pb_n_phases; meta[5] = M->pl_n_phases;
+    meta[6] = M->pl_rows_staged; meta[7] = M->pb_idx8;
     return USPMV_OK;
 }
 

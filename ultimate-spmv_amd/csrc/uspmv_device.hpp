@@ -54,6 +54,13 @@ struct uspmv_dmat {
     uint32_t *pb_c16_ptrs = nullptr;
     uint16_t *pb_col16 = nullptr;       // phase-local indices; ONE BYTE each when pb_idx8 (no phase lists more than 256 rows)
     bool pb_idx8 = false;
+    // the same plan once more with LINE lists (128 bytes of one column: 16 doubles / 32 floats) for column-major block vectors:
+    // shares pb_values / pb_c16_ptrs / the row map; one-byte local indices (line << shift | row in line)
+    bool pl = false;
+    int pl_shift = 0, pl_max_rows = 0;
+    int64_t pl_n_phases = 0, pl_rows_staged = 0;
+    int32_t *pl_ph_ptr = nullptr, *pl_g0 = nullptr, *pl_list_ptr = nullptr, *pl_lines = nullptr;
+    uint8_t *pl_col8 = nullptr;
     // column-window sweep plan (host/sweep_plan.cpp, uspmv_dmat_optimize_sweep[_ap]); the _b arrays are the sp part of
     // an ap[dp_sp] pair and live on the dp handle, the sp handle only carries the plan id
     bool sw = false;
@@ -96,11 +103,14 @@ struct Tuning {
     int sweep_threads = 0;     // threads per sweep workgroup (0 = min(tile rows, 1024); 256 | 512: a lane owns tile rows / threads rows, at most 4)
     int sweep_nbuf = 1;     // LDS buffers per workgroup: 1 = two 1024-thread workgroups per CU cover each other's staging (0.63 vs 0.72 ms on
                             // config 4b); 2 = one workgroup, window s+1 lands while window s is consumed
+    int sweep_pair = 1;     // two chains per lane side by side (two rows of the lane, or the dp and sp part of a row): twice the entries in flight per wave
     int sweep_unroll = 8;   // rounds per batch
     int sweep_remap = 8;    // consecutive sweep tiles per XCD (neighbouring tiles share their x windows)
     int sweep_wlog = 0;     // NEXT uspmv_dmat_optimize_sweep: log2 of the window width in elements (0 = 64 KiB of VT)
     int sweep_tile_rows = 0;  // NEXT uspmv_dmat_optimize_sweep: 256 | 512 | 1024 | 2048 | 4096 rows per tile (0 = default; above 1024: several rows per lane)
     int sweep_max_stage = 0;  // NEXT plan: largest staging cost in bytes per non-zero for a tile to sweep (0 = 24)
+    int spmmv_xline = 1;       // NEXT uspmv_dmat_optimize_block with 64-byte rows: also build the line plan (column-major X without a re-layout pass); uspmv_spmmv: use it
+    int spmmv_ycol_nt = 0;     // phased SpMMV kernel, column-major Y: 1 = non-temporal element stores, 0 = plain (write-back) stores that the L2 can merge into whole lines
     int spmmv_xcol = 0;        // phased SpMMV kernel on column-major X: 0 = separate re-layout pass first (1.078 ms on config 3), 1 = rows assembled in LDS by
                                // the kernel itself from the column-major vector (no workspace, no extra launch, but 1.123 ms: 74 registers, six workgroups per CU)
     int spmmv_phased = 1;      // NEXT uspmv_dmat_optimize_block with 64-byte rows: also build the phased plan (eight workgroups per CU)
@@ -129,8 +139,9 @@ int launch_csr(long n_rows, long nnz_hint, const int *rp, const int *ci, const V
 template <typename VT>
 int launch_spmmv(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int layout, hipStream_t st);            // spmmv_kernels.hip
 // phased block plan, 64-byte X rows (spmmv_phased.hip); false: no plan / schedule on the handle or it does not fit the compiled shapes
-bool spmmv_phased(const uspmv_dmat *A, const double *X, double *Y, long ld, bool ycol, bool xcol, hipStream_t st);
-bool spmmv_phased(const uspmv_dmat *A, const float *X, float *Y, long ld, bool ycol, bool xcol, hipStream_t st);
+// xmode: 0 = row-major X, 1 = column-major X assembled through registers, 2 = column-major X staged by 128-byte lines (line plan)
+bool spmmv_phased(const uspmv_dmat *A, const double *X, double *Y, long ld, bool ycol, int xmode, hipStream_t st);
+bool spmmv_phased(const uspmv_dmat *A, const float *X, float *Y, long ld, bool ycol, int xmode, hipStream_t st);
 int launch_spmv_ap(const uspmv_dmat *dp, const uspmv_dmat *sp, const double *d_x, const float *d_x_sp, double *d_y,
                    hipStream_t stream);                                                                           // ap_kernels.hip
 template <typename VT>

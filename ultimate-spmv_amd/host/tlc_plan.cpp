@@ -346,8 +346,15 @@ int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vect
 // 16-bit indices.  The workgroup stages one phase at a time (cap_rows * row bytes of LDS: 16 KB -> eight workgroups per CU) and
 // still walks every row's slots in order, so the FMA chains are unchanged.  An X row needed in two phases is staged twice; for
 // matrices whose rows are column-sorted the phases' row sets are (nearly) disjoint.
-int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_phased_plan *p) {
+int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_phased_plan *p, int line_shift) {
+    // line_shift > 0: the lists hold LINES of 2^line_shift consecutive X rows (what a column-major block vector is staged by: one
+    // 128-byte line per list entry and column); a phase lists at most cap_rows >> line_shift lines and the local index of an entry
+    // is (position of its line) << line_shift | (column & (2^line_shift - 1)).
     p->valid = false;
+    p->line_shift = line_shift;
+    if (line_shift < 0 || line_shift > 8 || (cap_rows >> line_shift) < 1) return USPMV_OK;
+    const int cap_items = cap_rows >> line_shift;
+    const int32_t sub_mask = (1 << line_shift) - 1;
     const int64_t C = s->C, nc = s->n_chunks;
     if ((C != 32 && C != 64 && C != 16) || nc < 1 || cap_rows < 256 || cap_rows > 65536 || ngp < 1) return USPMV_OK;
     if (s->n_cols > (int64_t)INT32_MAX) return USPMV_OK;
@@ -365,7 +372,7 @@ int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_pha
     std::vector<std::vector<int32_t>> t_g0((size_t)n_tiles), t_len((size_t)n_tiles), t_rows((size_t)n_tiles);
     int64_t max_col_seen = 0;
     for (int64_t k = 0; k < s->n_elements; ++k) max_col_seen = std::max<int64_t>(max_col_seen, s->col_idxs[(size_t)k]);
-    const size_t ncol = (size_t)max_col_seen + 1;
+    const size_t ncol = (size_t)(max_col_seen >> line_shift) + 1;      // items: X rows, or lines of them
 #pragma omp parallel
     {
         std::vector<int64_t> stamp(ncol, -1), gstamp(ncol, -1);
@@ -386,8 +393,10 @@ int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_pha
                     const int64_t cs = s->chunk_ptrs[(size_t)c], L = s->chunk_lengths[(size_t)c];
                     uint16_t *q = p->col16.data() + p->c16_ptrs[(size_t)c];
                     for (int64_t j = first_group * 4; j < std::min(end_group * 4, L); ++j)
-                        for (int64_t i = 0; i < C; ++i)
-                            q[(j / 4) * 4 * C + i * 4 + (j % 4)] = (uint16_t)pos[(size_t)s->col_idxs[(size_t)(cs + j * C + i)]];
+                        for (int64_t i = 0; i < C; ++i) {
+                            const int32_t col = s->col_idxs[(size_t)(cs + j * C + i)];
+                            q[(j / 4) * 4 * C + i * 4 + (j % 4)] = (uint16_t)((pos[(size_t)(col >> line_shift)] << line_shift) | (col & sub_mask));
+                        }
                 }
                 g0s.push_back((int32_t)first_group); lens.push_back((int32_t)cur.size());
                 rows.insert(rows.end(), cur.begin(), cur.end());
@@ -401,13 +410,13 @@ int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_pha
                     const int64_t cs = s->chunk_ptrs[(size_t)c], L = s->chunk_lengths[(size_t)c];
                     for (int64_t j = g * 4; j < std::min(g * 4 + 4, L); ++j)
                         for (int64_t i = 0; i < C; ++i) {
-                            const int32_t col = s->col_idxs[(size_t)(cs + j * C + i)];
+                            const int32_t col = s->col_idxs[(size_t)(cs + j * C + i)] >> line_shift;
                             if (gstamp[(size_t)col] != group_id) { gstamp[(size_t)col] = group_id; gc.push_back(col); }
                         }
                 }
                 int64_t fresh = 0;
                 for (int32_t col : gc) fresh += stamp[(size_t)col] != phase_id;
-                if (g > first && ((int64_t)cur.size() + fresh > cap_rows || g - first >= ngp)) {
+                if (g > first && ((int64_t)cur.size() + fresh > cap_items || g - first >= ngp)) {
                     close_phase(first, g);
                     first = g; ++phase_id;
                 }
@@ -436,7 +445,7 @@ int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_pha
             p->ph_list_ptr[(size_t)ph] = (int32_t)off;
             const int len = t_len[(size_t)t][k];
             std::copy(t_rows[(size_t)t].begin() + (long)ro, t_rows[(size_t)t].begin() + (long)(ro + (size_t)len), p->xrows.begin() + off);
-            ro += (size_t)len; off += len; mx = std::max(mx, len);
+            ro += (size_t)len; off += len; mx = std::max(mx, len << line_shift);
         }
     }
     p->ph_list_ptr[(size_t)n_ph] = (int32_t)off;

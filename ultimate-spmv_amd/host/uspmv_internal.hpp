@@ -83,7 +83,7 @@ int uspmv_build_sweep_plan(const uspmv_scs *s, const uspmv_scs *s2, int wlog, in
 // Phased block plan (host copy), see host/tlc_plan.cpp
 struct uspmv_phased_plan {
     bool valid = false;
-    int cap_rows = 256, ngp = 8, max_rows_used = 0;
+    int cap_rows = 256, ngp = 8, max_rows_used = 0, line_shift = 0;   // line_shift > 0: the lists hold lines of 2^line_shift X rows
     int64_t n_tiles = 0, n_phases = 0;
     std::vector<int32_t> ph_ptr;        // n_tiles+1: phases of a tile
     std::vector<int32_t> ph_g0;         // n_phases: first group (of four slots) of the phase; it ends where the tile's next phase starts
@@ -92,7 +92,7 @@ struct uspmv_phased_plan {
     std::vector<uint32_t> c16_ptrs;     // n_chunks+1
     std::vector<uint16_t> col16;        // [chunk][slot/4][row][slot%4], index into the list of the slot's phase
 };
-int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_phased_plan *plan);   // host/tlc_plan.cpp
+int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_phased_plan *plan, int line_shift = 0);   // host/tlc_plan.cpp
 
 int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *out);   // host/tlc_plan.cpp
 // private copy of the entries with the rows of equal-length chunks of a sigma window back in original order;
