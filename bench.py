@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="N > 1: eager C++ steps in the uspmv children")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vendor-baseline", action="store_true", help="N = 1: skip the rocSPARSE child process")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--tune", default="", help="key=value,... forwarded to uspmv_set_tuning")
     ap.add_argument("--no-tlc", action="store_true", help="skip the tile-local-column plan (plain gather kernel)")
@@ -130,6 +131,29 @@ def cpu_baseline(scs_arrays, C, n_chunks, nnz, x, seconds):
     return {"value": round(2.0 * nnz * reps / el / 1e9, 3), "unit": "GFLOP/s", "cores": cores, "kind": kind,
             "sample": f"whole matrix, {reps} SpMVs of spmv_omp_scs_adv<C=32,double> in {el:.1f} s, "
                       f"OMP threads = {cores}"}
+
+
+def vendor_baseline(grid):
+    """rocSPARSE on the same matrix (CSR default / adaptive / rowsplit / LRB and sliced ELL with slice 32), run by tools/rocsparse_baseline in
+    a child process: the ROCm twin of the reference's optional cuSPARSE path (USE_CUSPARSE: cusparseCreateCsr / cusparseCreateSlicedEll +
+    cusparseSpMV, code/utilities.hpp:3380-3550, code/classes_structs.hpp:998-1011).  A reported baseline, like cpu_baseline."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "rocsparse_baseline")
+    if not os.path.exists(exe):
+        return {"error": "tools/rocsparse_baseline is not built (rocSPARSE missing at build time)"}
+    try:
+        r = subprocess.run([exe, str(grid), "1", "--json"], capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"rc={r.returncode}: {(r.stdout + r.stderr)[-300:]}"}
+        d = json.loads(line[-1])
+    except (OSError, subprocess.TimeoutExpired, ValueError) as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+    best = min(d["ms"], key=d["ms"].get)
+    sell = d["ms"].get("rocsparse sliced-ELL (32)")
+    return {"library": d["library"], "value": round(2.0 * d["nnz"] / d["ms"][best] / 1e6, 1), "unit": "GFLOP/s", "best": best, "ms": d["ms"],
+            "sliced_ell_GFLOPs": round(2.0 * d["nnz"] / sell / 1e6, 1) if sell else None,
+            "note": "same matrix and x; CSR from the COO, sliced ELL = the SELL-32-512 arrays (slice 32)"}
 
 
 def _cpu_leg(flops, fn_ref, fn_port, y_cpu, y_gpu, seconds, name):
@@ -734,6 +758,8 @@ def main():
     if not args.no_cpu_baseline:
         a = s.arrays()
         out["cpu_baseline"] = cpu_baseline(a, s.C, s.n_chunks, s.nnz, x.cpu().numpy(), args.cpu_seconds)
+    if not args.no_vendor_baseline and not args.mtx:
+        out["vendor_baseline"] = vendor_baseline(args.grid or 253)
     which = [w for w in args.other_configs.split(",") if w]
     if which and not args.mtx:
         del A, x, y, s

@@ -299,6 +299,14 @@ int uspmv_get_tuning(const char *key, int *value);
 /* ------------------------------------------------------------------ L4: halo exchange     */
 /* seg_work_sharing_arr (code/mpi_funcs.hpp:424-622), seg-rows and seg-nnz: wsa[P+1]. */
 int uspmv_seg_work_sharing_arr(const uspmv_coo_t *total, int seg_method, int P, int32_t *wsa);
+/* -seg_metis (code/mpi_funcs.hpp:494-598) without METIS: a part id per row from the built-in partitioner (breadth-first level sets
+ * from a pseudo-peripheral vertex, P equal pieces of that ordering, boundary refinement; vertex counts balanced like
+ * METIS_PartGraphKway without weights) or from a file with one part id per line (the output format of gpmetis) ... */
+int uspmv_graph_partition(const uspmv_coo_t *total, int P, int32_t *part /* n_rows */);
+int uspmv_read_partition(const char *path, int64_t n_rows, int P, int32_t *part);
+/* ... and the reference's post-processing of it (:529-598): rows stable-sorted by part (new row r = old row perm[r]), the matrix
+ * permuted symmetrically (entry order inside a row kept), wsa[P+1] from the part sizes.  perm may be NULL. */
+int uspmv_coo_apply_partition(const uspmv_coo_t *total, int P, const int32_t *part, uspmv_coo_t **permuted, int32_t *wsa, int32_t *perm);
 /* the same rule from per-row entry counts alone (bit-identical wsa to the call above on the row-sorted COO) */
 int uspmv_seg_from_row_counts(const int32_t *row_nnz, int64_t n_rows, int seg_method, int P, int32_t *wsa);
 /* seg_mtx_struct + localize_row_idx (code/mpi_funcs.hpp:636-674, :862-877): rows

@@ -24,7 +24,7 @@ def test_cli_argument_checks(pkg, tmp_path):
                       ([m, "scs", "-bogus"], "unknown argument"),
                       ([m, "ell"], "kernel format not recognized"),
                       ([m, "scs", "-hp"], "Half precision selected"),
-                      ([m, "scs", "-seg_metis"], "USE_METIS not defined"),
+                      ([m, "scs", "-seg_metis"], "seg-metis selected, but this is a single-rank run"),
                       ([m, "scs", "-ap[dp_sp]", "-block_vec_size", "2"], "SpMMV is not yet implemented for AP kernels"),
                       ([m, "scs", "-mode", "x"], "Only bench (b) and solve (s) modes"),
                       ([m, "scs", "-equilibrate", "2"], "You can only choose to equilibrate data"),

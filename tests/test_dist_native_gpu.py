@@ -315,3 +315,33 @@ def test_cli_loopback_graph_replay_with_ba_synch_and_check(pkg, tmp_path):
         rep = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert rep["graph_replay"] is True and rep["y_checked"] is True and rep["ba_synch"] == int(ba) and rep["loopback"] is True
         assert rep["versions"]["rccl_runtime"] >= rep["versions"]["rccl_build"] > 0
+
+
+def test_cli_seg_metis_real_ranks(pkg, tmp_path):
+    """-seg_metis through the harness (rank 0 partitions the matrix graph with the built-in partitioner -- METIS is not linked --, sorts the
+    rows by part, permutes the matrix symmetrically and scatters the blocks; code/mpi_funcs.hpp:494-598), three real ranks, self-checked;
+    then the same with the part vector coming from a gpmetis-style file."""
+    m = pkg.read_mtx(mtx_path("bcsstk13"))
+    part = pkg.graph_partition(m, 3)
+    pf = tmp_path / "bcsstk13.part.3"
+    pf.write_text("\n".join(str(int(v)) for v in part) + "\n")
+    sizes = np.bincount(part, minlength=3)
+    import json
+    for extra in ([], ["-part_file", str(pf)]):
+        js = str(tmp_path / f"out{len(extra)}.json")
+        procs = []
+        for rank in range(3):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
+                       USPMV_JOB_ID=f"m{os.getpid()}_{len(extra)}", USPMV_HC_TIMEOUT="120")
+            env.pop("USPMV_LOOPBACK", None)
+            procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-seg_metis", "-comm_halos", "1", "-bench_steps", "3",
+                                           "-bench_warmup", "1", "-check_y", "1", "-json", js] + extra, cwd=tmp_path, env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=300)[0] for p in procs]
+        for p, o in zip(procs, outs):
+            assert p.returncode == 0, o
+        rep = json.load(open(js))
+        assert rep["y_checked"] is True and rep["y_mismatches"] == 0 and rep["ranks"] == 3
+        assert rep["rank0"]["n_local"] == int(sizes[0])
+        assert "seg-metis: METIS is not linked" in outs[0]
+    assert "seg_method: seg-metis" in open(tmp_path / "spmv_bench.txt").read()

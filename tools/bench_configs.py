@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--tune", default="", help="key=value,... passed to uspmv_set_tuning")
     ap.add_argument("--cpu-seconds", type=float, default=0.0, help="> 0: also time the genuine reference CPU kernel (oracle/_ref) for about this long")
+    ap.add_argument("--sigma", type=int, default=512, help="sorting scope (the BASELINE configurations use 512)")
     ap.add_argument("--sp", action="store_true", help="config 3 in single precision (block plan kernel)")
     ap.add_argument("--no-block-plan", action="store_true", help="config 3 --sp without uspmv_dmat_optimize_block")
     args = ap.parse_args()
@@ -35,7 +36,7 @@ def main():
         pkg.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
 
     def prep(coo, dtype, fixed=None):
-        s = pkg.convert_to_scs(coo, 32, 512, dtype, fixed_permutation=fixed)
+        s = pkg.convert_to_scs(coo, 32, args.sigma, dtype, fixed_permutation=fixed)
         return s
 
     for cfg in args.configs.split(","):

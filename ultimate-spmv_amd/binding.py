@@ -109,6 +109,9 @@ _SIGS = {
     "uspmv_get_tuning": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "uspmv_seg_work_sharing_arr": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "uspmv_seg_local_coo": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_vp)]),
+    "uspmv_graph_partition": (C.c_int, [_vp, C.c_int, _vp]),
+    "uspmv_read_partition": (C.c_int, [C.c_char_p, _i64, C.c_int, _vp]),
+    "uspmv_coo_apply_partition": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(_vp), _vp, _vp]),
     "uspmv_halo_discover": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "uspmv_halo_meta": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_i32p)]),
     "uspmv_halo_free": (None, [_vp]),
@@ -268,6 +271,29 @@ def gen_banded_random(n, nnz_per_row, band, seed=0x5EED, magnitude_decades=0.0, 
     h = _vp()
     _ck(lib().uspmv_gen_banded_random(n, nnz_per_row, band, seed, magnitude_decades, row_begin, n if row_end is None else row_end, C.byref(h)))
     return Coo(h)
+
+
+def graph_partition(coo, P):
+    """part id per row from the built-in -seg_metis stand-in (uspmv_graph_partition)"""
+    part = np.empty(coo.n_rows, np.int32)
+    _ck(lib().uspmv_graph_partition(coo.h, P, _np_ptr(part)))
+    return part
+
+
+def read_partition(path, n_rows, P):
+    part = np.empty(n_rows, np.int32)
+    _ck(lib().uspmv_read_partition(str(path).encode(), n_rows, P, _np_ptr(part)))
+    return part
+
+
+def apply_partition(coo, P, part):
+    """(permuted matrix, wsa[P+1], perm with new row r = old row perm[r]): the reference's seg-metis post-processing"""
+    part = np.ascontiguousarray(part, np.int32)
+    h = _vp()
+    wsa = np.empty(P + 1, np.int32)
+    perm = np.empty(coo.n_rows, np.int32)
+    _ck(lib().uspmv_coo_apply_partition(coo.h, P, _np_ptr(part), C.byref(h), _np_ptr(wsa), _np_ptr(perm)))
+    return Coo(h), wsa, perm
 
 
 def gen_kkt(N, seed=0x5EED, row_begin=0, row_end=None):

@@ -109,7 +109,10 @@ struct Tuning {
     int sweep_wlog = 0;     // NEXT uspmv_dmat_optimize_sweep: log2 of the window width in elements (0 = 64 KiB of VT)
     int sweep_tile_rows = 0;  // NEXT uspmv_dmat_optimize_sweep: 256 | 512 | 1024 | 2048 | 4096 rows per tile (0 = default; above 1024: several rows per lane)
     int sweep_max_stage = 0;  // NEXT plan: largest staging cost in bytes per non-zero for a tile to sweep (0 = 24)
-    int spmmv_xline = 1;       // NEXT uspmv_dmat_optimize_block with 64-byte rows: also build the line plan (column-major X without a re-layout pass); uspmv_spmmv: use it
+    int spmmv_xline = 0;       // 1: NEXT uspmv_dmat_optimize_block with 64-byte rows also builds the LINE plan and uspmv_spmmv stages column-major X by 128-byte
+                               // lines, without the re-layout pass.  Off by default: under sigma > 1 the column numbering is scrambled inside the windows (lines
+                               // are 1/3 used, the planner turns the plan down), and at sigma = 1, where it qualifies, it measures 0.930 ms against 0.905 ms
+                               // behind the re-layout pass on config 3 (1.35 x the phases; profiles/r03/config3_colwise.txt)
     int spmmv_ycol_nt = 0;     // phased SpMMV kernel, column-major Y: 1 = non-temporal element stores, 0 = plain (write-back) stores that the L2 can merge into whole lines
     int spmmv_xcol = 0;        // phased SpMMV kernel on column-major X: 0 = separate re-layout pass first (1.078 ms on config 3), 1 = rows assembled in LDS by
                                // the kernel itself from the column-major vector (no workspace, no extra launch, but 1.123 ms: 74 registers, six workgroups per CU)

@@ -140,7 +140,16 @@ int uspmv_run_distributed(const DistConfig &c) {
             CK(uspmv_read_mtx(c.matrix_name.c_str(), &total));
             int64_t nc;
             CK(uspmv_coo_dims(total, &n_rows_g, &nc, &nnz_g));
-            CK(uspmv_seg_work_sharing_arr(total, seg, P, wsa.data()));
+            if (c.seg_metis) {   // graph partition, rows sorted by part, matrix permuted symmetrically (code/mpi_funcs.hpp:494-598)
+                std::vector<int32_t> part((size_t)n_rows_g);
+                if (!c.part_file.empty()) CK(uspmv_read_partition(c.part_file.c_str(), n_rows_g, P, part.data()));
+                else CK(uspmv_graph_partition(total, P, part.data()));
+                uspmv_coo_t *permuted = nullptr;
+                CK(uspmv_coo_apply_partition(total, P, part.data(), &permuted, wsa.data(), nullptr));
+                uspmv_coo_free(total);
+                total = permuted;
+                printf("seg-metis: METIS is not linked; rows partitioned by %s\n", c.part_file.empty() ? "the built-in level-set partitioner" : c.part_file.c_str());
+            } else CK(uspmv_seg_work_sharing_arr(total, seg, P, wsa.data()));
             for (int r = 0; r < P; ++r) {
                 uspmv_coo_t *blk = nullptr;
                 CK(uspmv_seg_local_coo(total, wsa.data(), r, &blk));
@@ -314,7 +323,7 @@ int uspmv_run_distributed(const DistConfig &c) {
         std::ofstream f("spmv_bench.txt", std::ios::app);
         f << c.matrix_name << " with " << P << " RCCL ranks (one per GPU), halo exchange " << (c.comm_halos ? "on" : "off") << std::endl;
         f << "kernel: scs, block_vec_size: " << b << ", C: " << c.C << " sigma: " << c.sigma << ", data_type: double, revisions: " << n_iter
-          << ", seg_method: " << (c.seg_nnz ? "seg-nnz" : "seg-rows") << ", MPI_mode: " << (b == 1 || c.vec_mode == USPMV_SINGLEVEC ? "singlevec" : c.vec_mode == USPMV_MULTIVEC ? "multivec" : "bulkvec")
+          << ", seg_method: " << (c.seg_metis ? "seg-metis" : c.seg_nnz ? "seg-nnz" : "seg-rows") << ", MPI_mode: " << (b == 1 || c.vec_mode == USPMV_SINGLEVEC ? "singlevec" : c.vec_mode == USPMV_MULTIVEC ? "multivec" : "bulkvec")
           << ", ba_synch: " << (c.ba_synch && c.comm_halos ? 1 : 0) << std::endl << std::endl;
         char buf[256];
         snprintf(buf, sizeof buf, "%-32s%-32s\n%-32s%-32s\n%-32.16g%-32.16g\n\n", "Total Gflops:", "Total Walltime:", "-------------",

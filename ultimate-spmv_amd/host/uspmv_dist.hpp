@@ -6,6 +6,8 @@
 
 struct DistConfig {
     long C = 32, sigma = 1;
+    bool seg_metis = false;                    // -seg_metis: graph partition + symmetric permutation on rank 0 (code/mpi_funcs.hpp:494-598)
+    std::string part_file;                     // ... part ids from this file instead of the built-in partitioner
     bool seg_nnz = false, comm_halos = true, ba_synch = true, tlc = true, verbose = false;
     bool no_overlap = false, use_graph = true, print_comm_vol = false, no_pack = false;
     int block_vec_size = 1, layout = USPMV_COLWISE, vec_mode = USPMV_BULKVEC;   // -block_vec_size, -block_vec_layout, -mpi_mode

@@ -53,6 +53,7 @@ struct Config {  // subset of the reference's Config (code/classes_structs.hpp:4
     int vec_mode = USPMV_BULKVEC;  // -mpi_mode: message pattern of the block-vector halo exchange (a make knob in the reference, Makefile / config.mk)
     int bench_steps = 0, bench_warmup = -1, check_y = 0;   // multi-rank: -bench_steps K / -bench_warmup W (fixed-count protocol), -check_y 1
     std::string json;                                       // multi-rank: -json <file|->
+    std::string part_file;                                  // -seg_metis: part ids from this file (one per row, gpmetis format) instead of the built-in partitioner
 };
 
 [[noreturn]] void die(const std::string &msg) {
@@ -75,7 +76,8 @@ void usage() {
             "  -equilibrate <0|1> -ap_threshold_1 <float> -ap_threshold_2 <float> -dropout <0|1>\n"
             "  -dropout_threshold <float> -block_vec_layout <colwise|rowwise> -tlc <0|1> -graph <0|1> -dump_y <file>\n"
             "  -mpi_mode <singlevec|multivec|bulkvec>\n"
-            "  multi-rank runs: -bench_steps <int> -bench_warmup <int> -check_y <0|1> -json <file|->\n");
+            "  multi-rank runs: -bench_steps <int> -bench_warmup <int> -check_y <0|1> -json <file|->\n"
+            "  -seg_metis [-part_file <file>]: graph partition (built-in level-set partitioner, or part ids from a gpmetis-style file)\n");
 }
 
 Config parse(int argc, char **argv) {
@@ -112,6 +114,7 @@ Config parse(int argc, char **argv) {
         else if (a == "-seg_rows" || a == "-seg-rows") c.seg_method = "seg-rows";
         else if (a == "-seg_nnz" || a == "-seg-nnz") c.seg_method = "seg-nnz";
         else if (a == "-seg_metis" || a == "-seg-metis") c.seg_method = "seg-metis";
+        else if (a == "-part_file") c.part_file = need(i);
         else if (a == "-tlc") c.tlc = atoi(need(i));
         else if (a == "-dump_y") c.dump_y = need(i);
         else if (a == "-mpi_mode") { std::string v = need(i); if (v == "singlevec") c.vec_mode = USPMV_SINGLEVEC; else if (v == "multivec") c.vec_mode = USPMV_MULTIVEC; else if (v == "bulkvec") c.vec_mode = USPMV_BULKVEC; else die("mpi_mode must be singlevec, multivec or bulkvec."); }
@@ -128,7 +131,8 @@ Config parse(int argc, char **argv) {
         die("Row-wise block vector layout selected, but block vector width is 1.\n Please choose colwise block vector layout if using SpMV.");
     bool ap = c.value_type.rfind("ap[", 0) == 0;
     if (c.block_vec_size > 1 && ap) die("SpMMV is not yet implemented for AP kernels.");
-    if (c.seg_method == "seg-metis") die("seg-metis selected, but USE_METIS not defined in Makefile.");
+    if (c.seg_method == "seg-metis" && !uspmv_dist_requested()) die("seg-metis selected, but this is a single-rank run (the partition only matters across ranks).");
+    if (c.seg_method == "seg-metis" && c.matrix_file_name.rfind("gen:", 0) == 0) die("seg-metis needs the whole matrix on rank 0: use a .mtx file (generated matrices are built per rank).");
     if (c.value_type == "hp" || c.value_type == "ap[sp_hp]" || c.value_type == "ap[dp_hp]" || c.value_type == "ap[dp_sp_hp]")
         die("Half precision selected, but HAVE_HALF_MATH not defined.");
     if (!ap && c.ap_threshold_1 > 0.0) fprintf(stderr, "WARNING: First adaptive precision threshold entered, but not used.\n");
@@ -397,6 +401,7 @@ int main(int argc, char **argv) {
         if (c.layout == USPMV_ROWWISE && c.vec_mode != USPMV_BULKVEC) die("row-wise block vectors are exchanged in bulkvec mode only.");
         DistConfig d;
         d.C = c.chunk_size; d.sigma = c.sigma; d.seg_nnz = c.seg_method == "seg-nnz"; d.comm_halos = c.comm_halos != 0;
+        d.seg_metis = c.seg_method == "seg-metis"; d.part_file = c.part_file;
         d.ba_synch = c.ba_synch != 0; d.tlc = c.tlc != 0; d.verbose = c.verbose != 0; d.bench_time = c.bench_time;
         d.matrix_name = c.matrix_file_name;
         d.block_vec_size = c.block_vec_size; d.layout = c.layout; d.vec_mode = c.vec_mode;
