@@ -180,6 +180,14 @@ int uspmv_dmat_optimize_sweep_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv
                                  int tile_rows, int64_t *n_tiles, int64_t *n_sweep);
 /* Which single-vector plan uspmv_spmv / uspmv_spmv_ap will use: kind 0 none (gather kernel), 1 tile-local-column, 2 column-window
  * sweep; tiles of that plan and how many of them it covers (any pointer may be NULL). */
+/* The column-window sweep plan built on the DEVICE from the handle's own arrays (csrc/sweep_plan_kernels.hip): what
+ * uspmv_dmat_optimize_device[_ap] falls through to when the tile-local-column plan stages fewer than half of the tiles, so that
+ * handles without a host struct (uspmv_dmat_wrap, the launchers of include/uspmv_launchers.hpp) reach scs_spmv_sweep.  sp: the sp
+ * part of an ap[dp_sp] pair or NULL.  The arrays equal those of uspmv_dmat_optimize_sweep[_ap] bit for bit. */
+int uspmv_dmat_optimize_sweep_device(uspmv_dmat_t *m, uspmv_dmat_t *sp, int wlog, int tile_rows, int64_t *n_tiles, int64_t *n_sweep);
+/* FNV-1a digests of the sweep plan's device arrays and meta[8] = present, rows per tile, log2 window, sweep tiles, tiles, chunks
+ * left to the gather kernel, elements of the dp / sp stream (tests) */
+int uspmv_dmat_sweep_plan_digest(const uspmv_dmat_t *m, uint64_t digest[16], int64_t meta[8]);
 int uspmv_dmat_plan_info(const uspmv_dmat_t *m, int *kind, int64_t *n_tiles, int64_t *n_planned);
 /* block-vector plans of the handle: meta[8] = one-list-per-tile plan present, phased plan present, line plan present (column-major
  * block vectors staged by 128-byte lines, no re-layout pass), tiles, phases of the phased plan, phases of the line plan, X rows the

@@ -99,6 +99,19 @@ inline Entry pair(const ST *dC, const ST *dn, const void *dcp, const void *dcl, 
 
 }  // namespace detail
 
+// which MI355X plan the cached handle of a set of arrays runs on (uspmv_dmat_plan_info: 0 none, 1 tile-local-column, 2 column-window
+// sweep); -1: no handle cached for these arrays.  For logging / tests: the launchers pick the plan by themselves.
+inline int plan_kind(const void *chunk_ptrs) {
+    std::lock_guard<std::mutex> g(detail::lock());
+    for (const detail::Entry &e : detail::table())
+        if (e.cp == chunk_ptrs) {
+            int k = 0;
+            detail::ck(uspmv_dmat_plan_info(e.A, &k, nullptr, nullptr), "uspmv_dmat_plan_info");
+            return k;
+        }
+    return -1;
+}
+
 // forget (and free) every cached handle -- before the arrays behind them are freed or rewritten
 inline void release() {
     std::lock_guard<std::mutex> g(detail::lock());

@@ -71,6 +71,7 @@ static void one_prec(const std::string &dir, const std::string &pre, bool crs, l
         if (uspmv_stream_synchronize(nullptr) != USPMV_OK) exit(5);
         dump(dir + "/" + pre + "y" + std::to_string(rep) + ".bin", y, sizeof(VT) * (size_t)n_out);
     }
+    printf("PLAN_KIND %d\n", uspmv_launchers::plan_kind(cp));
 }
 
 static void two_prec(const std::string &dir, long C, long n_chunks) {
@@ -99,6 +100,7 @@ int main(int argc, char **argv) {
     const long C = atol(argv[3]), n_chunks = atol(argv[4]);
     if (mode == "scs64") one_prec<double>(dir, "f64_", false, C, n_chunks, C * n_chunks, 1, (int)(C * n_chunks));
     else if (mode == "scs32") one_prec<float>(dir, "f32_", false, C, n_chunks, C * n_chunks, 1, (int)(C * n_chunks));
+    else if (mode == "irr64") one_prec<double>(dir, "irr_", false, C, n_chunks, C * n_chunks, 1, (int)(C * n_chunks));
     else if (mode == "crs64") one_prec<double>(dir, "crs_", true, 1, n_chunks, n_chunks, 1, (int)n_chunks);
     else if (mode == "mm64") one_prec<double>(dir, "f64_", false, C, n_chunks, 8 * C * n_chunks, 8, (int)(C * n_chunks));
     else if (mode == "ap") two_prec(dir, C, n_chunks);
@@ -130,6 +132,7 @@ def test_function_pointer_launchers_match_golden(tmp_path, pkg):
     def run(mode, Cc=C, ncc=nc):
         r = subprocess.run([exe, d, mode, str(Cc), str(ncc)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (mode, r.stdout, r.stderr)
+        return r.stdout
 
     for dt in ("f64", "f32"):
         _dump(d, f"{dt}_cp.bin", g[f"{dt}_chunk_ptrs"]); _dump(d, f"{dt}_cl.bin", g[f"{dt}_chunk_lengths"])
@@ -139,6 +142,21 @@ def test_function_pointer_launchers_match_golden(tmp_path, pkg):
     for rep in range(3):
         assert np.array_equal(np.fromfile(os.path.join(d, f"f64_y{rep}.bin"), np.float64), g["f64_y_perm"]), rep
         assert np.array_equal(np.fromfile(os.path.join(d, f"f32_y{rep}.bin"), np.float32), g["f32_y_perm"]), rep
+    assert "PLAN_KIND 1" in run("scs64")               # bcsstk13: the tile-local-column plan, built on the device
+    # ---- wide irregular rows (HV15R-class, SURVEY 8(d) at reduced size): the launcher's device-built plan is the column-window SWEEP
+    #      (plan kind 2) -- no host struct, no copy of the matrix to the host -- and y is the oracle's, bit for bit
+    from oracle import oracle as orc
+    coo = pkg.gen_banded_random(120000, 140, 50000)
+    si = pkg.convert_to_scs(coo, 32, 512, pkg.F64)
+    ai = si.arrays(); pkg.permute_scs_cols(si, ai["old_to_new_idx"]); ai = si.arrays()
+    xi = np.zeros(si.n_rows_padded); xi[:si.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(si.n_rows) % 1000), ai["new_to_old_idx"])
+    _dump(d, "irr_cp.bin", ai["chunk_ptrs"]); _dump(d, "irr_cl.bin", ai["chunk_lengths"]); _dump(d, "irr_ci.bin", ai["col_idxs"])
+    _dump(d, "irr_va.bin", ai["values"]); _dump(d, "irr_x.bin", xi)
+    out = run("irr64", 32, si.n_chunks)
+    assert "PLAN_KIND 2" in out, out
+    yo = orc.spmv_scs(32, si.n_chunks, ai["chunk_ptrs"], ai["chunk_lengths"], ai["col_idxs"], ai["values"], xi)
+    for rep in range(3):
+        assert np.array_equal(np.fromfile(os.path.join(d, f"irr_y{rep}.bin"), np.float64), yo), rep
     # ---- block vectors through the same launcher (b = 8, column-wise, vec_length = n_rows_padded)
     sp = golden("spmmv.npz")
     _dump(d, "f64_X.bin", block_x(g["f64_x_perm"], n, 8, n, 0))

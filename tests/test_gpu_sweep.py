@@ -133,3 +133,97 @@ def test_optimize_picks_the_sweep_for_wide_irregular_rows(pkg, orc, torch_cuda):
     s2, a2 = _prep(pkg, pkg.gen_stencil27(30, 30, 30), 32, 512, pkg.F64)
     A2 = pkg.DeviceMatrix(s2, tlc=True)
     assert A2.plan_info()[0] == 1
+
+
+def test_device_sweep_plan_builder_equals_host_planner(pkg, orc, torch_cuda):
+    """uspmv_dmat_optimize_sweep_device (csrc/sweep_plan_kernels.hip) against host/sweep_plan.cpp: every plan array bit for bit (digests
+    of the device arrays), dp / sp / the ap[dp_sp] pair, full and partial coverage, several windows and tile heights; and y."""
+    t = torch_cuda
+    coo = pkg.gen_banded_random(60000, 60, 5000)
+    for code in (pkg.F64, pkg.F32):
+        for C, sigma in ((32, 512), (16, 128), (64, 1)):
+            s, a = _prep(pkg, coo, C, sigma, code)
+            xp = _xp(pkg, s, a)
+            y_or = orc.spmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+            for wlog, rows in ((10, 256), (12, 1024), (11, 4096), (0, 0)):
+                if sigma > 1 and wlog and (1 << wlog) % sigma:
+                    continue
+                Ah, Ad = pkg.DeviceMatrix(s), pkg.DeviceMatrix(s)
+                Ah.optimize_sweep(s, wlog, rows)
+                nt, nsw = Ad.optimize_sweep_device(None, wlog, rows)
+                dh, mh = Ah.sweep_plan_digest()
+                dd, md = Ad.sweep_plan_digest()
+                assert mh == md and mh[0] == 1 and nsw == mh[3] == nt, (C, sigma, wlog, rows, mh, md)
+                assert dh == dd, (C, sigma, wlog, rows, [k for k in range(16) if dh[k] != dd[k]])
+                y = t.full((s.n_rows_padded,), -7.0, dtype=Ad.torch_dtype, device="cuda")
+                pkg.spmv(Ad, t.from_numpy(xp).cuda(), y)
+                assert np.array_equal(y.cpu().numpy(), y_or)
+    # partial coverage and stripped padding on real matrices (rest chunks, pad columns)
+    pkg.set_tuning(sweep_max_stage=1 << 20)
+    for name in ("impcol_e", "matrix_band_klein", "bcsstk13"):
+        m = pkg.read_mtx(mtx_path(name))
+        for C, sigma, wlog in ((32, 512, 9), (16, 64, 8)):
+            s, a = _prep(pkg, m, C, sigma, pkg.F64)
+            Ah, Ad = pkg.DeviceMatrix(s), pkg.DeviceMatrix(s)
+            Ah.optimize_sweep(s, wlog, 256)
+            Ad.optimize_sweep_device(None, wlog, 256)
+            dh, mh = Ah.sweep_plan_digest()
+            dd, md = Ad.sweep_plan_digest()
+            assert mh == md and dh == dd, (name, C, sigma, mh, md, [k for k in range(16) if dh[k] != dd[k]])
+    pkg.set_tuning(sweep_max_stage=0)
+    # the ap[dp_sp] pair
+    coo = pkg.gen_banded_random(50000, 70, 6000, magnitude_decades=10.0)
+    dp, sp = pkg.partition_precisions(coo, 1e-3)
+    ds = pkg.convert_to_scs(dp, 32, 512, pkg.F64)
+    perm = ds.arrays()["old_to_new_idx"].copy()
+    ss = pkg.convert_to_scs(sp, 32, 512, pkg.F32, fixed_permutation=perm)
+    pkg.permute_scs_cols(ds, perm); pkg.permute_scs_cols(ss, perm)
+    da, sa = ds.arrays(), ss.arrays()
+    xp = _xp(pkg, ds, da)
+    y_or = orc.spmv_scs_ap_adv(32, ds.n_chunks, (da["chunk_ptrs"], da["chunk_lengths"], da["col_idxs"], da["values"]),
+                               (sa["chunk_ptrs"], sa["chunk_lengths"], sa["col_idxs"], sa["values"]), xp)
+    for wlog, rows in ((12, 1024), (0, 0)):
+        Ahd, Ahs, Add, Ads = pkg.DeviceMatrix(ds), pkg.DeviceMatrix(ss), pkg.DeviceMatrix(ds), pkg.DeviceMatrix(ss)
+        pkg.optimize_sweep_ap(Ahd, Ahs, ds, ss, wlog, rows)
+        Add.optimize_sweep_device(Ads, wlog, rows)
+        dh, mh = Ahd.sweep_plan_digest()
+        dd, md = Add.sweep_plan_digest()
+        assert mh == md and dh == dd and mh[7] > 0, (wlog, rows, mh, md, [k for k in range(16) if dh[k] != dd[k]])
+        y = t.full((ds.n_rows_padded,), -7.0, dtype=t.float64, device="cuda")
+        pkg.spmv_ap(Add, Ads, t.from_numpy(xp).cuda(), y)
+        assert np.array_equal(y.cpu().numpy(), y_or)
+
+
+def test_optimize_device_reaches_the_sweep_without_a_host_struct(pkg, orc, torch_cuda):
+    """uspmv_dmat_optimize_device[_ap] on wide irregular rows: the tile-local-column plan stages nothing, the sweep plan -- built on the device
+    from the handle's arrays -- takes over (plan kind 2), as uspmv_dmat_optimize does with a host struct."""
+    t = torch_cuda
+    coo = pkg.gen_banded_random(120000, 140, 50000, magnitude_decades=10.0)
+    s, a = _prep(pkg, coo, 32, 512, pkg.F64)
+    A = pkg.DeviceMatrix(s)
+    A.optimize_device()
+    kind, nt, nsw = A.plan_info()
+    assert kind == 2 and nsw == nt > 0
+    xp = _xp(pkg, s, a)
+    y = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
+    pkg.spmv(A, t.from_numpy(xp).cuda(), y)
+    assert np.array_equal(y.cpu().numpy(), orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp))
+    dp, sp = pkg.partition_precisions(coo, 1e-3)
+    ds = pkg.convert_to_scs(dp, 32, 512, pkg.F64)
+    perm = ds.arrays()["old_to_new_idx"].copy()
+    ss = pkg.convert_to_scs(sp, 32, 512, pkg.F32, fixed_permutation=perm)
+    pkg.permute_scs_cols(ds, perm); pkg.permute_scs_cols(ss, perm)
+    da, sa = ds.arrays(), ss.arrays()
+    Ad, As = pkg.DeviceMatrix(ds), pkg.DeviceMatrix(ss)
+    pkg.optimize_device_ap(Ad, As)
+    assert Ad.plan_info()[0] == 2
+    xp = _xp(pkg, ds, da)
+    y = t.zeros(ds.n_rows_padded, dtype=t.float64, device="cuda")
+    pkg.spmv_ap(Ad, As, t.from_numpy(xp).cuda(), y)
+    assert np.array_equal(y.cpu().numpy(), orc.spmv_scs_ap_adv(32, ds.n_chunks, (da["chunk_ptrs"], da["chunk_lengths"], da["col_idxs"], da["values"]),
+                                                               (sa["chunk_ptrs"], sa["chunk_lengths"], sa["col_idxs"], sa["values"]), xp))
+    # a stencil keeps the tile-local-column plan
+    s2, _ = _prep(pkg, pkg.gen_stencil27(30, 30, 30), 32, 512, pkg.F64)
+    A2 = pkg.DeviceMatrix(s2)
+    A2.optimize_device()
+    assert A2.plan_info()[0] == 1

@@ -106,7 +106,10 @@ int main(int argc, char **argv) {
         rocsparse_destroy_spmat_descr(A);
         hipFree(drp); hipFree(dci); hipFree(dva); uspmv_scs_free(s);
     }
-    {   // sliced ELL, slice = 32, from the SELL-32-512 struct (rows in sigma-sorted order; x is constant)
+    for (int variant = 0; variant < 3; ++variant) {   // sliced ELL, slice = 32, from the SELL-32-512 struct (rows in sigma-sorted order; x is constant)
+        // the descriptor's conventions are not documented beyond the argument list, so the forms it may expect are tried in turn:
+        // 0: nnz = true non-zeros, padding as the reference stores it (value 0, column 0)   1: nnz = size of the col / val arrays
+        // 2: as 1 with padding columns = -1 (the convention of rocSPARSE's ELL format)
         uspmv_scs_t *s;
         UK(uspmv_convert_to_scs(coo, 32, 512, USPMV_F64, nullptr, &s));
         int64_t meta[8]; uspmv_scs_meta(s, meta);
@@ -114,12 +117,15 @@ int main(int argc, char **argv) {
         uspmv_scs_arrays(s, &cp, nullptr, &ci, &va, &o2n, nullptr);
         uspmv_permute_scs_cols(s, o2n);
         uspmv_scs_arrays(s, &cp, nullptr, &ci, &va, nullptr, nullptr);
-        int32_t *dcp = to_dev<int32_t>(cp, (size_t)meta[5] + 1), *dci = to_dev<int32_t>(ci, (size_t)meta[6]);
+        std::vector<int32_t> cim(ci, ci + meta[6]);
+        if (variant == 2) { const double *vv = (const double *)va; for (int64_t k = 0; k < meta[6]; ++k) if (vv[k] == 0.0 && cim[(size_t)k] == 0) cim[(size_t)k] = -1; }
+        int32_t *dcp = to_dev<int32_t>(cp, (size_t)meta[5] + 1), *dci = to_dev<int32_t>(cim.data(), (size_t)meta[6]);
         double *dva = to_dev<double>(va, (size_t)meta[6]);
         rocsparse_spmat_descr A;
-        rocsparse_status st = rocsparse_create_sell_descr(&A, meta[4], meta[4], nnz, 32, meta[6], dcp, dci, dva, rocsparse_indextype_i32,
+        rocsparse_status st = rocsparse_create_sell_descr(&A, meta[4], meta[4], variant == 0 ? nnz : meta[6], 32, meta[6], dcp, dci, dva, rocsparse_indextype_i32,
                                                           rocsparse_indextype_i32, rocsparse_index_base_zero, rocsparse_datatype_f64_r);
-        if (st != rocsparse_status_success) printf("rocsparse sliced-ELL descriptor: status %d\n", (int)st);
+        bool done = false;
+        if (st != rocsparse_status_success) printf("rocsparse sliced-ELL descriptor (form %d): status %d\n", variant, (int)st);
         else {   // sliced ELL is served by the descriptor-based rocsparse_v2_spmv only (the staged rocsparse_spmv answers not_implemented)
             const char *name = "rocsparse sliced-ELL (32)";
             const long rows = meta[4];
@@ -136,16 +142,14 @@ int main(int argc, char **argv) {
             RK(rocsparse_create_dnvec_descr(&vy, rows, dy, rocsparse_datatype_f64_r));
             size_t bs = 0;
             rocsparse_status s2 = rocsparse_v2_spmv_buffer_size(h, sd, A, vx, vy, rocsparse_v2_spmv_stage_analysis, &bs, nullptr);
-            if (s2 != rocsparse_status_success) printf("%-28s not supported (status %d)\n", name, (int)s2);
+            void *buf = nullptr;
+            if (s2 == rocsparse_status_success) { HK(hipMalloc(&buf, bs + 16)); s2 = rocsparse_v2_spmv(h, sd, &alpha, A, vx, &beta, vy, rocsparse_v2_spmv_stage_analysis, bs, buf, nullptr); }
+            size_t bc = 0;
+            if (s2 == rocsparse_status_success) s2 = rocsparse_v2_spmv_buffer_size(h, sd, A, vx, vy, rocsparse_v2_spmv_stage_compute, &bc, nullptr);
+            void *bufc = nullptr;
+            if (s2 == rocsparse_status_success) { HK(hipMalloc(&bufc, bc + 16)); HK(hipMemset(dy, 0, sizeof(double) * (size_t)rows)); s2 = rocsparse_v2_spmv(h, sd, &alpha, A, vx, &beta, vy, rocsparse_v2_spmv_stage_compute, bc, bufc, nullptr); }
+            if (s2 != rocsparse_status_success) printf("%-28s form %d: status %d\n", name, variant, (int)s2);
             else {
-                void *buf = nullptr;
-                HK(hipMalloc(&buf, bs + 16));
-                RK(rocsparse_v2_spmv(h, sd, &alpha, A, vx, &beta, vy, rocsparse_v2_spmv_stage_analysis, bs, buf, nullptr));
-                size_t bc = 0;
-                RK(rocsparse_v2_spmv_buffer_size(h, sd, A, vx, vy, rocsparse_v2_spmv_stage_compute, &bc, nullptr));
-                void *bufc = nullptr;
-                HK(hipMalloc(&bufc, bc + 16));
-                HK(hipMemset(dy, 0, sizeof(double) * (size_t)rows));
                 for (int k = 0; k < 5; ++k) RK(rocsparse_v2_spmv(h, sd, &alpha, A, vx, &beta, vy, rocsparse_v2_spmv_stage_compute, bc, bufc, nullptr));
                 hipEventRecord(e0);
                 const int reps = 50;
@@ -153,13 +157,18 @@ int main(int argc, char **argv) {
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
                 if (check_y(name, n)) {
-                    printf("%-28s %8.4f ms  %8.1f GF/s  %7.0f GB/s (12 B/nnz + vectors)\n", name, ms, 2.0 * nnz / ms / 1e6, (12.0 * nnz + 16.0 * n) / ms / 1e6);
+                    printf("%-28s %8.4f ms  %8.1f GF/s  %7.0f GB/s (12 B/nnz + vectors)   [descriptor form %d]\n", name, ms, 2.0 * nnz / ms / 1e6, (12.0 * nnz + 16.0 * n) / ms / 1e6, variant);
                     char jb[128];
                     snprintf(jb, sizeof jb, "%s\"%s\": %.5f", g_json.empty() ? "" : ", ", name, ms);
                     g_json += jb;
+                    done = true;
                 }
             }
+            if (buf) hipFree(buf);
+            if (bufc) hipFree(bufc);
         }
+        hipFree(dcp); hipFree(dci); hipFree(dva); uspmv_scs_free(s);
+        if (done) break;
     }
     if (json) {
         int ver = 0;

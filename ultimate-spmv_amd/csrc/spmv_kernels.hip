@@ -20,9 +20,11 @@
 // multiply-add per element, which is bit-for-bit the summation the reference's CPU kernels
 // perform (g++ -O3 contracts `tmp += a*b` to an FMA).
 //
-// Workgroup -> chunk mapping: hardware deals workgroups round-robin over the 8 XCDs; with
-// xcd_remap the logical block id is permuted so that every XCD walks its own contiguous eighth of
-// the chunk range -- the x window of a region is then fetched into one L2 instead of eight.
+// Workgroup -> chunk mapping: hardware deals workgroups round-robin over the 8 XCDs; with xcd_remap = G >= 2 (default 256) the
+// logical block id is permuted so that every XCD processes GROUPS of G consecutive workgroups, the eight groups of a super-block
+// running side by side: neighbouring tiles -- which share x lines -- share an L2, and all XCDs stay inside one moving window of
+// DRAM.  (xcd_remap = 1, one contiguous eighth of the grid per XCD, measured 4 % SLOWER than hardware order; groups of 64-1024
+// measure 1-3 % faster: DESIGN.md 5.3, profiles/r01/sweepH.txt.)
 #include "uspmv_device.hpp"
 
 using namespace uspmv_dev;

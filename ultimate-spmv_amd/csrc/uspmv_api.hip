@@ -371,6 +371,7 @@ int uspmv_dmat_download(const uspmv_dmat_t *A, int32_t *chunk_ptrs, int32_t *chu
 }
 
 static void sw_release(uspmv_dmat_t *A);
+static int sweep_plan_install_device(uspmv_dmat_t *A, uspmv_dmat_t *B, int wlog, int tile_rows, int64_t *n_tiles, int64_t *n_sweep, const char *who);
 static int sweep_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, const uspmv_scs_t *s, const uspmv_scs_t *sB, int wlog, int tile_rows,
                               int64_t *n_tiles, int64_t *n_sweep, const char *who);
 static void tlc_release(uspmv_dmat_t *A) {
@@ -537,6 +538,25 @@ static int device_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, 
     return USPMV_OK;
 }
 
+// as uspmv_dmat_optimize[_ap]: when the tile-local-column plan stages fewer than half of the tiles (wide, irregular rows), try the
+// column-window sweep -- built on the device as well -- and let it take over when it covers at least half of the tiles
+static int device_sweep_if_irregular(uspmv_dmat_t *A, uspmv_dmat_t *B, int64_t *n_tiles, int64_t *n_staged, const char *who) {
+    if (A->sw) sw_release(A);
+    if (B && B->sw) sw_release(B);
+    if (!g_tune.sweep || (A->tlc && A->tlc_staged * 2 >= A->tlc_n_tiles)) return USPMV_OK;
+    int64_t swt = 0, sws = 0;
+    if (int rc = sweep_plan_install_device(A, B, 0, 0, &swt, &sws, who)) return rc;
+    if (A->sw && sws * 2 >= swt) {
+        if (A->tlc) tlc_release(A);
+        if (B && B->tlc) tlc_release(B);
+        if (n_tiles) *n_tiles = swt;
+        if (n_staged) *n_staged = sws;
+        return USPMV_OK;
+    }
+    if (A->sw) { sw_release(A); if (B) sw_release(B); }
+    return USPMV_OK;
+}
+
 int uspmv_dmat_optimize_device(uspmv_dmat_t *A, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
     if (int rc = check_dmat(A, "uspmv_dmat_optimize_device")) return rc;
     if (int rc = require_device()) return rc;
@@ -576,13 +596,15 @@ int uspmv_dmat_optimize_device(uspmv_dmat_t *A, int max_lines, int64_t *n_tiles,
             if (e == hipSuccess) e = hipMemsetAsync(d_va, 0, vsz * ne, nullptr);
             int rc = e == hipSuccess ? launch_rechunk32(A, (const int *)d_cp, (int *)d_ci, d_va, nullptr) : uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_device: %s", hipGetErrorString(e));
             if (!rc) rc = device_plan_install(alt, nullptr, max_lines, n_tiles, n_staged, "uspmv_dmat_optimize_device");
+            if (!rc) rc = device_sweep_if_irregular(alt, nullptr, n_tiles, n_staged, "uspmv_dmat_optimize_device");
             if (rc) { uspmv_dmat_free(alt); return rc; }
             if (A->tlc) tlc_release(A);
             A->alt = alt;
             return USPMV_OK;
         }
     }
-    return device_plan_install(A, nullptr, max_lines, n_tiles, n_staged, "uspmv_dmat_optimize_device");
+    if (int rc = device_plan_install(A, nullptr, max_lines, n_tiles, n_staged, "uspmv_dmat_optimize_device")) return rc;
+    return device_sweep_if_irregular(A, nullptr, n_tiles, n_staged, "uspmv_dmat_optimize_device");
 }
 
 int uspmv_dmat_optimize_device_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
@@ -591,7 +613,8 @@ int uspmv_dmat_optimize_device_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, int max_li
     if (dp->dtype != USPMV_F64 || sp->dtype != USPMV_F32 || dp->C != sp->C || dp->n_chunks != sp->n_chunks)
         return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_device_ap: handles do not form a dp+sp pair");
     if (int rc = require_device()) return rc;
-    return device_plan_install(dp, sp, max_lines, n_tiles, n_staged, "uspmv_dmat_optimize_device_ap");
+    if (int rc = device_plan_install(dp, sp, max_lines, n_tiles, n_staged, "uspmv_dmat_optimize_device_ap")) return rc;
+    return device_sweep_if_irregular(dp, sp, n_tiles, n_staged, "uspmv_dmat_optimize_device_ap");
 }
 
 int uspmv_dmat_plan_download(const uspmv_dmat_t *A, int64_t meta[4], int32_t *tile_line_ptr, int32_t *tile_lines, uint32_t *c16_ptrs,
@@ -907,7 +930,142 @@ static int sweep_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, const uspmv_scs_
     const uint64_t id = next_sweep_id++;
     A->sw = true; A->sw_tile_rows = p.tile_rows; A->sw_wlog = p.wlog; A->sw_n_tiles = p.n_sweep_tiles; A->sw_all_tiles = p.n_tiles;
     A->sw_x_len = p.x_len_min; A->sw_n_rest = (int64_t)p.rest_chunks.size(); A->sw_plan_id = id;
+    A->sw_n_vals = (int64_t)p.idx.size() - 64; A->sw_n_vals_b = B ? (int64_t)p.idx_b.size() - 64 : 0; A->sw_cnt_bytes = (int64_t)p.cnt.size();
     if (B) { B->sw = true; B->sw_plan_id = id; B->sw_n_tiles = p.n_sweep_tiles; B->sw_all_tiles = p.n_tiles; }
+    return USPMV_OK;
+}
+
+// The same plan from the handle's DEVICE arrays (csrc/sweep_plan_kernels.hip): a scan kernel per struct, the tile decisions and the
+// offsets on the host (O(n_tiles); 16 bytes per 64-row group come back), a fill kernel per struct.  Same defaults, same criteria and
+// -- by construction of the fill kernel -- the same arrays as sweep_plan_install builds from a host struct.
+static int sweep_plan_install_device(uspmv_dmat_t *A, uspmv_dmat_t *B, int wlog, int tile_rows, int64_t *n_tiles, int64_t *n_sweep, const char *who) {
+    if (A->sw) sw_release(A);
+    if (B && B->sw) sw_release(B);
+    if (n_tiles) *n_tiles = 0;
+    if (n_sweep) *n_sweep = 0;
+    const int64_t C = A->C, nc = A->n_chunks;
+    const size_t vsz = A->dtype == USPMV_F64 ? 8 : 4;
+    if (wlog <= 0) wlog = g_tune.sweep_wlog;
+    const int nbuf = g_tune.sweep_nbuf == 2 ? 2 : 1;
+    if (wlog <= 0) wlog = (vsz == 8 ? 13 : 14) + (nbuf == 1 ? 1 : 0);
+    if (((size_t)1 << wlog) * vsz * (size_t)nbuf > 160 * 1024)
+        return uspmv::fail(USPMV_ERR_INVALID, "%s: %d window buffer(s) of 2^%d elements do not fit the 160 KB of LDS", who, nbuf, wlog);
+    if (tile_rows <= 0) tile_rows = g_tune.sweep_tile_rows;
+    const int64_t n_pad = nc * C;
+    if (tile_rows <= 0) {
+        tile_rows = 4096;
+        while (tile_rows > 1024 && n_pad / tile_rows < 384) tile_rows /= 2;
+    }
+    if (tile_rows != 256 && tile_rows != 512 && tile_rows != 1024 && tile_rows != 2048 && tile_rows != 4096) tile_rows = 1024;
+    if (C < 1 || C > 64 || 64 % C != 0 || nc < 1 || wlog < 8 || wlog > 16) return USPMV_OK;
+    if (A->n_elements > (int64_t)UINT32_MAX || (B && B->n_elements > (int64_t)UINT32_MAX)) return USPMV_OK;
+    const int64_t R = tile_rows, nt = (n_pad + R - 1) / R, wpt = R / 64, n_groups = (n_pad + 63) / 64;
+    const int ns = B ? 2 : 1;
+    const uspmv_dmat_t *M[2] = {A, B};
+    const double max_stage = g_tune.sweep_max_stage > 0 ? (double)g_tune.sweep_max_stage : 24.0;
+    // ---- scan
+    int *d_le[2] = {nullptr, nullptr}, *d_pad[2] = {nullptr, nullptr}, *d_grp[2] = {nullptr, nullptr}, *d_max = nullptr;
+    auto scratch_free = [&]() { for (int w = 0; w < 2; ++w) { (void)hipFree(d_le[w]); (void)hipFree(d_pad[w]); (void)hipFree(d_grp[w]); } (void)hipFree(d_max); };
+    hipError_t e = hipMalloc((void **)&d_max, 4);
+    if (e == hipSuccess) e = hipMemset(d_max, 0, 4);
+    for (int w = 0; w < ns && e == hipSuccess; ++w) {
+        e = hipMalloc((void **)&d_le[w], 4 * (size_t)n_groups * 64);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_pad[w], 4 * (size_t)n_groups * 64);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_grp[w], 16 * (size_t)n_groups);
+    }
+    if (e != hipSuccess) { scratch_free(); return uspmv::fail(USPMV_ERR_ALLOC, "%s: %s", who, hipGetErrorString(e)); }
+    std::vector<int32_t> grp[2];
+    int max_col = 0;
+    int rc = USPMV_OK;
+    for (int w = 0; w < ns && !rc; ++w) rc = launch_sweep_scan(M[w], wlog, d_le[w], d_pad[w], d_grp[w], d_max, nullptr);
+    for (int w = 0; w < ns && !rc; ++w) {
+        grp[w].resize((size_t)n_groups * 4);
+        e = hipMemcpy(grp[w].data(), d_grp[w], 16 * (size_t)n_groups, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = uspmv::fail(USPMV_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
+    }
+    if (!rc && hipMemcpy(&max_col, d_max, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = uspmv::fail(USPMV_ERR_HIP, "%s: scan results", who);
+    if (rc) { scratch_free(); return rc; }
+    // ---- which tiles sweep (sweep_plan.cpp pass 1), offsets
+    std::vector<int32_t> tile_ids, t_smin, t_S, rest;
+    std::vector<uint64_t> t_cnt_off;
+    int64_t cnt_bytes = 0, tot[2] = {0, 0};
+    for (int64_t t = 0; t < nt; ++t) {
+        int32_t lo = INT32_MAX, hi = -1;
+        bool good = true;
+        int64_t nnz_t = 0;
+        for (int w = 0; w < ns; ++w)
+            for (int64_t g = t * wpt; g < std::min((t + 1) * wpt, n_groups); ++g) {
+                const int32_t *q = grp[w].data() + (size_t)g * 4;
+                nnz_t += q[0]; lo = std::min(lo, q[1]); hi = std::max(hi, q[2]); good = good && !q[3];
+            }
+        const int64_t nS = (int64_t)hi - lo + 1;
+        const bool ok = good && hi >= 0 && (double)nS * (double)((int64_t)1 << wlog) * (double)vsz <= max_stage * (double)std::max<int64_t>(nnz_t, 1) && nS <= 4096;
+        if (!ok) { for (int64_t c = t * R / C; c < std::min((t + 1) * R / C, nc); ++c) rest.push_back((int32_t)c); continue; }
+        tile_ids.push_back((int32_t)t); t_smin.push_back(lo); t_S.push_back((int32_t)nS); t_cnt_off.push_back((uint64_t)cnt_bytes);
+        cnt_bytes += nS * R;
+    }
+    const int64_t nsw = (int64_t)tile_ids.size();
+    if (n_tiles) *n_tiles = nt;
+    if (n_sweep) *n_sweep = nsw;
+    if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] sweep plan (device builder): tile_rows=%d wlog=%d tiles=%lld sweep=%lld rest_chunks=%zu cnt_bytes=%lld\n",
+                                         tile_rows, wlog, (long long)nt, (long long)nsw, rest.size(), (long long)cnt_bytes);
+    if (nsw == 0) { scratch_free(); return USPMV_OK; }
+    std::vector<uint32_t> wave_off[2];
+    for (int w = 0; w < ns; ++w) {
+        wave_off[w].assign((size_t)(nsw * wpt), 0);
+        for (int64_t k = 0; k < nsw; ++k)
+            for (int64_t v = 0; v < wpt; ++v) {
+                wave_off[w][(size_t)(k * wpt + v)] = (uint32_t)tot[w];
+                const int64_t g = (int64_t)tile_ids[(size_t)k] * wpt + v;
+                if (g < n_groups) tot[w] += grp[w][(size_t)g * 4];
+            }
+        if (tot[w] > (int64_t)UINT32_MAX) { scratch_free(); return USPMV_OK; }
+    }
+    // ---- device arrays of the plan
+    constexpr size_t SPARE = 64;
+    auto up = [&](const void *h, size_t bytes, void **d) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(d, bytes ? bytes : 4);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+    };
+    auto zeroed = [&](size_t bytes, void **d) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(d, bytes ? bytes : 4);
+        if (e == hipSuccess && bytes) e = hipMemset(*d, 0, bytes);
+    };
+    up(tile_ids.data(), tile_ids.size() * 4, (void **)&A->sw_tile_ids);
+    up(t_smin.data(), t_smin.size() * 4, (void **)&A->sw_smin);
+    up(t_S.data(), t_S.size() * 4, (void **)&A->sw_S);
+    up(t_cnt_off.data(), t_cnt_off.size() * 8, (void **)&A->sw_cnt_off);
+    up(wave_off[0].data(), wave_off[0].size() * 4, (void **)&A->sw_wave_off);
+    up(rest.data(), rest.size() * 4, (void **)&A->sw_rest);
+    zeroed((size_t)cnt_bytes, (void **)&A->sw_cnt);
+    zeroed(((size_t)tot[0] + SPARE) * vsz, &A->sw_vals);
+    zeroed(((size_t)tot[0] + SPARE) * 2, (void **)&A->sw_idx);
+    zeroed((size_t)(nsw * R) * 4, (void **)&A->sw_pad);
+    if (B) {
+        up(wave_off[1].data(), wave_off[1].size() * 4, (void **)&A->sw_wave_off_b);
+        zeroed((size_t)cnt_bytes, (void **)&A->sw_cnt_b);
+        zeroed(((size_t)tot[1] + SPARE) * 4, (void **)&A->sw_vals_b);
+        zeroed(((size_t)tot[1] + SPARE) * 2, (void **)&A->sw_idx_b);
+        zeroed((size_t)(nsw * R) * 4, (void **)&A->sw_pad_b);
+    }
+    if (e == hipSuccess && launch_sweep_fill(A, wlog, (int)R, (long)nsw, A->sw_tile_ids, A->sw_smin, A->sw_S, (const unsigned long long *)A->sw_cnt_off, A->sw_wave_off,
+                                             d_le[0], d_pad[0], A->sw_cnt, A->sw_vals, A->sw_idx, A->sw_pad, nullptr) != USPMV_OK) e = hipErrorUnknown;
+    if (e == hipSuccess && B && launch_sweep_fill(B, wlog, (int)R, (long)nsw, A->sw_tile_ids, A->sw_smin, A->sw_S, (const unsigned long long *)A->sw_cnt_off, A->sw_wave_off_b,
+                                                  d_le[1], d_pad[1], A->sw_cnt_b, A->sw_vals_b, A->sw_idx_b, A->sw_pad_b, nullptr) != USPMV_OK) e = hipErrorUnknown;
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    scratch_free();
+    if (e != hipSuccess) {
+        sw_release(A);
+        return uspmv::fail(USPMV_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
+    }
+    static uint64_t next_dev_sweep_id = (uint64_t)1 << 41;
+    const uint64_t id = next_dev_sweep_id++;
+    A->sw = true; A->sw_tile_rows = tile_rows; A->sw_wlog = wlog; A->sw_n_tiles = nsw; A->sw_all_tiles = nt;
+    A->sw_x_len = (int64_t)max_col + 1; A->sw_n_rest = (int64_t)rest.size(); A->sw_plan_id = id;
+    A->sw_n_vals = tot[0]; A->sw_n_vals_b = B ? tot[1] : 0; A->sw_cnt_bytes = cnt_bytes;
+    if (B) { B->sw = true; B->sw_plan_id = id; B->sw_n_tiles = nsw; B->sw_all_tiles = nt; }
     return USPMV_OK;
 }
 
@@ -994,6 +1152,57 @@ int uspmv_spmv_tiles(const uspmv_dmat_t *A, const int32_t *d_tile_ids, int64_t n
     if (int rc = require_device()) return rc;
     if (A->dtype == USPMV_F64) return launch_spmv_tlc<double>(A, d_tile_ids, (long)n_ids, (const double *)d_x, (double *)d_y, (hipStream_t)stream);
     return launch_spmv_tlc<float>(A, d_tile_ids, (long)n_ids, (const float *)d_x, (float *)d_y, (hipStream_t)stream);
+}
+
+int uspmv_dmat_optimize_sweep_device(uspmv_dmat_t *A, uspmv_dmat_t *sp, int wlog, int tile_rows, int64_t *n_tiles, int64_t *n_sweep) {
+    if (int rc = check_dmat(A, "uspmv_dmat_optimize_sweep_device")) return rc;
+    if (sp) {
+        if (int rc = check_dmat(sp, "uspmv_dmat_optimize_sweep_device")) return rc;
+        if (A->dtype != USPMV_F64 || sp->dtype != USPMV_F32 || A->C != sp->C || A->n_chunks != sp->n_chunks)
+            return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_sweep_device: handles do not form a dp+sp pair");
+    }
+    if (int rc = require_device()) return rc;
+    return sweep_plan_install_device(A, sp, wlog, tile_rows, n_tiles, n_sweep, "uspmv_dmat_optimize_sweep_device");
+}
+
+// FNV-1a digests of the sweep plan's device arrays (tests: a plan built on the device must equal the host planner's)
+int uspmv_dmat_sweep_plan_digest(const uspmv_dmat_t *A, uint64_t digest[16], int64_t meta[8]) {
+    if (int rc = check_dmat(A, "uspmv_dmat_sweep_plan_digest")) return rc;
+    if (!digest || !meta) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_sweep_plan_digest: NULL argument");
+    for (int k = 0; k < 16; ++k) digest[k] = 0;
+    meta[0] = A->sw; meta[1] = A->sw_tile_rows; meta[2] = A->sw_wlog; meta[3] = A->sw_n_tiles; meta[4] = A->sw_all_tiles; meta[5] = A->sw_n_rest;
+    meta[6] = A->sw_n_vals; meta[7] = A->sw_n_vals_b;
+    if (!A->sw || !A->sw_tile_ids) return USPMV_OK;
+    std::vector<unsigned char> buf;
+    auto fnv = [&](const void *d, size_t bytes, uint64_t *out) -> int {
+        uint64_t h = 1469598103934665603ull;
+        if (d && bytes) {
+            buf.resize(bytes);
+            HIP_TRY(hipMemcpy(buf.data(), d, bytes, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < bytes; ++k) { h ^= buf[k]; h *= 1099511628211ull; }
+        }
+        *out = h;
+        return USPMV_OK;
+    };
+    const size_t nsw = (size_t)A->sw_n_tiles, wpt = (size_t)A->sw_tile_rows / 64, vsz = A->dtype == USPMV_F64 ? 8 : 4;
+    int rc = fnv(A->sw_tile_ids, nsw * 4, &digest[0]);
+    if (!rc) rc = fnv(A->sw_smin, nsw * 4, &digest[1]);
+    if (!rc) rc = fnv(A->sw_S, nsw * 4, &digest[2]);
+    if (!rc) rc = fnv(A->sw_cnt_off, nsw * 8, &digest[3]);
+    if (!rc) rc = fnv(A->sw_wave_off, nsw * wpt * 4, &digest[4]);
+    if (!rc) rc = fnv(A->sw_cnt, (size_t)A->sw_cnt_bytes, &digest[5]);
+    if (!rc) rc = fnv(A->sw_vals, (size_t)A->sw_n_vals * vsz, &digest[6]);
+    if (!rc) rc = fnv(A->sw_idx, (size_t)A->sw_n_vals * 2, &digest[7]);
+    if (!rc) rc = fnv(A->sw_pad, nsw * (size_t)A->sw_tile_rows * 4, &digest[8]);
+    if (!rc) rc = fnv(A->sw_rest, (size_t)A->sw_n_rest * 4, &digest[9]);
+    if (!rc && A->sw_idx_b) {
+        rc = fnv(A->sw_wave_off_b, nsw * wpt * 4, &digest[10]);
+        if (!rc) rc = fnv(A->sw_cnt_b, (size_t)A->sw_cnt_bytes, &digest[11]);
+        if (!rc) rc = fnv(A->sw_vals_b, (size_t)A->sw_n_vals_b * 4, &digest[12]);
+        if (!rc) rc = fnv(A->sw_idx_b, (size_t)A->sw_n_vals_b * 2, &digest[13]);
+        if (!rc) rc = fnv(A->sw_pad_b, nsw * (size_t)A->sw_tile_rows * 4, &digest[14]);
+    }
+    return rc;
 }
 
 int uspmv_dmat_plan_info(const uspmv_dmat_t *A, int *kind, int64_t *n_tiles, int64_t *n_planned) {

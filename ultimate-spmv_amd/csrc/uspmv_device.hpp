@@ -66,6 +66,7 @@ struct uspmv_dmat {
     bool sw = false;
     int sw_tile_rows = 1024, sw_wlog = 13;
     int64_t sw_n_tiles = 0, sw_all_tiles = 0, sw_x_len = 0, sw_n_rest = 0;
+    int64_t sw_n_vals = 0, sw_n_vals_b = 0, sw_cnt_bytes = 0;   // elements of the compacted streams (without the spare tail), bytes of a count array
     uint64_t sw_plan_id = 0;
     int32_t *sw_tile_ids = nullptr, *sw_smin = nullptr, *sw_S = nullptr, *sw_pad = nullptr, *sw_pad_b = nullptr, *sw_rest = nullptr;
     uint64_t *sw_cnt_off = nullptr;
@@ -160,6 +161,11 @@ int launch_plan_write(const uspmv_dmat *A, long n_tiles, const int *d_tile_line_
                       unsigned short *d_col16, hipStream_t st, const uspmv_dmat *A2 = nullptr, const unsigned *d_c16_ptrs2 = nullptr,
                       unsigned short *d_col16_2 = nullptr, int tile_rows = 256);                                           // plan_kernels.hip
 int launch_rechunk32(const uspmv_dmat *A, const int *d_cp_new, int *d_ci_new, void *d_va_new, hipStream_t st);             // plan_kernels.hip
+// device-side builder of the column-window sweep plan (sweep_plan_kernels.hip)
+int launch_sweep_scan(const uspmv_dmat *A, int wlog, int *d_row_le, int *d_row_pad, int *d_grp, int *d_max_col, hipStream_t st);
+int launch_sweep_fill(const uspmv_dmat *A, int wlog, int R, long n_sweep_tiles, const int *d_tile_ids, const int *d_smin, const int *d_S,
+                      const unsigned long long *d_cnt_off, const unsigned *d_wave_off, const int *d_row_le, const int *d_row_pad,
+                      unsigned char *d_cnt, void *d_vals, unsigned short *d_idx, int *d_pad_col, hipStream_t st);
 
 }  // namespace uspmv_dev
 
