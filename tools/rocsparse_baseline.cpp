@@ -106,10 +106,11 @@ int main(int argc, char **argv) {
         rocsparse_destroy_spmat_descr(A);
         hipFree(drp); hipFree(dci); hipFree(dva); uspmv_scs_free(s);
     }
-    for (int variant = 0; variant < 3; ++variant) {   // sliced ELL, slice = 32, from the SELL-32-512 struct (rows in sigma-sorted order; x is constant)
+    for (int variant = 0; variant < 5; ++variant) {   // sliced ELL, slice = 32, from the SELL-32-512 struct (rows in sigma-sorted order; x is constant)
         // the descriptor's conventions are not documented beyond the argument list, so the forms it may expect are tried in turn:
         // 0: nnz = true non-zeros, padding as the reference stores it (value 0, column 0)   1: nnz = size of the col / val arrays
-        // 2: as 1 with padding columns = -1 (the convention of rocSPARSE's ELL format)
+        // 2: as 1 with padding columns = -1 (the convention of rocSPARSE's ELL format)   3 / 4: as 0 / 2 with rows = cols = the TRUE row count
+        //    (the last slice then holds fewer than 32 rows)
         uspmv_scs_t *s;
         UK(uspmv_convert_to_scs(coo, 32, 512, USPMV_F64, nullptr, &s));
         int64_t meta[8]; uspmv_scs_meta(s, meta);
@@ -118,17 +119,17 @@ int main(int argc, char **argv) {
         uspmv_permute_scs_cols(s, o2n);
         uspmv_scs_arrays(s, &cp, nullptr, &ci, &va, nullptr, nullptr);
         std::vector<int32_t> cim(ci, ci + meta[6]);
-        if (variant == 2) { const double *vv = (const double *)va; for (int64_t k = 0; k < meta[6]; ++k) if (vv[k] == 0.0 && cim[(size_t)k] == 0) cim[(size_t)k] = -1; }
+        if (variant == 2 || variant == 4) { const double *vv = (const double *)va; for (int64_t k = 0; k < meta[6]; ++k) if (vv[k] == 0.0 && cim[(size_t)k] == 0) cim[(size_t)k] = -1; }
         int32_t *dcp = to_dev<int32_t>(cp, (size_t)meta[5] + 1), *dci = to_dev<int32_t>(cim.data(), (size_t)meta[6]);
         double *dva = to_dev<double>(va, (size_t)meta[6]);
         rocsparse_spmat_descr A;
-        rocsparse_status st = rocsparse_create_sell_descr(&A, meta[4], meta[4], variant == 0 ? nnz : meta[6], 32, meta[6], dcp, dci, dva, rocsparse_indextype_i32,
+        rocsparse_status st = rocsparse_create_sell_descr(&A, variant >= 3 ? n : meta[4], variant >= 3 ? n : meta[4], (variant == 0 || variant == 3) ? nnz : meta[6], 32, meta[6], dcp, dci, dva, rocsparse_indextype_i32,
                                                           rocsparse_indextype_i32, rocsparse_index_base_zero, rocsparse_datatype_f64_r);
         bool done = false;
         if (st != rocsparse_status_success) printf("rocsparse sliced-ELL descriptor (form %d): status %d\n", variant, (int)st);
         else {   // sliced ELL is served by the descriptor-based rocsparse_v2_spmv only (the staged rocsparse_spmv answers not_implemented)
             const char *name = "rocsparse sliced-ELL (32)";
-            const long rows = meta[4];
+            const long rows = variant >= 3 ? n : meta[4];
             rocsparse_spmv_descr sd;
             RK(rocsparse_create_spmv_descr(&sd));
             const rocsparse_spmv_alg alg = rocsparse_spmv_alg_sell;

@@ -219,6 +219,43 @@ int launch_plan_write(const uspmv_dmat *A, long n_tiles, const int *d_tile_line_
     return USPMV_OK;
 }
 
+// The block plan's private copy of the entries, gathered ON THE DEVICE from the handle's values under the plan's row map:
+// plan row (chunk c, lane i) takes the entries of the caller's row row_map[c*C + i] (same chunk length: rows only move between chunks
+// of equal length).  GROUP_MAJOR: the layout scs_spmmv_quadph streams ([chunk][group of four slots][row][slot % 4], at c16_ptrs[c]);
+// otherwise column-major inside the chunk like the caller's arrays (the one-list-per-tile kernels).
+template <typename VT, bool GROUP_MAJOR>
+__global__ void __launch_bounds__(256) block_values_gather(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs, const int *__restrict__ chunk_lengths,
+        const VT *__restrict__ values, const int *__restrict__ row_map, const unsigned *__restrict__ c16_ptrs, VT *__restrict__ out) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const long c = q / C;
+    if (c >= n_chunks) return;
+    const int i = (int)(q - c * C);
+    const long src_row = row_map ? (long)row_map[q] : q;
+    const long sc = src_row / C;
+    const int si = (int)(src_row - sc * C);
+    const long cs = chunk_ptrs[c], scs = chunk_ptrs[sc];
+    const int L = chunk_lengths[c];
+    const long base = GROUP_MAJOR ? (long)c16_ptrs[c] : cs;
+    for (int j = 0; j < L; ++j) {
+        const VT v = values[scs + (long)j * C + si];
+        if (GROUP_MAJOR) out[base + (long)(j >> 2) * 4 * C + i * 4 + (j & 3)] = v;
+        else out[base + (long)j * C + i] = v;
+    }
+}
+
+int launch_block_values_gather(const uspmv_dmat *A, const int *d_row_map, const unsigned *d_c16_ptrs, void *d_out, bool group_major, hipStream_t st) {
+    const long n_pad = A->n_chunks * A->C;
+    if (n_pad == 0) return USPMV_OK;
+    const dim3 grid((unsigned)((n_pad + 255) / 256)), block(256);
+#define BVG(VT, GM) hipLaunchKernelGGL((block_values_gather<VT, GM>), grid, block, 0, st, (long)A->n_chunks, (int)A->C, A->chunk_ptrs, A->chunk_lengths, \
+                                       (const VT *)A->values, d_row_map, d_c16_ptrs, (VT *)d_out)
+    if (A->dtype == USPMV_F64) { if (group_major) BVG(double, true); else BVG(double, false); }
+    else { if (group_major) BVG(float, true); else BVG(float, false); }
+#undef BVG
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
 int launch_rechunk32(const uspmv_dmat *A, const int *d_cp_new, int *d_ci_new, void *d_va_new, hipStream_t st) {
     const long n_rows = (long)(A->n_chunks * A->C);
     if (n_rows == 0) return USPMV_OK;

@@ -658,6 +658,9 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
     if (A->bt || A->pb) bt_release(A);
     if (n_tiles) *n_tiles = 0;
     if (n_staged) *n_staged = 0;
+    // a struct rebuilt from the handle's device arrays (uspmv_dmat_optimize_block_device) carries the indices only: the plan's private
+    // copies of the VALUES are then gathered on the device from the handle's own array (launch_block_values_gather)
+    const bool host_values = (int64_t)(s->dtype == USPMV_F64 ? s->values_f64.size() : s->values_f32.size()) == s->n_elements;
     const size_t row_bytes = (size_t)block_vec_size * (s->dtype == USPMV_F64 ? 8 : 4);
     // only the 16-byte-piece kernels (b*sizeof(VT) in {16,32,64,128}) read the plan, compiled for C = 32 and 64
     if (row_bytes % 16 != 0 || (row_bytes & (row_bytes - 1)) != 0 || row_bytes > 128 || (s->C != 32 && s->C != 64)) return USPMV_OK;
@@ -715,7 +718,11 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
         if (e == hipSuccess) e = up(p.c16_ptrs.data(), p.c16_ptrs.size() * 4, (void **)&A->bt_c16_ptrs);
         if (e == hipSuccess) e = up(p.col16.data(), p.col16.size() * 2, (void **)&A->bt_col16);
         if (e == hipSuccess && moved) {
-            e = up(r.values_ptr(), (size_t)r.n_elements * (r.dtype == USPMV_F64 ? 8 : 4), &A->bt_values);
+            if (host_values) e = up(r.values_ptr(), (size_t)r.n_elements * (r.dtype == USPMV_F64 ? 8 : 4), &A->bt_values);
+            else {
+                e = hipMalloc(&A->bt_values, std::max<size_t>((size_t)r.n_elements, 1) * (r.dtype == USPMV_F64 ? 8 : 4));
+                if (e == hipSuccess && launch_block_values_gather(A, A->bt_row_map, nullptr, A->bt_values, false, nullptr) != USPMV_OK) e = hipErrorUnknown;
+            }
             if (e == hipSuccess && (p.n_staged_tiles < p.n_tiles || g_tune.spmmv_variant == 5)) e = up(r.col_idxs.data(), (size_t)r.n_elements * 4, (void **)&A->bt_cols);
         }
     }
@@ -732,7 +739,13 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
                 for (size_t k = 0; k < c8.size(); ++k) c8[k] = (uint8_t)pp.col16[k];
                 e = up(c8.data(), c8.size(), (void **)&A->pb_col16);
             } else if (e == hipSuccess) e = up(pp.col16.data(), pp.col16.size() * 2, (void **)&A->pb_col16);
-            if (e == hipSuccess) {
+            if (e == hipSuccess && !host_values) {
+                const size_t vs = s->dtype == USPMV_F64 ? 8 : 4;
+                e = hipMalloc(&A->pb_values, std::max<size_t>(pp.col16.size(), 1) * vs);
+                if (e == hipSuccess) e = hipMemset(A->pb_values, 0, std::max<size_t>(pp.col16.size(), 1) * vs);     // padded slots of the last group of a chunk
+                if (e == hipSuccess && launch_block_values_gather(A, moved ? A->bt_row_map : nullptr, A->pb_c16_ptrs, A->pb_values, true, nullptr) != USPMV_OK) e = hipErrorUnknown;
+                if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+            } else if (e == hipSuccess) {
                 // the entries once more, group-major like the indices (what scs_spmmv_quadph streams)
                 const uspmv_scs *src = moved ? &r : s;
                 const size_t vs = src->dtype == USPMV_F64 ? 8 : 4;
@@ -778,8 +791,10 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
 }
 
 // The block plan for a handle whose arrays exist only in HBM (uspmv_dmat_wrap around a harness' own device arrays -- what the
-// function-pointer launchers hold): the arrays are copied to the host once, the plan is built there like in
-// uspmv_dmat_optimize_block and uploaded.  Without the caller's permutation the tie re-ordering orders the rows of equal-length
+// function-pointer launchers hold): the INDEX arrays (4 of the 12 bytes per non-zero) are copied to the host once, the index part of
+// the plan (row order, phases, X-row lists, local indices) is built there like in uspmv_dmat_optimize_block and uploaded; the
+// plan's copies of the VALUES (8 bytes per non-zero, group-major under the plan's row map) are gathered on the device from the
+// handle's own array and never cross the bus.  Without the caller's permutation the tie re-ordering orders the rows of equal-length
 // chunks by their first column (uspmv_scs_reorder_ties), which for locally numbered matrices restores the original row order.
 int uspmv_dmat_optimize_block_device(uspmv_dmat_t *A, int block_vec_size, int64_t *n_tiles, int64_t *n_staged) {
     if (int rc = check_dmat(A, "uspmv_dmat_optimize_block_device")) return rc;
@@ -800,8 +815,7 @@ int uspmv_dmat_optimize_block_device(uspmv_dmat_t *A, int block_vec_size, int64_
     int32_t mc = 0;
     for (int32_t c : s.col_idxs) mc = std::max(mc, c);
     s.n_cols = (int64_t)mc + 1;
-    if (s.dtype == USPMV_F64) { s.values_f64.resize((size_t)s.n_elements); HIP_TRY(hipMemcpy(s.values_f64.data(), M->values, 8 * (size_t)s.n_elements, hipMemcpyDeviceToHost)); }
-    else { s.values_f32.resize((size_t)s.n_elements); HIP_TRY(hipMemcpy(s.values_f32.data(), M->values, 4 * (size_t)s.n_elements, hipMemcpyDeviceToHost)); }
+    // (the values stay where they are: uspmv_dmat_optimize_block gathers the plan's private copies on the device)
     return uspmv_dmat_optimize_block(M, &s, block_vec_size, n_tiles, n_staged);
 }
 

@@ -161,6 +161,7 @@ int launch_plan_write(const uspmv_dmat *A, long n_tiles, const int *d_tile_line_
                       unsigned short *d_col16, hipStream_t st, const uspmv_dmat *A2 = nullptr, const unsigned *d_c16_ptrs2 = nullptr,
                       unsigned short *d_col16_2 = nullptr, int tile_rows = 256);                                           // plan_kernels.hip
 int launch_rechunk32(const uspmv_dmat *A, const int *d_cp_new, int *d_ci_new, void *d_va_new, hipStream_t st);             // plan_kernels.hip
+int launch_block_values_gather(const uspmv_dmat *A, const int *d_row_map, const unsigned *d_c16_ptrs, void *d_out, bool group_major, hipStream_t st);   // plan_kernels.hip
 // device-side builder of the column-window sweep plan (sweep_plan_kernels.hip)
 int launch_sweep_scan(const uspmv_dmat *A, int wlog, int *d_row_le, int *d_row_pad, int *d_grp, int *d_max_col, hipStream_t st);
 int launch_sweep_fill(const uspmv_dmat *A, int wlog, int R, long n_sweep_tiles, const int *d_tile_ids, const int *d_smin, const int *d_S,

@@ -321,7 +321,10 @@ int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vect
     r->n_chunks = nc; r->n_rows_padded = s->n_rows_padded; r->n_elements = s->n_elements;
     r->chunk_ptrs = s->chunk_ptrs; r->chunk_lengths = s->chunk_lengths;
     r->col_idxs.resize((size_t)s->n_elements);
-    if (s->dtype == USPMV_F64) r->values_f64.resize((size_t)s->n_elements); else r->values_f32.resize((size_t)s->n_elements);
+    // (a struct rebuilt from device arrays may carry the indices only -- the values then stay on the device and the caller gathers them
+    //  there under row_map: uspmv_dmat_optimize_block_device)
+    const bool has_values = (int64_t)(s->dtype == USPMV_F64 ? s->values_f64.size() : s->values_f32.size()) == s->n_elements;
+    if (has_values) { if (s->dtype == USPMV_F64) r->values_f64.resize((size_t)s->n_elements); else r->values_f32.resize((size_t)s->n_elements); }
 #pragma omp parallel for schedule(static)
     for (int64_t c = 0; c < nc; ++c) {
         const int64_t cs = s->chunk_ptrs[(size_t)c], L = s->chunk_lengths[(size_t)c];
@@ -331,6 +334,7 @@ int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vect
             for (int64_t j = 0; j < L; ++j) {
                 const int64_t src = scs + j * C + si, dst = cs + j * C + i;
                 r->col_idxs[(size_t)dst] = s->col_idxs[(size_t)src];
+                if (!has_values) continue;
                 if (s->dtype == USPMV_F64) r->values_f64[(size_t)dst] = s->values_f64[(size_t)src];
                 else r->values_f32[(size_t)dst] = s->values_f32[(size_t)src];
             }
