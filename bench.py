@@ -152,7 +152,7 @@ def vendor_baseline(grid):
     best = min(d["ms"], key=d["ms"].get)
     sell = d["ms"].get("rocsparse sliced-ELL (32)")
     return {"library": d["library"], "value": round(2.0 * d["nnz"] / d["ms"][best] / 1e6, 1), "unit": "GFLOP/s", "best": best, "ms": d["ms"],
-            "sliced_ell_GFLOPs": round(2.0 * d["nnz"] / sell / 1e6, 1) if sell else None,
+            "sliced_ell_GFLOPs": round(2.0 * d["nnz"] / sell / 1e6, 1) if sell else None, "sliced_ell": d.get("sliced_ell"),
             "note": "same matrix and x; CSR from the COO, sliced ELL = the SELL-32-512 arrays (slice 32)"}
 
 

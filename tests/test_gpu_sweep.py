@@ -227,3 +227,47 @@ def test_optimize_device_reaches_the_sweep_without_a_host_struct(pkg, orc, torch
     A2 = pkg.DeviceMatrix(s2)
     A2.optimize_device()
     assert A2.plan_info()[0] == 1
+
+
+def test_sweep_chain_variants_bitexact(pkg, orc, torch_cuda):
+    """"sweep_pair" 0 (one chain at a time) / 1 (two chains of a lane side by side) / 2 (... with the FMAs under the rounds' lane masks
+    instead of selects): same bits as the oracle for dp, sp and ap[dp_sp], special values included."""
+    t = torch_cuda
+    coo = pkg.gen_banded_random(50000, 70, 6000, magnitude_decades=10.0)
+    try:
+        for code in (pkg.F64, pkg.F32):
+            s, a = _prep(pkg, coo, 32, 512, code)
+            for special in (False, True):
+                xp = _xp(pkg, s, a, special)
+                y_or = orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+                for rows in (1024, 2048, 4096):
+                    A = pkg.DeviceMatrix(s)
+                    A.optimize_sweep(s, 11, rows)
+                    for pair in (0, 1, 2):
+                        for un in (8, 4):
+                            pkg.set_tuning(sweep_pair=pair, sweep_unroll=un)
+                            y = t.full((s.n_rows_padded,), -7.0, dtype=A.torch_dtype, device="cuda")
+                            pkg.spmv(A, t.from_numpy(xp).cuda(), y)
+                            got = y.cpu().numpy()
+                            assert np.array_equal(np.isnan(got), np.isnan(y_or)) and np.array_equal(got[~np.isnan(got)], y_or[~np.isnan(y_or)]), (code, special, rows, pair, un)
+        dp, sp = pkg.partition_precisions(coo, 1e-3)
+        ds = pkg.convert_to_scs(dp, 32, 512, pkg.F64)
+        perm = ds.arrays()["old_to_new_idx"].copy()
+        ss = pkg.convert_to_scs(sp, 32, 512, pkg.F32, fixed_permutation=perm)
+        pkg.permute_scs_cols(ds, perm); pkg.permute_scs_cols(ss, perm)
+        da, sa = ds.arrays(), ss.arrays()
+        for special in (False, True):
+            xp = _xp(pkg, ds, da, special)
+            y_or = orc.spmv_scs_ap_adv(32, ds.n_chunks, (da["chunk_ptrs"], da["chunk_lengths"], da["col_idxs"], da["values"]),
+                                       (sa["chunk_ptrs"], sa["chunk_lengths"], sa["col_idxs"], sa["values"]), xp)
+            for rows in (1024, 4096):
+                Ad, As = pkg.DeviceMatrix(ds), pkg.DeviceMatrix(ss)
+                pkg.optimize_sweep_ap(Ad, As, ds, ss, 12, rows)
+                for pair in (0, 1, 2):
+                    pkg.set_tuning(sweep_pair=pair, sweep_unroll=8)
+                    y = t.full((ds.n_rows_padded,), -7.0, dtype=t.float64, device="cuda")
+                    pkg.spmv_ap(Ad, As, t.from_numpy(xp).cuda(), y)
+                    got = y.cpu().numpy()
+                    assert np.array_equal(np.isnan(got), np.isnan(y_or)) and np.array_equal(got[~np.isnan(got)], y_or[~np.isnan(y_or)]), (special, rows, pair)
+    finally:
+        pkg.set_tuning(sweep_pair=2, sweep_unroll=8)

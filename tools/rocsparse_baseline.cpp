@@ -171,10 +171,12 @@ int main(int argc, char **argv) {
         hipFree(dcp); hipFree(dci); hipFree(dva); uspmv_scs_free(s);
         if (done) break;
     }
+    const bool sell_ran = g_json.find("sliced-ELL") != std::string::npos;
     if (json) {
         int ver = 0;
         rocsparse_get_version(h, &ver);
-        printf("{\"library\": \"rocSPARSE %d.%d.%d\", \"n\": %ld, \"nnz\": %ld, \"ms\": {%s}}\n", ver / 100000, ver / 100 % 1000, ver % 100, (long)n, (long)nnz, g_json.c_str());
+        printf("{\"library\": \"rocSPARSE %d.%d.%d\", \"n\": %ld, \"nnz\": %ld, \"ms\": {%s}, \"sliced_ell\": \"%s\"}\n", ver / 100000, ver / 100 % 1000, ver % 100, (long)n, (long)nnz,
+               g_json.c_str(), sell_ran ? "ran" : "rocsparse_create_sell_descr succeeds, but rocsparse_v2_spmv answers invalid_size (and the staged rocsparse_spmv not_implemented) for every descriptor form tried: no sliced-ELL number from this rocSPARSE");
     }
     return 0;
 }

@@ -71,6 +71,71 @@ __device__ __forceinline__ void sweep_window(const XT *__restrict__ xs, const in
     }
 }
 
+// A batch of U fused multiply-adds, each under ITS round's lane mask: EXEC is set to the round's ballot, so that a lane that sits the
+// round out keeps its accumulator -- not even a signed zero is added -- without the copy + two selects per round that the
+// select form costs (v_mov_b64, v_fmac_f64, 2 x v_cndmask_b32: the rounds are issue-bound, profiles/r03/config4b.txt).  All lanes
+// of the wave are active around the call (the kernel's control flow is wave-uniform); EXEC is saved and restored regardless.
+template <int U>
+__device__ __forceinline__ void masked_fma_batch(double &acc, const double (&v)[U], const double (&x)[U], const unsigned long long (&m)[U]) {
+    static_assert(U == 4 || U == 8, "batch of 4 or 8 rounds");
+    unsigned long long save;
+    if constexpr (U == 8)
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, %[m0]\n\tv_fmac_f64 %[a], %[v0], %[x0]\n\t"
+                     "s_mov_b64 exec, %[m1]\n\tv_fmac_f64 %[a], %[v1], %[x1]\n\t"
+                     "s_mov_b64 exec, %[m2]\n\tv_fmac_f64 %[a], %[v2], %[x2]\n\t"
+                     "s_mov_b64 exec, %[m3]\n\tv_fmac_f64 %[a], %[v3], %[x3]\n\t"
+                     "s_mov_b64 exec, %[m4]\n\tv_fmac_f64 %[a], %[v4], %[x4]\n\t"
+                     "s_mov_b64 exec, %[m5]\n\tv_fmac_f64 %[a], %[v5], %[x5]\n\t"
+                     "s_mov_b64 exec, %[m6]\n\tv_fmac_f64 %[a], %[v6], %[x6]\n\t"
+                     "s_mov_b64 exec, %[m7]\n\tv_fmac_f64 %[a], %[v7], %[x7]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "+v"(acc), [sv] "=&s"(save)
+                     : [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[3]), [m4] "s"(m[4]), [m5] "s"(m[5]), [m6] "s"(m[6]), [m7] "s"(m[7]),
+                       [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7]),
+                       [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]));
+    else
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, %[m0]\n\tv_fmac_f64 %[a], %[v0], %[x0]\n\t"
+                     "s_mov_b64 exec, %[m1]\n\tv_fmac_f64 %[a], %[v1], %[x1]\n\t"
+                     "s_mov_b64 exec, %[m2]\n\tv_fmac_f64 %[a], %[v2], %[x2]\n\t"
+                     "s_mov_b64 exec, %[m3]\n\tv_fmac_f64 %[a], %[v3], %[x3]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "+v"(acc), [sv] "=&s"(save)
+                     : [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[3]),
+                       [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]));
+}
+template <int U>
+__device__ __forceinline__ void masked_fma_batch(float &acc, const float (&v)[U], const float (&x)[U], const unsigned long long (&m)[U]) {
+    static_assert(U == 4 || U == 8, "batch of 4 or 8 rounds");
+    unsigned long long save;
+    if constexpr (U == 8)
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, %[m0]\n\tv_fmac_f32 %[a], %[v0], %[x0]\n\t"
+                     "s_mov_b64 exec, %[m1]\n\tv_fmac_f32 %[a], %[v1], %[x1]\n\t"
+                     "s_mov_b64 exec, %[m2]\n\tv_fmac_f32 %[a], %[v2], %[x2]\n\t"
+                     "s_mov_b64 exec, %[m3]\n\tv_fmac_f32 %[a], %[v3], %[x3]\n\t"
+                     "s_mov_b64 exec, %[m4]\n\tv_fmac_f32 %[a], %[v4], %[x4]\n\t"
+                     "s_mov_b64 exec, %[m5]\n\tv_fmac_f32 %[a], %[v5], %[x5]\n\t"
+                     "s_mov_b64 exec, %[m6]\n\tv_fmac_f32 %[a], %[v6], %[x6]\n\t"
+                     "s_mov_b64 exec, %[m7]\n\tv_fmac_f32 %[a], %[v7], %[x7]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "+v"(acc), [sv] "=&s"(save)
+                     : [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[3]), [m4] "s"(m[4]), [m5] "s"(m[5]), [m6] "s"(m[6]), [m7] "s"(m[7]),
+                       [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7]),
+                       [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]));
+    else
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, %[m0]\n\tv_fmac_f32 %[a], %[v0], %[x0]\n\t"
+                     "s_mov_b64 exec, %[m1]\n\tv_fmac_f32 %[a], %[v1], %[x1]\n\t"
+                     "s_mov_b64 exec, %[m2]\n\tv_fmac_f32 %[a], %[v2], %[x2]\n\t"
+                     "s_mov_b64 exec, %[m3]\n\tv_fmac_f32 %[a], %[v3], %[x3]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "+v"(acc), [sv] "=&s"(save)
+                     : [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[3]),
+                       [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]));
+}
+
 // TWO independent chains of one lane through the same window in one loop -- two of the lane's rows (dp / sp kernels with several rows
 // per lane) or the dp and the sp part of one row (ap[dp_sp]: their accumulators only meet after the last window).  Per batch both
 // chains' ballots are taken, then BOTH batches of loads are issued before the first wait: twice the entries in flight per wave
@@ -82,7 +147,7 @@ __device__ __forceinline__ void sweep_window(const XT *__restrict__ xs, const in
 template <typename A0, typename A1>
 struct SweepPtrs { const A0 *v0; const unsigned short *i0; const A1 *v1; const unsigned short *i1; };
 
-template <typename A0, typename A1, typename X0, typename X1, int U, bool NT>
+template <typename A0, typename A1, typename X0, typename X1, int U, bool NT, bool MF>
 __device__ __forceinline__ SweepPtrs<A0, A1> sweep_window2(const X0 *__restrict__ xs0, const X1 *__restrict__ xs1, const int c0, const int c1,
                                                             SweepPtrs<A0, A1> p, X0 &acc0, X1 &acc1) {
     A0 v0[U];
@@ -113,12 +178,27 @@ __device__ __forceinline__ SweepPtrs<A0, A1> sweep_window2(const X0 *__restrict_
                 v1[u] = ld_stream_g<NT>(p.v1 + off); ix1[u] = ld_stream_g<NT>(p.i1 + off);
             }
         }
+        if constexpr (MF) {      // FMAs under the rounds' lane masks (EXEC), see masked_fma_batch
+            {
+                X0 w0[U], x0v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const X0 t0 = fma_t((X0)v0[u], xs0[ix0[u]], acc0);
-            acc0 = (k0 + u < c0) ? t0 : acc0;
-            const X1 t1 = fma_t((X1)v1[u], xs1[ix1[u]], acc1);
-            acc1 = (k0 + u < c1) ? t1 : acc1;
+                for (int u = 0; u < U; ++u) { w0[u] = (X0)v0[u]; x0v[u] = xs0[ix0[u]]; }
+                masked_fma_batch<U>(acc0, w0, x0v, m0);
+            }
+            {
+                X1 w1[U], x1v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { w1[u] = (X1)v1[u]; x1v[u] = xs1[ix1[u]]; }
+                masked_fma_batch<U>(acc1, w1, x1v, m1);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const X0 t0 = fma_t((X0)v0[u], xs0[ix0[u]], acc0);
+                acc0 = (k0 + u < c0) ? t0 : acc0;
+                const X1 t1 = fma_t((X1)v1[u], xs1[ix1[u]], acc1);
+                acc1 = (k0 + u < c1) ? t1 : acc1;
+            }
         }
         p.v0 += f0[U]; p.i0 += f0[U];
         p.v1 += f1[U]; p.i1 += f1[U];
@@ -128,7 +208,7 @@ __device__ __forceinline__ SweepPtrs<A0, A1> sweep_window2(const X0 *__restrict_
 
 // RPL rows per lane: a tile is RPL * blockDim.x rows, lane <-> rows tid, tid + blockDim.x, ...  The windows of x are staged once per
 // tile, so RPL = 2 halves the staging traffic per non-zero (the workgroup is already 1 024 threads).
-template <typename VT, bool AP, bool NT, int NBUF, int U, int RPL, bool PAIR = false>
+template <typename VT, bool AP, bool NT, int NBUF, int U, int RPL, int PAIRM = 0>
 __global__ void __launch_bounds__(1024) scs_spmv_sweep(const int wlog, const int *__restrict__ tile_ids, const int *__restrict__ t_smin,
         const int *__restrict__ t_S, const unsigned long long *__restrict__ t_cnt_off,
         const unsigned *__restrict__ wave_off, const unsigned char *__restrict__ cnt, const VT *__restrict__ vals, const unsigned short *__restrict__ idx,
@@ -208,12 +288,13 @@ __global__ void __launch_bounds__(1024) scs_spmv_sweep(const int wlog, const int
                 if (AP) cb_next[h] = cpb[(long)(s + 1) * R + h * T];
             }
         }
+        constexpr bool PAIR = PAIRM != 0, MF = PAIRM == 2;
         if constexpr (PAIR && AP) {            // the dp and the sp chain of a row side by side
 #pragma unroll
             for (int h = 0; h < RPL; ++h) {
                 SweepPtrs<double, float> pr{(const double *)vp[h], ip[h], vpb[h], ipb[h]};
                 double a0 = (double)acc[h];
-                pr = sweep_window2<double, float, double, double, U, NT>((const double *)cur, (const double *)cur, c_cur[h], cb_cur[h], pr, a0, acc_b[h]);
+                pr = sweep_window2<double, float, double, double, U, NT, MF>((const double *)cur, (const double *)cur, c_cur[h], cb_cur[h], pr, a0, acc_b[h]);
                 acc[h] = (VT)a0;
                 vp[h] = (const VT *)pr.v0; ip[h] = pr.i0; vpb[h] = pr.v1; ipb[h] = pr.i1;
                 c_cur[h] = c_next[h]; cb_cur[h] = cb_next[h];
@@ -222,7 +303,7 @@ __global__ void __launch_bounds__(1024) scs_spmv_sweep(const int wlog, const int
 #pragma unroll
             for (int h = 0; h < RPL; h += 2) {
                 SweepPtrs<VT, VT> pr{vp[h], ip[h], vp[h + 1], ip[h + 1]};
-                pr = sweep_window2<VT, VT, VT, VT, U, NT>(cur, cur, c_cur[h], c_cur[h + 1], pr, acc[h], acc[h + 1]);
+                pr = sweep_window2<VT, VT, VT, VT, U, NT, MF>(cur, cur, c_cur[h], c_cur[h + 1], pr, acc[h], acc[h + 1]);
                 vp[h] = pr.v0; ip[h] = pr.i0; vp[h + 1] = pr.v1; ip[h + 1] = pr.i1;
                 c_cur[h] = c_next[h]; c_cur[h + 1] = c_next[h + 1];
             }
@@ -265,7 +346,7 @@ int launch_sweep(const uspmv_dmat *A, const VT *x, VT *y, hipStream_t st) {
 #define SW_LAUNCH(NTV, NB, UU, RP)                                                                                          \
     do {                                                                                                                    \
         auto kfn = scs_spmv_sweep<VT, AP, NTV, NB, UU, RP>;                                                                 \
-        if (pair) kfn = scs_spmv_sweep<VT, AP, NTV, NB, UU, RP, true>;                                                      \
+        if (pair) kfn = g_tune.sweep_pair == 2 ? scs_spmv_sweep<VT, AP, NTV, NB, UU, RP, 2> : scs_spmv_sweep<VT, AP, NTV, NB, UU, RP, 1>; \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)A->sw_n_tiles), dim3(threads), lds, st, A->sw_wlog, A->sw_tile_ids,           \
                            A->sw_smin, A->sw_S, (const unsigned long long *)A->sw_cnt_off, A->sw_wave_off, A->sw_cnt,        \

@@ -164,7 +164,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "sweep")) g_tune.sweep = value != 0;
     else if (!strcmp(key, "sweep_nbuf")) g_tune.sweep_nbuf = value == 1 ? 1 : 2;
     else if (!strcmp(key, "sweep_unroll")) g_tune.sweep_unroll = value >= 8 ? 8 : value >= 4 ? 4 : 2;
-    else if (!strcmp(key, "sweep_pair")) g_tune.sweep_pair = value != 0;
+    else if (!strcmp(key, "sweep_pair")) g_tune.sweep_pair = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (!strcmp(key, "sweep_remap")) g_tune.sweep_remap = value < 0 ? 0 : value;
     else if (!strcmp(key, "sweep_wlog")) {
         if (value != 0 && (value < 8 || value > 16)) return uspmv::fail(USPMV_ERR_INVALID, "sweep_wlog must be 0 or 8..16");

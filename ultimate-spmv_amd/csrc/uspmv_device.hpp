@@ -104,7 +104,9 @@ struct Tuning {
     int sweep_threads = 0;     // threads per sweep workgroup (0 = min(tile rows, 1024); 256 | 512: a lane owns tile rows / threads rows, at most 4)
     int sweep_nbuf = 1;     // LDS buffers per workgroup: 1 = two 1024-thread workgroups per CU cover each other's staging (0.63 vs 0.72 ms on
                             // config 4b); 2 = one workgroup, window s+1 lands while window s is consumed
-    int sweep_pair = 1;     // two chains per lane side by side (two rows of the lane, or the dp and sp part of a row): twice the entries in flight per wave
+    int sweep_pair = 2;     // 1: two chains per lane side by side (two rows of the lane, or the dp and the sp part of a row): twice the entries in flight per
+                            // wave (config 4b: ap 0.536 -> 0.514 ms, dp 0.585 -> 0.576); 2: ... and the FMAs under the rounds' lane masks (EXEC) instead of
+                            // copy + FMA + two selects (ap 0.527 -> 0.511, dp 0.578 -> 0.570; profiles/r03/config4b_sweep.txt); 0: one chain at a time
     int sweep_unroll = 8;   // rounds per batch
     int sweep_remap = 8;    // consecutive sweep tiles per XCD (neighbouring tiles share their x windows)
     int sweep_wlog = 0;     // NEXT uspmv_dmat_optimize_sweep: log2 of the window width in elements (0 = 64 KiB of VT)
