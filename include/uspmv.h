@@ -193,6 +193,9 @@ int uspmv_dmat_plan_info(const uspmv_dmat_t *m, int *kind, int64_t *n_tiles, int
  * block vectors staged by 128-byte lines, no re-layout pass), tiles, phases of the phased plan, phases of the line plan, X rows the
  * line plan stages, one-byte indices */
 int uspmv_dmat_block_plan_info(const uspmv_dmat_t *m, int64_t meta[8]);
+/* FNV-1a digests of the phased block plan's device arrays: phase pointers, first groups, list pointers, X-row lists, index offsets,
+ * local indices, the group-major values, the row map (tests: a plan built on the device equals the host planner's) */
+int uspmv_dmat_block_plan_digest(const uspmv_dmat_t *m, uint64_t digest[8]);
 
 /* The block plan for a handle without a host struct (uspmv_dmat_wrap): the device arrays are copied to the host once and the plan is
  * built there.  No permutation is known then: ties of the sigma sort are ordered by first column instead of by original row. */

@@ -866,3 +866,36 @@ def test_spmmv_line_plan_column_major_without_relayout(pkg, orc, torch_cuda):
         assert np.array_equal(res[1], res[0])
         used += info["line_plan"]
     assert used >= 1
+
+
+def test_device_block_plan_builder_equals_host_planner(pkg, orc, torch_cuda):
+    """uspmv_dmat_optimize_block_device with the plan built entirely on the device (csrc/block_plan_kernels.hip: row order, phases, X-row
+    lists, one-byte indices, group-major values) against the same entry point planning the index part on the host ("block_plan_device" 0):
+    every plan array bit for bit (digests of the device arrays), and Y against the oracle, both layouts."""
+    t = torch_cuda
+    cases = [(pkg.gen_stencil27(20, 18, 16, dof=3), 32, 512, pkg.F64, 8), (pkg.gen_stencil27(20, 18, 16, dof=3), 32, 1, pkg.F64, 8),
+             (pkg.gen_stencil27(16, 15, 14, dof=2), 64, 64, pkg.F64, 8), (pkg.gen_stencil27(14, 13, 12, dof=3), 32, 512, pkg.F32, 16),
+             (pkg.read_mtx(mtx_path("bcsstk13")), 32, 512, pkg.F64, 8), (pkg.read_mtx(mtx_path("impcol_e")), 64, 64, pkg.F32, 16),
+             (pkg.gen_banded_random(20000, 40, 3000), 32, 512, pkg.F64, 8)]
+    try:
+        for coo, C, sigma, code, b in cases:
+            s, a, xp = _prep(pkg, coo, C, sigma, code, make_x(coo.n_rows))
+            ld = s.n_rows_padded
+            digests = {}
+            for dev in (0, 1):
+                pkg.set_tuning(block_plan_device=dev)
+                A = pkg.DeviceMatrix(s)
+                A.optimize_block_device(b)
+                info = A.block_plan_info()
+                assert info["phased_plan"] == 1 and info["idx8"] == 1, (C, sigma, dev, info)
+                digests[dev] = (A.block_plan_digest(), info)
+                for rowwise in (0, 1):
+                    X = block_x(xp, s.n_rows_padded, b, ld, rowwise)
+                    Yo = orc.spmmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, b, ld, bool(rowwise))
+                    Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
+                    pkg.spmmv(A, _dev(t, X), Y, b, ld, pkg.ROWWISE if rowwise else pkg.COLWISE)
+                    assert np.array_equal(Y.cpu().numpy(), Yo), (C, sigma, code, dev, rowwise)
+            assert digests[0][1] == digests[1][1], (C, sigma, digests[0][1], digests[1][1])
+            assert digests[0][0] == digests[1][0], (C, sigma, code, [k for k in range(8) if digests[0][0][k] != digests[1][0][k]])
+    finally:
+        pkg.set_tuning(block_plan_device=1)

@@ -94,6 +94,7 @@ _SIGS = {
     "uspmv_dmat_optimize_sweep_ap": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_plan_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_block_plan_info": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "uspmv_dmat_block_plan_digest": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "uspmv_dmat_optimize_sweep_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_sweep_plan_digest": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(_i64)]),
     "uspmv_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp]),
@@ -818,6 +819,11 @@ class DeviceMatrix:
         k, a, b = C.c_int(), _i64(), _i64()
         _ck(lib().uspmv_dmat_plan_info(self.h, C.byref(k), C.byref(a), C.byref(b)))
         return k.value, a.value, b.value
+
+    def block_plan_digest(self):
+        d = (C.c_uint64 * 8)()
+        _ck(lib().uspmv_dmat_block_plan_digest(self.h, d))
+        return [int(v) for v in d]
 
     def optimize_sweep_device(self, sp=None, wlog=0, tile_rows=0):
         """the column-window sweep plan from the device arrays alone (uspmv_dmat_optimize_sweep_device); returns (tiles, sweep tiles)"""

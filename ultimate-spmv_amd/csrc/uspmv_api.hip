@@ -158,6 +158,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_xcol")) g_tune.spmmv_xcol = value != 0;
     else if (!strcmp(key, "spmmv_ycol_nt")) g_tune.spmmv_ycol_nt = value != 0;
     else if (!strcmp(key, "spmmv_xline")) g_tune.spmmv_xline = value != 0;
+    else if (!strcmp(key, "block_plan_device")) g_tune.block_plan_device = value != 0;
     else if (!strcmp(key, "spmmv_phase_rows")) g_tune.spmmv_phase_rows = value == 512 ? 512 : 256;
     else if (!strcmp(key, "spmmv_idx8")) g_tune.spmmv_idx8 = value != 0;
     else if (!strcmp(key, "spmmv_list_plan")) g_tune.spmmv_list_plan = value != 0;
@@ -221,6 +222,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_xcol")) *value = g_tune.spmmv_xcol;
     else if (!strcmp(key, "spmmv_ycol_nt")) *value = g_tune.spmmv_ycol_nt;
     else if (!strcmp(key, "spmmv_xline")) *value = g_tune.spmmv_xline;
+    else if (!strcmp(key, "block_plan_device")) *value = g_tune.block_plan_device;
     else if (!strcmp(key, "spmmv_phase_rows")) *value = g_tune.spmmv_phase_rows;
     else if (!strcmp(key, "spmmv_idx8")) *value = g_tune.spmmv_idx8;
     else if (!strcmp(key, "spmmv_list_plan")) *value = g_tune.spmmv_list_plan;
@@ -540,17 +542,15 @@ static int device_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, 
 
 // as uspmv_dmat_optimize[_ap]: when the tile-local-column plan stages fewer than half of the tiles (wide, irregular rows), try the
 // column-window sweep -- built on the device as well -- and let it take over when it covers at least half of the tiles
-static int device_sweep_if_irregular(uspmv_dmat_t *A, uspmv_dmat_t *B, int64_t *n_tiles, int64_t *n_staged, const char *who) {
+static int device_sweep_if_irregular(uspmv_dmat_t *A, uspmv_dmat_t *B, int64_t * /*n_tiles*/, int64_t * /*n_staged*/, const char *who) {
     if (A->sw) sw_release(A);
     if (B && B->sw) sw_release(B);
     if (!g_tune.sweep || (A->tlc && A->tlc_staged * 2 >= A->tlc_n_tiles)) return USPMV_OK;
     int64_t swt = 0, sws = 0;
     if (int rc = sweep_plan_install_device(A, B, 0, 0, &swt, &sws, who)) return rc;
     if (A->sw && sws * 2 >= swt) {
-        if (A->tlc) tlc_release(A);
-        if (B && B->tlc) tlc_release(B);
-        if (n_tiles) *n_tiles = swt;
-        if (n_staged) *n_staged = sws;
+        if (A->tlc) tlc_release(A);         // (n_tiles / n_staged keep describing the tile-local-column attempt, as in uspmv_dmat_optimize;
+        if (B && B->tlc) tlc_release(B);    //  uspmv_dmat_plan_info tells which plan the handle ended up with)
         return USPMV_OK;
     }
     if (A->sw) { sw_release(A); if (B) sw_release(B); }
@@ -790,6 +790,85 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
     return USPMV_OK;
 }
 
+// The phased block plan built entirely on the device (csrc/block_plan_kernels.hip): row order, phases, X-row lists, one-byte indices and
+// the group-major value copy; the host sees the chunk lengths (offsets of the index array) and two integers per tile (exclusive scans).
+// Returns 1 when the shape / tuning is not the default one this builder covers (the caller then plans the index part on the host).
+static int block_plan_install_device(uspmv_dmat_t *A, int block_vec_size, int64_t *n_tiles, int64_t *n_staged) {
+    const size_t vsz = A->dtype == USPMV_F64 ? 8 : 4;
+    const size_t row_bytes = (size_t)block_vec_size * vsz;
+    if (row_bytes != 64 || (A->C != 32 && A->C != 64) || !g_tune.spmmv_phased || g_tune.spmmv_phase_rows != 256 || g_tune.spmmv_list_plan ||
+        g_tune.spmmv_reorder != 1 || !g_tune.spmmv_idx8 || g_tune.spmmv_tile_rows == 32 || g_tune.spmmv_xline || !g_tune.block_plan_device) return 1;
+    const int64_t C = A->C, nc = A->n_chunks, n_pad = nc * C, nt = (n_pad + 63) / 64;
+    if (A->bt || A->pb) bt_release(A);
+    std::vector<int32_t> cl((size_t)nc);
+    std::vector<uint32_t> c16p;
+    int64_t tot16 = 0;
+    HIP_TRY(hipMemcpy(cl.data(), A->chunk_lengths, 4 * (size_t)nc, hipMemcpyDeviceToHost));
+    if (!c16_offsets(cl, C, &c16p, &tot16)) return USPMV_OK;
+    int *d_changed = nullptr, *d_tph = nullptr, *d_tl = nullptr, *d_max = nullptr;
+    hipError_t e = hipMalloc((void **)&d_changed, 8);
+    d_max = d_changed ? d_changed + 1 : nullptr;
+    if (e == hipSuccess) e = hipMemset(d_changed, 0, 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&A->bt_row_map, 4 * (size_t)std::max<int64_t>(n_pad, 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&A->pb_c16_ptrs, 4 * ((size_t)nc + 1));
+    if (e == hipSuccess) e = hipMemcpy(A->pb_c16_ptrs, c16p.data(), 4 * ((size_t)nc + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_tph, 4 * (size_t)nt);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_tl, 4 * (size_t)nt);
+    auto fail_out = [&](const char *what) {
+        (void)hipFree(d_changed); (void)hipFree(d_tph); (void)hipFree(d_tl);
+        bt_release(A);
+        return uspmv::fail(USPMV_ERR_HIP, "uspmv_dmat_optimize_block_device: %s: %s", what, hipGetErrorString(e));
+    };
+    if (e != hipSuccess) return fail_out("allocation");
+    // ---- row order (ties of the sigma sort undone by first column), then the phases: count, scan, write
+    int rc = launch_block_reorder(A, A->bt_row_map, d_changed, nullptr);
+    int changed = 0;
+    if (!rc) { e = hipMemcpy(&changed, d_changed, 4, hipMemcpyDeviceToHost); if (e != hipSuccess) return fail_out("row order"); }
+    const int *rmap = changed ? A->bt_row_map : nullptr;
+    if (!changed) { (void)hipFree(A->bt_row_map); A->bt_row_map = nullptr; }
+    if (!rc) rc = launch_block_phase_plan(A, false, 256, 8, rmap, A->pb_c16_ptrs, d_tph, d_tl, nullptr, nullptr, nullptr, nullptr, d_max, nullptr);
+    std::vector<int32_t> tph((size_t)nt + 1, 0), tl((size_t)nt + 1, 0);
+    if (!rc) {
+        e = hipMemcpy(tph.data(), d_tph, 4 * (size_t)nt, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(tl.data(), d_tl, 4 * (size_t)nt, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail_out("phase counts");
+    }
+    if (rc) { (void)hipFree(d_changed); (void)hipFree(d_tph); (void)hipFree(d_tl); bt_release(A); return rc; }
+    int64_t n_ph = 0, n_list = 0;
+    for (int64_t t = 0; t < nt; ++t) {   // exclusive scans (ph_ptr of the plan; list bases)
+        const int32_t a = tph[(size_t)t], b = tl[(size_t)t];
+        tph[(size_t)t] = (int32_t)n_ph; tl[(size_t)t] = (int32_t)n_list;
+        n_ph += a; n_list += b;
+        if (n_ph > INT32_MAX || n_list > INT32_MAX) { (void)hipFree(d_changed); (void)hipFree(d_tph); (void)hipFree(d_tl); bt_release(A); return USPMV_OK; }
+    }
+    tph[(size_t)nt] = (int32_t)n_ph; tl[(size_t)nt] = (int32_t)n_list;
+    if (n_tiles) *n_tiles = nt;
+    if (n_staged) *n_staged = n_ph > 0 ? nt : 0;
+    if (n_ph == 0) { (void)hipFree(d_changed); (void)hipFree(d_tph); (void)hipFree(d_tl); bt_release(A); return USPMV_OK; }
+    e = hipMalloc((void **)&A->pb_ph_ptr, 4 * ((size_t)nt + 1));
+    if (e == hipSuccess) e = hipMemcpy(A->pb_ph_ptr, tph.data(), 4 * ((size_t)nt + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_tl, tl.data(), 4 * (size_t)nt, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&A->pb_g0, 4 * (size_t)n_ph);
+    if (e == hipSuccess) e = hipMalloc((void **)&A->pb_list_ptr, 4 * ((size_t)n_ph + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&A->pb_xrows, 4 * (size_t)std::max<int64_t>(n_list, 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&A->pb_col16, (size_t)std::max<int64_t>(tot16, 1));
+    if (e == hipSuccess) e = hipMemset(A->pb_col16, 0, (size_t)std::max<int64_t>(tot16, 1));
+    if (e == hipSuccess) { const int32_t last = (int32_t)n_list; e = hipMemcpy(A->pb_list_ptr + n_ph, &last, 4, hipMemcpyHostToDevice); }
+    if (e == hipSuccess) e = hipMalloc(&A->pb_values, (size_t)std::max<int64_t>(tot16, 1) * vsz);
+    if (e == hipSuccess) e = hipMemset(A->pb_values, 0, (size_t)std::max<int64_t>(tot16, 1) * vsz);
+    if (e != hipSuccess) return fail_out("plan arrays");
+    rc = launch_block_phase_plan(A, true, 256, 8, rmap, A->pb_c16_ptrs, A->pb_ph_ptr, d_tl, A->pb_g0, A->pb_list_ptr, A->pb_xrows, (unsigned char *)A->pb_col16, d_max, nullptr);
+    if (!rc) rc = launch_block_values_gather(A, rmap, A->pb_c16_ptrs, A->pb_values, true, nullptr);
+    int max_rows = 0;
+    if (!rc) { e = hipMemcpy(&max_rows, d_max, 4, hipMemcpyDeviceToHost); if (e != hipSuccess) return fail_out("plan kernels"); }
+    (void)hipFree(d_changed); (void)hipFree(d_tph); (void)hipFree(d_tl);
+    if (rc) { bt_release(A); return rc; }
+    A->pb = true; A->pb_idx8 = true; A->pb_cap_rows = 256; A->pb_ngp = 8; A->pb_max_rows = max_rows; A->pb_n_tiles = nt; A->pb_n_phases = n_ph;
+    if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] phased block plan (device builder): tiles=%lld phases=%lld rows_total=%lld max_rows=%d rows %s\n",
+                                         (long long)nt, (long long)n_ph, (long long)n_list, max_rows, changed ? "re-ordered" : "in the caller's order");
+    return USPMV_OK;
+}
+
 // The block plan for a handle whose arrays exist only in HBM (uspmv_dmat_wrap around a harness' own device arrays -- what the
 // function-pointer launchers hold): the INDEX arrays (4 of the 12 bytes per non-zero) are copied to the host once, the index part of
 // the plan (row order, phases, X-row lists, local indices) is built there like in uspmv_dmat_optimize_block and uploaded; the
@@ -804,6 +883,10 @@ int uspmv_dmat_optimize_block_device(uspmv_dmat_t *A, int block_vec_size, int64_
     if (n_tiles) *n_tiles = 0;
     if (n_staged) *n_staged = 0;
     if ((M->C != 32 && M->C != 64) || M->n_chunks < 1) return USPMV_OK;
+    {   // the default shape: everything on the device
+        const int rc = block_plan_install_device(M, block_vec_size, n_tiles, n_staged);
+        if (rc != 1) return rc;
+    }
     uspmv_scs s;
     s.C = M->C; s.sigma = 0; s.n_chunks = M->n_chunks; s.n_rows = s.n_rows_padded = M->n_chunks * M->C; s.dtype = M->dtype;
     s.chunk_ptrs.resize((size_t)M->n_chunks + 1); s.chunk_lengths.resize((size_t)M->n_chunks);
@@ -1229,6 +1312,40 @@ int uspmv_dmat_plan_info(const uspmv_dmat_t *A, int *kind, int64_t *n_tiles, int
     if (n_tiles) *n_tiles = nt;
     if (n_planned) *n_planned = np;
     return USPMV_OK;
+}
+
+// FNV-1a digests of the phased block plan's device arrays (tests: device-built == host-planned)
+int uspmv_dmat_block_plan_digest(const uspmv_dmat_t *A0, uint64_t digest[8]) {
+    if (int rc = check_dmat(A0, "uspmv_dmat_block_plan_digest")) return rc;
+    if (!digest) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_block_plan_digest: NULL argument");
+    const uspmv_dmat_t *A = (A0->alt && g_tune.rechunk) ? A0->alt : A0;
+    for (int k = 0; k < 8; ++k) digest[k] = 0;
+    if (!A->pb) return USPMV_OK;
+    std::vector<unsigned char> buf;
+    auto fnv = [&](const void *d, size_t bytes, uint64_t *out) -> int {
+        uint64_t h = 1469598103934665603ull;
+        if (d && bytes) {
+            buf.resize(bytes);
+            HIP_TRY(hipMemcpy(buf.data(), d, bytes, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < bytes; ++k) { h ^= buf[k]; h *= 1099511628211ull; }
+        }
+        *out = h;
+        return USPMV_OK;
+    };
+    const size_t nt = (size_t)A->pb_n_tiles, nph = (size_t)A->pb_n_phases, nc = (size_t)A->n_chunks, vsz = A->dtype == USPMV_F64 ? 8 : 4;
+    int32_t n_list = 0;
+    uint32_t tot16 = 0;
+    HIP_TRY(hipMemcpy(&n_list, A->pb_list_ptr + nph, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&tot16, A->pb_c16_ptrs + nc, 4, hipMemcpyDeviceToHost));
+    int rc = fnv(A->pb_ph_ptr, (nt + 1) * 4, &digest[0]);
+    if (!rc) rc = fnv(A->pb_g0, nph * 4, &digest[1]);
+    if (!rc) rc = fnv(A->pb_list_ptr, (nph + 1) * 4, &digest[2]);
+    if (!rc) rc = fnv(A->pb_xrows, (size_t)n_list * 4, &digest[3]);
+    if (!rc) rc = fnv(A->pb_c16_ptrs, (nc + 1) * 4, &digest[4]);
+    if (!rc) rc = fnv(A->pb_col16, (size_t)tot16 * (A->pb_idx8 ? 1 : 2), &digest[5]);
+    if (!rc) rc = fnv(A->pb_values, (size_t)tot16 * vsz, &digest[6]);
+    if (!rc) rc = fnv(A->bt_row_map, A->bt_row_map ? nc * (size_t)A->C * 4 : 0, &digest[7]);
+    return rc;
 }
 
 int uspmv_dmat_block_plan_info(const uspmv_dmat_t *A, int64_t meta[8]) {

@@ -112,6 +112,8 @@ struct Tuning {
     int sweep_wlog = 0;     // NEXT uspmv_dmat_optimize_sweep: log2 of the window width in elements (0 = 64 KiB of VT)
     int sweep_tile_rows = 0;  // NEXT uspmv_dmat_optimize_sweep: 256 | 512 | 1024 | 2048 | 4096 rows per tile (0 = default; above 1024: several rows per lane)
     int sweep_max_stage = 0;  // NEXT plan: largest staging cost in bytes per non-zero for a tile to sweep (0 = 24)
+    int block_plan_device = 1;  // uspmv_dmat_optimize_block_device: 1 = row order, phases, lists and indices built on the device (block_plan_kernels.hip),
+                               // 0 = index arrays copied to the host and planned there (values gathered on the device either way)
     int spmmv_xline = 0;       // 1: NEXT uspmv_dmat_optimize_block with 64-byte rows also builds the LINE plan and uspmv_spmmv stages column-major X by 128-byte
                                // lines, without the re-layout pass.  Off by default: under sigma > 1 the column numbering is scrambled inside the windows (lines
                                // are 1/3 used, the planner turns the plan down), and at sigma = 1, where it qualifies, it measures 0.930 ms against 0.905 ms
@@ -164,6 +166,10 @@ int launch_plan_write(const uspmv_dmat *A, long n_tiles, const int *d_tile_line_
                       unsigned short *d_col16_2 = nullptr, int tile_rows = 256);                                           // plan_kernels.hip
 int launch_rechunk32(const uspmv_dmat *A, const int *d_cp_new, int *d_ci_new, void *d_va_new, hipStream_t st);             // plan_kernels.hip
 int launch_block_values_gather(const uspmv_dmat *A, const int *d_row_map, const unsigned *d_c16_ptrs, void *d_out, bool group_major, hipStream_t st);   // plan_kernels.hip
+// device-side builder of the phased block plan (block_plan_kernels.hip)
+int launch_block_reorder(const uspmv_dmat *A, int *d_row_map, int *d_changed, hipStream_t st);
+int launch_block_phase_plan(const uspmv_dmat *A, bool write, int cap, int ngp, const int *d_row_map, const unsigned *d_c16_ptrs, int *d_t_phases,
+                            int *d_t_list, int *d_ph_g0, int *d_ph_list_ptr, int *d_xrows, unsigned char *d_col8, int *d_max_rows, hipStream_t st);
 // device-side builder of the column-window sweep plan (sweep_plan_kernels.hip)
 int launch_sweep_scan(const uspmv_dmat *A, int wlog, int *d_row_le, int *d_row_pad, int *d_grp, int *d_max_col, hipStream_t st);
 int launch_sweep_fill(const uspmv_dmat *A, int wlog, int R, long n_sweep_tiles, const int *d_tile_ids, const int *d_smin, const int *d_S,
