@@ -189,10 +189,10 @@ int uspmv_dmat_optimize_sweep_device(uspmv_dmat_t *m, uspmv_dmat_t *sp, int wlog
  * left to the gather kernel, elements of the dp / sp stream (tests) */
 int uspmv_dmat_sweep_plan_digest(const uspmv_dmat_t *m, uint64_t digest[16], int64_t meta[8]);
 int uspmv_dmat_plan_info(const uspmv_dmat_t *m, int *kind, int64_t *n_tiles, int64_t *n_planned);
-/* block-vector plans of the handle: meta[8] = one-list-per-tile plan present, phased plan present, line plan present (column-major
+/* block-vector plans of the handle: meta[10] = one-list-per-tile plan present, phased plan present, line plan present (column-major
  * block vectors staged by 128-byte lines, no re-layout pass), tiles, phases of the phased plan, phases of the line plan, X rows the
- * line plan stages, one-byte indices */
-int uspmv_dmat_block_plan_info(const uspmv_dmat_t *m, int64_t meta[8]);
+ * line plan stages, one-byte indices, index part built on the device, most X rows of a phase */
+int uspmv_dmat_block_plan_info(const uspmv_dmat_t *m, int64_t meta[10]);
 /* FNV-1a digests of the phased block plan's device arrays: phase pointers, first groups, list pointers, X-row lists, index offsets,
  * local indices, the group-major values, the row map (tests: a plan built on the device equals the host planner's) */
 int uspmv_dmat_block_plan_digest(const uspmv_dmat_t *m, uint64_t digest[8]);

@@ -839,9 +839,9 @@ class DeviceMatrix:
 
     def block_plan_info(self):
         """dict of the handle's block-vector plans (uspmv_dmat_block_plan_info)"""
-        m = (_i64 * 8)()
+        m = (_i64 * 10)()
         _ck(lib().uspmv_dmat_block_plan_info(self.h, m))
-        keys = ("list_plan", "phased_plan", "line_plan", "tiles", "phases", "line_phases", "line_rows_staged", "idx8")
+        keys = ("list_plan", "phased_plan", "line_plan", "tiles", "phases", "line_phases", "line_rows_staged", "idx8", "device_built", "max_rows")
         return dict(zip(keys, [int(v) for v in m]))
 
     def optimize_block_device(self, block_vec_size):

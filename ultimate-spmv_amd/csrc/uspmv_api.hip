@@ -640,7 +640,7 @@ static void bt_release(uspmv_dmat_t *A) {
     (void)hipFree(A->bt_values); (void)hipFree(A->bt_cols); (void)hipFree(A->bt_row_map);
     A->bt_values = nullptr; A->bt_cols = A->bt_row_map = nullptr;
     (void)hipFree(A->pb_ph_ptr); (void)hipFree(A->pb_g0); (void)hipFree(A->pb_list_ptr); (void)hipFree(A->pb_xrows); (void)hipFree(A->pb_c16_ptrs); (void)hipFree(A->pb_col16);
-    (void)hipFree(A->pb_values); A->pb_values = nullptr; A->pb_idx8 = false;
+    (void)hipFree(A->pb_values); A->pb_values = nullptr; A->pb_idx8 = false; A->pb_device_built = false;
     A->pb_ph_ptr = A->pb_g0 = A->pb_list_ptr = A->pb_xrows = nullptr; A->pb_c16_ptrs = nullptr; A->pb_col16 = nullptr; A->pb = false;
     A->bt_line_ptr = A->bt_xrows = nullptr; A->bt_c16_ptrs = nullptr; A->bt_col16 = nullptr;
     A->bt = false;
@@ -863,7 +863,7 @@ static int block_plan_install_device(uspmv_dmat_t *A, int block_vec_size, int64_
     if (!rc) { e = hipMemcpy(&max_rows, d_max, 4, hipMemcpyDeviceToHost); if (e != hipSuccess) return fail_out("plan kernels"); }
     (void)hipFree(d_changed); (void)hipFree(d_tph); (void)hipFree(d_tl);
     if (rc) { bt_release(A); return rc; }
-    A->pb = true; A->pb_idx8 = true; A->pb_cap_rows = 256; A->pb_ngp = 8; A->pb_max_rows = max_rows; A->pb_n_tiles = nt; A->pb_n_phases = n_ph;
+    A->pb = true; A->pb_idx8 = true; A->pb_device_built = true; A->pb_cap_rows = 256; A->pb_ngp = 8; A->pb_max_rows = max_rows; A->pb_n_tiles = nt; A->pb_n_phases = n_ph;
     if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] phased block plan (device builder): tiles=%lld phases=%lld rows_total=%lld max_rows=%d rows %s\n",
                                          (long long)nt, (long long)n_ph, (long long)n_list, max_rows, changed ? "re-ordered" : "in the caller's order");
     return USPMV_OK;
@@ -1348,11 +1348,11 @@ int uspmv_dmat_block_plan_digest(const uspmv_dmat_t *A0, uint64_t digest[8]) {
     return rc;
 }
 
-int uspmv_dmat_block_plan_info(const uspmv_dmat_t *A, int64_t meta[8]) {
+int uspmv_dmat_block_plan_info(const uspmv_dmat_t *A, int64_t meta[10]) {
     if (!A || !meta) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_block_plan_info: NULL argument");
     const uspmv_dmat_t *M = (A->alt && g_tune.rechunk) ? A->alt : A;
     meta[0] = M->bt; meta[1] = M->pb; meta[2] = M->pl; meta[3] = M->pb_n_tiles; meta[4] = M->pb_n_phases; meta[5] = M->pl_n_phases;
-    meta[6] = M->pl_rows_staged; meta[7] = M->pb_idx8;
+    meta[6] = M->pl_rows_staged; meta[7] = M->pb_idx8; meta[8] = M->pb_device_built; meta[9] = M->pb_max_rows;
     return USPMV_OK;
 }
 

@@ -54,6 +54,7 @@ struct uspmv_dmat {
     uint32_t *pb_c16_ptrs = nullptr;
     uint16_t *pb_col16 = nullptr;       // phase-local indices; ONE BYTE each when pb_idx8 (no phase lists more than 256 rows)
     bool pb_idx8 = false;
+    bool pb_device_built = false;       // the plan's index part was built by csrc/block_plan_kernels.hip
     // the same plan once more with LINE lists (128 bytes of one column: 16 doubles / 32 floats) for column-major block vectors:
     // shares pb_values / pb_c16_ptrs / the row map; one-byte local indices (line << shift | row in line)
     bool pl = false;
