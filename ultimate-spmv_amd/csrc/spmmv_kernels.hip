@@ -570,16 +570,21 @@ __global__ void __launch_bounds__(256) scs_spmmv_quad(const long n_chunks, const
 // the rows are assembled in LDS (16 bytes of padding per row against bank conflicts) and written back as 16-byte pieces in linear
 // order, so every store instruction of a wave covers 1 KiB of contiguous output (the lane-per-row form above it replaces wrote
 // B scalars per lane, B*sizeof(VT) bytes apart: 4.4 TB/s for the 2 x 262 MB of config 3).  Row-major `out` must be 16-byte aligned.
-template <typename VT, int B>
-__global__ void __launch_bounds__(256) block_vector_to_rowmajor(const VT *__restrict__ in, VT *__restrict__ out, const long n, const long ld) {
+// PERM: out row r = in row perm[r] for r < n_perm (identity beyond): the re-layout pass of a column-major caller undoes the sigma
+// permutation on the way (perm = old_to_new_idx), so that the phased kernel's X rows are runs of the workspace (the handle's
+// "unscrambled" plan).  The reads of a workgroup stay inside one or two sigma windows per column.
+template <typename VT, int B, bool PERM = false>
+__global__ void __launch_bounds__(256) block_vector_to_rowmajor(const VT *__restrict__ in, VT *__restrict__ out, const long n, const long ld,
+                                                                const int *__restrict__ perm = nullptr, const long n_perm = 0) {
     constexpr int RB = B * (int)sizeof(VT), PPR = RB / 16, STRIDE = RB + 16;     // bytes per row, 16-byte pieces per row, padded LDS row
     __shared__ __attribute__((aligned(16))) unsigned char tile[256 * STRIDE];
     typedef VT vec_t __attribute__((ext_vector_type(16 / (int)sizeof(VT))));
     const long r0 = (long)blockIdx.x * 256, r = r0 + threadIdx.x;
     if (r < n) {
         VT tv[B];
+        const long rs = (PERM && r < n_perm) ? (long)perm[r] : r;
 #pragma unroll
-        for (int v = 0; v < B; ++v) tv[v] = __builtin_nontemporal_load(in + r + (long)v * ld);
+        for (int v = 0; v < B; ++v) tv[v] = PERM ? in[rs + (long)v * ld] : __builtin_nontemporal_load(in + rs + (long)v * ld);
 #pragma unroll
         for (int v = 0; v < B; ++v) *(VT *)(tile + threadIdx.x * STRIDE + v * (int)sizeof(VT)) = tv[v];
     }
@@ -817,6 +822,13 @@ int spmmv_fast(const uspmv_dmat *A, const VT *X, VT *Y, long ld, int layout, hip
         A->ws_bytes = need;
     }
     VT *Xr = (VT *)A->ws;
+    if constexpr (B * (int)sizeof(VT) == 64) {
+        // the re-layout pass undoes the sigma permutation, the kernel runs on the plan over original X-row numbering
+        if ((g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 8) && !g_tune.ablate && g_tune.spmmv_unscramble && A->pu && A->pu_perm && A->pu_n_perm <= ld) {
+            hipLaunchKernelGGL((block_vector_to_rowmajor<VT, B, true>), dim3(grid_for(ld, 256)), dim3(256), 0, st, X, Xr, ld, ld, (const int *)A->pu_perm, (long)A->pu_n_perm);
+            if (launch_spmmv_quadph<VT, B>(A, Xr, Y, ld, true, 3, st)) return USPMV_OK;
+        }
+    }
     if constexpr ((B * (int)sizeof(VT)) % 16 == 0)
         hipLaunchKernelGGL((block_vector_to_rowmajor<VT, B>), dim3(grid_for(ld, 256)), dim3(256), 0, st, X, Xr, ld, ld);
     else

@@ -212,6 +212,18 @@ void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
         hipLaunchKernelGGL(kfn, dim3((unsigned)A->pb_n_tiles), dim3(256), lds, st, QH_ARGS(A->pb_ph_ptr, A->pb_g0, A->pb_list_ptr, A->pb_xrows, A->pb_col16)); \
     } while (0)
     if constexpr (MAXP == 4 && sizeof(IT) == 1) {
+        if (xmode == 3) {   // row-major workspace in ORIGINAL row numbering (the re-layout pass undid the sigma permutation): the handle's third plan
+            if (g_tune.nontemporal && g_tune.spmmv_ycol_nt)
+                hipLaunchKernelGGL((scs_spmmv_quadph<VT, IT, B, true, true, CT, 8, MAXP, 0>), dim3((unsigned)A->pb_n_tiles), dim3(256), lds, st,
+                                   QH_ARGS(A->pu_ph_ptr, A->pu_g0, A->pu_list_ptr, A->pu_xrows, A->pu_col8));
+            else if (g_tune.nontemporal)
+                hipLaunchKernelGGL((scs_spmmv_quadph<VT, IT, B, true, true, CT, 8, MAXP, 0, 0, false>), dim3((unsigned)A->pb_n_tiles), dim3(256), lds, st,
+                                   QH_ARGS(A->pu_ph_ptr, A->pu_g0, A->pu_list_ptr, A->pu_xrows, A->pu_col8));
+            else
+                hipLaunchKernelGGL((scs_spmmv_quadph<VT, IT, B, false, true, CT, 8, MAXP, 0>), dim3((unsigned)A->pb_n_tiles), dim3(256), lds, st,
+                                   QH_ARGS(A->pu_ph_ptr, A->pu_g0, A->pu_list_ptr, A->pu_xrows, A->pu_col8));
+            return;
+        }
         if (xmode == 2) {   // column-major X staged by lines (the handle's second phased plan); Y column-major as well
             if (g_tune.nontemporal && g_tune.spmmv_ycol_nt)
                 hipLaunchKernelGGL((scs_spmmv_quadph<VT, IT, B, true, true, CT, 8, MAXP, 2>), dim3((unsigned)A->pb_n_tiles), dim3(256), lds, st,
@@ -245,6 +257,13 @@ void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
 template <typename VT, int B>
 bool launch_spmmv_quadph(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, int xmode, hipStream_t st) {
     if (!A->pb || !A->pb_values || A->pb_ngp > 8) return false;
+    if (xmode == 3) {
+        if (!A->pu || !ycol || !A->pu_col8 || A->pu_max_rows > 256) return false;
+#define QU_C(CTV) launch_spmmv_quadph_m<VT, unsigned char, B, CTV, 4>(A, X, Y, ld, ycol, 3, st)
+        if (A->C == 32) QU_C(32); else if (A->C == 64) QU_C(64); else if (A->C == 16) QU_C(16); else return false;
+#undef QU_C
+        return true;
+    }
     if (xmode == 2) {
         constexpr int VW = 16 / (int)sizeof(VT);
         if (!A->pl || !ycol || !A->pl_col8 || A->pl_max_rows > 256 || ld % VW != 0 || ((uintptr_t)X % 16) != 0) return false;

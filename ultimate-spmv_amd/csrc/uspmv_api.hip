@@ -159,6 +159,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_ycol_nt")) g_tune.spmmv_ycol_nt = value != 0;
     else if (!strcmp(key, "spmmv_xline")) g_tune.spmmv_xline = value != 0;
     else if (!strcmp(key, "block_plan_device")) g_tune.block_plan_device = value != 0;
+    else if (!strcmp(key, "spmmv_unscramble")) g_tune.spmmv_unscramble = value != 0;
     else if (!strcmp(key, "spmmv_phase_rows")) g_tune.spmmv_phase_rows = value == 512 ? 512 : 256;
     else if (!strcmp(key, "spmmv_idx8")) g_tune.spmmv_idx8 = value != 0;
     else if (!strcmp(key, "spmmv_list_plan")) g_tune.spmmv_list_plan = value != 0;
@@ -223,6 +224,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_ycol_nt")) *value = g_tune.spmmv_ycol_nt;
     else if (!strcmp(key, "spmmv_xline")) *value = g_tune.spmmv_xline;
     else if (!strcmp(key, "block_plan_device")) *value = g_tune.block_plan_device;
+    else if (!strcmp(key, "spmmv_unscramble")) *value = g_tune.spmmv_unscramble;
     else if (!strcmp(key, "spmmv_phase_rows")) *value = g_tune.spmmv_phase_rows;
     else if (!strcmp(key, "spmmv_idx8")) *value = g_tune.spmmv_idx8;
     else if (!strcmp(key, "spmmv_list_plan")) *value = g_tune.spmmv_list_plan;
@@ -646,6 +648,8 @@ static void bt_release(uspmv_dmat_t *A) {
     A->bt = false;
     (void)hipFree(A->pl_ph_ptr); (void)hipFree(A->pl_g0); (void)hipFree(A->pl_list_ptr); (void)hipFree(A->pl_lines); (void)hipFree(A->pl_col8);
     A->pl_ph_ptr = A->pl_g0 = A->pl_list_ptr = A->pl_lines = nullptr; A->pl_col8 = nullptr; A->pl = false;
+    (void)hipFree(A->pu_ph_ptr); (void)hipFree(A->pu_g0); (void)hipFree(A->pu_list_ptr); (void)hipFree(A->pu_xrows); (void)hipFree(A->pu_col8); (void)hipFree(A->pu_perm);
+    A->pu_ph_ptr = A->pu_g0 = A->pu_list_ptr = A->pu_xrows = A->pu_perm = nullptr; A->pu_col8 = nullptr; A->pu = false;
 }
 
 int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_vec_size, int64_t *n_tiles, int64_t *n_staged) {
@@ -692,6 +696,24 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
                     (int)pl.valid, (long long)pl.n_phases, pl.xrows.size(), pl.xrows.size() << shift, pp.xrows.size(), pl.max_rows_used, (long long)over);
         }
         if (pl.valid && (pl.max_rows_used > 256 || pl.ngp > 8 || ((int64_t)pl.xrows.size() << shift) > 2 * (int64_t)pp.xrows.size())) pl.valid = false;
+    }
+    // ... and once more over ORIGINAL X-row numbering (column index c -> new_to_old[c]) for column-major callers: their re-layout pass
+    // undoes the sigma permutation on the way, so the rows a tile needs are runs of the workspace again
+    uspmv_phased_plan pu;
+    const bool have_perm = host_values && s->sigma > 1 && (int64_t)s->new_to_old_idx.size() >= s->n_rows && (int64_t)s->old_to_new_idx.size() >= s->n_rows;
+    if (phased_ok && g_tune.spmmv_unscramble && have_perm && pp.max_rows_used <= 256 && g_tune.spmmv_idx8) {
+        uspmv_scs u;                                    // indices only: a struct with the renumbered columns
+        const uspmv_scs *src = moved ? &r : s;
+        u.C = src->C; u.sigma = src->sigma; u.n_rows = src->n_rows; u.n_cols = src->n_cols; u.n_rows_padded = src->n_rows_padded; u.n_chunks = src->n_chunks;
+        u.n_elements = src->n_elements; u.nnz = src->nnz; u.dtype = src->dtype;
+        u.chunk_ptrs = src->chunk_ptrs; u.chunk_lengths = src->chunk_lengths;
+        u.col_idxs.resize(src->col_idxs.size());
+        const int32_t *n2o = s->new_to_old_idx.data();
+        const int64_t nr = s->n_rows;
+#pragma omp parallel for schedule(static)
+        for (int64_t k = 0; k < (int64_t)src->col_idxs.size(); ++k) { const int32_t c = src->col_idxs[(size_t)k]; u.col_idxs[(size_t)k] = c < nr ? n2o[c] : c; }
+        if (int rc = uspmv_build_phased_plan(&u, 256, 8, &pu)) return rc;
+        if (pu.valid && (pu.max_rows_used > 256 || pu.ngp > 8)) pu.valid = false;
     }
     const bool list_plan = !phased_ok || g_tune.spmmv_list_plan;
     if (list_plan) {
@@ -765,6 +787,20 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
             }
             if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] phased block plan: tiles=%lld phases=%lld rows_total=%zu max_rows=%d (cap %d)\n",
                                                  (long long)pp.n_tiles, (long long)pp.n_phases, pp.xrows.size(), pp.max_rows_used, pp.cap_rows);
+            if (e == hipSuccess && pu.valid) {
+                e = up(pu.ph_ptr.data(), pu.ph_ptr.size() * 4, (void **)&A->pu_ph_ptr);
+                if (e == hipSuccess) e = up(pu.ph_g0.data(), pu.ph_g0.size() * 4, (void **)&A->pu_g0);
+                if (e == hipSuccess) e = up(pu.ph_list_ptr.data(), pu.ph_list_ptr.size() * 4, (void **)&A->pu_list_ptr);
+                if (e == hipSuccess) e = up(pu.xrows.data(), pu.xrows.size() * 4, (void **)&A->pu_xrows);
+                if (e == hipSuccess) e = up(s->old_to_new_idx.data(), (size_t)s->n_rows * 4, (void **)&A->pu_perm);
+                if (e == hipSuccess) {
+                    std::vector<uint8_t> c8(pu.col16.size());
+                    for (size_t k = 0; k < c8.size(); ++k) c8[k] = (uint8_t)pu.col16[k];
+                    e = up(c8.data(), c8.size(), (void **)&A->pu_col8);
+                }
+                if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] unscrambled plan (column-major X behind the permuting re-layout): phases=%lld rows_total=%zu (scrambled: %zu) max_rows=%d\n",
+                                                     (long long)pu.n_phases, pu.xrows.size(), pp.xrows.size(), pu.max_rows_used);
+            }
             if (e == hipSuccess && pl.valid) {
                 e = up(pl.ph_ptr.data(), pl.ph_ptr.size() * 4, (void **)&A->pl_ph_ptr);
                 if (e == hipSuccess) e = up(pl.ph_g0.data(), pl.ph_g0.size() * 4, (void **)&A->pl_g0);
@@ -784,6 +820,7 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
         bt_release(A);
         return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_block: device copy failed: %s", hipGetErrorString(e));
     }
+    if (pp.valid && pu.valid) { A->pu = true; A->pu_max_rows = pu.max_rows_used; A->pu_n_phases = pu.n_phases; A->pu_n_perm = s->n_rows; }
     if (pp.valid && pl.valid) { A->pl = true; A->pl_shift = pl.line_shift; A->pl_max_rows = pl.max_rows_used; A->pl_n_phases = pl.n_phases; A->pl_rows_staged = (int64_t)pl.xrows.size() << pl.line_shift; }
     if (pp.valid) { A->pb = true; A->pb_cap_rows = pp.cap_rows; A->pb_ngp = pp.ngp; A->pb_max_rows = pp.max_rows_used; A->pb_n_tiles = pp.n_tiles; A->pb_n_phases = pp.n_phases; }
     if (list_plan && p.valid) { A->bt = true; A->bt_tile_rows = p.tile_rows; A->bt_max_rows = p.max_lines_used; A->bt_n_tiles = p.n_tiles; A->bt_staged = p.n_staged_tiles; }

@@ -62,6 +62,15 @@ struct uspmv_dmat {
     int64_t pl_n_phases = 0, pl_rows_staged = 0;
     int32_t *pl_ph_ptr = nullptr, *pl_g0 = nullptr, *pl_list_ptr = nullptr, *pl_lines = nullptr;
     uint8_t *pl_col8 = nullptr;
+    // ... and once more for column-major block vectors behind the re-layout pass, with the X rows numbered in the ORIGINAL row order:
+    // the pass that turns the caller's column-major X into the row-major workspace also undoes the sigma permutation
+    // (Xr[r] = X[old_to_new[r]]), so a tile's X rows form long runs again instead of ~30 fragments per phase and a 128-byte line of the
+    // workspace holds two rows the tile needs instead of 1.1 (shares pb_values / pb_c16_ptrs / the row map)
+    bool pu = false;
+    int pu_max_rows = 0;
+    int64_t pu_n_phases = 0, pu_n_perm = 0;
+    int32_t *pu_ph_ptr = nullptr, *pu_g0 = nullptr, *pu_list_ptr = nullptr, *pu_xrows = nullptr, *pu_perm = nullptr;
+    uint8_t *pu_col8 = nullptr;
     // column-window sweep plan (host/sweep_plan.cpp, uspmv_dmat_optimize_sweep[_ap]); the _b arrays are the sp part of
     // an ap[dp_sp] pair and live on the dp handle, the sp handle only carries the plan id
     bool sw = false;
@@ -113,6 +122,10 @@ struct Tuning {
     int sweep_wlog = 0;     // NEXT uspmv_dmat_optimize_sweep: log2 of the window width in elements (0 = 64 KiB of VT)
     int sweep_tile_rows = 0;  // NEXT uspmv_dmat_optimize_sweep: 256 | 512 | 1024 | 2048 | 4096 rows per tile (0 = default; above 1024: several rows per lane)
     int sweep_max_stage = 0;  // NEXT plan: largest staging cost in bytes per non-zero for a tile to sweep (0 = 24)
+    int spmmv_unscramble = 0;  // 1: NEXT uspmv_dmat_optimize_block (64-byte rows, sigma > 1, host struct with its permutation) also builds the plan over
+                               // ORIGINAL X-row numbering; uspmv_spmmv on column-major vectors then lets the re-layout pass undo the sigma permutation (a tile's X
+                               // rows become runs of the workspace, two needed rows per 128-byte line instead of 1.1).  Measured 1 % SLOWER on config 3
+                               // (0.925 vs 0.912-0.919 ms, profiles/r03/config3_colwise.txt): the staging is not bound by L2 -> L1 lines.  Off by default.
     int block_plan_device = 1;  // uspmv_dmat_optimize_block_device: 1 = row order, phases, lists and indices built on the device (block_plan_kernels.hip),
                                // 0 = index arrays copied to the host and planned there (values gathered on the device either way)
     int spmmv_xline = 0;       // 1: NEXT uspmv_dmat_optimize_block with 64-byte rows also builds the LINE plan and uspmv_spmmv stages column-major X by 128-byte
