@@ -259,6 +259,41 @@ def C_tile_rows(pkg, A):
     return tr.value
 
 
+def test_tile_rows_follow_the_lines_a_tile_needs(pkg, orc, torch_cuda):
+    """uspmv_dmat_optimize[_device] with tlc_tile_rows 0: 256-row tiles, unless the largest of them needs more than 250 x lines and
+    1024-row (or 512-row) tiles still stage >= 99 % of the tiles (csrc/uspmv_api.hip tile_rows_grow).  Host and device planners take the
+    same decision and build the same arrays; y has the reference's bits whatever the tile size; tlc_auto_tile 0 keeps 256."""
+    t = torch_cuda
+    for gen, want in ((lambda: pkg.gen_banded_random(40000, 30, 2000), 1024),      # ~270 lines per 256-row tile, ~320 per 1024-row tile
+                      (lambda: pkg.gen_stencil27(40, 40, 24), 256)):               # a stencil: few lines, stays at 256
+        m = gen()
+        s, a, xp = _prep(pkg, m, 32, 512, pkg.F64, make_x(m.n_rows))
+        yo = orc.spmv_scs(s.C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+        Ah = pkg.DeviceMatrix(s); Ah.optimize(s)
+        Ad = pkg.DeviceMatrix(s); Ad.optimize_device()
+        assert C_tile_rows(pkg, Ah) == C_tile_rows(pkg, Ad) == want, (C_tile_rows(pkg, Ah), C_tile_rows(pkg, Ad), want)
+        assert Ah.plan_info() == Ad.plan_info() and Ah.plan_info()[0] == 1
+        ph, pd = Ah.plan_download(), Ad.plan_download()
+        for k in ("tile_line_ptr", "tile_lines", "c16_ptrs", "col16"):
+            assert np.array_equal(ph[k], pd[k]), (want, k)
+        for A in (Ah, Ad):
+            y = t.full((s.n_rows_padded,), 3.0, dtype=t.float64, device="cuda")
+            pkg.spmv(A, _dev(t, xp), y)
+            assert np.array_equal(y.cpu().numpy(), yo), want
+        pkg.set_tuning(tlc_auto_tile=0)
+        try:
+            A0 = pkg.DeviceMatrix(s); A0.optimize(s)
+            A1 = pkg.DeviceMatrix(s); A1.optimize_device()
+        finally:
+            pkg.set_tuning(tlc_auto_tile=1)
+        assert C_tile_rows(pkg, A0) == C_tile_rows(pkg, A1) == 256
+        if want != 256:
+            assert ph["max_lines_used"] <= 512 and A0.plan_download()["max_lines_used"] > 250
+        y = t.full((s.n_rows_padded,), 3.0, dtype=t.float64, device="cuda")
+        pkg.spmv(A0, _dev(t, xp), y)
+        assert np.array_equal(y.cpu().numpy(), yo)
+
+
 def test_device_plan_builder_matches_host_planner(pkg, orc, torch_cuda):
     """uspmv_dmat_optimize_device: the plan built on the GPU from the handle's arrays equals the host planner's
     (line lists, 16-bit indices) and the SpMV on it is bit-exact; also on handles made by convert_to_scs_device and

@@ -189,6 +189,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_unroll")) g_tune.spmmv_unroll = value;
     else if (!strcmp(key, "tlc")) g_tune.tlc = value != 0;
     else if (!strcmp(key, "rechunk")) g_tune.rechunk = value != 0;
+    else if (!strcmp(key, "tlc_auto_tile")) g_tune.tlc_auto_tile = value != 0;
     else if (!strcmp(key, "tlc_tile_rows")) {
         if (value != 0 && value != 256 && value != 512 && value != 1024) return uspmv::fail(USPMV_ERR_INVALID, "tlc_tile_rows must be 0|256|512|1024");
         g_tune.tlc_tile_rows = value;
@@ -246,6 +247,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "tlc")) *value = g_tune.tlc;
     else if (!strcmp(key, "rechunk")) *value = g_tune.rechunk;
     else if (!strcmp(key, "tlc_tile_rows")) *value = g_tune.tlc_tile_rows;
+    else if (!strcmp(key, "tlc_auto_tile")) *value = g_tune.tlc_auto_tile;
     else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_get_tuning: unknown key '%s'", key);
     return USPMV_OK;
 }
@@ -387,6 +389,15 @@ static void tlc_release(uspmv_dmat_t *A) {
 // rows per tile of the next tile-local-column plan (g_tune.tlc_tile_rows = 0: by kind)
 static int plan_tile_rows(bool ap) { return g_tune.tlc_tile_rows ? g_tune.tlc_tile_rows : (ap ? 512 : 256); }
 
+// Rows per tile by what the 256-row plan turned out to be (tuning tlc_auto_tile, default on; only when tlc_tile_rows is 0).  The x lines
+// of a tile live in LDS (128 B each): when the largest 256-row tile needs more than 250 of them, at most 4 workgroups = 16 waves fit a
+// CU, too few to cover the staging latency, and every line is fetched by several neighbouring tiles.  1024-row tiles (or 512-row ones)
+// fetch each line fewer times and keep 32 (16) waves per CU when their lines still fit; they are taken when they stage >= 99 % of the
+// tiles.  Measured (tools/tile_rows_sweep.py, profiles/r03/tile_rows_sweep.txt): KKT N = 200 0.82 -> 0.73 ms, banded 30 per row over
+// +-2000 columns 0.27 -> 0.22 ms; matrices whose 256-row tiles need <= 217 lines (all the stencils) are fastest at 256 and stay there.
+static bool tile_rows_grow(int rows, int lines_used) { return g_tune.tlc_auto_tile && g_tune.tlc_tile_rows == 0 && rows == 256 && lines_used > 250; }
+static bool tile_rows_accept(int64_t n_tiles, int64_t n_staged) { return n_staged * 100 >= n_tiles * 99; }
+
 int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
     if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: NULL argument");
     if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: layout-only struct; the plan builder needs the host column indices");
@@ -414,6 +425,12 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     if (max_lines > cap) max_lines = cap;
     uspmv_tlc_plan p;
     if (int rc = uspmv_build_tlc_plan(s, nullptr, max_lines, plan_tile_rows(false), &p)) return rc;
+    if (p.valid && tile_rows_grow(p.tile_rows, p.max_lines_used))
+        for (int R : {1024, 512}) {
+            uspmv_tlc_plan q;
+            if (int rc = uspmv_build_tlc_plan(s, nullptr, max_lines, R, &q)) return rc;
+            if (q.valid && tile_rows_accept(q.n_tiles, q.n_staged_tiles)) { p = std::move(q); break; }
+        }
     if (n_tiles) *n_tiles = p.n_tiles;
     if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
     if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] tlc plan: tile_rows=%d tiles=%lld staged=%lld max_lines=%d lines_total=%zu col16=%zu\n",
@@ -462,7 +479,22 @@ static bool c16_offsets(const std::vector<int32_t> &cl, int64_t C, std::vector<u
 }
 
 // the tile-local-column plan of A (and of the pair A + B sharing one line list when B != nullptr), built on the device
+static int device_plan_install_rows(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, int R, int64_t *n_tiles, int64_t *n_staged, const char *who);
+
+// ... with the rows per tile chosen as uspmv_dmat_optimize chooses them (tile_rows_grow above)
 static int device_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, int64_t *n_tiles, int64_t *n_staged, const char *who) {
+    const int R0 = plan_tile_rows(B != nullptr);
+    if (int rc = device_plan_install_rows(A, B, max_lines, R0, n_tiles, n_staged, who)) return rc;
+    if (B || !A->tlc || !tile_rows_grow(R0, A->tlc_max_lines)) return USPMV_OK;
+    for (int R : {1024, 512}) {
+        int64_t nt = 0, ns = 0;
+        if (int rc = device_plan_install_rows(A, nullptr, max_lines, R, &nt, &ns, who)) return rc;
+        if (A->tlc && tile_rows_accept(nt, ns)) { if (n_tiles) *n_tiles = nt; if (n_staged) *n_staged = ns; return USPMV_OK; }
+    }
+    return device_plan_install_rows(A, nullptr, max_lines, R0, n_tiles, n_staged, who);
+}
+
+static int device_plan_install_rows(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, const int R, int64_t *n_tiles, int64_t *n_staged, const char *who) {
     if (A->tlc) tlc_release(A);
     if (B && B->tlc) tlc_release(B);
     if (n_tiles) *n_tiles = 0;
@@ -472,7 +504,6 @@ static int device_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, 
     if (max_lines <= 0) max_lines = 512;
     max_lines = std::min(max_lines, (int)(160 * 1024 / (16 * (A->dtype == USPMV_F64 ? 8 : 4))));
     max_lines = std::min(max_lines, B ? 1280 : 4096);
-    const int R = plan_tile_rows(B != nullptr);
     const int64_t T = R / C, nt = (nc + T - 1) / T;
     std::vector<int32_t> cl((size_t)nc);
     std::vector<uint32_t> c16p, c16p_b;
