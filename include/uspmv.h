@@ -436,7 +436,9 @@ int uspmv_dist_comm_plan(const uspmv_dist_t *d, int64_t *n_send, const int64_t *
 /* Options by name: "overlap" 1|0, "no_pack" 0|1, "ba_synch" 0|1 (a stream-ordered one-element all-reduce after every step: the
  * MPI_Barrier the reference issues per iteration by default, code/main.cpp:467, :417; part of the captured graph),
  * "capture_mode" 0 global | 1 thread-local | 2 relaxed (hipStreamCaptureMode of uspmv_dist_run's capture),
- * "diag_skip_exchange" 0|1 (diagnosis only: the step skips the RCCL group, results are wrong). */
+ * "diag_skip_exchange" 0|1 (diagnosis only: the step skips the RCCL group, results are wrong),
+ * "diag_spmmv_part" 0|1|2 (diagnosis only: the two-part block-vector step runs both parts, its interior part, its boundary part),
+ * "block_plan" b (block vectors: build the phased block plan for b columns on the rank's matrix, 0 drops it; see uspmv_dist_spmmv). */
 int uspmv_dist_set_option(uspmv_dist_t *d, const char *key, int value);
 /* Self-check of the whole distributed path (partition, halo discovery, exchange plan, exchange, kernels) on the object's own
  * matrix: one step with x_global[j] = 1 + 1e-3 * (j mod 1000) -- every halo element differs from its neighbours, unlike the
@@ -464,9 +466,19 @@ int uspmv_dist_run(uspmv_dist_t *d, void *d_x, void *d_y, int n_steps, int use_g
 /* Block vectors: Y = A X with the halo exchange of the b vectors in one of the reference's message patterns (compile-time modes
  * there: SINGLEVEC / MULTIVEC / BULKVEC_MPI_MODE, code/classes_structs.hpp:875-924, code/mpi_funcs.hpp:35-60), then uspmv_spmmv on
  * the block (ld = padded_vec_size).  Column-wise X: all three; row-wise X: USPMV_BULKVEC (its per-neighbour block IS the halo
- * region of X, no staging).  No interior / boundary split: the exchange completes first, as in the reference. */
+ * region of X, no staging).
+ * The reference exchanges first and computes then (code/mpi_funcs.hpp:25-60).  Here the step has the same two parts as the
+ * single-vector one ("overlap" 1, the default): the chunks that touch no halo row run on a side stream while the exchange is under
+ * way, the others after it -- the same kernel twice over chunk-length arrays in which the other part's chunks are marked, so every
+ * row's FMA chain is the one-part step's (bit-identical Y).  Column-wise X: the interior part re-lays out the local rows into the
+ * handle's row-major workspace, the boundary part the halo rows once they are there.  uspmv_dist_set_option(d, "block_plan", b)
+ * builds the phased block plan of uspmv_dmat_optimize_block on the rank's matrix (64-byte X rows) together with the
+ * interior / boundary classes of its tiles; uspmv_dist_set_option(d, "overlap", 0) restores exchange-then-compute. */
 typedef enum { USPMV_BULKVEC = 0, USPMV_MULTIVEC = 1, USPMV_SINGLEVEC = 2 } uspmv_vecmode;
 int uspmv_dist_spmmv(uspmv_dist_t *d, void *d_X, void *d_Y, int b, int layout, int mode, int comm_halos, void *stream);
+/* meta[6] = block-vector steps taken in two parts, in one part, block width of the plan built through "block_plan" (0 = none),
+ * tiles of that plan, its boundary tiles, 1 when the handle can run two-part steps at all */
+int uspmv_dist_spmmv_info(const uspmv_dist_t *d, int64_t meta[6]);
 /* MPI_Barrier / MPI_Allreduce(MAX) / MPI_Allgather twins on the object's communicator (bench loop, code/main.cpp:461-474) */
 int uspmv_dist_barrier(uspmv_dist_t *d, void *stream);
 int uspmv_dist_allreduce_max(uspmv_dist_t *d, double *value, void *stream);

@@ -114,6 +114,82 @@ def test_native_block_vector_exchange_loopback_bitexact(pkg, orc):
         d.close()
 
 
+def test_native_block_vector_step_in_two_parts_loopback_bitexact(pkg, orc):
+    """uspmv_dist_spmmv with "overlap" 1 (default): interior chunks on the side stream while the block exchange runs, boundary chunks
+    after it -- the same kernels over chunk-length arrays that mark the other part (csrc/uspmv_dist_api.hip).  Per column bit-identical
+    to the oracle's single-rank SpMV of the whole matrix, in both layouts: gather kernels (b = 3 generic, b = 4 / 8 row-major form) and
+    the phased block plan built through set_option("block_plan", 8), whose tiles are classified from the plan's own row lists; and
+    identical to the exchange-then-compute step ("overlap" 0).  The step counters prove which form ran."""
+    import torch
+    torch.cuda.set_device(0)
+    P, shape, C, sigma = 2, (24, 24, 48), 32, 512
+    counts = pkg.gen_stencil27_row_counts(*shape)
+    wsa = pkg.seg_from_row_counts(counts, "seg-rows", P)
+    refs = {}
+    for b, plan in ((3, 0), (4, 0), (8, 0), (8, 8), (4, 4)):
+        for v in range(b):
+            if v not in refs: refs[v] = _global_reference(pkg, orc, shape, P, C, sigma, scale=1.0 + v / 8.0)
+        nl = refs[0][1]
+        for rank in range(P):
+            loc = pkg.gen_stencil27(*shape, row_begin=int(wsa[rank]), row_end=int(wsa[rank + 1]))
+            d = pkg.DistNative(loc, wsa, C, sigma, rank, P, pkg.comm_unique_id(), comm_rank=0, comm_size=1)
+            assert d.n_interior > 0 and d.n_boundary > 0 and d.spmmv_info()["parts"] == 1
+            if plan:
+                d.set_option("block_plan", plan)
+                info = d.spmmv_info()
+                if plan == 8:
+                    assert info["plan_b"] == 8 and 0 < info["plan_boundary_tiles"] < info["plan_tiles"], info
+                else:
+                    assert info["plan_b"] == 0            # 32-byte rows: the one-list-per-tile plan, whole-matrix kernels only
+            Xo = [make_x(nl) * (1.0 + v / 8.0) for v in range(b)]
+            ld = d.padded_vec_size
+            for layout, mode in ((pkg.COLWISE, 0), (pkg.COLWISE, 1), (pkg.ROWWISE, 0)):
+                got = {}
+                for overlap in (1, 0):
+                    d.set_option("overlap", overlap)
+                    before = d.spmmv_info()
+                    X = d.new_X(Xo, b, layout)
+                    Y = torch.full((b * ld,), 7.0, dtype=torch.float64, device="cuda")
+                    d.spmmv(X, Y, b, layout, mode); d.synchronize()
+                    after = d.spmmv_info()
+                    two = overlap == 1 and plan != 4
+                    assert after["two_part"] - before["two_part"] == (1 if two else 0), (b, plan, layout, overlap, before, after)
+                    assert after["one_part"] - before["one_part"] == (0 if two else 1)
+                    Yh = Y.cpu().numpy()
+                    got[overlap] = Yh
+                    for v in range(b):
+                        col = Yh[v:d.n_rows_padded * b:b] if layout == pkg.ROWWISE else Yh[v * ld:v * ld + d.n_rows_padded]
+                        res = pkg.apply_permutation(np.ascontiguousarray(col), d.old_to_new)[:nl]
+                        assert np.array_equal(res, refs[v][0][wsa[rank]:wsa[rank + 1]]), (b, plan, rank, layout, mode, overlap, v)
+                n = d.n_rows_padded * b if layout == pkg.ROWWISE else None
+                if n is not None: assert np.array_equal(got[0][:n], got[1][:n])
+            d.set_option("overlap", 1)
+            if plan in (0, 8) and b == 8:                  # each part alone writes its own rows and leaves the others' prefill untouched
+                parts = {}
+                for part in (1, 2):
+                    d.set_option("diag_spmmv_part", part)
+                    Y = torch.full((b * ld,), 7.0, dtype=torch.float64, device="cuda")
+                    d.spmmv(d.new_X(Xo, b, pkg.ROWWISE), Y, b, pkg.ROWWISE, 0); d.synchronize()
+                    parts[part] = Y.cpu().numpy()[:d.n_rows_padded * b].reshape(-1, b)
+                d.set_option("diag_spmmv_part", 0)
+                full = got[1][:d.n_rows_padded * b].reshape(-1, b)
+                w1, w2 = (parts[1] != 7.0).any(axis=1), (parts[2] != 7.0).any(axis=1)
+                assert not (w1 & w2).any() and w1.sum() > 0 and w2.sum() > 0
+                live = (full != 7.0).any(axis=1)            # (rows whose result is all 7.0 cannot be told apart: none on this matrix)
+                assert (w1 | w2)[live].all()
+                assert np.array_equal(np.where(w1[:, None], parts[1], parts[2])[live], full[live])
+                if plan == 8: assert 0 < w2.sum() <= 64 * d.spmmv_info()["plan_boundary_tiles"]
+            if plan == 8:                                  # dropping the plan drops its classes: back to the gather kernels, still two parts
+                d.set_option("block_plan", 0)
+                assert d.spmmv_info()["plan_b"] == 0
+                X = d.new_X(Xo, b, pkg.ROWWISE)
+                Y = torch.zeros(b * ld, dtype=torch.float64, device="cuda")
+                d.spmmv(X, Y, b, pkg.ROWWISE, 0); d.synchronize()
+                col = Y.cpu().numpy()[0:d.n_rows_padded * b:b]
+                assert np.array_equal(pkg.apply_permutation(np.ascontiguousarray(col), d.old_to_new)[:nl], refs[0][0][wsa[rank]:wsa[rank + 1]])
+            d.close()
+
+
 def test_cli_distributed_loopback_dumps_the_right_y(pkg, orc, tmp_path):
     """`uspmv gen:... scs -seg_rows -comm_halos 1` through host/uspmv_dist.cpp with USPMV_LOOPBACK=2: per-rank generation, the
     bench loop on hipGraph replays, the spmv_bench.txt block -- and y of the block against the oracle."""
@@ -144,6 +220,16 @@ def test_cli_distributed_loopback_dumps_the_right_y(pkg, orc, tmp_path):
         yv, _ = _global_reference(pkg, orc, shape, P, 32, 512, scale=1.0 + v / 8.0)
         assert np.array_equal(Y[v], yv[nl:2 * nl]), v
     assert "block_vec_size: 2" in open(tmp_path / "spmv_bench.txt").read() and "MPI_mode: multivec" in open(tmp_path / "spmv_bench.txt").read()
+    assert "steps in two parts" in r.stdout and "phased block plan: no" in r.stdout, r.stdout
+    # ... and 8 columns (64-byte X rows): the harness builds the phased block plan and runs the step in two parts on it, row-wise X
+    r = subprocess.run([EXE, "gen:24x24x24", "scs", "-c", "32", "-s", "512", "-seg_rows", "-comm_halos", "1", "-bench_time", "0.05", "-block_vec_size", "8",
+                        "-block_vec_layout", "rowwise"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "phased block plan: yes" in r.stdout and " 0 exchange-then-compute" in r.stdout, r.stdout
+    Y = np.fromfile(pre + ".1", np.float64).reshape(8, nl)
+    for v in range(8):
+        yv, _ = _global_reference(pkg, orc, shape, P, 32, 512, scale=1.0 + v / 8.0)
+        assert np.array_equal(Y[v], yv[nl:2 * nl]), v
 
 
 # ------------------------------------------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@
 //                          group, and the phase-local one-byte index of every entry (binary search in the sorted list).
 // Same sets, same rule, sorted lists: the arrays equal the host planner's bit for bit (tests/test_gpu_parity.py compares digests).
 #include "uspmv_device.hpp"
+#include <algorithm>
 
 using namespace uspmv_dev;
 
@@ -176,9 +177,52 @@ __global__ void __launch_bounds__(256) block_phase_plan(const long n_chunks, con
     if (!WRITE && tid == 0) { t_phases[tile] = n_ph; t_list[tile] = n_list; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Two-part SpMMV (uspmv_dist_spmmv): which 64-row tiles of the phased plan touch an X row >= n_local (a halo row), and the two
+// chunk-length arrays in which the other part's chunks carry USPMV_SKIP_LEN.
+__global__ void block_tile_class(const long n_tiles, const int *__restrict__ ph_ptr, const int *__restrict__ list_ptr, const int *__restrict__ xrows,
+                                 const int n_local, unsigned char *__restrict__ flags) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int p0 = ph_ptr[t], p1 = ph_ptr[t + 1];
+    unsigned char f = 0;
+    if (p1 > p0)
+        for (int k = list_ptr[p0], e = list_ptr[p1]; k < e; ++k) f |= (unsigned char)(xrows[k] >= n_local);
+    flags[t] = f;
+}
+
+__global__ void part_len_fill(const long n_chunks, const int C, const int rows_per_flag, const unsigned char *__restrict__ flags,
+                              const int *__restrict__ chunk_lengths, int *__restrict__ len_int, int *__restrict__ len_bnd) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    // a chunk spans C / rows_per_flag flags (C >= rows_per_flag) or shares one with its neighbours
+    unsigned char f = 0;
+    const long r0 = c * C, r1 = r0 + C;
+    for (long k = r0 / rows_per_flag; k * rows_per_flag < r1; ++k) f |= flags[k];
+    const int L = chunk_lengths[c];
+    len_int[c] = f ? USPMV_SKIP_LEN : L;
+    len_bnd[c] = f ? L : USPMV_SKIP_LEN;
+}
+
 }  // namespace
 
 namespace uspmv_dev {
+
+int launch_block_tile_class(const uspmv_dmat *A, long n_local, unsigned char *d_flags, hipStream_t st) {
+    if (A->pb_n_tiles == 0) return USPMV_OK;
+    hipLaunchKernelGGL(block_tile_class, dim3((unsigned)((A->pb_n_tiles + 255) / 256)), dim3(256), 0, st, (long)A->pb_n_tiles, A->pb_ph_ptr, A->pb_list_ptr,
+                       A->pb_xrows, (int)std::min<long>(n_local, INT32_MAX), d_flags);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int launch_part_len_fill(const uspmv_dmat *A, int rows_per_flag, const unsigned char *d_flags, int *d_len_int, int *d_len_bnd, hipStream_t st) {
+    if (A->n_chunks == 0) return USPMV_OK;
+    hipLaunchKernelGGL(part_len_fill, dim3((unsigned)((A->n_chunks + 255) / 256)), dim3(256), 0, st, (long)A->n_chunks, (int)A->C, rows_per_flag, d_flags,
+                       A->chunk_lengths, d_len_int, d_len_bnd);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
 
 int launch_block_reorder(const uspmv_dmat *A, int *d_row_map, int *d_changed, hipStream_t st) {
     const long nw = (A->n_chunks + 15) / 16;

@@ -20,6 +20,7 @@ __global__ void scs_spmmv_rows(const long n_chunks, const int C, const int *__re
     if (c >= n_chunks) return;
     const long cs = chunk_ptrs[c];
     const int L = chunk_lengths[c];
+    if (L < 0) return;                        // (USPMV_SKIP_LEN: the chunk belongs to the other part of a two-part SpMMV)
     const VT *vp = values + cs + i;
     const int *cp = col_idxs + cs + i;
     for (int v0 = 0; v0 < b; v0 += VB) {
@@ -70,6 +71,7 @@ __global__ void __launch_bounds__(256) scs_spmmv_rowmajor(const long n_chunks, c
     if (c >= n_chunks) return;
     const long cs = chunk_ptrs[c];
     const int L = chunk_lengths[c];
+    if (L < 0) return;                        // (USPMV_SKIP_LEN: the chunk belongs to the other part of a two-part SpMMV)
     const VT *vp = values + cs + i;
     const int *cp = col_idxs + cs + i;
     VT acc[B];
@@ -628,7 +630,7 @@ void launch_spmmv_vb(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, in
     const bool nt = g_tune.nontemporal != 0;
 #define SPMMV_LAUNCH(RW, NTV)                                                                                     \
     hipLaunchKernelGGL((scs_spmmv_rows<VT, VB, RW, NTV>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks,      \
-                       (int)A->C, A->chunk_ptrs, A->chunk_lengths, A->col_idxs, (const VT *)A->values, X, Y, b, ld, \
+                       (int)A->C, A->chunk_ptrs, part_lengths(A, 0), A->col_idxs, (const VT *)A->values, X, Y, b, ld, \
                        g_tune.xcd_remap, (long)A->n_store)
     if (layout == USPMV_ROWWISE) { if (nt) SPMMV_LAUNCH(true, true); else SPMMV_LAUNCH(true, false); }
     else { if (nt) SPMMV_LAUNCH(false, true); else SPMMV_LAUNCH(false, false); }
@@ -641,7 +643,7 @@ void launch_spmmv_rowmajor_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, b
     const unsigned grid = grid_for(A->n_chunks * A->C, block);
     // variant 5: the gather kernel over the block plan's tie-reordered copy of the entries (neighbouring lanes then read
     // neighbouring X rows, which is what L1 can exploit)
-    const bool ro = g_tune.spmmv_variant == 5 && A->bt_values && A->bt_cols && A->bt_row_map;
+    const bool ro = g_tune.spmmv_variant == 5 && A->bt_values && A->bt_cols && A->bt_row_map && !A->part;
     const int *cols = ro ? A->bt_cols : A->col_idxs;
     const VT *vals = (const VT *)(ro ? A->bt_values : A->values);
     const int *rmap = ro ? A->bt_row_map : nullptr;
@@ -649,11 +651,11 @@ void launch_spmmv_rowmajor_u(const uspmv_dmat *A, const VT *X, VT *Y, long ld, b
     do {                                                                                                            \
         if (g_tune.spmmv_prefetch)                                                                                  \
             hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, NTV, YC, true>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
-                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, cols, vals, X, Y, ld, \
+                               (int)A->C, A->chunk_ptrs, part_lengths(A, 0), cols, vals, X, Y, ld, \
                                g_tune.xcd_remap, (long)A->n_store, rmap);                                                             \
         else                                                                                                        \
             hipLaunchKernelGGL((scs_spmmv_rowmajor<VT, B, U, NTV, YC, false>), dim3(grid), dim3(block), 0, st, (long)A->n_chunks, \
-                               (int)A->C, A->chunk_ptrs, A->chunk_lengths, cols, vals, X, Y, ld, \
+                               (int)A->C, A->chunk_ptrs, part_lengths(A, 0), cols, vals, X, Y, ld, \
                                g_tune.xcd_remap, (long)A->n_store, rmap);                                                             \
     } while (0)
     if (g_tune.nontemporal) { if (ycol) RM_LAUNCH(true, true); else RM_LAUNCH(true, false); }
@@ -749,7 +751,7 @@ void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
         // 64-byte rows, phased plan (variant 8; auto when the handle carries one): eight workgroups per CU
         if ((g_tune.spmmv_variant == 8 || (g_tune.spmmv_variant == 0 && !g_tune.ablate)) && launch_spmmv_quadph<VT, B>(A, X, Y, ld, ycol, 0, st)) return;
         // 64-byte rows: the four-lanes-per-row kernel over 64-row tiles of the block plan (variant 6; auto when the plan is there)
-        if (A->bt && A->bt_tile_rows == 64 && (g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 6) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
+        if (A->bt && !A->part && A->bt_tile_rows == 64 && (g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 6) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
             // one tile per workgroup, three workgroups per CU (a persistent, software-pipelined form of it -- 222 registers, two workgroups
             // per CU -- measured 5-7 % slower and was removed: profiles/r02/spmmv_variants.txt)
             launch_spmmv_quad<VT, B>(A, X, Y, ld, ycol, st);
@@ -761,7 +763,7 @@ void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
         // auto takes the plan for rows of <= 32 bytes only: there 4+ tiles fit a CU and the kernel is 12-15 % ahead of
         // the gather form; with 64-byte rows (2-3 tiles per CU) each tile's chain of dependent fetches is exposed and
         // it is 20 % behind (profiles/r01/spmmv_probe13.txt).  Variant 4 forces it.
-        if (A->bt && ((g_tune.spmmv_variant == 0 && RB <= 32) || g_tune.spmmv_variant == 4) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
+        if (A->bt && !A->part && ((g_tune.spmmv_variant == 0 && RB <= 32) || g_tune.spmmv_variant == 4) && (size_t)A->bt_max_rows * RB <= BT_LDS_CAP) {
             const bool swz = g_tune.spmmv_swizzle != 0;
             if (A->bt_tile_rows == 32) {
                 if constexpr (RB >= 32) {
@@ -777,7 +779,7 @@ void launch_spmmv_rowmajor(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
         }
     }
     if constexpr (RB >= 32) {                        // at least two 16-byte pieces per X row
-        if (g_tune.spmmv_variant == 2) {             // transposing X phase: 2-7 % over the plain lane-per-row loop,
+        if (g_tune.spmmv_variant == 2 && !A->part) { // transposing X phase: 2-7 % over the plain lane-per-row loop,
             int Up = g_tune.spmmv_unroll ? g_tune.spmmv_unroll : 4;         // level with its prefetching form (spmmv_probe7.txt)
             if (g_tune.spmmv_prefetch && RB >= 64 && Up > 2) Up = 2;        // 4 prefetching slots of 64-byte rows spill
             if (Up >= 4) launch_spmmv_xpose_u<VT, B, 4>(A, X, Y, ld, ycol, st);
@@ -808,7 +810,7 @@ int spmmv_fast(const uspmv_dmat *A, const VT *X, VT *Y, long ld, int layout, hip
     if constexpr (B * (int)sizeof(VT) == 64) {
         // 64-byte rows with a phased plan: the kernel stages X straight from the column-major vector -- by 128-byte lines when the
         // handle carries the line plan (default), through registers with "spmmv_xcol" 1 -- no re-layout pass, no workspace
-        if ((g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 8) && !g_tune.ablate) {
+        if ((g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 8) && !g_tune.ablate && !A->part) {
             if (g_tune.spmmv_xcol && launch_spmmv_quadph<VT, B>(A, X, Y, ld, true, 1, st)) return USPMV_OK;
             if (g_tune.spmmv_xline && launch_spmmv_quadph<VT, B>(A, X, Y, ld, true, 2, st)) return USPMV_OK;
         }
@@ -824,15 +826,20 @@ int spmmv_fast(const uspmv_dmat *A, const VT *X, VT *Y, long ld, int layout, hip
     VT *Xr = (VT *)A->ws;
     if constexpr (B * (int)sizeof(VT) == 64) {
         // the re-layout pass undoes the sigma permutation, the kernel runs on the plan over original X-row numbering
-        if ((g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 8) && !g_tune.ablate && g_tune.spmmv_unscramble && A->pu && A->pu_perm && A->pu_n_perm <= ld) {
+        if ((g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 8) && !g_tune.ablate && !A->part && g_tune.spmmv_unscramble && A->pu && A->pu_perm && A->pu_n_perm <= ld) {
             hipLaunchKernelGGL((block_vector_to_rowmajor<VT, B, true>), dim3(grid_for(ld, 256)), dim3(256), 0, st, X, Xr, ld, ld, (const int *)A->pu_perm, (long)A->pu_n_perm);
             if (launch_spmmv_quadph<VT, B>(A, Xr, Y, ld, true, 3, st)) return USPMV_OK;
         }
     }
-    if constexpr ((B * (int)sizeof(VT)) % 16 == 0)
-        hipLaunchKernelGGL((block_vector_to_rowmajor<VT, B>), dim3(grid_for(ld, 256)), dim3(256), 0, st, X, Xr, ld, ld);
-    else
-        hipLaunchKernelGGL((block_vector_relayout<VT, B, true>), dim3(grid_for(ld, 256)), dim3(256), 0, st, X, Xr, ld, ld);
+    // (two-part SpMMV: the interior part needs the local X rows only, the boundary part brings the halo rows after the exchange)
+    const long split = std::min<long>(std::max<long>(A->part_split, 0), ld);
+    const long r0 = A->part == 2 ? split : 0, nr = (A->part == 1 ? split : ld) - r0;
+    if (nr > 0) {
+        if constexpr ((B * (int)sizeof(VT)) % 16 == 0)
+            hipLaunchKernelGGL((block_vector_to_rowmajor<VT, B>), dim3(grid_for(nr, 256)), dim3(256), 0, st, X + r0, Xr + r0 * B, nr, ld);
+        else
+            hipLaunchKernelGGL((block_vector_relayout<VT, B, true>), dim3(grid_for(nr, 256)), dim3(256), 0, st, X + r0, Xr + r0 * B, nr, ld);
+    }
     launch_spmmv_rowmajor<VT, B>(A, Xr, Y, ld, true, st);
     return USPMV_OK;
 }

@@ -56,6 +56,7 @@ __global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, con
     unsigned q0 = 0;
     if (valid) { cs = chunk_ptrs[c]; L = chunk_lengths[c]; q0 = c16_ptrs[c]; }
     L = __builtin_amdgcn_readfirstlane(L);
+    if (L < 0) return;                                           // USPMV_SKIP_LEN: the tile belongs to the other part of a two-part SpMMV (all of its chunks do)
     const int ngf = L >> 2, rem = L & 3;
     const int p0 = ph_ptr[tile], p1 = ph_ptr[tile + 1];
     vec_t acc;
@@ -202,7 +203,7 @@ template <typename VT, typename IT, int B, int CT, int MAXP>
 void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, int xmode, hipStream_t st) {
     const bool xcol = xmode == 1;
     const size_t lds = xcol ? (size_t)MAXP * 64 * 80 : (size_t)MAXP * 4 * 1024;   // MAXP*64 rows of 64 (row-major X / lines, DMA pieces) or 80 bytes
-#define QH_ARGS(PH, G0, LP, XR, C16) (long)A->n_chunks, A->chunk_ptrs, A->chunk_lengths, (const VT *)A->pb_values, X, Y, ld, PH, G0, LP, XR, A->pb_c16_ptrs, \
+#define QH_ARGS(PH, G0, LP, XR, C16) (long)A->n_chunks, A->chunk_ptrs, part_lengths(A, 1), (const VT *)A->pb_values, X, Y, ld, PH, G0, LP, XR, A->pb_c16_ptrs, \
                            (const IT *)C16, g_tune.xcd_remap, (long)A->n_store, (const int *)A->bt_row_map
 #define QH_LAUNCH(NTV, YC)                                                                                              \
     do {                                                                                                                \
@@ -256,7 +257,8 @@ void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
 // registers (measured slower, kept as "spmmv_xcol" 1), 2 = column-major X staged by 128-byte lines (needs the handle's line plan)
 template <typename VT, int B>
 bool launch_spmmv_quadph(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, int xmode, hipStream_t st) {
-    if (!A->pb || !A->pb_values || A->pb_ngp > 8) return false;
+    if (!A->pb || !A->pb_values || A->pb_ngp > 8 || !part_ok(A, 1)) return false;
+    if (A->part && xmode != 0) return false;                   // (the two-part form runs on the row-major plan only)
     if (xmode == 3) {
         if (!A->pu || !ycol || !A->pu_col8 || A->pu_max_rows > 256) return false;
 #define QU_C(CTV) launch_spmmv_quadph_m<VT, unsigned char, B, CTV, 4>(A, X, Y, ld, ycol, 3, st)

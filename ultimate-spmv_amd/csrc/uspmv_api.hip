@@ -668,7 +668,55 @@ int uspmv_dmat_plan_download(const uspmv_dmat_t *A, int64_t meta[4], int32_t *ti
     return USPMV_OK;
 }
 
+static void part_release(uspmv_dmat_t *A, int order) {
+    (void)hipFree(A->part_len[order][0]); (void)hipFree(A->part_len[order][1]);
+    A->part_len[order][0] = A->part_len[order][1] = nullptr;
+}
+
+extern "C++" {
+namespace uspmv_dev {
+
+namespace { struct FlagBuf { unsigned char *p = nullptr; ~FlagBuf() { (void)hipFree(p); } }; }
+
+static int part_build(uspmv_dmat *A, int order, int rows_per_flag, const unsigned char *d_flags) {
+    part_release(A, order);
+    const size_t bytes = 4 * (size_t)std::max<int64_t>(A->n_chunks, 1);
+    hipError_t e = hipMalloc((void **)&A->part_len[order][0], bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&A->part_len[order][1], bytes);
+    int rc = e == hipSuccess ? launch_part_len_fill(A, rows_per_flag, d_flags, A->part_len[order][0], A->part_len[order][1], nullptr)
+                             : uspmv::fail(USPMV_ERR_ALLOC, "two-part SpMMV: %s", hipGetErrorString(e));
+    if (!rc && (e = hipStreamSynchronize(nullptr)) != hipSuccess) rc = uspmv::fail(USPMV_ERR_HIP, "two-part SpMMV: %s", hipGetErrorString(e));
+    if (rc) part_release(A, order);
+    return rc;
+}
+
+int dmat_part_set_chunks(uspmv_dmat *A, const unsigned char *h_chunk_flags) {
+    FlagBuf f;
+    HIP_TRY(hipMalloc((void **)&f.p, (size_t)std::max<int64_t>(A->n_chunks, 1)));
+    if (A->n_chunks) HIP_TRY(hipMemcpy(f.p, h_chunk_flags, (size_t)A->n_chunks, hipMemcpyHostToDevice));
+    return part_build(A, 0, (int)A->C, f.p);
+}
+
+int dmat_part_set_plan(uspmv_dmat *A, long n_local, int64_t *n_boundary_tiles) {
+    part_release(A, 1);
+    if (n_boundary_tiles) *n_boundary_tiles = 0;
+    if (!A->pb || A->pb_n_tiles == 0) return USPMV_OK;
+    FlagBuf f;
+    HIP_TRY(hipMalloc((void **)&f.p, (size_t)A->pb_n_tiles));
+    if (int rc = launch_block_tile_class(A, n_local, f.p, nullptr)) return rc;
+    if (n_boundary_tiles) {
+        std::vector<unsigned char> h((size_t)A->pb_n_tiles);
+        HIP_TRY(hipMemcpy(h.data(), f.p, h.size(), hipMemcpyDeviceToHost));
+        for (unsigned char v : h) *n_boundary_tiles += v;
+    }
+    return part_build(A, 1, 64, f.p);
+}
+
+}  // namespace uspmv_dev
+}  // extern "C++"
+
 static void bt_release(uspmv_dmat_t *A) {
+    part_release(A, 1);                                         // (classified per tile of the plan that goes away)
     (void)hipFree(A->bt_line_ptr); (void)hipFree(A->bt_xrows); (void)hipFree(A->bt_c16_ptrs); (void)hipFree(A->bt_col16);
     (void)hipFree(A->bt_values); (void)hipFree(A->bt_cols); (void)hipFree(A->bt_row_map);
     A->bt_values = nullptr; A->bt_cols = A->bt_row_map = nullptr;
@@ -682,6 +730,8 @@ static void bt_release(uspmv_dmat_t *A) {
     (void)hipFree(A->pu_ph_ptr); (void)hipFree(A->pu_g0); (void)hipFree(A->pu_list_ptr); (void)hipFree(A->pu_xrows); (void)hipFree(A->pu_col8); (void)hipFree(A->pu_perm);
     A->pu_ph_ptr = A->pu_g0 = A->pu_list_ptr = A->pu_xrows = A->pu_perm = nullptr; A->pu_col8 = nullptr; A->pu = false;
 }
+
+extern "C++" { namespace uspmv_dev { void dmat_block_plan_release(uspmv_dmat *A) { if (A->bt || A->pb) bt_release(A); } } }
 
 int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_vec_size, int64_t *n_tiles, int64_t *n_staged) {
     if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block: NULL argument");
@@ -1262,6 +1312,7 @@ void uspmv_dmat_free(uspmv_dmat_t *A) {
     if (A->alt) { uspmv_dmat_free(A->alt); A->alt = nullptr; }
     if (A->tlc) tlc_release(A);
     if (A->bt || A->pb) bt_release(A);
+    part_release(A, 0); part_release(A, 1);
     if (A->ws) (void)hipFree(A->ws);
     if (A->owns) {
         (void)hipFree((void *)A->chunk_ptrs); (void)hipFree((void *)A->chunk_lengths);

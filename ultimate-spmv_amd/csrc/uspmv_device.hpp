@@ -25,6 +25,14 @@ struct uspmv_dmat {
     // on demand, released with the handle.  Not thread-safe per handle, like the reference's kernel object.
     mutable void *ws = nullptr;
     mutable size_t ws_bytes = 0;
+    // SpMMV in two parts (the halo overlap of uspmv_dist_spmmv, csrc/uspmv_dist_api.hip): chunk-length arrays in which the chunks of the
+    // OTHER part carry USPMV_SKIP_LEN -- a kernel that meets it leaves those rows of Y alone.  [order][part - 1]: order 0 = the caller's
+    // row order (gather kernels), order 1 = the phased plan's tie-re-ordered rows (scs_spmmv_quadph), classified per 64-row plan tile.
+    // `part` selects around ONE launch: 0 the whole matrix, 1 interior, 2 boundary; column-major callers: part 1 re-lays out X rows
+    // [0, part_split) into the workspace, part 2 the rest (the halo rows, after the exchange).
+    int32_t *part_len[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int part = 0;
+    long part_split = 0;
     // tile-local-column plan (host/tlc_plan.cpp), device copies owned by the handle
     bool tlc = false;
     int tlc_max_lines = 0, tlc_tile_rows = 256;
@@ -88,6 +96,15 @@ struct uspmv_dmat {
 };
 
 namespace uspmv_dev {
+
+constexpr int USPMV_SKIP_LEN = -4;     // (a multiple of four: no kernel sees a partial group or a tail in it)
+
+// the chunk lengths a launcher hands to its kernel: the handle's own, or the selected part's (order 0 caller's rows, 1 phased plan rows)
+inline const int32_t *part_lengths(const uspmv_dmat *A, int order) {
+    return A->part && A->part_len[order][A->part - 1] ? A->part_len[order][A->part - 1] : A->chunk_lengths;
+}
+// false: a part is selected and this order has no arrays for it -- the launcher must not run
+inline bool part_ok(const uspmv_dmat *A, int order) { return !A->part || A->part_len[order][A->part - 1]; }
 
 struct Tuning {
     // defaults = fastest of the interleaved sweep on the nlpkkt200-class matrix (profiles/r01_sweep253.txt)
@@ -184,6 +201,13 @@ int launch_rechunk32(const uspmv_dmat *A, const int *d_cp_new, int *d_ci_new, vo
 int launch_block_values_gather(const uspmv_dmat *A, const int *d_row_map, const unsigned *d_c16_ptrs, void *d_out, bool group_major, hipStream_t st);   // plan_kernels.hip
 // device-side builder of the phased block plan (block_plan_kernels.hip)
 int launch_block_reorder(const uspmv_dmat *A, int *d_row_map, int *d_changed, hipStream_t st);
+int launch_block_tile_class(const uspmv_dmat *A, long n_local, unsigned char *d_flags, hipStream_t st);
+int launch_part_len_fill(const uspmv_dmat *A, int rows_per_flag, const unsigned char *d_flags, int *d_len_int, int *d_len_bnd, hipStream_t st);
+// two-part SpMMV (uspmv_dmat::part_len): order 0 from per-chunk flags (1 = the chunk touches a halo column), order 1 from the lists of the
+// handle's phased plan (no-op without one); the arrays belong to the handle (order 1 goes with the plan)
+void dmat_block_plan_release(uspmv_dmat *A);
+int dmat_part_set_chunks(uspmv_dmat *A, const unsigned char *h_chunk_flags);
+int dmat_part_set_plan(uspmv_dmat *A, long n_local, int64_t *n_boundary_tiles);
 int launch_block_phase_plan(const uspmv_dmat *A, bool write, int cap, int ngp, const int *d_row_map, const unsigned *d_c16_ptrs, int *d_t_phases,
                             int *d_t_list, int *d_ph_g0, int *d_ph_list_ptr, int *d_xrows, unsigned char *d_col8, int *d_max_rows, hipStream_t st);
 // device-side builder of the column-window sweep plan (sweep_plan_kernels.hip)

@@ -32,6 +32,7 @@ struct uspmv_dist {
     int rank = 0, P = 1, comm_rank = 0, comm_size = 1;
     bool loopback = false, overlap = true, tiles = false, owns_setup = false, no_pack = false, ba_synch = false, host_exchange = false;
     bool diag_skip_exchange = false;
+    int diag_spmmv_part = 0;          // diagnosis: the two-part block-vector step runs only its interior (1) or boundary (2) part
     int capture_mode = hipStreamCaptureModeRelaxed;
     ncclComm_t comm = nullptr;
     uspmv_transport_t tr{};           // set-up transport (and the per-step one of USPMV_EXCHANGE_HOST)
@@ -64,6 +65,10 @@ struct uspmv_dist {
     };
     std::vector<BlockPlan> block_plans;
     std::vector<int32_t> h_send_idxs, h_perm;        // host copies for building those plans
+    // two-part SpMMV (interior chunks while the block-vector exchange runs): see uspmv_dmat::part_len
+    bool parts = false;                              // the handle carries the caller's-order arrays
+    int64_t plan_b = 0, plan_bnd_tiles = 0;          // block width of the phased plan built through "block_plan", its boundary tiles
+    int64_t spmmv_two_part = 0, spmmv_one_part = 0;  // steps taken in either form
 };
 
 namespace {
@@ -357,6 +362,20 @@ int uspmv_dist_create_ex(const void *comm_id, int comm_rank, int comm_size, int 
     }
     D->n_rows_padded = A->n_chunks * A->C;
     D->vec_len = D->n_local + std::max(D->n_rows_padded - D->n_local, D->n_halo);       // padded_vec_size (code/main.cpp:1406-1412)
+    if (P > 1 && !A->alt && A->n_chunks > 0) {
+        // the same split for block vectors: per chunk, does it (or its tile) touch a halo column
+        std::vector<unsigned char> flag((size_t)A->n_chunks, 0);
+        const int64_t cpt = ids_are_tiles ? std::max<int64_t>(A->tlc_tile_rows / A->C, 1) : 1;
+        bool ok = true;
+        for (int64_t k = 0; k < n_boundary && ok; ++k) {
+            const int64_t c0 = (int64_t)boundary_ids[k] * cpt;
+            if (boundary_ids[k] < 0 || c0 >= A->n_chunks) { ok = false; break; }
+            for (int64_t c = c0; c < std::min(c0 + cpt, A->n_chunks); ++c) flag[(size_t)c] = 1;
+        }
+        if (!ok) return bail(uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create: boundary id outside the matrix"));
+        if (int rc = uspmv_dev::dmat_part_set_chunks(A, flag.data())) return bail(rc);
+        D->parts = true;
+    }
 #undef D_HIP
 #undef D_NCCL
     *out = D;
@@ -433,6 +452,25 @@ int uspmv_dist_set_option(uspmv_dist_t *D, const char *key, int value) {
     if (k == "overlap") { if ((value != 0) != D->overlap) drop_graph(D); D->overlap = value != 0; }
     else if (k == "no_pack") { if ((value != 0) != D->no_pack) drop_graph(D); D->no_pack = value != 0; }
     else if (k == "ba_synch") { if ((value != 0) != D->ba_synch) drop_graph(D); D->ba_synch = value != 0; }
+    else if (k == "diag_spmmv_part") {
+        if (value < 0 || value > 2) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_option: diag_spmmv_part is 0 (both), 1 (interior only) or 2 (boundary only)");
+        D->diag_spmmv_part = value;
+    }
+    else if (k == "block_plan") {
+        // the phased block plan for block vectors of `value` columns on the rank's matrix (64-byte X rows: dp 8, sp 16; other widths
+        // and shapes the planner turns down keep the gather kernels) + its interior / boundary tiles.  0: drop the plan.
+        if (value < 0) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_option: block_plan takes a block width >= 0");
+        D->plan_b = 0; D->plan_bnd_tiles = 0;
+        int64_t nt = 0, ns = 0;
+        if (value == 0) { uspmv_dev::dmat_block_plan_release(D->A); return USPMV_OK; }
+        int rc = D->scs ? uspmv_dmat_optimize_block(D->A, D->scs, value, &nt, &ns) : uspmv_dmat_optimize_block_device(D->A, value, &nt, &ns);
+        if (rc) return rc;
+        if (D->A->pb) {
+            D->plan_b = value;
+            if (D->parts) rc = uspmv_dev::dmat_part_set_plan(D->A, (long)D->n_local, &D->plan_bnd_tiles);
+        }
+        return rc;
+    }
     else if (k == "capture_mode") {
         if (value < 0 || value > 2) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_option: capture_mode is 0 (global), 1 (thread-local) or 2 (relaxed)");
         D->capture_mode = value == 0 ? hipStreamCaptureModeGlobal : value == 1 ? hipStreamCaptureModeThreadLocal : hipStreamCaptureModeRelaxed;
@@ -440,6 +478,13 @@ int uspmv_dist_set_option(uspmv_dist_t *D, const char *key, int value) {
     }
     else if (k == "diag_skip_exchange") { drop_graph(D); D->diag_skip_exchange = value != 0; }
     else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_option: unknown key '%s'", key);
+    return USPMV_OK;
+}
+
+int uspmv_dist_spmmv_info(const uspmv_dist_t *D, int64_t meta[6]) {
+    if (!D || !meta) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_spmmv_info: NULL argument");
+    meta[0] = D->spmmv_two_part; meta[1] = D->spmmv_one_part; meta[2] = D->A->pb ? D->plan_b : 0; meta[3] = D->A->pb ? D->A->pb_n_tiles : 0;
+    meta[4] = D->A->pb ? D->plan_bnd_tiles : 0; meta[5] = D->parts && !D->A->alt;
     return USPMV_OK;
 }
 
@@ -693,10 +738,37 @@ extern "C" int uspmv_dist_spmmv(uspmv_dist_t *D, void *d_X, void *d_Y, int b, in
     if (mode != USPMV_BULKVEC && mode != USPMV_MULTIVEC && mode != USPMV_SINGLEVEC) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_spmmv: unknown mode %d", mode);
     if (layout == USPMV_ROWWISE && mode != USPMV_BULKVEC)
         return uspmv::fail(USPMV_ERR_UNSUPPORTED, "uspmv_dist_spmmv: row-wise block vectors travel in one message per neighbour (bulkvec) only");
-    if (D->P > 1 && comm_halos) {
-        if (D->host_exchange) return uspmv::fail(USPMV_ERR_UNSUPPORTED, "uspmv_dist_spmmv: block vectors are exchanged on RCCL only (USPMV_EXCHANGE_HOST is the single-vector test transport)");
-        if (int rc = exchange_block(D, d_X, b, layout, mode, (hipStream_t)stream)) return rc;
+    hipStream_t main = (hipStream_t)stream;
+    if (!(D->P > 1 && comm_halos)) return uspmv_spmmv(D->A, d_X, d_Y, b, D->vec_len, layout, stream);
+    if (D->host_exchange) return uspmv::fail(USPMV_ERR_UNSUPPORTED, "uspmv_dist_spmmv: block vectors are exchanged on RCCL only (USPMV_EXCHANGE_HOST is the single-vector test transport)");
+    // (a handle whose only block plan is the one-list-per-tile one runs that plan's kernels on the whole matrix: they are ahead of the
+    //  gather kernels by more than the exchange costs)
+    if (!(D->overlap && D->parts && !D->A->alt) || (D->A->bt && !(D->A->pb && D->A->part_len[1][0]))) {
+        // exchange first, then the whole matrix (the reference's order, code/mpi_funcs.hpp:25-60)
+        if (int rc = exchange_block(D, d_X, b, layout, mode, main)) return rc;
+        if (int rc = uspmv_spmmv(D->A, d_X, d_Y, b, D->vec_len, layout, stream)) return rc;
+        ++D->spmmv_one_part;
+        return step_barrier(D, main);
     }
-    if (int rc = uspmv_spmmv(D->A, d_X, d_Y, b, D->vec_len, layout, stream)) return rc;
-    return D->P > 1 && comm_halos ? step_barrier(D, (hipStream_t)stream) : USPMV_OK;   // -ba_synch
+    // Two parts, as the single-vector step: the chunks (plan tiles) that touch no halo row run on the side stream while the
+    // exchange is under way on the caller's stream, the others after it.  A part is the same kernel over chunk lengths in which the
+    // other part's chunks are marked (uspmv_dmat::part_len), so every row's FMA chain is what the one-part step computes.
+    // Column-wise X: the interior part re-lays out the local rows into the handle's row-major workspace, the boundary part the
+    // halo rows once they have arrived.
+    uspmv_dmat_t *A = D->A;
+    struct PartGuard { uspmv_dmat_t *A; ~PartGuard() { A->part = 0; } } guard{A};
+    A->part_split = (long)D->n_local;
+    HIP_TRY(hipEventRecord(D->ev_main, main));
+    HIP_TRY(hipStreamWaitEvent(D->side_stream, D->ev_main, 0));
+    A->part = 1;
+    if (D->diag_spmmv_part != 2)
+        if (int rc = uspmv_spmmv(A, d_X, d_Y, b, D->vec_len, layout, D->side_stream)) return rc;
+    HIP_TRY(hipEventRecord(D->ev_comm, D->side_stream));
+    if (int rc = exchange_block(D, d_X, b, layout, mode, main)) return rc;
+    HIP_TRY(hipStreamWaitEvent(main, D->ev_comm, 0));
+    A->part = 2;
+    if (D->diag_spmmv_part != 1)
+        if (int rc = uspmv_spmmv(A, d_X, d_Y, b, D->vec_len, layout, main)) return rc;
+    ++D->spmmv_two_part;
+    return step_barrier(D, main);
 }

@@ -186,6 +186,7 @@ int uspmv_run_distributed(const DistConfig &c) {
     CK(uspmv_dist_barrier(D, st));
     if (c.no_overlap) CK(uspmv_dist_set_option(D, "overlap", 0));
     if (c.no_pack) CK(uspmv_dist_set_option(D, "no_pack", 1));   // -no_pack 1: the exchange sends a stale buffer (code/classes_structs.hpp:941)
+    if (c.block_vec_size > 1 && c.tlc) CK(uspmv_dist_set_option(D, "block_plan", c.block_vec_size));   // (64-byte X rows: the phased block plan + its interior / boundary tiles)
     CK(uspmv_dist_set_option(D, "ba_synch", c.ba_synch && c.comm_halos ? 1 : 0));   // -ba_synch (code/main.cpp:467; default 1, code/classes_structs.hpp:90)
     int64_t meta[12];
     CK(uspmv_dist_info(D, meta));
@@ -342,6 +343,12 @@ int uspmv_run_distributed(const DistConfig &c) {
                runtime / n_iter * 1e3, rank, bytes / (runtime / n_iter) / 1e9, (long)n_halo, (long)meta[4], (long)meta[5], meta[6] ? "tiles" : "chunks",
                meta[9] ? "hipGraph replay" : "eager steps", c.ba_synch && c.comm_halos ? 1 : 0,
                mism_total < 0 ? "" : mism_total == 0 ? ", y checked bitwise on every rank: ok" : ", y CHECK FAILED");
+        if (b > 1) {
+            int64_t bm[6];
+            CK(uspmv_dist_spmmv_info(D, bm));
+            printf("block vectors (b = %d): %ld steps in two parts (interior chunks during the exchange), %ld exchange-then-compute; phased block plan: %s (%ld of %ld tiles boundary)\n",
+                   b, (long)bm[0], (long)bm[1], bm[2] ? "yes" : "no", (long)bm[4], (long)bm[3]);
+        }
         if (!c.json.empty()) {
             char js[2048];
             snprintf(js, sizeof js,
