@@ -85,6 +85,76 @@ def test_native_step_loopback_bitexact(pkg, orc, P, shape, C, sigma):
         d.close()
 
 
+def _global_reference_x(pkg, orc, shape, P, C, sigma, xblock):
+    """as _global_reference for an arbitrary block of x (x_global = P copies of it)"""
+    coo = pkg.gen_stencil27(*shape)
+    n = coo.n_rows
+    s = pkg.convert_to_scs(coo, C, sigma)
+    a = s.arrays()
+    pkg.permute_scs_cols(s, a["old_to_new_idx"])
+    a = s.arrays()
+    xp = np.zeros(s.n_rows_padded)
+    xp[:n] = pkg.apply_permutation(np.tile(xblock, P), a["new_to_old_idx"])
+    with np.errstate(invalid="ignore"):
+        y = orc.spmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+    return pkg.apply_permutation(y, a["old_to_new_idx"])
+
+
+def test_padding_tiles_run_with_the_interior_and_rerun_when_they_must(pkg, orc):
+    """The reference pads chunks with (+0, column 0), a halo column on ranks > 0: tiles that touch the halo only that way run before
+    the exchange (uspmv_dist_pad_info).  Bit-exact against the oracle's single-rank product in every case: positive x[0] (no re-run:
+    the slot held +0 before), negative x[0] (sign differs from the slot's old content: one re-run, none on the next step), x[0] = Inf
+    (0 * Inf = NaN in every padded row, as in the reference: re-run every step), eager and graph replay, and with "pad_split" 0."""
+    import torch
+    torch.cuda.set_device(0)
+    P, shape, C, sigma = 4, (16, 16, 40), 32, 512
+    counts = pkg.gen_stencil27_row_counts(*shape)
+    wsa = pkg.seg_from_row_counts(counts, "seg-rows", P)
+    nl = int(wsa[1] - wsa[0])
+    cases = {}
+    for tag, x0 in (("pos", 3.25), ("neg", -2.5), ("inf", np.inf)):
+        xb = make_x(nl).copy(); xb[0] = x0
+        cases[tag] = (xb, _global_reference_x(pkg, orc, shape, P, C, sigma, xb))
+    assert np.isnan(cases["inf"][1]).any() and not np.isnan(cases["neg"][1]).any()
+    for rank in (0, 2):
+        loc = pkg.gen_stencil27(*shape, row_begin=int(wsa[rank]), row_end=int(wsa[rank + 1]))
+        d = pkg.DistNative(loc, wsa, C, sigma, rank, P, pkg.comm_unique_id(), comm_rank=0, comm_size=1)
+        info = d.pad_info()
+        if rank == 0:
+            assert info["pad_tiles"] == 0 and info["pad_col"] == -1          # column 0 is local there
+            d.close(); continue
+        assert info["pad_tiles"] > 0 and info["pad_col"] >= d.n_local and info["real_boundary_tiles"] > 0, info
+        assert info["pad_tiles"] + info["real_boundary_tiles"] == d.n_boundary
+        want = {k: v[1][wsa[rank]:wsa[rank + 1]] for k, v in cases.items()}
+
+        def run(tag, graph=False, steps=1):
+            x = d.new_x(cases[tag][0]); y = d.new_y()
+            if graph: d.run(x, y, steps, use_graph=True)
+            else:
+                for _ in range(steps): d.spmv(x, y)
+            d.synchronize()
+            got = d.y_to_original_order(y)
+            assert np.array_equal(got, want[tag], equal_nan=True), (tag, graph, steps)
+            return d.pad_info()["reruns"]
+
+        r0 = d.pad_info()["reruns"]
+        assert run("pos") == r0                               # slot held +0 (fresh x): same sign, no re-run
+        r1 = run("neg")                                       # fresh x again: +0 -> -2.5
+        assert r1 == r0 + 1
+        x = d.new_x(cases["neg"][0]); y = d.new_y()
+        d.spmv(x, y); d.spmv(x, y); d.synchronize()           # second step on the SAME x: the slot already holds -2.5
+        assert np.array_equal(d.y_to_original_order(y), want["neg"]) and d.pad_info()["reruns"] == r1 + 1
+        r2 = d.pad_info()["reruns"]
+        assert run("inf", steps=2) == r2 + 2                  # not finite: every step
+        r3 = run("neg", graph=True, steps=3)                  # the captured step carries guard and conditional list too
+        assert r3 == r2 + 2 + 1
+        d.set_option("pad_split", 0)
+        assert run("neg") == r3 and run("inf") == r3 and run("pos") == r3
+        d.set_option("pad_split", 1)
+        assert run("pos") == r3
+        d.close()
+
+
 def test_native_block_vector_exchange_loopback_bitexact(pkg, orc):
     """uspmv_dist_spmmv: the halo exchange of b vectors in the reference's three message patterns (bulkvec / multivec / singlevec,
     code/classes_structs.hpp:875-924) + the SpMMV kernel, per column against the oracle's single-rank SpMV of the whole matrix."""

@@ -129,6 +129,7 @@ _SIGS = {
     "uspmv_dist_create_from_coo": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64, _i64, C.c_int, C.c_int, C.POINTER(_vp)]),
     "uspmv_dist_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dist_spmmv_info": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "uspmv_dist_pad_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dist_parts": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "uspmv_dist_set_overlap": (C.c_int, [_vp, C.c_int]),
     "uspmv_dist_set_no_pack": (C.c_int, [_vp, C.c_int]),
@@ -650,6 +651,12 @@ class DistNative:
         self._order(X, Y)
         _ck(lib().uspmv_dist_spmmv(self.h, _dp(X), _dp(Y), int(b), int(layout), int(mode), int(bool(comm_halos)), self.stream.cuda_stream))
         return Y
+
+    def pad_info(self):
+        """dict(pad_tiles, real_boundary_tiles, pad_col, reruns) (uspmv_dist_pad_info)"""
+        m = (C.c_int64 * 4)()
+        _ck(lib().uspmv_dist_pad_info(self.h, m))
+        return dict(zip(("pad_tiles", "real_boundary_tiles", "pad_col", "reruns"), (int(v) for v in m)))
 
     def spmmv_info(self):
         """dict(two_part, one_part, plan_b, plan_tiles, plan_boundary_tiles, parts) (uspmv_dist_spmmv_info)"""

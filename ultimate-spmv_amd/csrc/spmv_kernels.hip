@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const 
     const int C = CT > 0 ? CT : C_rt;
     const unsigned lbt = remap_block(blockIdx.x, gridDim.x, xcd_remap);
     const unsigned tile = IDS ? (unsigned)tile_ids[lbt] : lbt;
+    if (IDS && (int)tile < 0) return;          // (an entry of a conditional tile list that was switched off: uspmv_dist's padding re-run)
     const int lp0 = tile_line_ptr[tile];
     const int nl = tile_line_ptr[tile + 1] - lp0;
     const long row = (long)tile * blockDim.x + threadIdx.x;

@@ -47,6 +47,20 @@ struct uspmv_dist {
     std::vector<int64_t> send_off, recv_off;
     std::vector<int32_t> recv_counts;
     int32_t *d_send_idxs = nullptr, *d_perm = nullptr, *d_int = nullptr, *d_bnd = nullptr;
+    int32_t *d_src = nullptr;         // pack: send[i] = x[d_src[i]], d_src = perm[send_idxs] composed once
+    // Padding tiles (tile lists only).  The reference pads chunks with (value +0, column 0); on ranks > 0 column 0 is a halo column
+    // (code/mpi_funcs.hpp:279-306), so more than half of a rank's tiles "touch the halo" only through fma(+0, x[pad_col], acc).  Those
+    // run with the interior tiles, before the exchange has delivered x[pad_col]: for a finite operand of the same sign the product is
+    // the same signed zero and every row's chain comes out bit for bit as with the delivered value.  The step keeps the value the
+    // slot held before the exchange, compares it with the delivered one (pad_guard_kernel), and only when either is not finite or the
+    // signs differ runs the padding tiles AGAIN after the boundary tiles (a conditional tile list: ids or -1).
+    // d_early = interior and padding tiles in ascending order (ONE launch before the exchange completes); d_late = the boundary tiles
+    // with real halo references followed by n_pad conditional entries (ONE launch after it): the guard writes ids or -1 there
+    int32_t *d_early = nullptr, *d_late = nullptr, *d_pad = nullptr;
+    int64_t n_bnd_real = 0, n_pad = 0;
+    int32_t pad_col = -1;
+    bool pad_split = true;
+    void *d_stale = nullptr;
     void *d_send = nullptr;
     void *h_send = nullptr, *h_recv = nullptr;   // pinned staging of USPMV_EXCHANGE_HOST
     int *d_scratch = nullptr;
@@ -145,10 +159,57 @@ int self_allgather(void *ctx, const void *send, void *recv, int64_t bytes) {
 int self_barrier(void *) { return USPMV_OK; }
 
 // ---- the per-step exchange
+// pack_send_buf (code/mpi_funcs.hpp:25-33) with the two index levels composed at set-up; thread 0 also keeps the value the padding
+// column's slot holds BEFORE the exchange overwrites it (see uspmv_dist::pad_col)
+template <typename VT>
+__global__ void pack_kernel(VT *__restrict__ out, const VT *__restrict__ x, const int *__restrict__ src, const long n, const int pad_col, VT *__restrict__ stale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[src[i]];
+    if (i == 0 && pad_col >= 0) *stale = x[pad_col];
+}
+
+// after the exchange: must the padding tiles run again?  (not when the slot held, and now holds, finite values of one sign:
+// fma(+0, s, acc) == fma(+0, c, acc) bit for bit then)
+template <typename VT>
+__global__ void pad_guard_kernel(const VT *__restrict__ x, const int pad_col, const VT *__restrict__ stale, const int *__restrict__ pad_ids,
+                                 int *__restrict__ rerun, const long n_pad, int *__restrict__ counter) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const VT s = *stale, c = x[pad_col];
+    const bool need = !(isfinite(s) && isfinite(c) && (signbit(s) == signbit(c)));
+    if (k < n_pad) rerun[k] = need ? pad_ids[k] : -1;
+    if (k == 0 && need) atomicAdd(counter, 1);
+}
+
+inline bool pads_on(const uspmv_dist *D) { return D->pad_split && D->overlap && D->tiles && D->n_pad > 0 && D->pad_col >= 0; }
+
+int pack(uspmv_dist *D, void *d_x, hipStream_t st) {
+    const long n = D->no_pack ? 0 : (long)D->n_send;           // (-no_pack 1: a stale buffer travels, timing only)
+    const int pc = pads_on(D) ? D->pad_col : -1;
+    if (n == 0 && pc < 0) return USPMV_OK;
+    const unsigned grid = (unsigned)std::max<long>((n + 255) / 256, 1);
+    if (D->dtype == USPMV_F64)
+        hipLaunchKernelGGL(pack_kernel<double>, dim3(grid), dim3(256), 0, st, (double *)D->d_send, (const double *)d_x, D->d_src, n, pc, (double *)D->d_stale);
+    else
+        hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, st, (float *)D->d_send, (const float *)d_x, D->d_src, n, pc, (float *)D->d_stale);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int pad_guard(uspmv_dist *D, const void *d_x, hipStream_t st) {
+    const unsigned grid = (unsigned)((D->n_pad + 255) / 256);
+    if (D->dtype == USPMV_F64)
+        hipLaunchKernelGGL(pad_guard_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)d_x, D->pad_col, (const double *)D->d_stale, D->d_pad, D->d_late + D->n_bnd_real,
+                           (long)D->n_pad, D->d_scratch + 2);
+    else
+        hipLaunchKernelGGL(pad_guard_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)d_x, D->pad_col, (const float *)D->d_stale, D->d_pad, D->d_late + D->n_bnd_real,
+                           (long)D->n_pad, D->d_scratch + 2);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
 int exchange_rccl(uspmv_dist *D, void *d_x, hipStream_t st) {
     const size_t vsz = vsize(D);
-    if (!D->no_pack)
-        if (int rc = uspmv_pack_send_buf(d_x, D->d_perm, D->d_send_idxs, D->n_send, 0, D->d_send, D->dtype, st)) return rc;
+    if (int rc = pack(D, d_x, st)) return rc;
     if (D->diag_skip_exchange) return USPMV_OK;
     NCCL_TRY(ncclGroupStart());
     for (int p = 0; p < D->P; ++p) {
@@ -164,8 +225,7 @@ int exchange_rccl(uspmv_dist *D, void *d_x, hipStream_t st) {
 // pack (and returns with the upload queued on `st`), so the caller may queue independent device work on another stream first.
 int exchange_host(uspmv_dist *D, void *d_x, hipStream_t st) {
     const size_t vsz = vsize(D);
-    if (!D->no_pack)
-        if (int rc = uspmv_pack_send_buf(d_x, D->d_perm, D->d_send_idxs, D->n_send, 0, D->d_send, D->dtype, st)) return rc;
+    if (int rc = pack(D, d_x, st)) return rc;
     if (D->n_send) HIP_TRY(hipMemcpyAsync(D->h_send, D->d_send, (size_t)D->n_send * vsz, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     std::vector<int64_t> so((size_t)D->P + 1), ro((size_t)D->P + 1);
@@ -208,13 +268,16 @@ int step(uspmv_dist *D, void *d_x, void *d_y, hipStream_t main, bool comm_halos)
         if (int rc = uspmv_spmv(D->A, d_x, d_y, main)) return rc;
         return step_barrier(D, main);
     }
+    const bool pads = pads_on(D);                                    // padding tiles run with the interior ones (see uspmv_dist::pad_col)
     HIP_TRY(hipEventRecord(D->ev_main, main));                       // fork: everything queued on `main` so far precedes the interior tiles
     HIP_TRY(hipStreamWaitEvent(D->side_stream, D->ev_main, 0));
-    if (int rc = part(D, D->d_int, D->n_int, d_x, d_y, D->side_stream)) return rc;
+    if (int rc = pads ? part(D, D->d_early, D->n_int + D->n_pad, d_x, d_y, D->side_stream) : part(D, D->d_int, D->n_int, d_x, d_y, D->side_stream)) return rc;
     HIP_TRY(hipEventRecord(D->ev_comm, D->side_stream));
     if (int rc = exchange(D, d_x, main)) return rc;                  // pack kernel + grouped send / recv into the tail of x (host mode: blocks the host)
+    if (pads) if (int rc = pad_guard(D, d_x, main)) return rc;
     HIP_TRY(hipStreamWaitEvent(main, D->ev_comm, 0));                // join
-    if (int rc = part(D, D->d_bnd, D->n_bnd, d_x, d_y, main)) return rc;
+    // (pads: the conditional entries are switched off by the guard unless x[pad_col] changed sign or is not finite)
+    if (int rc = pads ? part(D, D->d_late, D->n_bnd_real + D->n_pad, d_x, d_y, main) : part(D, D->d_bnd, D->n_bnd, d_x, d_y, main)) return rc;
     return step_barrier(D, main);
 }
 
@@ -277,6 +340,7 @@ void uspmv_dist_free(uspmv_dist_t *D) {
         for (int32_t *u : bp.d_unpack) (void)hipFree(u);
     }
     (void)hipFree(D->d_send_idxs); (void)hipFree(D->d_perm); (void)hipFree(D->d_int); (void)hipFree(D->d_bnd); (void)hipFree(D->d_send); (void)hipFree(D->d_scratch);
+    (void)hipFree(D->d_src); (void)hipFree(D->d_early); (void)hipFree(D->d_late); (void)hipFree(D->d_pad); (void)hipFree(D->d_stale);
     if (D->h_send) (void)hipHostFree(D->h_send);
     if (D->h_recv) (void)hipHostFree(D->h_recv);
     if (D->ev_main) (void)hipEventDestroy(D->ev_main);
@@ -351,6 +415,14 @@ int uspmv_dist_create_ex(const void *comm_id, int comm_rank, int comm_size, int 
     if (D->n_send) D_HIP(hipMemcpy(D->d_send_idxs, D->h_send_idxs.data(), 4 * (size_t)D->n_send, hipMemcpyHostToDevice));
     D_HIP(hipMalloc((void **)&D->d_perm, 4 * (size_t)std::max<int64_t>(D->n_local, 1)));
     if (D->n_local) D_HIP(hipMemcpy(D->d_perm, old_to_new_idx, 4 * (size_t)D->n_local, hipMemcpyHostToDevice));
+    {
+        std::vector<int32_t> src((size_t)D->n_send);
+        for (int64_t i = 0; i < D->n_send; ++i) src[(size_t)i] = old_to_new_idx[D->h_send_idxs[(size_t)i]];     // (ids validated in [0, n_local) by the plan)
+        D_HIP(hipMalloc((void **)&D->d_src, 4 * (size_t)std::max<int64_t>(D->n_send, 1)));
+        if (D->n_send) D_HIP(hipMemcpy(D->d_src, src.data(), 4 * (size_t)D->n_send, hipMemcpyHostToDevice));
+        D_HIP(hipMalloc(&D->d_stale, 16));
+        D_HIP(hipMemset(D->d_stale, 0, 16));
+    }
     D_HIP(hipMalloc((void **)&D->d_int, 4 * (size_t)std::max<int64_t>(n_interior, 1)));
     D_HIP(hipMalloc((void **)&D->d_bnd, 4 * (size_t)std::max<int64_t>(n_boundary, 1)));
     if (n_interior) D_HIP(hipMemcpy(D->d_int, interior_ids, 4 * (size_t)n_interior, hipMemcpyHostToDevice));
@@ -415,13 +487,21 @@ int uspmv_dist_create_from_coo_ex(const void *comm_id, int comm_rank, int comm_s
     int64_t n_int = 0, n_bnd = 0;
     if (!rc) rc = uspmv_scs_split_chunks(scs, n_local, &interior, &n_int, &boundary, &n_bnd);
     if (rc) { cleanup(); return rc; }
-    std::vector<int32_t> ids_int, ids_bnd;
+    std::vector<int32_t> ids_int, ids_bnd, ids_pad, ids_real;
+    int32_t pad_col = -1;
     const bool use_tiles = tile_rows > 0 && n_staged > 0 && !A->alt;
     if (use_tiles) {   // interior / boundary at tile granularity (a tile = tile_rows/C chunks)
+        // three classes per tile: no halo column at all / halo only through the +0.0 padding on one column / real halo references
+        std::vector<uint8_t> cls;
+        rc = uspmv_scs_classify_chunks(scs, n_local, &cls, &pad_col);
+        if (rc) { cleanup(); return rc; }
         const int64_t cpt = tile_rows / C;
-        std::vector<char> is_b((size_t)n_tiles, 0);
-        for (int64_t k = 0; k < n_bnd; ++k) is_b[(size_t)(boundary[k] / cpt)] = 1;
-        for (int64_t t = 0; t < n_tiles; ++t) (is_b[(size_t)t] ? ids_bnd : ids_int).push_back((int32_t)t);
+        std::vector<uint8_t> tc((size_t)n_tiles, 0);
+        for (int64_t c = 0; c < (int64_t)cls.size(); ++c) tc[(size_t)(c / cpt)] = std::max(tc[(size_t)(c / cpt)], cls[(size_t)c]);
+        for (int64_t t = 0; t < n_tiles; ++t) {
+            if (tc[(size_t)t] == 0) ids_int.push_back((int32_t)t);
+            else { ids_bnd.push_back((int32_t)t); (tc[(size_t)t] == 1 ? ids_pad : ids_real).push_back((int32_t)t); }
+        }
     } else {
         ids_int.assign(interior, interior + n_int);
         ids_bnd.assign(boundary, boundary + n_bnd);
@@ -431,6 +511,22 @@ int uspmv_dist_create_from_coo_ex(const void *comm_id, int comm_rank, int comm_s
     rc = uspmv_dist_create_ex(comm_id, comm_rank, comm_size, rank, P, A, halo, o2n, ids_int.data(), (int64_t)ids_int.size(), ids_bnd.data(),
                               (int64_t)ids_bnd.size(), use_tiles ? 1 : 0, opt, &D);
     if (rc) { cleanup(); return rc; }
+    if (use_tiles && pad_col >= 0 && !ids_pad.empty()) {
+        std::vector<int32_t> early(ids_int.size() + ids_pad.size()), late(ids_real.size() + ids_pad.size(), -1);
+        std::merge(ids_int.begin(), ids_int.end(), ids_pad.begin(), ids_pad.end(), early.begin());
+        std::copy(ids_real.begin(), ids_real.end(), late.begin());
+        hipError_t e = hipMalloc((void **)&D->d_pad, 4 * ids_pad.size());
+        if (e == hipSuccess) e = hipMalloc((void **)&D->d_early, 4 * early.size());
+        if (e == hipSuccess) e = hipMalloc((void **)&D->d_late, 4 * late.size());
+        if (e == hipSuccess) e = hipMemcpy(D->d_pad, ids_pad.data(), 4 * ids_pad.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(D->d_early, early.data(), 4 * early.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(D->d_late, late.data(), 4 * late.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            uspmv_dist_free(D); cleanup();
+            return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dist_create_from_coo: %s", hipGetErrorString(e));
+        }
+        D->n_pad = (int64_t)ids_pad.size(); D->n_bnd_real = (int64_t)ids_real.size(); D->pad_col = pad_col;
+    }
     D->owns_setup = true; D->scs = scs; D->halo = halo;
     *out = D;
     return USPMV_OK;
@@ -452,6 +548,7 @@ int uspmv_dist_set_option(uspmv_dist_t *D, const char *key, int value) {
     if (k == "overlap") { if ((value != 0) != D->overlap) drop_graph(D); D->overlap = value != 0; }
     else if (k == "no_pack") { if ((value != 0) != D->no_pack) drop_graph(D); D->no_pack = value != 0; }
     else if (k == "ba_synch") { if ((value != 0) != D->ba_synch) drop_graph(D); D->ba_synch = value != 0; }
+    else if (k == "pad_split") { if ((value != 0) != D->pad_split) drop_graph(D); D->pad_split = value != 0; }
     else if (k == "diag_spmmv_part") {
         if (value < 0 || value > 2) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_option: diag_spmmv_part is 0 (both), 1 (interior only) or 2 (boundary only)");
         D->diag_spmmv_part = value;
@@ -478,6 +575,14 @@ int uspmv_dist_set_option(uspmv_dist_t *D, const char *key, int value) {
     }
     else if (k == "diag_skip_exchange") { drop_graph(D); D->diag_skip_exchange = value != 0; }
     else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_option: unknown key '%s'", key);
+    return USPMV_OK;
+}
+
+int uspmv_dist_pad_info(const uspmv_dist_t *D, int64_t meta[4]) {
+    if (!D || !meta) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_pad_info: NULL argument");
+    int reruns = 0;
+    if (D->d_scratch) HIP_TRY(hipMemcpy(&reruns, D->d_scratch + 2, 4, hipMemcpyDeviceToHost));
+    meta[0] = D->n_pad; meta[1] = D->n_pad ? D->n_bnd_real : D->n_bnd; meta[2] = D->pad_col; meta[3] = reruns;
     return USPMV_OK;
 }
 

@@ -217,3 +217,39 @@ int uspmv_scs_split_chunks(const uspmv_scs_t *s, int64_t n_local, int32_t **inte
 void uspmv_free(void *p) { free(p); }
 
 }  // extern "C"
+
+// Per chunk: 0 = no halo column; 1 = halo columns only through entries that are +0.0 on ONE column (*pad_col) -- the padding the
+// reference fills chunks with (value 0, column 0: code/utilities.hpp:1991-2002), which is a halo column on every rank but the first
+// (code/mpi_funcs.hpp:279-306); 2 = some other halo reference.  *pad_col = -1 when no chunk is of class 1.
+int uspmv_scs_classify_chunks(const uspmv_scs_t *s, int64_t n_local, std::vector<uint8_t> *cls, int32_t *pad_col) {
+    if (!s || !cls || !pad_col) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_scs_classify_chunks: NULL argument");
+    if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_scs_classify_chunks: layout-only struct");
+    const int64_t nc = s->n_chunks, C = s->C;
+    const int32_t *ci = s->col_idxs.data();
+    const bool dp = s->dtype == USPMV_F64;
+    auto pos_zero = [&](int64_t k) -> bool {
+        if (dp) { uint64_t b; memcpy(&b, &s->values_f64[(size_t)k], 8); return b == 0; }
+        uint32_t b; memcpy(&b, &s->values_f32[(size_t)k], 4); return b == 0;
+    };
+    // the padding column: the lowest halo column that carries a +0.0 entry
+    int32_t h0 = INT32_MAX;
+#pragma omp parallel for schedule(static) reduction(min : h0)
+    for (int64_t c = 0; c < nc; ++c) {
+        const int64_t b = s->chunk_ptrs[(size_t)c], e = b + (int64_t)s->chunk_lengths[(size_t)c] * C;
+        for (int64_t k = b; k < e; ++k)
+            if (ci[k] >= n_local && ci[k] < h0 && pos_zero(k)) h0 = ci[k];
+    }
+    cls->assign((size_t)nc, 0);
+    int64_t n_pad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n_pad)
+    for (int64_t c = 0; c < nc; ++c) {
+        const int64_t b = s->chunk_ptrs[(size_t)c], e = b + (int64_t)s->chunk_lengths[(size_t)c] * C;
+        uint8_t f = 0;
+        for (int64_t k = b; k < e && f < 2; ++k)
+            if (ci[k] >= n_local) f = (ci[k] == h0 && pos_zero(k)) ? std::max<uint8_t>(f, 1) : 2;
+        (*cls)[(size_t)c] = f;
+        n_pad += f == 1;
+    }
+    *pad_col = n_pad ? h0 : -1;
+    return USPMV_OK;
+}

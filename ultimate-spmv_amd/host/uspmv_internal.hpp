@@ -95,6 +95,8 @@ struct uspmv_phased_plan {
 int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_phased_plan *plan, int line_shift = 0);   // host/tlc_plan.cpp
 
 int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *out);   // host/tlc_plan.cpp
+// per chunk 0 = no halo column, 1 = halo only through +0.0 padding entries on the one column *pad_col, 2 = other halo references (host/halo_plan.cpp)
+int uspmv_scs_classify_chunks(const uspmv_scs *s, int64_t n_local, std::vector<uint8_t> *cls, int32_t *pad_col);
 // private copy of the entries with the rows of equal-length chunks of a sigma window back in original order;
 // returns 1 when anything moved, 0 when the copy is identical (row_map = identity)
 int uspmv_scs_reorder_ties(const uspmv_scs *s, uspmv_scs *r, std::vector<int32_t> *row_map);   // host/tlc_plan.cpp
