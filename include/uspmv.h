@@ -437,7 +437,10 @@ int uspmv_dist_comm_plan(const uspmv_dist_t *d, int64_t *n_send, const int64_t *
  * MPI_Barrier the reference issues per iteration by default, code/main.cpp:467, :417; part of the captured graph),
  * "capture_mode" 0 global | 1 thread-local | 2 relaxed (hipStreamCaptureMode of uspmv_dist_run's capture),
  * "diag_skip_exchange" 0|1 (diagnosis only: the step skips the RCCL group, results are wrong),
- * "pad_split" 1|0 (padding tiles run with the interior ones, see uspmv_dist_pad_info; 0: with the boundary tiles as in round 2),
+ * "fused_step" 0|1 (default 0; tile lists: the step's tiles in ONE launch -- interior and padding tiles first, the boundary tiles at the end of
+ *   the grid, each of which looks once whether the exchange has completed and otherwise defers itself to a small second launch behind
+ *   the exchange; nothing spins.  0: interior launch, exchange, boundary launch),
+ * "pad_split" 0|1 (default 0; 1: padding tiles run with the interior ones, see uspmv_dist_pad_info; 0: with the boundary tiles),
  * "diag_spmmv_part" 0|1|2 (diagnosis only: the two-part block-vector step runs both parts, its interior part, its boundary part),
  * "block_plan" b (block vectors: build the phased block plan for b columns on the rank's matrix, 0 drops it; see uspmv_dist_spmmv). */
 int uspmv_dist_set_option(uspmv_dist_t *d, const char *key, int value);
@@ -477,7 +480,7 @@ int uspmv_dist_run(uspmv_dist_t *d, void *d_x, void *d_y, int n_steps, int use_g
  * interior / boundary classes of its tiles; uspmv_dist_set_option(d, "overlap", 0) restores exchange-then-compute. */
 typedef enum { USPMV_BULKVEC = 0, USPMV_MULTIVEC = 1, USPMV_SINGLEVEC = 2 } uspmv_vecmode;
 int uspmv_dist_spmmv(uspmv_dist_t *d, void *d_X, void *d_Y, int b, int layout, int mode, int comm_halos, void *stream);
-/* Padding tiles of the single-vector step (tile lists, "pad_split" 1 = default).  The reference pads chunks with (value +0, column 0);
+/* Padding tiles of the single-vector step (tile lists, "pad_split" 1; an option, off by default -- see DESIGN 6.4 for the A/B).  The reference pads chunks with (value +0, column 0);
  * on every rank but the first, column 0 is a halo column (code/mpi_funcs.hpp:279-306), so most tiles of a rank touch the halo only
  * through fma(+0, x[pad_col], acc).  They run with the interior tiles, before the exchange has delivered x[pad_col]: for finite
  * operands of one sign the product is the same signed zero and y comes out bit for bit as with the delivered value; a guard kernel

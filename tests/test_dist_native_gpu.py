@@ -120,8 +120,14 @@ def test_padding_tiles_run_with_the_interior_and_rerun_when_they_must(pkg, orc):
         loc = pkg.gen_stencil27(*shape, row_begin=int(wsa[rank]), row_end=int(wsa[rank + 1]))
         d = pkg.DistNative(loc, wsa, C, sigma, rank, P, pkg.comm_unique_id(), comm_rank=0, comm_size=1)
         info = d.pad_info()
+        d.set_option("pad_split", 1)                                         # (an option: off by default)
         if rank == 0:
             assert info["pad_tiles"] == 0 and info["pad_col"] == -1          # column 0 is local there
+            for fused in (0, 1):                                             # the one-launch step without padding tiles
+                d.set_option("fused_step", fused)
+                x = d.new_x(cases["neg"][0]); y = d.new_y()
+                d.spmv(x, y); d.spmv(x, y); d.synchronize()
+                assert np.array_equal(d.y_to_original_order(y), cases["neg"][1][wsa[0]:wsa[1]])
             d.close(); continue
         assert info["pad_tiles"] > 0 and info["pad_col"] >= d.n_local and info["real_boundary_tiles"] > 0, info
         assert info["pad_tiles"] + info["real_boundary_tiles"] == d.n_boundary
@@ -137,21 +143,21 @@ def test_padding_tiles_run_with_the_interior_and_rerun_when_they_must(pkg, orc):
             assert np.array_equal(got, want[tag], equal_nan=True), (tag, graph, steps)
             return d.pad_info()["reruns"]
 
-        r0 = d.pad_info()["reruns"]
-        assert run("pos") == r0                               # slot held +0 (fresh x): same sign, no re-run
-        r1 = run("neg")                                       # fresh x again: +0 -> -2.5
-        assert r1 == r0 + 1
-        x = d.new_x(cases["neg"][0]); y = d.new_y()
-        d.spmv(x, y); d.spmv(x, y); d.synchronize()           # second step on the SAME x: the slot already holds -2.5
-        assert np.array_equal(d.y_to_original_order(y), want["neg"]) and d.pad_info()["reruns"] == r1 + 1
-        r2 = d.pad_info()["reruns"]
-        assert run("inf", steps=2) == r2 + 2                  # not finite: every step
-        r3 = run("neg", graph=True, steps=3)                  # the captured step carries guard and conditional list too
-        assert r3 == r2 + 2 + 1
-        d.set_option("pad_split", 0)
-        assert run("neg") == r3 and run("inf") == r3 and run("pos") == r3
-        d.set_option("pad_split", 1)
-        assert run("pos") == r3
+        for fused in (0, 1):                                  # two launches around the exchange / one launch + deferred entries
+            d.set_option("pad_split", 1); d.set_option("fused_step", fused)
+            r0 = d.pad_info()["reruns"]
+            assert run("pos") == r0                           # a fresh x: the slot held +0, same sign, no re-run
+            r1 = run("neg")                                   # fresh x again: +0 -> -2.5
+            assert r1 == r0 + 1, (fused, r0, r1)
+            x = d.new_x(cases["neg"][0]); y = d.new_y()
+            d.spmv(x, y); d.spmv(x, y); d.synchronize()       # second step on the SAME x: the slot already holds -2.5
+            assert np.array_equal(d.y_to_original_order(y), want["neg"]) and d.pad_info()["reruns"] == r1 + 1
+            r2 = d.pad_info()["reruns"]
+            assert run("inf", steps=2) == r2 + 2              # not finite: every step
+            r3 = run("neg", graph=True, steps=3)              # the captured step (always the two-launch form) carries guard and conditional list too
+            assert r3 == r2 + 2 + 1
+            d.set_option("pad_split", 0)
+            assert run("neg") == r3 and run("inf") == r3 and run("pos") == r3
         d.close()
 
 

@@ -189,13 +189,23 @@ __global__ void scs_spmv_rows_pipe(const long n_work_chunks, const int C_rt, con
 // but the column stream is the 2-byte LDS-local index array (four slots per 8-byte load) and the x
 // operand comes from LDS (ds_read) instead of a 64-lane global gather.  Same slot-ordered FMA chain
 // per row -> bit-exact.  Tiles without a line list (footprint too wide) take the global-gather path.
-template <typename VT, int CT, bool NT, bool IDS>
+template <typename T>
+__device__ __forceinline__ T ld_now(const T *p) { return *(const volatile T *)p; }   // a load the compiler may neither cache nor hoist
+// system-scope (sc0 sc1) load: served from memory, not from an L1 / L2 line that another kernel or GPU has made stale meanwhile
+__device__ __forceinline__ double ld_sys(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__device__ __forceinline__ float ld_sys(const float *p) {
+    return __uint_as_float(__hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+
+template <typename VT, int CT, bool NT, bool IDS, int SYNC = 0>
 __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const int C_rt, const int *__restrict__ chunk_ptrs,
         const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const VT *__restrict__ values,
-        const VT *__restrict__ x, VT *__restrict__ y, const int *__restrict__ tile_line_ptr,
+        const VT *__restrict__ x_arg, VT *__restrict__ y, const int *__restrict__ tile_line_ptr,
         const int *__restrict__ tile_lines, const unsigned *__restrict__ c16_ptrs,
         const unsigned short *__restrict__ col16, const long x_len, const int *__restrict__ tile_ids,
-        const int xcd_remap, const long n_store) {
+        const int xcd_remap, const long n_store, const StepArgs sa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tlc_smem[];
     VT *xs = (VT *)tlc_smem;
     constexpr int EPL = 16 / (int)sizeof(VT);   // elements per 16-byte load
@@ -203,8 +213,46 @@ __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const 
     typedef VT vec_t __attribute__((ext_vector_type(EPL)));
     const int C = CT > 0 ? CT : C_rt;
     const unsigned lbt = remap_block(blockIdx.x, gridDim.x, xcd_remap);
-    const unsigned tile = IDS ? (unsigned)tile_ids[lbt] : lbt;
-    if (IDS && (int)tile < 0) return;          // (an entry of a conditional tile list that was switched off: uspmv_dist's padding re-run)
+    const VT *x = x_arg;
+    bool coh = false;                              // (SYNC 1: a late entry that runs inside the launch; wave-uniform)
+    unsigned tile;
+    if constexpr (SYNC == 0) {
+        tile = IDS ? (unsigned)tile_ids[lbt] : lbt;
+        if (IDS && (int)tile < 0) return;          // (an entry of a conditional tile list that was switched off: uspmv_dist's padding re-run)
+    } else {
+        // one-launch distributed step (StepSync in uspmv_device.hpp)
+        __shared__ int s_go;
+        long pos = lbt;
+        if constexpr (SYNC == 2) {                 // the launch behind the exchange: entry lbt of this step's deferred list
+            const int e = ld_now(&sa.ss->flag);
+            if (lbt == 0 && threadIdx.x == 0) { sa.ss->count[(e + 1) & 1] = 0; sa.ss->expect = e + 1; }   // (nobody reads these before this launch ends)
+            if ((long)lbt >= (long)ld_now(&sa.ss->count[e & 1])) return;
+            pos = sa.defer[(long)(e & 1) * sa.defer_cap + lbt];
+        } else if (pos >= sa.late0 && pos < sa.late0 + sa.n_real + sa.n_cond) {
+            if (threadIdx.x == 0) {
+                const int e = ld_now(&sa.ss->expect);
+                // (relaxed: an acquire load would invalidate the caches like the fence below; the x loads that depend on it are issued
+                //  after the barrier and go to memory themselves)
+                const int go = __hip_atomic_load(&sa.ss->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= e;
+                if (!go) sa.defer[(long)(e & 1) * sa.defer_cap + atomicAdd(&sa.ss->count[e & 1], 1)] = (int)pos;
+                s_go = go;
+            }
+            __syncthreads();
+            if (!s_go) return;
+            // the tail of x was written by another kernel (RCCL, possibly a peer GPU) while this one was running: this workgroup reads x
+            // with system-scope loads, which are served from memory instead of a stale L1 / L2 line.  (An acquire FENCE here would be
+            // correct too, but every such fence invalidates the XCD's L2 under the 12 000 other workgroups of the launch: 425 instead
+            // of 178 us for the step's kernel, profiles/r03/dist_step_fused.txt.)
+            coh = true;
+        }
+        if (pos >= sa.late0 + sa.n_real && pos < sa.late0 + sa.n_real + sa.n_cond) {
+            // a padding tile again -- only when the delivered x[pad_col] differs in sign / finiteness from what the slot held
+            const VT s = ld_now((const VT *)sa.stale), c = ld_now(x + sa.pad_col);
+            if (isfinite(s) && isfinite(c) && (signbit(s) == signbit(c))) return;
+            if (pos == sa.late0 + sa.n_real && threadIdx.x == 0) atomicAdd(&sa.ss->reruns, 1);
+        }
+        tile = (unsigned)tile_ids[pos];
+    }
     const int lp0 = tile_line_ptr[tile];
     const int nl = tile_line_ptr[tile + 1] - lp0;
     const long row = (long)tile * blockDim.x + threadIdx.x;
@@ -220,7 +268,10 @@ __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const 
         for (int k = lk; k < nl; k += blockDim.x / LPL) {
             const long idx = (long)tile_lines[lp0 + k] * 16 + sub * EPL;
             vec_t v;
-            if (idx + EPL <= x_len) {
+            if (SYNC == 1 && coh) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) v[e] = idx + e < x_len ? ld_sys(x + idx + e) : VT(0);
+            } else if (idx + EPL <= x_len) {
                 v = *(const vec_t *)(x + idx);
             } else {
 #pragma unroll
@@ -267,11 +318,14 @@ __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const 
 #pragma unroll
             for (int u = 0; u < 8; ++u) { v[u] = ld_stream<NT>(vp + (long)(j + u) * C); ci[u] = ld_stream<NT>(cp + (long)(j + u) * C); }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = x[ci[u]];
+            for (int u = 0; u < 8; ++u) xv[u] = (SYNC == 1 && coh) ? ld_sys(x + ci[u]) : x[ci[u]];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = fma_t(v[u], xv[u], acc);
         }
-        for (; j < L; ++j) acc = fma_t(ld_stream<NT>(vp + (long)j * C), x[ld_stream<NT>(cp + (long)j * C)], acc);
+        for (; j < L; ++j) {
+            const int cj = ld_stream<NT>(cp + (long)j * C);
+            acc = fma_t(ld_stream<NT>(vp + (long)j * C), (SYNC == 1 && coh) ? ld_sys(x + cj) : x[cj], acc);
+        }
     }
     if (valid && row < n_store) st_y<NT>(y + row, acc);
 }
@@ -406,13 +460,34 @@ int launch_spmv_tlc(const uspmv_dmat *A, const int *tile_ids, long n_tiles, cons
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(A->tlc_tile_rows), lds, st, (long)A->n_chunks, C, A->chunk_ptrs,        \
                            A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, A->tlc_line_ptr, A->tlc_lines,   \
-                           A->tlc_c16_ptrs, A->tlc_col16, (long)A->tlc_x_len, tile_ids, g_tune.xcd_remap, A->n_store);              \
+                           A->tlc_c16_ptrs, A->tlc_col16, (long)A->tlc_x_len, tile_ids, g_tune.xcd_remap, A->n_store, StepArgs{});  \
     } while (0)
 #define TLC_LAUNCH_C(NTV, IDSV) do { if (C == 32) TLC_LAUNCH(32, NTV, IDSV); else TLC_LAUNCH(0, NTV, IDSV); } while (0)
     if (tile_ids) { if (g_tune.nontemporal) TLC_LAUNCH_C(true, true); else TLC_LAUNCH_C(false, true); }
     else { if (g_tune.nontemporal) TLC_LAUNCH_C(true, false); else TLC_LAUNCH_C(false, false); }
 #undef TLC_LAUNCH_C
 #undef TLC_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+template <typename VT>
+int launch_spmv_tlc_step(const uspmv_dmat *A, const int *step_ids, const StepArgs &sa, int sync, const VT *x, VT *y, hipStream_t st) {
+    const long n = sync == 1 ? sa.n_early + sa.n_real + sa.n_cond : sa.n_real + sa.n_cond;
+    if (n == 0) return USPMV_OK;
+    const int C = (int)A->C;
+    const size_t lds = (size_t)A->tlc_max_lines * 16 * sizeof(VT);
+#define TLC_STEP(CTV, SY)                                                                                             \
+    do {                                                                                                              \
+        auto kfn = scs_spmv_tlc<VT, CTV, true, true, SY>;                                                             \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)n), dim3(A->tlc_tile_rows), lds, st, (long)A->n_chunks, C, A->chunk_ptrs,  \
+                           A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, A->tlc_line_ptr, A->tlc_lines,   \
+                           A->tlc_c16_ptrs, A->tlc_col16, (long)A->tlc_x_len, step_ids, g_tune.xcd_remap, A->n_store, sa); \
+    } while (0)
+    if (sync == 1) { if (C == 32) TLC_STEP(32, 1); else TLC_STEP(0, 1); }
+    else { if (C == 32) TLC_STEP(32, 2); else TLC_STEP(0, 2); }
+#undef TLC_STEP
     HIP_TRY(hipGetLastError());
     return USPMV_OK;
 }
@@ -503,6 +578,8 @@ template int launch_spmv_scs<double>(const uspmv_dmat *, const int *, long, cons
 template int launch_spmv_scs<float>(const uspmv_dmat *, const int *, long, const float *, float *, hipStream_t);
 template int launch_spmv_tlc<double>(const uspmv_dmat *, const int *, long, const double *, double *, hipStream_t);
 template int launch_spmv_tlc<float>(const uspmv_dmat *, const int *, long, const float *, float *, hipStream_t);
+template int launch_spmv_tlc_step<double>(const uspmv_dmat *, const int *, const StepArgs &, int, const double *, double *, hipStream_t);
+template int launch_spmv_tlc_step<float>(const uspmv_dmat *, const int *, const StepArgs &, int, const float *, float *, hipStream_t);
 template int launch_csr<double>(long, long, const int *, const int *, const double *, const double *, double *, hipStream_t);
 template int launch_csr<float>(long, long, const int *, const int *, const float *, const float *, float *, hipStream_t);
 

@@ -97,6 +97,27 @@ struct uspmv_dmat {
 
 namespace uspmv_dev {
 
+// One-launch distributed step (csrc/uspmv_dist_api.hip): the tile list of a step is [early | late | conditional | early].  Early entries
+// (interior + padding tiles) run at once.  A late entry (a tile with real halo references) looks ONCE at the exchange counter: if the
+// exchange of this step has completed it proceeds (acquire), otherwise it appends its position to the step's deferred list and
+// leaves -- nothing ever spins, so no schedule can deadlock.  A second, small launch after the exchange runs the deferred entries.
+// Conditional entries are the padding tiles again; they only run when x[pad_col] changed sign or is not finite (uspmv_dist::pad_col).
+struct StepSync {          // device memory, 32 bytes
+    int flag;              // exchanges completed so far (incremented by a one-thread kernel behind the RCCL group)
+    int expect;            // value `flag` must have reached for the current step's late entries
+    int count[2];          // deferred entries of the current / next step (indexed by expect & 1)
+    int reruns;            // steps whose conditional entries ran
+    int spare[3];
+};
+struct StepArgs {
+    long n_early = 0, n_real = 0, n_cond = 0, defer_cap = 0;
+    long late0 = 0;                // the late + conditional entries sit at [late0, late0 + n_real + n_cond) of the list, early entries around them
+    StepSync *ss = nullptr;
+    int *defer = nullptr;          // [2][defer_cap] positions in the step list
+    const void *stale = nullptr;   // value of x[pad_col] before the exchange
+    int pad_col = -1;
+};
+
 constexpr int USPMV_SKIP_LEN = -4;     // (a multiple of four: no kernel sees a partial group or a tail in it)
 
 // the chunk lengths a launcher hands to its kernel: the handle's own, or the selected part's (order 0 caller's rows, 1 phased plan rows)
@@ -175,6 +196,9 @@ template <typename VT>
 int launch_spmv_scs(const uspmv_dmat *A, const int *chunk_ids, long n_ids, const VT *x, VT *y, hipStream_t st);   // spmv_kernels.hip
 template <typename VT>
 int launch_spmv_tlc(const uspmv_dmat *A, const int *tile_ids, long n_tiles, const VT *x, VT *y, hipStream_t st);  // spmv_kernels.hip
+// the one-launch distributed step over `step_ids` = [early | late | conditional] (sync 1) and its deferred entries (sync 2)
+template <typename VT>
+int launch_spmv_tlc_step(const uspmv_dmat *A, const int *step_ids, const StepArgs &sa, int sync, const VT *x, VT *y, hipStream_t st);
 template <typename VT>
 int launch_csr(long n_rows, long nnz_hint, const int *rp, const int *ci, const VT *va, const VT *x, VT *y, hipStream_t st);  // spmv_kernels.hip
 template <typename VT>

@@ -57,9 +57,16 @@ struct uspmv_dist {
     // d_early = interior and padding tiles in ascending order (ONE launch before the exchange completes); d_late = the boundary tiles
     // with real halo references followed by n_pad conditional entries (ONE launch after it): the guard writes ids or -1 there
     int32_t *d_early = nullptr, *d_late = nullptr, *d_pad = nullptr;
+    // ONE-launch step ("fused_step" 1, the default with tile lists): d_step = [early | real boundary | padding again (conditional)] in one
+    // launch on the side stream; late entries that find the exchange unfinished defer themselves to a second, small launch behind it
+    // (uspmv_dev::StepSync -- nothing spins).  Saves the second launch's ramp-up and the join in the common case.
+    int32_t *d_step = nullptr, *d_defer = nullptr;
+    uspmv_dev::StepSync *d_ss = nullptr;
+    uspmv_dev::StepArgs sa;
+    bool fused = false, sync_dirty = false, capturing = false;   // (off by default: 0.222 against 0.209 ms, same file)
     int64_t n_bnd_real = 0, n_pad = 0;
     int32_t pad_col = -1;
-    bool pad_split = true;
+    bool pad_split = false;           // (off by default: on one GPU it measures 0.221 against 0.209 ms per step, profiles/r03/dist_step_ab.txt)
     void *d_stale = nullptr;
     void *d_send = nullptr;
     void *h_send = nullptr, *h_recv = nullptr;   // pinned staging of USPMV_EXCHANGE_HOST
@@ -180,6 +187,20 @@ __global__ void pad_guard_kernel(const VT *__restrict__ x, const int pad_col, co
     if (k == 0 && need) atomicAdd(counter, 1);
 }
 
+__global__ void exchange_done_kernel(uspmv_dev::StepSync *ss) { __hip_atomic_store(&ss->flag, ss->flag + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+int sync_reset(uspmv_dist *D) {
+    if (!D->d_ss) return USPMV_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    uspmv_dev::StepSync z{};
+    z.expect = 1;
+    HIP_TRY(hipMemcpy(D->d_ss, &z, sizeof z, hipMemcpyHostToDevice));
+    D->sync_dirty = false;
+    return USPMV_OK;
+}
+
+inline bool fused_on(const uspmv_dist *D) { return D->fused && D->overlap && D->tiles && D->d_step && D->sa.n_real + D->sa.n_cond > 0; }
+
 inline bool pads_on(const uspmv_dist *D) { return D->pad_split && D->overlap && D->tiles && D->n_pad > 0 && D->pad_col >= 0; }
 
 int pack(uspmv_dist *D, void *d_x, hipStream_t st) {
@@ -256,6 +277,27 @@ int step_barrier(uspmv_dist *D, hipStream_t main) {
     return USPMV_OK;
 }
 
+// The one-launch form of the step below (uspmv_dist::d_step)
+int step_fused(uspmv_dist *D, void *d_x, void *d_y, hipStream_t main) {
+    if (D->sync_dirty) if (int rc = sync_reset(D)) return rc;
+    D->sync_dirty = true;                                            // (cleared when every launch of the step has been issued)
+    HIP_TRY(hipEventRecord(D->ev_main, main));
+    HIP_TRY(hipStreamWaitEvent(D->side_stream, D->ev_main, 0));
+    int rc = D->dtype == USPMV_F64 ? uspmv_dev::launch_spmv_tlc_step<double>(D->A, D->d_step, D->sa, 1, (const double *)d_x, (double *)d_y, D->side_stream)
+                                   : uspmv_dev::launch_spmv_tlc_step<float>(D->A, D->d_step, D->sa, 1, (const float *)d_x, (float *)d_y, D->side_stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(D->ev_comm, D->side_stream));
+    if ((rc = exchange(D, d_x, main))) return rc;                    // (a failure here leaves the counters out of step: sync_dirty stays set)
+    hipLaunchKernelGGL(exchange_done_kernel, dim3(1), dim3(1), 0, main, D->d_ss);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamWaitEvent(main, D->ev_comm, 0));                // join: the deferred list is complete
+    rc = D->dtype == USPMV_F64 ? uspmv_dev::launch_spmv_tlc_step<double>(D->A, D->d_step, D->sa, 2, (const double *)d_x, (double *)d_y, main)
+                               : uspmv_dev::launch_spmv_tlc_step<float>(D->A, D->d_step, D->sa, 2, (const float *)d_x, (float *)d_y, main);
+    if (rc) return rc;
+    D->sync_dirty = false;
+    return step_barrier(D, main);
+}
+
 // One SpMV: the interior tiles on the side stream, the exchange meanwhile on the caller's stream, the boundary tiles after both.
 // The RCCL group stays on the CALLER's stream on purpose: when the step is captured, that is the capture's origin stream.  Under
 // the HIP 7.0 / RCCL 2.26 pair that torch bundles, hipStreamEndCapture crashes if an RCCL p2p group was captured on a stream that
@@ -268,6 +310,8 @@ int step(uspmv_dist *D, void *d_x, void *d_y, hipStream_t main, bool comm_halos)
         if (int rc = uspmv_spmv(D->A, d_x, d_y, main)) return rc;
         return step_barrier(D, main);
     }
+    // (not under capture: replayed from a hipGraph the one-launch form measured 0.54 ms against 0.21 ms, profiles/r03/dist_step_ab.txt)
+    if (fused_on(D) && !D->capturing && (pads_on(D) || D->n_pad == 0)) return step_fused(D, d_x, d_y, main);
     const bool pads = pads_on(D);                                    // padding tiles run with the interior ones (see uspmv_dist::pad_col)
     HIP_TRY(hipEventRecord(D->ev_main, main));                       // fork: everything queued on `main` so far precedes the interior tiles
     HIP_TRY(hipStreamWaitEvent(D->side_stream, D->ev_main, 0));
@@ -294,7 +338,9 @@ int capture(uspmv_dist *D, void *d_x, void *d_y, hipStream_t main) {
     DBG("begin");
     hipError_t e = hipStreamBeginCapture(main, (hipStreamCaptureMode)D->capture_mode);
     if (e != hipSuccess) { (void)hipGetLastError(); return uspmv::fail(USPMV_ERR_HIP, "uspmv_dist_run: hipStreamBeginCapture: %s", hipGetErrorString(e)); }
+    D->capturing = true;
     const int rc = step(D, d_x, d_y, main, true);
+    D->capturing = false;
     DBG("step issued");
     e = hipStreamEndCapture(main, &g);
     DBG("end capture");
@@ -341,6 +387,7 @@ void uspmv_dist_free(uspmv_dist_t *D) {
     }
     (void)hipFree(D->d_send_idxs); (void)hipFree(D->d_perm); (void)hipFree(D->d_int); (void)hipFree(D->d_bnd); (void)hipFree(D->d_send); (void)hipFree(D->d_scratch);
     (void)hipFree(D->d_src); (void)hipFree(D->d_early); (void)hipFree(D->d_late); (void)hipFree(D->d_pad); (void)hipFree(D->d_stale);
+    (void)hipFree(D->d_step); (void)hipFree(D->d_defer); (void)hipFree(D->d_ss);
     if (D->h_send) (void)hipHostFree(D->h_send);
     if (D->h_recv) (void)hipHostFree(D->h_recv);
     if (D->ev_main) (void)hipEventDestroy(D->ev_main);
@@ -511,21 +558,40 @@ int uspmv_dist_create_from_coo_ex(const void *comm_id, int comm_rank, int comm_s
     rc = uspmv_dist_create_ex(comm_id, comm_rank, comm_size, rank, P, A, halo, o2n, ids_int.data(), (int64_t)ids_int.size(), ids_bnd.data(),
                               (int64_t)ids_bnd.size(), use_tiles ? 1 : 0, opt, &D);
     if (rc) { cleanup(); return rc; }
-    if (use_tiles && pad_col >= 0 && !ids_pad.empty()) {
-        std::vector<int32_t> early(ids_int.size() + ids_pad.size()), late(ids_real.size() + ids_pad.size(), -1);
+    if (use_tiles && P > 1) {
+        const bool pads = pad_col >= 0 && !ids_pad.empty();
+        if (!pads) { ids_real = ids_bnd; ids_pad.clear(); }
+        std::vector<int32_t> early(ids_int.size() + ids_pad.size()), late(ids_real.size() + ids_pad.size(), -1), stepl;
         std::merge(ids_int.begin(), ids_int.end(), ids_pad.begin(), ids_pad.end(), early.begin());
         std::copy(ids_real.begin(), ids_real.end(), late.begin());
-        hipError_t e = hipMalloc((void **)&D->d_pad, 4 * ids_pad.size());
-        if (e == hipSuccess) e = hipMalloc((void **)&D->d_early, 4 * early.size());
-        if (e == hipSuccess) e = hipMalloc((void **)&D->d_late, 4 * late.size());
-        if (e == hipSuccess) e = hipMemcpy(D->d_pad, ids_pad.data(), 4 * ids_pad.size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(D->d_early, early.data(), 4 * early.size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(D->d_late, late.data(), 4 * late.size(), hipMemcpyHostToDevice);
+        // the late entries three quarters into the grid: late enough for the exchange to have completed in the common case, early enough
+        // for their slower (system-scope) loads not to be the tail of the launch
+        const size_t late0 = early.size() - early.size() / 4;
+        stepl.assign(early.begin(), early.begin() + (long)late0);
+        stepl.insert(stepl.end(), ids_real.begin(), ids_real.end());
+        stepl.insert(stepl.end(), ids_pad.begin(), ids_pad.end());
+        stepl.insert(stepl.end(), early.begin() + (long)late0, early.end());
+        const size_t n_late = late.size();
+        auto up = [](int32_t **d, const std::vector<int32_t> &h) -> hipError_t {
+            hipError_t e = hipMalloc((void **)d, 4 * std::max<size_t>(h.size(), 1));
+            if (e == hipSuccess && !h.empty()) e = hipMemcpy(*d, h.data(), 4 * h.size(), hipMemcpyHostToDevice);
+            return e;
+        };
+        hipError_t e = up(&D->d_step, stepl);
+        if (e == hipSuccess && pads) e = up(&D->d_pad, ids_pad);
+        if (e == hipSuccess && pads) e = up(&D->d_early, early);
+        if (e == hipSuccess && pads) e = up(&D->d_late, late);
+        if (e == hipSuccess) e = hipMalloc((void **)&D->d_defer, 4 * 2 * std::max<size_t>(n_late, 1));
+        if (e == hipSuccess) e = hipMalloc((void **)&D->d_ss, sizeof(uspmv_dev::StepSync));
         if (e != hipSuccess) {
             uspmv_dist_free(D); cleanup();
             return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dist_create_from_coo: %s", hipGetErrorString(e));
         }
-        D->n_pad = (int64_t)ids_pad.size(); D->n_bnd_real = (int64_t)ids_real.size(); D->pad_col = pad_col;
+        if (pads) { D->n_pad = (int64_t)ids_pad.size(); D->n_bnd_real = (int64_t)ids_real.size(); D->pad_col = pad_col; }
+        D->sa.n_early = (long)early.size(); D->sa.n_real = (long)ids_real.size(); D->sa.n_cond = (long)ids_pad.size(); D->sa.defer_cap = (long)std::max<size_t>(n_late, 1);
+        D->sa.late0 = (long)late0;
+        D->sa.ss = D->d_ss; D->sa.defer = D->d_defer; D->sa.stale = D->d_stale; D->sa.pad_col = pads ? pad_col : -1;
+        if ((rc = sync_reset(D))) { uspmv_dist_free(D); cleanup(); return rc; }
     }
     D->owns_setup = true; D->scs = scs; D->halo = halo;
     *out = D;
@@ -548,6 +614,7 @@ int uspmv_dist_set_option(uspmv_dist_t *D, const char *key, int value) {
     if (k == "overlap") { if ((value != 0) != D->overlap) drop_graph(D); D->overlap = value != 0; }
     else if (k == "no_pack") { if ((value != 0) != D->no_pack) drop_graph(D); D->no_pack = value != 0; }
     else if (k == "ba_synch") { if ((value != 0) != D->ba_synch) drop_graph(D); D->ba_synch = value != 0; }
+    else if (k == "fused_step") { if ((value != 0) != D->fused) drop_graph(D); D->fused = value != 0; }
     else if (k == "pad_split") { if ((value != 0) != D->pad_split) drop_graph(D); D->pad_split = value != 0; }
     else if (k == "diag_spmmv_part") {
         if (value < 0 || value > 2) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_option: diag_spmmv_part is 0 (both), 1 (interior only) or 2 (boundary only)");
@@ -580,8 +647,9 @@ int uspmv_dist_set_option(uspmv_dist_t *D, const char *key, int value) {
 
 int uspmv_dist_pad_info(const uspmv_dist_t *D, int64_t meta[4]) {
     if (!D || !meta) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_pad_info: NULL argument");
-    int reruns = 0;
+    int reruns = 0, r2 = 0;
     if (D->d_scratch) HIP_TRY(hipMemcpy(&reruns, D->d_scratch + 2, 4, hipMemcpyDeviceToHost));
+    if (D->d_ss) { HIP_TRY(hipMemcpy(&r2, &D->d_ss->reruns, 4, hipMemcpyDeviceToHost)); reruns += r2; }
     meta[0] = D->n_pad; meta[1] = D->n_pad ? D->n_bnd_real : D->n_bnd; meta[2] = D->pad_col; meta[3] = reruns;
     return USPMV_OK;
 }

@@ -185,6 +185,7 @@ int uspmv_run_distributed(const DistConfig &c) {
     HK(hipStreamCreate(&st));
     CK(uspmv_dist_barrier(D, st));
     if (c.no_overlap) CK(uspmv_dist_set_option(D, "overlap", 0));
+    if (const char *fs = getenv("USPMV_FUSED_STEP")) CK(uspmv_dist_set_option(D, "fused_step", atoi(fs) != 0));
     if (const char *ps = getenv("USPMV_PAD_SPLIT")) CK(uspmv_dist_set_option(D, "pad_split", atoi(ps) != 0));   // (A/B of the padding tiles, tools/ab_dist_step.sh)
     if (c.no_pack) CK(uspmv_dist_set_option(D, "no_pack", 1));   // -no_pack 1: the exchange sends a stale buffer (code/classes_structs.hpp:941)
     if (c.block_vec_size > 1 && c.tlc) CK(uspmv_dist_set_option(D, "block_plan", c.block_vec_size));   // (64-byte X rows: the phased block plan + its interior / boundary tiles)
