@@ -436,6 +436,7 @@ def cli_result(args, rep, scaling, grid, world):
         "protocol": f"exactly {rep['steps']} steps between barriers after {rep['warmup']} warm-ups, slowest rank's clock; -ba_synch {rep['ba_synch']} "
                     f"(with -ba_synch {1 - rep['ba_synch']}: {rep['other_ba_synch_ms_per_step']:.5f} ms per step; 1 = the reference's default, a barrier behind every step, code/main.cpp:467)",
         "y_checked": rep["y_checked"], "y_mismatches": rep["y_mismatches"],
+        "step_form": rep.get("step_form"), "step_form_candidates_ms": rep.get("step_form_candidates_ms"),
         "rank0": {"n_local": r0["n_local"], "n_halo": r0["n_halo"], "n_send": r0["n_send"], "interior": r0["interior"], "boundary": r0["boundary"],
                   "tiles": r0["tiles"], "plan_kind": 1 if r0["tiles"] else 0, "local_kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(r0["algorithmic_bytes"]),
                   "local_kernel_GBs": round(r0["algorithmic_bytes"] / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None},
@@ -662,7 +663,8 @@ def main():
                 "y_checked": res.get("y_checked"), "y_mismatches": res.get("y_mismatches"),
                 "config": {"workload": res["workload"], "C": args.chunk, "sigma": args.sigma, "n_rows": res["n_rows"], "nnz": res["nnz"], "beta": res["beta"],
                            "x": "5.0 (DefaultValues) in the timed steps; x_global[j] = 1 + 1e-3 (j mod 1000) in the checked step", "partition": args.seg,
-                           "halo_overlap": not args.no_overlap, "step": res["step"], "protocol": res.get("protocol"),
+                           "halo_overlap": (res.get("step_form") or ("plain" if args.no_overlap else "overlap")) != "plain", "step": res["step"], "protocol": res.get("protocol"),
+                           "step_form": res.get("step_form"), "step_form_candidates_ms": res.get("step_form_candidates_ms"),
                            "rank0": r0, "tuning": tuning, "versions": res.get("versions"), "cmd": res.get("cmd")},
                 "roofline": {"bound": "hbm", "achieved": r0["local_kernel_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(r0["local_kernel_GBs"] / HBM_PEAK_GBS, 4) if r0["local_kernel_GBs"] else None, "traffic": None,

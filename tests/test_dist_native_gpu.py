@@ -479,6 +479,34 @@ def test_cli_loopback_graph_replay_with_ba_synch_and_check(pkg, tmp_path):
         assert rep["versions"]["rccl_runtime"] >= rep["versions"]["rccl_build"] > 0
 
 
+def test_cli_step_forms_all_check_and_auto_picks_one(pkg, tmp_path):
+    """-step_form: every arrangement of the step (overlap | plain | pad | fused) passes the bitwise self-check through the harness, and
+    auto times the candidates on this machine, reports them and keeps the fastest (graph replay: without the one-launch form)."""
+    import json
+    import subprocess
+    env = dict(os.environ, USPMV_LOOPBACK="4", USPMV_LOOPBACK_RANK="2", USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID="sf")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    base = [EXE, "gen:32x32x64", "scs", "-c", "32", "-s", "512", "-seg_rows", "-comm_halos", "1", "-bench_steps", "20", "-bench_warmup", "3", "-check_y", "1"]
+    for form, graph in (("overlap", 1), ("plain", 1), ("pad", 1), ("pad", 0), ("fused", 0)):
+        js = tmp_path / f"{form}{graph}.json"
+        r = subprocess.run(base + ["-step_form", form, "-graph", str(graph), "-json", str(js)], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        rep = json.load(open(js))
+        assert rep["step_form"] == form and rep["y_checked"] is True and rep["y_mismatches"] == 0, rep
+        assert rep["overlap"] == (form != "plain") and rep["graph_replay"] == bool(graph)
+        assert f"step form: {form}" in r.stdout
+    for graph, cands in ((1, {"overlap", "plain", "pad"}), (0, {"overlap", "plain", "pad", "fused"})):
+        js = tmp_path / f"auto{graph}.json"
+        r = subprocess.run(base + ["-graph", str(graph), "-json", str(js)], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        rep = json.load(open(js))
+        assert set(rep["step_form_candidates_ms"]) == cands and rep["step_form"] in cands, rep
+        assert rep["step_form_candidates_ms"][rep["step_form"]] == min(rep["step_form_candidates_ms"].values())
+        assert rep["y_checked"] is True and rep["y_mismatches"] == 0
+    r = subprocess.run(base + ["-step_form", "sideways"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "step_form must be" in (r.stdout + r.stderr)
+
+
 def test_cli_seg_metis_real_ranks(pkg, tmp_path):
     """-seg_metis through the harness (rank 0 partitions the matrix graph with the built-in partitioner -- METIS is not linked --, sorts the
     rows by part, permutes the matrix symmetrically and scatters the blocks; code/mpi_funcs.hpp:494-598), three real ranks, self-checked;

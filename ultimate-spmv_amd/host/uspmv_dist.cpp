@@ -239,6 +239,40 @@ int uspmv_run_distributed(const DistConfig &c) {
         publish(std::string(dump) + "." + std::to_string(rank), yo.data(), yo.size() * 8);
     }
 
+    // ---- the arrangement of the step (-step_form): fixed, or the fastest of the candidates on this machine
+    std::string form = c.step_form, form_report;
+    const bool legacy_knobs = c.no_overlap || getenv("USPMV_PAD_SPLIT") || getenv("USPMV_FUSED_STEP");
+    if (!(P > 1 && comm_halos && b == 1) || legacy_knobs) form = c.no_overlap ? "plain" : "overlap";
+    auto apply_form = [&](const std::string &f) -> int {
+        if (int rc = uspmv_dist_set_option(D, "overlap", f == "plain" ? 0 : 1)) return rc;
+        if (int rc = uspmv_dist_set_option(D, "pad_split", f == "pad" || f == "fused" ? 1 : 0)) return rc;
+        return uspmv_dist_set_option(D, "fused_step", f == "fused" ? 1 : 0);
+    };
+    if (P > 1 && comm_halos && b == 1 && !legacy_knobs) {
+        if (form == "auto") {
+            std::vector<std::string> cand = {"overlap", "plain", "pad"};
+            if (!c.use_graph) cand.push_back("fused");          // (a captured step never takes the one-launch form)
+            double best = 0;
+            for (const std::string &f : cand) {
+                CK(apply_form(f));
+                steps(10);
+                HK(hipStreamSynchronize(st));
+                CK(uspmv_dist_barrier(D, st));
+                auto t0 = std::chrono::steady_clock::now();
+                steps(40);
+                HK(hipStreamSynchronize(st));
+                CK(uspmv_dist_barrier(D, st));
+                double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 40 * 1e3;
+                CK(uspmv_dist_allreduce_max(D, &t, st));         // every rank sees the same numbers and takes the same decision
+                char buf[64];
+                snprintf(buf, sizeof buf, "%s\"%s\": %.6f", form_report.empty() ? "" : ", ", f.c_str(), t);
+                form_report += buf;
+                if (form == "auto" || t < best) { best = t; form = f; }
+            }
+        }
+        CK(apply_form(form));
+    }
+
     // ---- timed region
     int n_iter = 2;
     double runtime = 0, runtime_other = 0;
@@ -345,6 +379,8 @@ int uspmv_run_distributed(const DistConfig &c) {
                runtime / n_iter * 1e3, rank, bytes / (runtime / n_iter) / 1e9, (long)n_halo, (long)meta[4], (long)meta[5], meta[6] ? "tiles" : "chunks",
                meta[9] ? "hipGraph replay" : "eager steps", c.ba_synch && c.comm_halos ? 1 : 0,
                mism_total < 0 ? "" : mism_total == 0 ? ", y checked bitwise on every rank: ok" : ", y CHECK FAILED");
+        if (P > 1 && comm_halos && b == 1)
+            printf("step form: %s%s%s%s\n", form.c_str(), form_report.empty() ? "" : " (ms per step of the candidates, slowest rank: {", form_report.c_str(), form_report.empty() ? "" : "})");
         if (b > 1) {
             int64_t bm[6];
             CK(uspmv_dist_spmmv_info(D, bm));
@@ -352,16 +388,16 @@ int uspmv_run_distributed(const DistConfig &c) {
                    b, (long)bm[0], (long)bm[1], bm[2] ? "yes" : "no", (long)bm[4], (long)bm[3]);
         }
         if (!c.json.empty()) {
-            char js[2048];
+            char js[3072];
             snprintf(js, sizeof js,
                      "{\"gflops\": %.4f, \"ms_per_step\": %.6f, \"steps\": %d, \"warmup\": %d, \"runtime_s\": %.6f, \"ranks\": %d, \"loopback\": %s, "
                      "\"exchange\": \"%s\", \"n_rows\": %ld, \"nnz\": %ld, \"protocol\": \"%s\", \"ba_synch\": %d, \"graph_replay\": %s, \"graph_launches\": %ld, "
-                     "\"eager_steps\": %ld, \"overlap\": %s, \"other_ba_synch_ms_per_step\": %.6f, \"y_checked\": %s, \"y_mismatches\": %ld, \"y_checksum_rank0\": %.17g, "
+                     "\"eager_steps\": %ld, \"overlap\": %s, \"step_form\": \"%s\", \"step_form_candidates_ms\": {%s}, \"other_ba_synch_ms_per_step\": %.6f, \"y_checked\": %s, \"y_mismatches\": %ld, \"y_checksum_rank0\": %.17g, "
                      "\"rank0\": {\"n_local\": %ld, \"n_halo\": %ld, \"n_send\": %ld, \"interior\": %ld, \"boundary\": %ld, \"tiles\": %s, \"n_elements\": %ld, "
                      "\"n_chunks\": %ld, \"n_rows_padded\": %ld, \"algorithmic_bytes\": %.0f, \"local_kernel_ms\": %.6f}, "
                      "\"versions\": {\"hip_build\": %d, \"hip_runtime\": %d, \"rccl_build\": %d, \"rccl_runtime\": %d}}",
                      perf, runtime / n_iter * 1e3, n_iter, warm, runtime, P, meta[8] ? "true" : "false", host_exchange ? "host" : "rccl", (long)n_rows_g, (long)nnz_g,
-                     protocol, c.ba_synch && c.comm_halos ? 1 : 0, meta[9] ? "true" : "false", (long)meta[10], (long)meta[11], c.no_overlap ? "false" : "true", runtime_other / n_iter * 1e3,
+                     protocol, c.ba_synch && c.comm_halos ? 1 : 0, meta[9] ? "true" : "false", (long)meta[10], (long)meta[11], form == "plain" ? "false" : "true", form.c_str(), form_report.c_str(), runtime_other / n_iter * 1e3,
                      mism_total < 0 ? "null" : mism_total == 0 ? "true" : "false", (long)mism_total, checksum, (long)n_local, (long)n_halo, (long)n_send,
                      (long)meta[4], (long)meta[5], meta[6] ? "true" : "false", (long)n_el, (long)n_chunks, (long)n_pad, bytes, kernel_ms,
                      ver[0], ver[1], ver[2], ver[3]);

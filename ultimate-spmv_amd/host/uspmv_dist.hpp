@@ -14,6 +14,11 @@ struct DistConfig {
     double bench_time = 5.0;
     int bench_steps = 0, bench_warmup = -1;   // -bench_steps K: time exactly K steps between barriers (0 = the reference's doubling loop); -bench_warmup W (-1 = 100)
     bool check_y = false;                      // -check_y 1: bitwise self-check of one distributed step (uspmv_dist_check)
+    // -step_form overlap|plain|pad|fused|auto: how the single-vector step is arranged around the exchange.  overlap = interior tiles
+    // during the exchange, boundary tiles after it; plain = exchange, then the whole matrix (the reference's order); pad = overlap with
+    // the padding-only tiles in front of the exchange; fused = pad in one launch (eager steps only); auto = time each for a few steps
+    // on THIS machine, all ranks agreeing on the slowest rank's clock, and keep the fastest (all forms give the same bits).
+    std::string step_form = "auto";
     std::string json;                          // -json <file|->: one JSON line with everything measured (rank 0)
     std::string matrix_name;
 };

@@ -51,6 +51,7 @@ struct Config {  // subset of the reference's Config (code/classes_structs.hpp:4
     int tlc = 1;                 // build the tile-local-column plan (MI355X-specific, results unchanged)
     int use_graph = 1;           // bench loop replays hipGraphs of 64 launches
     int vec_mode = USPMV_BULKVEC;  // -mpi_mode: message pattern of the block-vector halo exchange (a make knob in the reference, Makefile / config.mk)
+    std::string step_form = "auto";
     int bench_steps = 0, bench_warmup = -1, check_y = 0;   // multi-rank: -bench_steps K / -bench_warmup W (fixed-count protocol), -check_y 1
     std::string json;                                       // multi-rank: -json <file|->
     std::string part_file;                                  // -seg_metis: part ids from this file (one per row, gpmetis format) instead of the built-in partitioner
@@ -76,7 +77,7 @@ void usage() {
             "  -equilibrate <0|1> -ap_threshold_1 <float> -ap_threshold_2 <float> -dropout <0|1>\n"
             "  -dropout_threshold <float> -block_vec_layout <colwise|rowwise> -tlc <0|1> -graph <0|1> -dump_y <file>\n"
             "  -mpi_mode <singlevec|multivec|bulkvec>\n"
-            "  multi-rank runs: -bench_steps <int> -bench_warmup <int> -check_y <0|1> -json <file|->\n"
+            "  multi-rank runs: -bench_steps <int> -bench_warmup <int> -check_y <0|1> -json <file|-> -step_form <auto|overlap|plain|pad|fused>\n"
             "  -seg_metis [-part_file <file>]: graph partition (built-in level-set partitioner, or part ids from a gpmetis-style file)\n");
 }
 
@@ -123,6 +124,7 @@ Config parse(int argc, char **argv) {
         else if (a == "-bench_warmup") { c.bench_warmup = atoi(need(i)); if (c.bench_warmup < 0) die("bench_warmup must be >= 0."); }
         else if (a == "-check_y") c.check_y = atoi(need(i));
         else if (a == "-json") c.json = need(i);
+        else if (a == "-step_form") { c.step_form = need(i); if (c.step_form != "auto" && c.step_form != "overlap" && c.step_form != "plain" && c.step_form != "pad" && c.step_form != "fused") die("step_form must be auto, overlap, plain, pad or fused."); }
         else if (a == "-block_vec_layout") { std::string v = need(i); if (v == "colwise") c.layout = USPMV_COLWISE; else if (v == "rowwise") c.layout = USPMV_ROWWISE; else die("block_vec_layout must be colwise or rowwise."); }
         else { usage(); die("unknown argument: " + a); }
     }
@@ -407,6 +409,7 @@ int main(int argc, char **argv) {
         d.block_vec_size = c.block_vec_size; d.layout = c.layout; d.vec_mode = c.vec_mode;
         d.use_graph = c.use_graph != 0; d.print_comm_vol = c.print_comm_vol != 0; d.no_pack = c.no_pack != 0;
         d.no_overlap = getenv("USPMV_NO_OVERLAP") != nullptr;
+        d.step_form = c.step_form;
         d.bench_steps = c.bench_steps; d.bench_warmup = c.bench_warmup; d.check_y = c.check_y != 0; d.json = c.json;
         if (c.equilibrate) die("-equilibrate is a single-rank option in this round");
         // (-par_pack: on the device the send buffer is packed by one kernel either way, as in the reference's device branch, code/classes_structs.hpp:787-806)
