@@ -163,22 +163,62 @@ __global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, con
         const int ge = min(g1, ngf);                         // full groups of this wave's rows in the phase: [g0, ge)
         VT a[NGP], at = VT(0);
         unsigned ix[NGP], ixt = 0u;
-#pragma unroll
-        for (int d = 0; d < NGP; ++d) {
-            a[d] = VT(0); ix[d] = 0u;
-            if (g0 + d < ge) {
-                if (!(ABL & 8)) ix[d] = lds_off(ld_stream<NT>(ip + (long)(g0 + d) * 4 * C));
-                if (!(ABL & 4)) a[d] = ld_stream<NT>(vp + (long)(g0 + d) * 4 * C);
-            }
-        }
         const bool tail_here = rem && ngf >= g0 && ngf < g1;  // the partial last group of this wave's rows belongs to this phase
-        if (tail_here) { ixt = lds_off(ld_stream<NT>(ip + (long)ngf * 4 * C)); if (q < rem) at = ld_stream<NT>(vp + (long)ngf * 4 * C); }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr ((ABL & 32) != 0) {
+            // measurement only (ablate 32): the n = ge - g0 <= NGP full groups in register slots NGP - n .. NGP - 1, one uniform switch
+            // into a straight line of NGP blocks instead of a compare + branch + zero fill per group.  Same chains (ascending slots
+            // = ascending groups).  78 instead of 64 registers and MORE scalar instructions (a branch tree, no jump table): see
+            // profiles/r03/config3_colwise.txt, block 5.
+            const int skip = NGP - max(min(ge - g0, NGP), 0);
+            const VT *vpg = vp + (long)(g0 - skip) * 4 * C;      // (never dereferenced below slot `skip`)
+            const IT *ipg = ip + (long)(g0 - skip) * 4 * C;
+#define PH_LOAD(K) { ix[K] = lds_off(ld_stream<NT>(ipg + (K) * 4 * C)); a[K] = ld_stream<NT>(vpg + (K) * 4 * C); }
+            static_assert(NGP == 8, "eight slots per phase");
+            switch (skip) {
+                case 0: PH_LOAD(0) [[fallthrough]];
+                case 1: PH_LOAD(1) [[fallthrough]];
+                case 2: PH_LOAD(2) [[fallthrough]];
+                case 3: PH_LOAD(3) [[fallthrough]];
+                case 4: PH_LOAD(4) [[fallthrough]];
+                case 5: PH_LOAD(5) [[fallthrough]];
+                case 6: PH_LOAD(6) [[fallthrough]];
+                case 7: PH_LOAD(7) [[fallthrough]];
+                default: break;
+            }
+#undef PH_LOAD
+            if (tail_here) { ixt = lds_off(ld_stream<NT>(ip + (long)ngf * 4 * C)); if (q < rem) at = ld_stream<NT>(vp + (long)ngf * 4 * C); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#define PH_STEPS(K) { QUAD_STEP(0, a[K], ix[K]) QUAD_STEP(1, a[K], ix[K]) QUAD_STEP(2, a[K], ix[K]) QUAD_STEP(3, a[K], ix[K]) }
+            switch (skip) {
+                case 0: PH_STEPS(0) [[fallthrough]];
+                case 1: PH_STEPS(1) [[fallthrough]];
+                case 2: PH_STEPS(2) [[fallthrough]];
+                case 3: PH_STEPS(3) [[fallthrough]];
+                case 4: PH_STEPS(4) [[fallthrough]];
+                case 5: PH_STEPS(5) [[fallthrough]];
+                case 6: PH_STEPS(6) [[fallthrough]];
+                case 7: PH_STEPS(7) [[fallthrough]];
+                default: break;
+            }
+#undef PH_STEPS
+        } else {
 #pragma unroll
-        for (int d = 0; d < NGP; ++d) {
-            if (ABL & 2) { if (ix[d] == 0xdeadbeefu) acc[0] += a[d]; continue; }
-            if (g0 + d < ge) { QUAD_STEP(0, a[d], ix[d]) QUAD_STEP(1, a[d], ix[d]) QUAD_STEP(2, a[d], ix[d]) QUAD_STEP(3, a[d], ix[d]) }
+            for (int d = 0; d < NGP; ++d) {
+                a[d] = VT(0); ix[d] = 0u;
+                if (g0 + d < ge) {
+                    if (!(ABL & 8)) ix[d] = lds_off(ld_stream<NT>(ip + (long)(g0 + d) * 4 * C));
+                    if (!(ABL & 4)) a[d] = ld_stream<NT>(vp + (long)(g0 + d) * 4 * C);
+                }
+            }
+            if (tail_here) { ixt = lds_off(ld_stream<NT>(ip + (long)ngf * 4 * C)); if (q < rem) at = ld_stream<NT>(vp + (long)ngf * 4 * C); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma unroll
+            for (int d = 0; d < NGP; ++d) {
+                if (ABL & 2) { if (ix[d] == 0xdeadbeefu) acc[0] += a[d]; continue; }
+                if (g0 + d < ge) { QUAD_STEP(0, a[d], ix[d]) QUAD_STEP(1, a[d], ix[d]) QUAD_STEP(2, a[d], ix[d]) QUAD_STEP(3, a[d], ix[d]) }
+            }
         }
         if (tail_here) {
             if (rem > 0) QUAD_STEP(0, at, ixt)
@@ -242,7 +282,7 @@ void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
         if (g_tune.ablate >= 1 && !xcol && !ycol) {   // measurement only
 #define QH_ABL(N) case N: hipLaunchKernelGGL((scs_spmmv_quadph<VT, IT, B, true, false, CT, 8, MAXP, 0, N>), dim3((unsigned)A->pb_n_tiles), dim3(256), lds, st, \
                            QH_ARGS(A->pb_ph_ptr, A->pb_g0, A->pb_list_ptr, A->pb_xrows, A->pb_col16)); break;
-            switch (g_tune.ablate) { QH_ABL(1) QH_ABL(2) QH_ABL(4) QH_ABL(8) QH_ABL(17) QH_ABL(14) QH_ABL(3) QH_ABL(19) default: break; }
+            switch (g_tune.ablate) { QH_ABL(1) QH_ABL(2) QH_ABL(4) QH_ABL(8) QH_ABL(17) QH_ABL(14) QH_ABL(3) QH_ABL(19) QH_ABL(32) default: break; }
 #undef QH_ABL
             return;
         }
