@@ -217,7 +217,7 @@ int uspmv_dmat_plan_download(const uspmv_dmat_t *m, int64_t meta[4], int32_t *ti
 /* Rows per tile of the plan (256 | 512 | 1024; 0 = no plan).  A tile covers tile_rows/C consecutive chunks. */
 int uspmv_dmat_tile_rows(const uspmv_dmat_t *m, int *tile_rows);
 /* uspmv_spmv over a subset of tiles (d_tile_ids[n_ids]) of a handle with a plan: the interior /
- * boundary split of the halo-overlap scheme at tile granularity. */
+ * boundary split of the halo-overlap scheme at tile granularity.  Entries < 0 are skipped (a list another kernel switches on or off). */
 int uspmv_spmv_tiles(const uspmv_dmat_t *A, const int32_t *d_tile_ids, int64_t n_ids, const void *d_x, void *d_y,
                      void *stream);
 /* Mark a C = 1 struct as "crs" (uspmv <mtx> crs): uspmv_spmv then uses the CRS kernel (several lanes
