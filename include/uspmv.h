@@ -338,6 +338,11 @@ void uspmv_halo_free(uspmv_halo_t *h);
  * are malloc'ed; release with uspmv_free. */
 int uspmv_scs_split_chunks(const uspmv_scs_t *s, int64_t n_local, int32_t **interior, int64_t *n_interior,
                            int32_t **boundary, int64_t *n_boundary);
+/* The same split in three classes, classes[n_chunks]: 0 = no halo column; 1 = halo columns only through the reference's padding -- entries
+ * that are +0.0 on the ONE column *pad_col (value 0, column 0: code/utilities.hpp:1991-2002; a halo column on every rank but the first,
+ * code/mpi_funcs.hpp:279-306); 2 = other halo references.  *pad_col = -1 when no chunk is of class 1.  (What "pad_split" of
+ * uspmv_dist_set_option is built on.) */
+int uspmv_scs_chunk_classes(const uspmv_scs_t *s, int64_t n_local, uint8_t *classes, int32_t *pad_col);
 void uspmv_free(void *p);
 /* Send-buffer gather for ALL neighbours in one launch over the concatenated index list:
  * d_send[i] = d_x[d_perm[d_send_idxs[i]] + block_offset].  Replaces pack_send_buf /

@@ -226,6 +226,22 @@ def test_halo_setup(pkg):
                 assert ci[cp[c]:cp[c] + cl[c] * Cc].max(initial=0) < plan.n_local
             for c in bnd:
                 assert ci[cp[c]:cp[c] + cl[c] * Cc].max() >= plan.n_local
+            # ... and in three classes: halo columns only through the reference's (+0.0, one column) padding form a class of their own
+            cls, pad_col = s.chunk_classes(plan.n_local)
+            va = s.arrays()["values"]
+            zero_halo = (ci >= plan.n_local) & (va.view(np.uint64 if va.dtype == np.float64 else np.uint32) == 0)
+            want_col = int(ci[zero_halo].min()) if zero_halo.any() else None
+            want = np.zeros(s.n_chunks, np.uint8)
+            for c in range(s.n_chunks):
+                sl = slice(cp[c], cp[c] + cl[c] * Cc)
+                halo = ci[sl] >= plan.n_local
+                if halo.any():
+                    want[c] = 1 if (zero_halo[sl][halo] & (ci[sl][halo] == want_col)).all() else 2
+            assert np.array_equal(cls, want), (key, r)
+            assert pad_col == (want_col if (want == 1).any() else -1), (key, r, pad_col, want_col)
+            assert np.array_equal(np.flatnonzero(cls == 0), inner) and np.array_equal(np.flatnonzero(cls > 0), bnd)
+            if r > 0 and s.n_elements > s.nnz:                   # padded chunks exist: their column 0 is a halo column on ranks > 0
+                assert (cls == 1).any() or (cls == 2).all() or pad_col == -1
 
 
 def test_seg_errors(pkg):

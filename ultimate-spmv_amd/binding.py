@@ -118,6 +118,7 @@ _SIGS = {
     "uspmv_halo_discover": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "uspmv_halo_meta": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_i32p)]),
     "uspmv_halo_free": (None, [_vp]),
+    "uspmv_scs_chunk_classes": (C.c_int, [_vp, _i64, C.POINTER(C.c_uint8), C.POINTER(C.c_int32)]),
     "uspmv_scs_split_chunks": (C.c_int, [_vp, _i64, C.POINTER(_i32p), C.POINTER(_i64), C.POINTER(_i32p),
                                          C.POINTER(_i64)]),
     "uspmv_free": (None, [_vp]),
@@ -359,6 +360,13 @@ class Scs:
         ib = _view(b, nb.value, np.int32).copy()
         lib().uspmv_free(a); lib().uspmv_free(b)
         return ia, ib
+
+    def chunk_classes(self, n_local):
+        """(classes[n_chunks], pad_col): 0 no halo column, 1 halo only through +0.0 padding on column pad_col, 2 other halo references"""
+        cls = np.zeros(max(self.n_chunks, 1), np.uint8)
+        pc = C.c_int32(-1)
+        _ck(lib().uspmv_scs_chunk_classes(self.h, n_local, cls.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(pc)))
+        return cls[:self.n_chunks], pc.value
 
     def __del__(self):
         if getattr(self, "h", None) and _LIB is not None:

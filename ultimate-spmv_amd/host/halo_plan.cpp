@@ -253,3 +253,11 @@ int uspmv_scs_classify_chunks(const uspmv_scs_t *s, int64_t n_local, std::vector
     *pad_col = n_pad ? h0 : -1;
     return USPMV_OK;
 }
+
+extern "C" int uspmv_scs_chunk_classes(const uspmv_scs_t *s, int64_t n_local, uint8_t *classes, int32_t *pad_col) {
+    if (!classes || !pad_col) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_scs_chunk_classes: NULL argument");
+    std::vector<uint8_t> cls;
+    if (int rc = uspmv_scs_classify_chunks(s, n_local, &cls, pad_col)) return rc;
+    if (!cls.empty()) memcpy(classes, cls.data(), cls.size());
+    return USPMV_OK;
+}
