@@ -271,6 +271,25 @@ int uspmv_run_distributed(const DistConfig &c) {
             }
         }
         CK(apply_form(form));
+        // a form beyond the two plain ones is only kept if one step of it passes the bitwise self-check on every rank (the check is
+        // collective: all ranks see the same verdict); otherwise the faster of overlap / plain takes over
+        if (c.step_form == "auto" && (form == "pad" || form == "fused")) {
+            int64_t mm = 0;
+            CK(uspmv_dist_check(D, local, wsa.data(), d_x, d_y, c.use_graph ? 1 : 0, st, &mm, nullptr));
+            std::vector<int64_t> all((size_t)std::max(P, comm_size), 0);
+            CK(uspmv_dist_allgather_i64(D, mm, all.data(), st));
+            int64_t tot = 0;
+            for (int p = 0; p < (meta[8] ? 1 : comm_size); ++p) tot += all[(size_t)p];
+            HK(hipMemcpy(d_x, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
+            if (tot) {
+                if (rank == 0) fprintf(stderr, "step form %s failed the self-check on this machine (%ld rows): not used\n", form.c_str(), (long)tot);
+                const size_t po = form_report.find("\"plain\": "), oo = form_report.find("\"overlap\": ");
+                const double tp = po == std::string::npos ? 0 : atof(form_report.c_str() + po + 9), to = oo == std::string::npos ? 0 : atof(form_report.c_str() + oo + 11);
+                form = (tp > 0 && tp < to) ? "plain" : "overlap";
+                form_report += ", \"rejected\": 1";
+                CK(apply_form(form));
+            }
+        }
     }
 
     // ---- timed region
