@@ -359,6 +359,16 @@ def _hx_worker(rank, world, q, job, case):
                 d.synchronize()
                 assert np.array_equal(x.cpu().numpy()[:len(gx)], gx), "x_local (halo tail) differs from the reference's"
                 assert np.array_equal(d.y_to_original_order(y)[:nl], want), (overlap, ba)
+        # the optional arrangements of the step (padding tiles in front of the exchange; one launch with deferred boundary tiles) on
+        # unequal blocks and asymmetric lists, eager steps (where the handle has tile lists; otherwise the options change nothing)
+        d.set_option("overlap", 1); d.set_option("ba_synch", 0)
+        for pad, fused in ((1, 0), (1, 1), (0, 1)):
+            d.set_option("pad_split", pad); d.set_option("fused_step", fused)
+            x = d.new_x(xg[wsa[rank]:wsa[rank + 1]]); y = d.new_y()
+            d.spmv(x, y); d.spmv(x, y); d.synchronize()
+            assert np.array_equal(x.cpu().numpy()[:len(gx)], gx), (pad, fused)
+            assert np.array_equal(d.y_to_original_order(y)[:nl], want), (pad, fused)
+        d.set_option("pad_split", 0); d.set_option("fused_step", 0)
         # the product's own self-check agrees (same x as the golden: x_global[j] = 1 + 1e-3 (j mod 1000))
         x, y = d.new_x(np.zeros(nl)), d.new_y()
         bad, cs = d.check(loc, x, y)
