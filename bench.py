@@ -495,8 +495,10 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
             except Exception:
                 pass
             native = False
+    y_ref_twin = None
     if not native:
         d = DistSpmv(loc, wsa, args.chunk, args.sigma, B.F64, device=dev, overlap=not args.no_overlap, tlc=not args.no_tlc)
+        y_ref_twin = pkg.dist_check_reference(loc, wsa, rank, world)   # host side of the checked step below (entry-ordered FMA chains)
         del loc
         loc = None
     x = d.new_x(np.full(d.n_local, 5.0))          # DefaultValues::x (code/classes_structs.hpp:1799-1800)
@@ -550,6 +552,17 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
         k_ms = e0.elapsed_time(e1) / 20
         kind = d.plan_info()[0]
     else:
+        # the twin's checked step: the same ramp, y of the local rows bitwise against the host chains
+        xr = d.new_x(1.0 + 1e-3 * (np.arange(int(wsa[rank]), int(wsa[rank + 1])) % 1000))
+        yr = d.new_y()
+        d.spmv(xr, yr)
+        torch.cuda.synchronize(dev)
+        got = d.y_to_original_order(yr)[:d.n_local]
+        tb = torch.tensor([int(np.count_nonzero(got.view(np.uint64) != y_ref_twin.view(np.uint64)))], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tb)
+        y_bad = int(tb.item())
+        y_checked = y_bad == 0
+        del xr, yr, y_ref_twin
         k_ms = B.time_launches(0, 20, A=d.A, x=x, y=y)
         kind = 1 if d.use_tiles else 0
     klass = "nlpkkt240-class" if g == 304 else "nlpkkt200-class" if g == 253 else "stencil"

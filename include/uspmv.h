@@ -456,6 +456,9 @@ int uspmv_dist_set_option(uspmv_dist_t *d, const char *key, int value);
  * mismatches = rows that differ on this rank, checksum = sum of the local y in original order (both optional). */
 int uspmv_dist_check(uspmv_dist_t *d, const uspmv_coo_t *local, const int32_t *wsa, void *d_x, void *d_y, int use_graph,
                      void *stream, int64_t *mismatches, double *checksum);
+/* The host half of that check alone (no GPU): y_ref[i] (n_rows of `local`, dtype) = the entry-ordered FMA chain of local row i over
+ * x_global[j] = 1 + 1e-3 * (j mod 1000), for steps that do not run on a uspmv_dist object (bench.py's torch.distributed twin). */
+int uspmv_dist_check_reference(const uspmv_coo_t *local, const int32_t *wsa, int rank, int P, int dtype, void *y_ref);
 /* HIP / RCCL versions this library was COMPILED against and the ones it RUNS on in this process:
  * v[0] HIP_VERSION (build), v[1] hipRuntimeGetVersion, v[2] NCCL_VERSION_CODE (build), v[3] ncclGetVersion. */
 int uspmv_runtime_versions(int v[4]);

@@ -211,6 +211,8 @@ def test_halo_setup(pkg):
             assert (loc.n_rows, loc.nnz) == (m["n_local"][r], m["nnz"][r])
             s = pkg.convert_to_scs(loc, Cc, sg)
             assert s.n_elements == m["n_elements"][r]
+            if key + "_y_global" in h.files:   # the host half of uspmv_dist_check: entry-ordered chains == the reference's y for the ramp x
+                assert np.array_equal(pkg.dist_check_reference(loc, wsa, r, P), h[key + "_y_global"][wsa[r]:wsa[r + 1]]), (key, r)
             plan = pkg.HaloPlan(s, wsa, r, P)
             assert plan.n_halo == m["n_halo"][r] and plan.recv_counts.tolist() == m["recv_counts"][r]
             assert np.array_equal(plan.recv_counts_cumsum, h[f"{key}_r{r}_recv_cumsum"])

@@ -131,6 +131,7 @@ _SIGS = {
     "uspmv_dist_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dist_spmmv_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dist_pad_info": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "uspmv_dist_check_reference": (C.c_int, [_vp, _i32p, C.c_int, C.c_int, C.c_int, _vp]),
     "uspmv_dist_parts": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "uspmv_dist_set_overlap": (C.c_int, [_vp, C.c_int]),
     "uspmv_dist_set_no_pack": (C.c_int, [_vp, C.c_int]),
@@ -548,6 +549,14 @@ class CommPlan:
         if getattr(self, "h", None) and _LIB is not None:
             _LIB.uspmv_comm_plan_free(self.h)
             self.h = None
+
+
+def dist_check_reference(local, wsa, rank, P, dtype=F64):
+    """y of the local rows (original order) for x_global[j] = 1 + 1e-3 (j mod 1000): entry-ordered FMA chains on the host (uspmv_dist_check_reference)"""
+    w = np.ascontiguousarray(wsa, np.int32)
+    y = np.zeros(local.n_rows, np.float64 if dtype == F64 else np.float32)
+    _ck(lib().uspmv_dist_check_reference(local.h, w.ctypes.data_as(_i32p), int(rank), int(P), int(dtype), y.ctypes.data_as(_vp)))
+    return y
 
 
 def runtime_versions():

@@ -55,3 +55,12 @@ int dist_reference_rows(const uspmv_coo *local, const int32_t *wsa, int P, int r
 }
 
 }  // namespace uspmv
+
+// The rows of the check on the host alone (no GPU): y_ref[i] = the entry-ordered FMA chain of local row i over
+// x_global[j] = 1 + 1e-3 (j mod 1000) -- what uspmv_dist_check compares the device's y with; for steps that do not run on a
+// uspmv_dist object (the torch.distributed twin of bench.py).
+extern "C" int uspmv_dist_check_reference(const uspmv_coo_t *local, const int32_t *wsa, int rank, int P, int dtype, void *y_ref) {
+    if (P < 1 || rank < 0 || rank >= P) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_check_reference: bad rank / P");
+    if (dtype != USPMV_F64 && dtype != USPMV_F32) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_check_reference: unknown dtype %d", dtype);
+    return uspmv::dist_reference_rows(local, wsa, P, rank, /*loopback=*/false, dtype, y_ref);
+}
