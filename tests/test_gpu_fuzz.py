@@ -1,0 +1,171 @@
+"""Randomised GPU parity: random matrices (ragged, empty rows, heavy ties, banded, a few very long rows, special values) x chunk
+heights x sorting scopes x precisions through every way a handle can be set up -- plain upload, host plans, device plans, device
+conversion, block plans, adaptive-precision pairs, the column-window sweep -- each result compared BITWISE with the oracle's loops
+(oracle/uspmv_oracle.c = code/kernels.hpp:159-398, code/ap_kernels.hpp:24-82).  Seeds are fixed; USPMV_FUZZ_CASES raises the number
+of cases for a long run (tools/README.md; profiles/r03/fuzz.txt holds one)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = int(os.environ.get("USPMV_FUZZ_CASES", "36"))
+SEED0 = int(os.environ.get("USPMV_FUZZ_SEED", "20260"))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(pkg):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def random_matrix(rng):
+    kind = rng.choice(["poisson", "ties", "banded", "longrows", "tiny", "stencil"])
+    n = int(rng.choice([1, 2, 5, 31, 32, 33, 100, 257, 700, 1500, 4100]))
+    if kind == "tiny":
+        n = int(rng.integers(1, 12))
+    n_cols = n
+    if kind == "poisson":
+        lens = rng.poisson(rng.choice([1.0, 4.0, 12.0]), n)
+    elif kind == "ties":
+        lens = rng.choice([0, 1, 2, 2, 3, 3, 3, 7], n)
+    elif kind == "banded":
+        lens = rng.integers(1, 9, n)
+    elif kind == "longrows":
+        lens = rng.poisson(3.0, n)
+        for r in rng.choice(n, max(1, n // 200), replace=False):
+            lens[r] = min(n_cols, int(rng.integers(100, 400)))
+    elif kind == "stencil":
+        lens = np.full(n, 5)
+    else:
+        lens = rng.integers(0, 4, n)
+    lens = np.minimum(lens, n_cols).astype(np.int64)
+    I = np.repeat(np.arange(n), lens)
+    cols = []
+    for r, k in enumerate(lens):
+        if k == 0:
+            continue
+        if kind in ("banded", "stencil"):
+            w = 40 if kind == "banded" else 3
+            lo, hi = max(0, r - w), min(n_cols, r + w + 1)
+            k2 = min(k, hi - lo)
+            c = np.sort(rng.choice(np.arange(lo, hi), k2, replace=False))
+            if k2 < k:
+                c = np.concatenate([c, c[:k - k2]])[:k]
+        else:
+            c = rng.choice(n_cols, k, replace=False)
+            if rng.random() < 0.5:
+                c = np.sort(c)
+        cols.append(c)
+    J = np.concatenate(cols) if cols else np.zeros(0, np.int64)
+    if J.size != I.size:            # (a banded row shorter than asked for)
+        I = I[:J.size]
+    V = rng.standard_normal(I.size) * 10.0 ** rng.integers(-6, 4, I.size)
+    if I.size and rng.random() < 0.3:
+        V[rng.choice(I.size, max(1, I.size // 50), replace=False)] = 0.0      # explicit zeros
+    if I.size == 0:
+        I, J, V = np.array([0]), np.array([0]), np.array([1.5])
+    return kind, n, n_cols, I.astype(np.int32), J.astype(np.int32), V.astype(np.float64)
+
+
+def _dev(t, a):
+    return t.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("case", range(N_CASES))
+def test_random_matrix_every_setup_bitexact(pkg, orc, torch_cuda, case):
+    t = torch_cuda
+    rng = np.random.default_rng(SEED0 + case)
+    kind, n, n_cols, I, J, V = random_matrix(rng)
+    C = int(rng.choice([1, 2, 4, 8, 16, 32, 32, 32, 64, 128, 10, 3]))
+    sigma = int(rng.choice([1, C, 2 * C, 512, 1000]))
+    code, ndt, tdt = (pkg.F64, np.float64, t.float64) if rng.random() < 0.6 else (pkg.F32, np.float32, t.float32)
+    tag = (case, kind, n, C, sigma, ndt.__name__)
+    m = pkg.Coo.from_arrays(n, n_cols, I, J, V)
+    s = pkg.convert_to_scs(m, C, sigma, code)
+    a = s.arrays()
+    pkg.permute_scs_cols(s, a["old_to_new_idx"])
+    a = s.arrays()
+    ld = s.n_rows_padded
+    xo = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 3, n)).astype(ndt)
+    xp = np.zeros(ld, ndt)
+    xp[:n] = pkg.apply_permutation(xo, a["new_to_old_idx"])
+    want = orc.spmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+
+    def check_spmv(A, what):
+        y = t.full((ld,), 3.0, dtype=tdt, device="cuda")
+        pkg.spmv(A, _dev(t, xp), y)
+        assert np.array_equal(y.cpu().numpy(), want), tag + (what,)
+
+    # ---- single vector: plain upload, host plan, device plan, device conversion (+ device plan), forced sweep plan
+    A = pkg.DeviceMatrix(s); check_spmv(A, "upload")
+    A.optimize(s); check_spmv(A, "host plan")
+    A2 = pkg.DeviceMatrix(s); A2.optimize_device(); check_spmv(A2, "device plan")
+    assert A.plan_info() == A2.plan_info(), tag
+    lay, A3 = pkg.convert_to_scs_device(m, C, sigma, code)
+    assert np.array_equal(lay.arrays()["old_to_new_idx"], a["old_to_new_idx"]), tag
+    check_spmv(A3, "device conversion"); A3.optimize_device(); check_spmv(A3, "device conversion + device plan")
+    if 256 % C == 0:
+        A4 = pkg.DeviceMatrix(s)
+        try:
+            A4.optimize_sweep(s)
+        except pkg.UspmvError:
+            pass                                   # (shapes the sweep planner refuses keep their kernel)
+        check_spmv(A4, "sweep plan (where tiles qualify)")
+        A5 = pkg.DeviceMatrix(s)
+        try:
+            A5.optimize_sweep_device()
+        except pkg.UspmvError:
+            pass
+        check_spmv(A5, "sweep plan built on the device")
+
+    # ---- block vectors: both layouts, without a plan, with the host block plan, with the device block plan
+    b = int(rng.choice([1, 2, 3, 4, 5, 8, 8, 13, 16]))
+    cols_ = [(xp * ndt(1.0 + v / 8.0)).astype(ndt) for v in range(b)]
+    handles = [("no plan", pkg.DeviceMatrix(s))]
+    Ab = pkg.DeviceMatrix(s); Ab.optimize_block(s, b); handles.append(("host block plan", Ab))
+    Ad = pkg.DeviceMatrix(s); Ad.optimize_block_device(b); handles.append(("device block plan", Ad))
+    for lay_code, rowwise in ((pkg.COLWISE, False), (pkg.ROWWISE, True)):
+        X = np.zeros(b * ld, ndt)
+        for v in range(b):
+            if rowwise: X[np.arange(ld) * b + v] = cols_[v]
+            else: X[v * ld:(v + 1) * ld] = cols_[v]
+        wantb = orc.spmmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, b, ld, rowwise)
+        for what, H in handles:
+            Y = t.full((b * ld,), 3.0, dtype=tdt, device="cuda")
+            pkg.spmmv(H, _dev(t, X), Y, b, ld, lay_code)
+            got = Y.cpu().numpy()
+            n_out = s.n_rows_padded * b if rowwise else None
+            if rowwise:
+                assert np.array_equal(got[:n_out], wantb[:n_out]), tag + (what, "rowwise", b)
+            else:
+                for v in range(b):
+                    assert np.array_equal(got[v * ld:v * ld + s.n_rows_padded], wantb[v * ld:v * ld + s.n_rows_padded]), tag + (what, "colwise", b, v)
+
+    # ---- adaptive precision pair (dp struct sorted on its own, sp struct placed with its permutation): plain, host plan, device plan
+    if code == pkg.F64 and n >= C:
+        th = float(np.median(np.abs(V))) if V.size else 1.0
+        dp, sp = pkg.partition_precisions(m, th)
+        if dp.nnz and sp.nnz:
+            ds = pkg.convert_to_scs(dp, C, sigma, pkg.F64)
+            perm = ds.arrays()["old_to_new_idx"].copy()
+            if np.all(perm < n):
+                try:
+                    ss = pkg.convert_to_scs(sp, C, sigma, pkg.F32, fixed_permutation=perm)
+                except pkg.UspmvError:
+                    return                         # (a non-empty sp row on a shorter dp chunk: refused like the reference would overrun)
+                pkg.permute_scs_cols(ds, perm); pkg.permute_scs_cols(ss, perm)
+                da, sa = ds.arrays(), ss.arrays()
+                xq = np.zeros(ds.n_rows_padded); xq[:n] = pkg.apply_permutation(xo.astype(np.float64), da["new_to_old_idx"])
+                wanta = orc.spmv_scs_ap_adv(C, ds.n_chunks, (da["chunk_ptrs"], da["chunk_lengths"], da["col_idxs"], da["values"]),
+                                            (sa["chunk_ptrs"], sa["chunk_lengths"], sa["col_idxs"], sa["values"]), xq)
+                for what in ("plain", "host plan", "device plan"):
+                    Pd, Ps = pkg.DeviceMatrix(ds), pkg.DeviceMatrix(ss)
+                    if what == "host plan": pkg.optimize_ap(Pd, Ps, ds, ss)
+                    elif what == "device plan": pkg.optimize_device_ap(Pd, Ps)
+                    y = t.full((ds.n_rows_padded,), 3.0, dtype=t.float64, device="cuda")
+                    pkg.spmv_ap(Pd, Ps, _dev(t, xq), y)
+                    assert np.array_equal(y.cpu().numpy(), wanta), tag + ("ap", what)
