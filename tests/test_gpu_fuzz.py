@@ -82,9 +82,39 @@ def test_random_matrix_every_setup_bitexact(pkg, orc, torch_cuda, case):
     kind, n, n_cols, I, J, V = random_matrix(rng)
     C = int(rng.choice([1, 2, 4, 8, 16, 32, 32, 32, 64, 128, 10, 3]))
     sigma = int(rng.choice([1, C, 2 * C, 512, 1000]))
-    code, ndt, tdt = (pkg.F64, np.float64, t.float64) if rng.random() < 0.6 else (pkg.F32, np.float32, t.float32)
-    tag = (case, kind, n, C, sigma, ndt.__name__)
+    f64 = rng.random() < 0.6
     m = pkg.Coo.from_arrays(n, n_cols, I, J, V)
+    check_every_setup(pkg, orc, t, rng, m, C, sigma, f64, (case, kind, n, C, sigma, "f64" if f64 else "f32"))
+
+
+GENERATED = [   # (name, generator, C, sigma, f64[, what the automatic choices must come out as]): sizes at which tiles, plans and the automatic choices between them are all in play
+    ("stencil27 40x40x30", lambda pkg: pkg.gen_stencil27(40, 40, 30), 32, 512, True, dict(kind=1, tile_rows=256)),
+    ("stencil27 24^3 x 3 dof", lambda pkg: pkg.gen_stencil27(24, 24, 24, dof=3), 32, 512, True, dict(b=8, phased=True)),
+    ("stencil27 24^3 x 3 dof sp C64", lambda pkg: pkg.gen_stencil27(24, 24, 24, dof=3), 64, 64, False),
+    ("stencil27 slab 150x150x2", lambda pkg: pkg.gen_stencil27(150, 150, 2), 32, 512, True),
+    ("stencil27 30^3 C16", lambda pkg: pkg.gen_stencil27(30, 30, 30), 16, 16, True),
+    ("stencil27 30^3 C8 sigma 64", lambda pkg: pkg.gen_stencil27(30, 30, 30), 8, 64, False),
+    ("kkt N=14", lambda pkg: pkg.gen_kkt(14), 32, 512, True),
+    ("kkt N=12 C64", lambda pkg: pkg.gen_kkt(12), 64, 512, True),
+    ("banded 30000 x 30 +-2000 (1024-row tiles)", lambda pkg: pkg.gen_banded_random(30000, 30, 2000), 32, 512, True, dict(kind=1, tile_rows=1024)),
+    ("banded 20000 x 140 +-9000 (sweep)", lambda pkg: pkg.gen_banded_random(20000, 140, 9000, magnitude_decades=8.0), 32, 512, True, dict(kind=2)),
+    ("banded 20000 x 140 +-9000 sp", lambda pkg: pkg.gen_banded_random(20000, 140, 9000), 32, 512, False),
+    ("banded 50000 x 12 +-300", lambda pkg: pkg.gen_banded_random(50000, 12, 300), 32, 1, True),
+]
+
+
+@pytest.mark.parametrize("spec", GENERATED, ids=[g[0] for g in GENERATED])
+def test_generated_matrix_every_setup_bitexact(pkg, orc, torch_cuda, spec):
+    name, gen, C, sigma, f64 = spec[:5]
+    rng = np.random.default_rng(sum(map(ord, name)))
+    check_every_setup(pkg, orc, torch_cuda, rng, gen(pkg), C, sigma, f64, (name, C, sigma, "f64" if f64 else "f32"), spec[5] if len(spec) > 5 else {})
+
+
+def check_every_setup(pkg, orc, t, rng, m, C, sigma, f64, tag, expect=None):
+    expect = expect or {}
+    code, ndt, tdt = (pkg.F64, np.float64, t.float64) if f64 else (pkg.F32, np.float32, t.float32)
+    n, n_cols = m.n_rows, m.n_cols
+    V = m.arrays()[2]
     s = pkg.convert_to_scs(m, C, sigma, code)
     a = s.arrays()
     pkg.permute_scs_cols(s, a["old_to_new_idx"])
@@ -105,6 +135,12 @@ def test_random_matrix_every_setup_bitexact(pkg, orc, torch_cuda, case):
     A.optimize(s); check_spmv(A, "host plan")
     A2 = pkg.DeviceMatrix(s); A2.optimize_device(); check_spmv(A2, "device plan")
     assert A.plan_info() == A2.plan_info(), tag
+    if "kind" in expect: assert A.plan_info()[0] == expect["kind"], tag + (A.plan_info(),)
+    if "tile_rows" in expect:
+        import ctypes
+        from ultimate_spmv_amd import binding
+        tr = ctypes.c_int()
+        assert binding.lib().uspmv_dmat_tile_rows(A.h, ctypes.byref(tr)) == 0 and tr.value == expect["tile_rows"], tag + (tr.value,)
     lay, A3 = pkg.convert_to_scs_device(m, C, sigma, code)
     assert np.array_equal(lay.arrays()["old_to_new_idx"], a["old_to_new_idx"]), tag
     check_spmv(A3, "device conversion"); A3.optimize_device(); check_spmv(A3, "device conversion + device plan")
@@ -123,11 +159,13 @@ def test_random_matrix_every_setup_bitexact(pkg, orc, torch_cuda, case):
         check_spmv(A5, "sweep plan built on the device")
 
     # ---- block vectors: both layouts, without a plan, with the host block plan, with the device block plan
-    b = int(rng.choice([1, 2, 3, 4, 5, 8, 8, 13, 16]))
+    b = expect.get("b") or int(rng.choice([1, 2, 3, 4, 5, 8, 8, 13, 16]))
     cols_ = [(xp * ndt(1.0 + v / 8.0)).astype(ndt) for v in range(b)]
     handles = [("no plan", pkg.DeviceMatrix(s))]
     Ab = pkg.DeviceMatrix(s); Ab.optimize_block(s, b); handles.append(("host block plan", Ab))
     Ad = pkg.DeviceMatrix(s); Ad.optimize_block_device(b); handles.append(("device block plan", Ad))
+    if expect.get("phased"):
+        assert Ab.block_plan_info()["phased_plan"] == 1 and Ad.block_plan_info()["phased_plan"] == 1, tag + (Ab.block_plan_info(), Ad.block_plan_info())
     for lay_code, rowwise in ((pkg.COLWISE, False), (pkg.ROWWISE, True)):
         X = np.zeros(b * ld, ndt)
         for v in range(b):
