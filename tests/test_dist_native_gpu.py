@@ -407,6 +407,90 @@ def test_native_step_real_ranks_unequal_seg_nnz_blocks(pkg, case, world):
         assert msg == "ok", f"rank {rank}: {msg}"
 
 
+def _fuzz_worker(rank, world, q, job, n_cases, seed0):
+    try:
+        sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import torch
+        import __graft_entry__ as ge
+        pkg = ge.load_package()
+        from ultimate_spmv_amd import binding as B
+        from oracle import oracle as orc
+        torch.cuda.set_device(0)
+        hc = pkg.HostComm(job, rank, world, timeout_s=180)
+        done = []
+        for case in range(n_cases):
+            rng = np.random.default_rng(seed0 + case)            # the same matrix on every rank
+            n = int(rng.choice([7, 40, 333, 1200, 5000]))
+            kind = rng.choice(["banded", "scattered", "ties"])
+            lens = rng.integers(1, 12, n) if kind != "ties" else rng.choice([1, 2, 2, 3, 3, 3, 7], n)
+            lens = np.minimum(lens, n)
+            I = np.repeat(np.arange(n), lens)
+            cols = []
+            for r, k in enumerate(lens):
+                if kind == "banded":
+                    lo, hi = max(0, r - 60), min(n, r + 61)
+                    k = min(k, hi - lo)
+                    cols.append(np.sort(rng.choice(np.arange(lo, hi), k, replace=False)))
+                else:
+                    cols.append(rng.choice(n, k, replace=False))
+            J = np.concatenate(cols)
+            I = np.repeat(np.arange(n), [len(c) for c in cols])
+            V = rng.standard_normal(I.size) * 10.0 ** rng.integers(-4, 3, I.size)
+            C_, sigma = int(rng.choice([4, 16, 32, 32, 64])), int(rng.choice([1, 64, 512]))
+            method = str(rng.choice(["seg-rows", "seg-nnz"]))
+            tot = pkg.Coo.from_arrays(n, n, I.astype(np.int32), J.astype(np.int32), V)
+            wsa = pkg.seg_work_sharing_arr(tot, method, world)
+            if np.any(np.diff(wsa) == 0):
+                continue                                         # (a rank without rows: refused at conversion, like a matrix without rows)
+            xg = rng.standard_normal(n)
+            # single-rank product of the whole matrix (row chains do not depend on C / sigma / the partition)
+            sg = pkg.convert_to_scs(tot, C_, sigma)
+            ag = sg.arrays(); pkg.permute_scs_cols(sg, ag["old_to_new_idx"]); ag = sg.arrays()
+            xpg = np.zeros(sg.n_rows_padded); xpg[:n] = pkg.apply_permutation(xg, ag["new_to_old_idx"])
+            yg = pkg.apply_permutation(orc.spmv_scs(C_, sg.n_chunks, ag["chunk_ptrs"], ag["chunk_lengths"], ag["col_idxs"], ag["values"], xpg), ag["old_to_new_idx"])[:n]
+            loc = B.seg_local_coo(tot, wsa, rank)
+            d = pkg.DistNative(loc, wsa, C_, sigma, rank, world, hostcomm=hc, host_exchange=True)
+            nl = int(wsa[rank + 1] - wsa[rank])
+            want = yg[wsa[rank]:wsa[rank + 1]]
+            for overlap, pad, fused in ((1, 0, 0), (0, 0, 0), (1, 1, 0), (1, 1, 1), (1, 0, 1)):
+                d.set_option("overlap", overlap); d.set_option("pad_split", pad); d.set_option("fused_step", fused)
+                x = d.new_x(xg[wsa[rank]:wsa[rank + 1]]); y = d.new_y()
+                d.spmv(x, y); d.spmv(x, y); d.synchronize()
+                assert np.array_equal(d.y_to_original_order(y)[:nl], want), (case, kind, n, C_, sigma, method, overlap, pad, fused)
+            d.barrier()
+            d.close()
+            done.append((kind, n, C_, sigma, method))
+        hc.close()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+def test_random_matrices_real_ranks_every_step_form(pkg):
+    """Random matrices, chunk heights, sorting scopes and partitions (seg-rows / seg-nnz: unequal blocks, asymmetric lists, ranks without
+    neighbours) with three real processes on one GPU (host-staged exchange): every arrangement of the step gives, bit for bit, the rows of
+    the oracle's single-rank product.  USPMV_FUZZ_DIST_CASES raises the number of matrices."""
+    world, n_cases = 3, int(os.environ.get("USPMV_FUZZ_DIST_CASES", "6"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    job = f"fz{os.getpid()}_{time.monotonic_ns()}"
+    procs = [ctx.Process(target=_fuzz_worker, args=(r, world, q, job, n_cases, 424200)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in procs:
+            res.append(q.get(timeout=300 + 20 * n_cases))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for rank, msg in sorted(res):
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
 def test_loopback_refuses_unequal_blocks_cleanly(pkg):
     """seg-nnz blocks of different heights in LOOPBACK: the ids a rank asks block p for index p's rows, not its own -- the set-up
     must say so (USPMV_ERR_INVALID) instead of letting the pack kernel gather out of bounds."""
@@ -421,6 +505,20 @@ def test_loopback_refuses_unequal_blocks_cleanly(pkg):
     with pytest.raises(pkg.UspmvError) as e:
         pkg.DistNative(loc, wsa, 32, 512, small, P, pkg.comm_unique_id(), comm_rank=0, comm_size=1)
     assert e.value.status == 1 and "equal block heights" in str(e.value)
+
+
+def test_a_block_without_rows_is_refused_by_every_rank_alike(pkg):
+    """work_sharing_arr with an empty block (seg-nnz around a very heavy row can produce one in the middle): every rank refuses at once,
+    whichever block it plays -- not only the rank whose conversion would fail."""
+    import torch
+    torch.cuda.set_device(0)
+    wsa = np.array([0, 40, 40, 96], np.int32)
+    full = pkg.gen_stencil27(4, 4, 6)
+    from ultimate_spmv_amd import binding as B
+    for rank in (0, 2):
+        loc = B.seg_local_coo(full, wsa, rank)
+        with pytest.raises(pkg.UspmvError, match="owns no rows"):
+            pkg.DistNative(loc, wsa, 32, 512, rank, 3, pkg.comm_unique_id(), comm_rank=0, comm_size=1)
 
 
 def test_self_check_passes_in_loopback_and_catches_a_missing_exchange(pkg):

@@ -513,6 +513,12 @@ int uspmv_dist_create_from_coo_ex(const void *comm_id, int comm_rank, int comm_s
                                   uspmv_dist_t **out) {
     if (!local || !wsa || !out) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create_from_coo: NULL argument");
     if (P < 1 || rank < 0 || rank >= P) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create_from_coo: bad rank / P");
+    // every rank sees the whole work_sharing_arr: a block without rows is refused HERE, by all ranks alike, before the first collective
+    // (the conversion of that block would fail on its rank alone and leave the others waiting in the set-up exchange)
+    for (int p = 0; p < P; ++p)
+        if (wsa[p + 1] <= wsa[p])
+            return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_create_from_coo: block %d of %d owns no rows (work_sharing_arr %d .. %d) -- fewer ranks or another "
+                               "partition (the reference's seg methods only repair an empty LAST block, code/mpi_funcs.hpp:602-606)", p, P, (int)wsa[p], (int)wsa[p + 1]);
     if (int rc = uspmv_dev::require_device()) return rc;
     uspmv_scs_t *scs = nullptr;
     uspmv_halo_t *halo = nullptr;
