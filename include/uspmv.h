@@ -485,7 +485,9 @@ int uspmv_dist_run(uspmv_dist_t *d, void *d_x, void *d_y, int n_steps, int use_g
  * row's FMA chain is the one-part step's (bit-identical Y).  Column-wise X: the interior part re-lays out the local rows into the
  * handle's row-major workspace, the boundary part the halo rows once they are there.  uspmv_dist_set_option(d, "block_plan", b)
  * builds the phased block plan of uspmv_dmat_optimize_block on the rank's matrix (64-byte X rows) together with the
- * interior / boundary classes of its tiles; uspmv_dist_set_option(d, "overlap", 0) restores exchange-then-compute. */
+ * interior / boundary classes of its tiles; uspmv_dist_set_option(d, "overlap", 0) restores exchange-then-compute.
+ * With USPMV_EXCHANGE_HOST the same wire formats travel through pinned host memory and the transport's all-to-all-v (tests: real ranks
+ * sharing one GPU on unequal blocks). */
 typedef enum { USPMV_BULKVEC = 0, USPMV_MULTIVEC = 1, USPMV_SINGLEVEC = 2 } uspmv_vecmode;
 int uspmv_dist_spmmv(uspmv_dist_t *d, void *d_X, void *d_Y, int b, int layout, int mode, int comm_halos, void *stream);
 /* Padding tiles of the single-vector step (tile lists, "pad_split" 1; an option, off by default -- see DESIGN 6.4 for the A/B).  The reference pads chunks with (value +0, column 0);

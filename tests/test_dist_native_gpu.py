@@ -457,9 +457,35 @@ def _fuzz_worker(rank, world, q, job, n_cases, seed0):
                 x = d.new_x(xg[wsa[rank]:wsa[rank + 1]]); y = d.new_y()
                 d.spmv(x, y); d.spmv(x, y); d.synchronize()
                 assert np.array_equal(d.y_to_original_order(y)[:nl], want), (case, kind, n, C_, sigma, method, overlap, pad, fused)
+            # block vectors on the same partition: message patterns x layouts, exchange-then-compute and the two-part step, gather kernels
+            # and (dp b = 8, C 32 | 64) the phased block plan -- per column against the oracle's single-rank product
+            d.set_option("pad_split", 0); d.set_option("fused_step", 0)
+            b = int(rng.choice([2, 3, 4, 8, 8]))
+            ld = d.padded_vec_size
+            Xo = [xg[wsa[rank]:wsa[rank + 1]] * (1.0 + v / 8.0) for v in range(b)]
+            wants = []
+            for v in range(b):
+                xv = np.zeros(sg.n_rows_padded); xv[:n] = pkg.apply_permutation(xg * (1.0 + v / 8.0), ag["new_to_old_idx"])
+                yv = orc.spmv_scs(C_, sg.n_chunks, ag["chunk_ptrs"], ag["chunk_lengths"], ag["col_idxs"], ag["values"], xv)
+                wants.append(pkg.apply_permutation(yv, ag["old_to_new_idx"])[:n][wsa[rank]:wsa[rank + 1]])
+            for plan in ((0, b) if (b == 8 and C_ in (32, 64)) else (0,)):
+                if plan: d.set_option("block_plan", plan)
+                for overlap in (1, 0):
+                    d.set_option("overlap", overlap)
+                    for layout, mode in ((pkg.COLWISE, 0), (pkg.COLWISE, 1), (pkg.COLWISE, 2), (pkg.ROWWISE, 0)):
+                        X = d.new_X(Xo, b, layout)
+                        Y = torch.full((b * ld,), 7.0, dtype=torch.float64, device="cuda")
+                        d.spmmv(X, Y, b, layout, mode); d.synchronize()
+                        Yh = Y.cpu().numpy()
+                        for v in range(b):
+                            col = Yh[v:d.n_rows_padded * b:b] if layout == pkg.ROWWISE else Yh[v * ld:v * ld + d.n_rows_padded]
+                            got = pkg.apply_permutation(np.ascontiguousarray(col), d.old_to_new)[:nl]
+                            assert np.array_equal(got, wants[v]), (case, kind, n, C_, sigma, method, "spmmv", b, plan, overlap, layout, mode, v)
             d.barrier()
             d.close()
             done.append((kind, n, C_, sigma, method))
+            if rank == 0:
+                print(f"[fuzz] case {case}: {kind} n={n} C={C_} sigma={sigma} {method} b={b} ok", flush=True)
         hc.close()
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
@@ -475,7 +501,7 @@ def test_random_matrices_real_ranks_every_step_form(pkg):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     job = f"fz{os.getpid()}_{time.monotonic_ns()}"
-    procs = [ctx.Process(target=_fuzz_worker, args=(r, world, q, job, n_cases, 424200)) for r in range(world)]
+    procs = [ctx.Process(target=_fuzz_worker, args=(r, world, q, job, n_cases, int(os.environ.get("USPMV_FUZZ_DIST_SEED", "424200")))) for r in range(world)]
     for p in procs:
         p.start()
     res = []

@@ -83,6 +83,7 @@ struct uspmv_dist {
         int32_t *d_src = nullptr;                    // wire order of the send buffer: send[i] = X[d_src[i]]
         std::vector<int32_t *> d_unpack;             // staged receive (bulk, column-wise): per vector, halo slot -> position in d_recv
         void *d_send = nullptr, *d_recv = nullptr;
+        void *h_send = nullptr, *h_recv = nullptr;   // pinned staging of USPMV_EXCHANGE_HOST
     };
     std::vector<BlockPlan> block_plans;
     std::vector<int32_t> h_send_idxs, h_perm;        // host copies for building those plans
@@ -383,6 +384,8 @@ void uspmv_dist_free(uspmv_dist_t *D) {
     drop_graph(D);
     for (auto &bp : D->block_plans) {
         (void)hipFree(bp.d_src); (void)hipFree(bp.d_send); (void)hipFree(bp.d_recv);
+        if (bp.h_send) (void)hipHostFree(bp.h_send);
+        if (bp.h_recv) (void)hipHostFree(bp.h_recv);
         for (int32_t *u : bp.d_unpack) (void)hipFree(u);
     }
     (void)hipFree(D->d_send_idxs); (void)hipFree(D->d_perm); (void)hipFree(D->d_int); (void)hipFree(D->d_bnd); (void)hipFree(D->d_send); (void)hipFree(D->d_scratch);
@@ -878,6 +881,34 @@ int exchange_block(uspmv_dist *D, void *d_X, int b, int layout, int mode, hipStr
         if (int rc = uspmv_apply_permutation_dev(bp->d_send, d_X, bp->d_src, ns * b, D->dtype, st)) return rc;
     char *X = (char *)d_X;
     const char *S = (const char *)bp->d_send;
+    if (D->host_exchange) {
+        // USPMV_EXCHANGE_HOST: the same wire formats staged through pinned host memory and the transport's all-to-all-v, so that real
+        // ranks sharing one GPU exercise the block plans on unequal blocks and asymmetric lists (tests); the host waits for the pack
+        const int64_t nh = D->n_halo;
+        if (!bp->h_send) {
+            HIP_TRY(hipHostMalloc(&bp->h_send, vsz * (size_t)std::max<int64_t>(ns * b, 1), hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc(&bp->h_recv, vsz * (size_t)std::max<int64_t>(nh * b, 1), hipHostMallocDefault));
+        }
+        if (ns * b > 0) HIP_TRY(hipMemcpyAsync(bp->h_send, bp->d_send, (size_t)(ns * b) * vsz, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<int64_t> so((size_t)D->P + 1), ro((size_t)D->P + 1);
+        if (mode == USPMV_BULKVEC) {                         // one message per neighbour: b * count elements
+            for (int p = 0; p <= D->P; ++p) { so[(size_t)p] = D->send_off[(size_t)p] * b * (int64_t)vsz; ro[(size_t)p] = D->recv_off[(size_t)p] * b * (int64_t)vsz; }
+            if (int rc = D->tr.alltoallv(D->tr.ctx, bp->h_send, so.data(), bp->h_recv, ro.data())) return rc;
+            char *R = layout == USPMV_ROWWISE ? X + (size_t)D->n_local * b * vsz : (char *)bp->d_recv;
+            if (nh * b > 0) HIP_TRY(hipMemcpyAsync(R, bp->h_recv, (size_t)(nh * b) * vsz, hipMemcpyHostToDevice, st));
+            if (layout == USPMV_COLWISE && nh)
+                for (int v = 0; v < b; ++v)
+                    if (int rc = uspmv_apply_permutation_dev(X + (size_t)(v * ld + D->n_local) * vsz, bp->d_recv, bp->d_unpack[(size_t)v], nh, D->dtype, st)) return rc;
+            return USPMV_OK;
+        }
+        for (int p = 0; p <= D->P; ++p) { so[(size_t)p] = D->send_off[(size_t)p] * (int64_t)vsz; ro[(size_t)p] = D->recv_off[(size_t)p] * (int64_t)vsz; }
+        for (int v = 0; v < b; ++v) {                        // per-vector messages (multivec and singlevec differ in posting order only)
+            if (int rc = D->tr.alltoallv(D->tr.ctx, (const char *)bp->h_send + (size_t)(v * ns) * vsz, so.data(), (char *)bp->h_recv + (size_t)(v * nh) * vsz, ro.data())) return rc;
+            if (nh) HIP_TRY(hipMemcpyAsync(X + (size_t)(v * ld + D->n_local) * vsz, (const char *)bp->h_recv + (size_t)(v * nh) * vsz, (size_t)nh * vsz, hipMemcpyHostToDevice, st));
+        }
+        return USPMV_OK;
+    }
     auto group = [&](int v0, int v1) -> int {                // per-vector messages of vectors [v0, v1)
         NCCL_TRY(ncclGroupStart());
         for (int v = v0; v < v1; ++v)
@@ -919,7 +950,6 @@ extern "C" int uspmv_dist_spmmv(uspmv_dist_t *D, void *d_X, void *d_Y, int b, in
         return uspmv::fail(USPMV_ERR_UNSUPPORTED, "uspmv_dist_spmmv: row-wise block vectors travel in one message per neighbour (bulkvec) only");
     hipStream_t main = (hipStream_t)stream;
     if (!(D->P > 1 && comm_halos)) return uspmv_spmmv(D->A, d_X, d_Y, b, D->vec_len, layout, stream);
-    if (D->host_exchange) return uspmv::fail(USPMV_ERR_UNSUPPORTED, "uspmv_dist_spmmv: block vectors are exchanged on RCCL only (USPMV_EXCHANGE_HOST is the single-vector test transport)");
     // (a handle whose only block plan is the one-list-per-tile one runs that plan's kernels on the whole matrix: they are ahead of the
     //  gather kernels by more than the exchange costs)
     if (!(D->overlap && D->parts && !D->A->alt) || (D->A->bt && !(D->A->pb && D->A->part_len[1][0]))) {
