@@ -239,6 +239,43 @@ int uspmv_run_distributed(const DistConfig &c) {
         publish(std::string(dump) + "." + std::to_string(rank), yo.data(), yo.size() * 8);
     }
 
+    // ---- solve mode (-mode s): COMM - spmv - SWAP, -rev times (code/main.cpp:528-607; the last swap is undone by reading y), y of the
+    //      local rows in original order to <dump_y>.<rank>, the optional bitwise self-check, no timing
+    if (c.mode == 's') {
+        double *sx = d_x, *sy = d_y;
+        for (unsigned long i = 0; i < c.n_repetitions; ++i) {
+            CK(uspmv_dist_spmv(D, sx, sy, comm_halos, st));
+            if (i + 1 < c.n_repetitions) std::swap(sx, sy);
+        }
+        HK(hipStreamSynchronize(st));
+        if (!c.dump_y.empty()) {
+            std::vector<double> hy((size_t)n_pad), yo((size_t)n_local);
+            HK(hipMemcpy(hy.data(), sy, sizeof(double) * hy.size(), hipMemcpyDeviceToHost));
+            CK(uspmv_apply_permutation(yo.data(), hy.data(), o2n, n_local, USPMV_F64));
+            publish(c.dump_y + "." + std::to_string(rank), yo.data(), yo.size() * 8);
+        }
+        int64_t mm = -1, tot = -1;
+        if (c.check_y && comm_halos) {
+            CK(uspmv_dist_check(D, local, wsa.data(), d_x, d_y, 0, st, &mm, nullptr));
+            std::vector<int64_t> all((size_t)std::max(P, comm_size), 0);
+            CK(uspmv_dist_allgather_i64(D, mm, all.data(), st));
+            tot = 0;
+            for (int p = 0; p < (meta[8] ? 1 : comm_size); ++p) tot += all[(size_t)p];
+        }
+        uspmv_coo_free(local);
+        if (rank == 0)
+            printf("solve mode: %lu revision(s) done on %d ranks%s%s\n", c.n_repetitions, P, meta[8] ? " (loopback)" : "",
+                   tot < 0 ? "" : tot == 0 ? ", y checked bitwise on every rank: ok" : ", y CHECK FAILED");
+        CK(uspmv_dist_barrier(D, st));
+        (void)hipFree(d_x); (void)hipFree(d_y);
+        uspmv_dist_free(D);
+        (void)hipStreamDestroy(st);
+        uspmv_hostcomm_t *hcs = g.hc;
+        g.hc = nullptr;
+        uspmv_hostcomm_free(hcs);
+        return tot > 0 ? 3 : 0;
+    }
+
     // ---- the arrangement of the step (-step_form): fixed, or the fastest of the candidates on this machine
     std::string form = c.step_form, form_report;
     const bool legacy_knobs = c.no_overlap || getenv("USPMV_PAD_SPLIT") || getenv("USPMV_FUSED_STEP");

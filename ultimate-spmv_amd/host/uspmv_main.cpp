@@ -397,9 +397,13 @@ int run(const Config &c, uspmv_coo_t *coo) {
 int main(int argc, char **argv) {
     Config c = parse(argc, argv);
     if (uspmv_dist_requested()) {  // one process per GPU, halo exchange on RCCL (uspmv_dist.cpp)
-        if (c.mode != 'b' || c.kernel_format != "scs" || c.value_type != "dp")
-            die("multi-rank runs support `scs -dp -mode b` (single vector or -block_vec_size b) in this round "
+        if (c.value_type != "dp")
+            die("multi-rank runs are -dp (single vector or -block_vec_size b, crs or scs, -mode b or s) "
                 "(the reference also refuses ap with MPI, code/utilities.hpp:1443-1450)");
+        if (c.mode == 's' && c.block_vec_size > 1) die("multi-rank solve mode takes a single vector.");
+        // crs across ranks: the reference's C = 1, sigma = 1 struct (code/utilities.hpp:1420-1424) on the SELL kernels -- every row still the
+        // entry-ordered FMA chain (the single-rank crs kernel reassociates like the reference's omp simd loop)
+        if (c.kernel_format == "crs") { c.chunk_size = 1; c.sigma = 1; }
         if (c.layout == USPMV_ROWWISE && c.vec_mode != USPMV_BULKVEC) die("row-wise block vectors are exchanged in bulkvec mode only.");
         DistConfig d;
         d.C = c.chunk_size; d.sigma = c.sigma; d.seg_nnz = c.seg_method == "seg-nnz"; d.comm_halos = c.comm_halos != 0;
@@ -410,6 +414,7 @@ int main(int argc, char **argv) {
         d.use_graph = c.use_graph != 0; d.print_comm_vol = c.print_comm_vol != 0; d.no_pack = c.no_pack != 0;
         d.no_overlap = getenv("USPMV_NO_OVERLAP") != nullptr;
         d.step_form = c.step_form;
+        d.mode = c.mode; d.n_repetitions = c.n_repetitions; d.dump_y = c.dump_y;
         d.bench_steps = c.bench_steps; d.bench_warmup = c.bench_warmup; d.check_y = c.check_y != 0; d.json = c.json;
         if (c.equilibrate) die("-equilibrate is a single-rank option in this round");
         // (-par_pack: on the device the send buffer is packed by one kernel either way, as in the reference's device branch, code/classes_structs.hpp:787-806)
