@@ -599,36 +599,51 @@ def test_cli_real_ranks_host_exchange_mtx_scatter_and_check(pkg, tmp_path):
 
 
 def test_cli_solve_mode_and_crs_across_real_ranks(pkg, orc, tmp_path):
-    """`uspmv bcsstk13.mtx <scs -c 32 -s 512 | crs> -mode s -rev 3 -seg_nnz` as three real rank processes (the multi-rank half of the
-    reference's scripts/validate_master.sh): COMM - spmv - SWAP three times, every rank dumps y of its rows.  Each row is the same
-    entry-ordered chain as in a single-rank run, so the dumps must equal, bit for bit, three applications of the oracle's product to
-    the concatenated per-rank ramps (USPMV_DIST_X=ramp)."""
+    """`uspmv bcsstk13.mtx <scs -c 32 -s 512 | crs> <-dp | -sp> -mode s -rev 3 -seg_nnz` as three real rank processes (the multi-rank
+    half of the reference's scripts/validate_master.sh): COMM - spmv - SWAP three times, every rank dumps y of its rows.  Each row is
+    the same entry-ordered chain as in a single-rank run, so the dumps must equal, bit for bit, three applications of the oracle's
+    product (in the run's precision) to the concatenated per-rank ramps (USPMV_DIST_X=ramp)."""
     tot = pkg.read_mtx(mtx_path("bcsstk13"))
     n, P = tot.n_rows, 3
     wsa = pkg.seg_work_sharing_arr(tot, "seg-nnz", P)
-    xg = np.concatenate([1.0 + 1e-3 * (np.arange(int(wsa[r + 1] - wsa[r])) % 1000) for r in range(P)])
-    s = pkg.convert_to_scs(tot, 32, 512)
-    a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
-    y = xg
-    for _ in range(3):
-        xp = np.zeros(s.n_rows_padded); xp[:n] = pkg.apply_permutation(y, a["new_to_old_idx"])
-        y = pkg.apply_permutation(orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp), a["old_to_new_idx"])[:n]
-    for fmt in (["scs", "-c", "32", "-s", "512"], ["crs"]):
-        pre = str(tmp_path / ("y_" + fmt[0]))
-        procs = []
-        for rank in range(P):
-            env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(P), LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
-                       USPMV_JOB_ID=f"s{os.getpid()}{fmt[0]}", USPMV_HC_TIMEOUT="120", USPMV_DIST_X="ramp")
-            env.pop("USPMV_LOOPBACK", None)
-            procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13")] + fmt + ["-mode", "s", "-rev", "3", "-seg_nnz", "-comm_halos", "1", "-check_y", "1",
-                                           "-dump_y", pre], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-        outs = [p.communicate(timeout=300)[0] for p in procs]
-        for p, o in zip(procs, outs):
-            assert p.returncode == 0, o
-        assert "solve mode: 3 revision(s) done on 3 ranks, y checked bitwise on every rank: ok" in outs[0], outs[0]
-        for rank in range(P):
-            got = np.fromfile(pre + f".{rank}", np.float64)
-            assert np.array_equal(got, y[wsa[rank]:wsa[rank + 1]]), (fmt[0], rank)
+    for prec, code, ndt in (("-dp", pkg.F64, np.float64), ("-sp", pkg.F32, np.float32)):
+        xg = np.concatenate([1.0 + 1e-3 * (np.arange(int(wsa[r + 1] - wsa[r])) % 1000) for r in range(P)]).astype(ndt)
+        s = pkg.convert_to_scs(tot, 32, 512, code)
+        a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
+        y = xg
+        for _ in range(3):
+            xp = np.zeros(s.n_rows_padded, ndt); xp[:n] = pkg.apply_permutation(y, a["new_to_old_idx"])
+            y = pkg.apply_permutation(orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp), a["old_to_new_idx"])[:n]
+        assert y.dtype == ndt
+        for fmt in (["scs", "-c", "32", "-s", "512"], ["crs"]):
+            pre = str(tmp_path / ("y_" + fmt[0] + prec))
+            procs = []
+            for rank in range(P):
+                env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(P), LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
+                           USPMV_JOB_ID=f"s{os.getpid()}{fmt[0]}{prec}", USPMV_HC_TIMEOUT="120", USPMV_DIST_X="ramp")
+                env.pop("USPMV_LOOPBACK", None)
+                procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13")] + fmt + [prec, "-mode", "s", "-rev", "3", "-seg_nnz", "-comm_halos", "1", "-check_y", "1",
+                                               "-dump_y", pre], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+            outs = [p.communicate(timeout=300)[0] for p in procs]
+            for p, o in zip(procs, outs):
+                assert p.returncode == 0, o
+            assert "solve mode: 3 revision(s) done on 3 ranks, y checked bitwise on every rank: ok" in outs[0], outs[0]
+            for rank in range(P):
+                got = np.fromfile(pre + f".{rank}", ndt)
+                assert np.array_equal(got, y[wsa[rank]:wsa[rank + 1]]), (prec, fmt[0], rank)
+    # bench mode in single precision across ranks: the fixed-step protocol with the self-check
+    procs = []
+    for rank in range(P):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(P), LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
+                   USPMV_JOB_ID=f"b{os.getpid()}", USPMV_HC_TIMEOUT="120")
+        env.pop("USPMV_LOOPBACK", None)
+        procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-sp", "-seg_nnz", "-comm_halos", "1", "-bench_steps", "5",
+                                       "-bench_warmup", "2", "-check_y", "1"], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert "y checked bitwise on every rank: ok" in outs[0], outs[0]
+    assert "data_type: float" in open(tmp_path / "spmv_bench.txt").read()
 
 
 def test_cli_loopback_graph_replay_with_ba_synch_and_check(pkg, tmp_path):

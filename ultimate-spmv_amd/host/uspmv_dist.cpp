@@ -179,7 +179,7 @@ int uspmv_run_distributed(const DistConfig &c) {
     const char *stk = getenv("USPMV_SETUP_TRANSPORT");
     const bool setup_on_rccl = stk && !strcmp(stk, "rccl") && !host_exchange;
     if (comm_size == P && P > 1 && !setup_on_rccl) { CK(uspmv_hostcomm_transport(g.hc, &tr)); opt.transport = &tr; }
-    CK(uspmv_dist_create_from_coo_ex(host_exchange ? nullptr : id, comm_rank, comm_size, rank, P, local, wsa.data(), c.C, c.sigma, USPMV_F64, c.tlc ? 1 : 0, &opt, &D));
+    CK(uspmv_dist_create_from_coo_ex(host_exchange ? nullptr : id, comm_rank, comm_size, rank, P, local, wsa.data(), c.C, c.sigma, c.sp ? USPMV_F32 : USPMV_F64, c.tlc ? 1 : 0, &opt, &D));
     if (!c.check_y) { uspmv_coo_free(local); local = nullptr; }
     hipStream_t st = nullptr;
     HK(hipStreamCreate(&st));
@@ -204,21 +204,25 @@ int uspmv_run_distributed(const DistConfig &c) {
     // ---- vectors: x = DefaultValues::x = 5.0 on the local rows (or the test ramp, scaled by 1 + v/8 for vector v), permuted
     //      (code/main.cpp:86-93); 0 elsewhere.  Block vectors: b * padded_vec_size elements, column- or row-wise.
     const int b = c.block_vec_size;
-    double *d_x = nullptr, *d_y = nullptr;
-    HK(hipMalloc((void **)&d_x, sizeof(double) * (size_t)vec_len * b));
-    HK(hipMalloc((void **)&d_y, sizeof(double) * (size_t)vec_len * b));
-    HK(hipMemset(d_y, 0, sizeof(double) * (size_t)vec_len * b));
-    std::vector<double> hx((size_t)vec_len * b, 0.0);
+    const int dtype = c.sp ? USPMV_F32 : USPMV_F64;          // -sp across ranks: float matrix, vectors and exchange (code/main.cpp:1710-1720)
+    const size_t vsz = c.sp ? 4 : 8;
+    char *d_x = nullptr, *d_y = nullptr;
+    HK(hipMalloc((void **)&d_x, vsz * (size_t)vec_len * b));
+    HK(hipMalloc((void **)&d_y, vsz * (size_t)vec_len * b));
+    HK(hipMemset(d_y, 0, vsz * (size_t)vec_len * b));
+    std::vector<char> hx(vsz * (size_t)vec_len * b, 0);
+    auto put = [&](std::vector<char> &buf, size_t k, double v) { if (c.sp) ((float *)buf.data())[k] = (float)v; else ((double *)buf.data())[k] = v; };
+    auto get = [&](const std::vector<char> &buf, size_t k) -> double { return c.sp ? (double)((const float *)buf.data())[k] : ((const double *)buf.data())[k]; };
     {
-        std::vector<double> xo((size_t)n_local), xp((size_t)n_local);
+        std::vector<char> xo(vsz * (size_t)std::max<int64_t>(n_local, 1)), xp(vsz * (size_t)std::max<int64_t>(n_local, 1));
         const char *xk = getenv("USPMV_DIST_X");
         const bool ramp = xk && !strcmp(xk, "ramp");
         for (int v = 0; v < b; ++v) {
-            for (int64_t i = 0; i < n_local; ++i) xo[(size_t)i] = ramp ? (1.0 + 1e-3 * (double)(i % 1000)) * (1.0 + v / 8.0) : 5.0;
-            CK(uspmv_apply_permutation(xp.data(), xo.data(), n2o, n_local, USPMV_F64));
-            for (int64_t i = 0; i < n_local; ++i) hx[(size_t)(c.layout == USPMV_ROWWISE ? i * b + v : (int64_t)v * vec_len + i)] = xp[(size_t)i];
+            for (int64_t i = 0; i < n_local; ++i) put(xo, (size_t)i, ramp ? (1.0 + 1e-3 * (double)(i % 1000)) * (1.0 + v / 8.0) : 5.0);
+            CK(uspmv_apply_permutation(xp.data(), xo.data(), n2o, n_local, dtype));
+            for (int64_t i = 0; i < n_local; ++i) put(hx, (size_t)(c.layout == USPMV_ROWWISE ? i * b + v : (int64_t)v * vec_len + i), get(xp, (size_t)i));
         }
-        HK(hipMemcpy(d_x, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
+        HK(hipMemcpy(d_x, hx.data(), hx.size(), hipMemcpyHostToDevice));
     }
     const int comm_halos = c.comm_halos ? 1 : 0;
     auto steps = [&](int n) {
@@ -230,29 +234,29 @@ int uspmv_run_distributed(const DistConfig &c) {
     if (const char *dump = getenv("USPMV_DUMP_Y")) {   // one step, y of the local rows back in original order (copy_back_result), vector after vector
         steps(1);
         HK(hipStreamSynchronize(st));
-        std::vector<double> hy((size_t)vec_len * b), col((size_t)n_pad), yo((size_t)n_local * b);
-        HK(hipMemcpy(hy.data(), d_y, sizeof(double) * hy.size(), hipMemcpyDeviceToHost));
+        std::vector<char> hy(vsz * (size_t)vec_len * b), col(vsz * (size_t)std::max<int64_t>(n_pad, 1)), yo(vsz * (size_t)std::max<int64_t>(n_local * b, 1));
+        HK(hipMemcpy(hy.data(), d_y, hy.size(), hipMemcpyDeviceToHost));
         for (int v = 0; v < b; ++v) {
-            for (int64_t i = 0; i < n_pad; ++i) col[(size_t)i] = hy[(size_t)(c.layout == USPMV_ROWWISE ? i * b + v : (int64_t)v * vec_len + i)];
-            CK(uspmv_apply_permutation(yo.data() + (size_t)v * n_local, col.data(), o2n, n_local, USPMV_F64));
+            for (int64_t i = 0; i < n_pad; ++i) put(col, (size_t)i, get(hy, (size_t)(c.layout == USPMV_ROWWISE ? i * b + v : (int64_t)v * vec_len + i)));
+            CK(uspmv_apply_permutation(yo.data() + vsz * (size_t)v * n_local, col.data(), o2n, n_local, dtype));
         }
-        publish(std::string(dump) + "." + std::to_string(rank), yo.data(), yo.size() * 8);
+        publish(std::string(dump) + "." + std::to_string(rank), yo.data(), vsz * (size_t)n_local * b);
     }
 
     // ---- solve mode (-mode s): COMM - spmv - SWAP, -rev times (code/main.cpp:528-607; the last swap is undone by reading y), y of the
     //      local rows in original order to <dump_y>.<rank>, the optional bitwise self-check, no timing
     if (c.mode == 's') {
-        double *sx = d_x, *sy = d_y;
+        char *sx = d_x, *sy = d_y;
         for (unsigned long i = 0; i < c.n_repetitions; ++i) {
             CK(uspmv_dist_spmv(D, sx, sy, comm_halos, st));
             if (i + 1 < c.n_repetitions) std::swap(sx, sy);
         }
         HK(hipStreamSynchronize(st));
         if (!c.dump_y.empty()) {
-            std::vector<double> hy((size_t)n_pad), yo((size_t)n_local);
-            HK(hipMemcpy(hy.data(), sy, sizeof(double) * hy.size(), hipMemcpyDeviceToHost));
-            CK(uspmv_apply_permutation(yo.data(), hy.data(), o2n, n_local, USPMV_F64));
-            publish(c.dump_y + "." + std::to_string(rank), yo.data(), yo.size() * 8);
+            std::vector<char> hy(vsz * (size_t)std::max<int64_t>(n_pad, 1)), yo(vsz * (size_t)std::max<int64_t>(n_local, 1));
+            HK(hipMemcpy(hy.data(), sy, vsz * (size_t)n_pad, hipMemcpyDeviceToHost));
+            CK(uspmv_apply_permutation(yo.data(), hy.data(), o2n, n_local, dtype));
+            publish(c.dump_y + "." + std::to_string(rank), yo.data(), vsz * (size_t)n_local);
         }
         int64_t mm = -1, tot = -1;
         if (c.check_y && comm_halos) {
@@ -317,7 +321,7 @@ int uspmv_run_distributed(const DistConfig &c) {
             CK(uspmv_dist_allgather_i64(D, mm, all.data(), st));
             int64_t tot = 0;
             for (int p = 0; p < (meta[8] ? 1 : comm_size); ++p) tot += all[(size_t)p];
-            HK(hipMemcpy(d_x, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
+            HK(hipMemcpy(d_x, hx.data(), hx.size(), hipMemcpyHostToDevice));
             if (tot) {
                 if (rank == 0) fprintf(stderr, "step form %s failed the self-check on this machine (%ld rows): not used\n", form.c_str(), (long)tot);
                 const size_t po = form_report.find("\"plain\": "), oo = form_report.find("\"overlap\": ");
@@ -398,7 +402,7 @@ int uspmv_run_distributed(const DistConfig &c) {
         CK(uspmv_dist_allgather_i64(D, mism, all.data(), st));
         mism_total = 0;
         for (int p = 0; p < (meta[8] ? 1 : comm_size); ++p) mism_total += all[(size_t)p];
-        HK(hipMemcpy(d_x, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
+        HK(hipMemcpy(d_x, hx.data(), hx.size(), hipMemcpyHostToDevice));
         if (mism) fprintf(stderr, "[rank %d] CHECK FAILED: %ld of %ld local rows differ from the entry-ordered FMA chains\n", rank, (long)mism, (long)n_local);
     }
     uspmv_coo_free(local);
@@ -412,10 +416,10 @@ int uspmv_run_distributed(const DistConfig &c) {
     CK(uspmv_runtime_versions(ver));
     const char *protocol = c.bench_steps > 0 ? "fixed steps between barriers" : "reference bench loop (doubling batches)";
     if (comm_rank == 0) {
-        const double bytes = n_el * 12.0 + 8.0 * n_chunks + 8.0 * b * (n_local + n_halo) + 8.0 * b * n_pad;  // this rank's share
+        const double bytes = n_el * (vsz + 4.0) + 8.0 * n_chunks + (double)vsz * b * (n_local + n_halo) + (double)vsz * b * n_pad;  // this rank's share
         std::ofstream f("spmv_bench.txt", std::ios::app);
         f << c.matrix_name << " with " << P << " RCCL ranks (one per GPU), halo exchange " << (c.comm_halos ? "on" : "off") << std::endl;
-        f << "kernel: scs, block_vec_size: " << b << ", C: " << c.C << " sigma: " << c.sigma << ", data_type: double, revisions: " << n_iter
+        f << "kernel: scs, block_vec_size: " << b << ", C: " << c.C << " sigma: " << c.sigma << ", data_type: " << (c.sp ? "float" : "double") << ", revisions: " << n_iter
           << ", seg_method: " << (c.seg_metis ? "seg-metis" : c.seg_nnz ? "seg-nnz" : "seg-rows") << ", MPI_mode: " << (b == 1 || c.vec_mode == USPMV_SINGLEVEC ? "singlevec" : c.vec_mode == USPMV_MULTIVEC ? "multivec" : "bulkvec")
           << ", ba_synch: " << (c.ba_synch && c.comm_halos ? 1 : 0) << std::endl << std::endl;
         char buf[256];

@@ -19,6 +19,7 @@ struct DistConfig {
     // the padding-only tiles in front of the exchange; fused = pad in one launch (eager steps only); auto = time each for a few steps
     // on THIS machine, all ranks agreeing on the slowest rank's clock, and keep the fastest (all forms give the same bits).
     std::string step_form = "auto";
+    bool sp = false;                           // -sp: single precision matrix, vectors and exchange
     char mode = 'b';                           // -mode s: the reference's COMM-spmv-SWAP loop (code/main.cpp:528-607), -rev iterations, no timing
     unsigned long n_repetitions = 1;
     std::string dump_y;                        // -dump_y <file>: every rank writes y of its rows (original order, raw doubles) to <file>.<rank>

@@ -397,8 +397,8 @@ int run(const Config &c, uspmv_coo_t *coo) {
 int main(int argc, char **argv) {
     Config c = parse(argc, argv);
     if (uspmv_dist_requested()) {  // one process per GPU, halo exchange on RCCL (uspmv_dist.cpp)
-        if (c.value_type != "dp")
-            die("multi-rank runs are -dp (single vector or -block_vec_size b, crs or scs, -mode b or s) "
+        if (c.value_type != "dp" && c.value_type != "sp")
+            die("multi-rank runs are -dp or -sp (single vector or -block_vec_size b, crs or scs, -mode b or s) "
                 "(the reference also refuses ap with MPI, code/utilities.hpp:1443-1450)");
         if (c.mode == 's' && c.block_vec_size > 1) die("multi-rank solve mode takes a single vector.");
         // crs across ranks: the reference's C = 1, sigma = 1 struct (code/utilities.hpp:1420-1424) on the SELL kernels -- every row still the
@@ -414,7 +414,7 @@ int main(int argc, char **argv) {
         d.use_graph = c.use_graph != 0; d.print_comm_vol = c.print_comm_vol != 0; d.no_pack = c.no_pack != 0;
         d.no_overlap = getenv("USPMV_NO_OVERLAP") != nullptr;
         d.step_form = c.step_form;
-        d.mode = c.mode; d.n_repetitions = c.n_repetitions; d.dump_y = c.dump_y;
+        d.mode = c.mode; d.n_repetitions = c.n_repetitions; d.dump_y = c.dump_y; d.sp = c.value_type == "sp";
         d.bench_steps = c.bench_steps; d.bench_warmup = c.bench_warmup; d.check_y = c.check_y != 0; d.json = c.json;
         if (c.equilibrate) die("-equilibrate is a single-rank option in this round");
         // (-par_pack: on the device the send buffer is packed by one kernel either way, as in the reference's device branch, code/classes_structs.hpp:787-806)
