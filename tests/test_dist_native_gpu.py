@@ -497,7 +497,7 @@ def test_random_matrices_real_ranks_every_step_form(pkg):
     """Random matrices, chunk heights, sorting scopes and partitions (seg-rows / seg-nnz: unequal blocks, asymmetric lists, ranks without
     neighbours) with three real processes on one GPU (host-staged exchange): every arrangement of the step gives, bit for bit, the rows of
     the oracle's single-rank product.  USPMV_FUZZ_DIST_CASES raises the number of matrices."""
-    world, n_cases = 3, int(os.environ.get("USPMV_FUZZ_DIST_CASES", "6"))
+    world, n_cases = 3, int(os.environ.get("USPMV_FUZZ_DIST_CASES", "3"))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     job = f"fz{os.getpid()}_{time.monotonic_ns()}"
