@@ -281,7 +281,9 @@ int uspmv_apply_permutation_dev(void *d_out, const void *d_in, const int32_t *d_
  *   "tlc_tile_rows" 0|256|512|1024 rows (= threads) per tile of the NEXT uspmv_dmat_optimize[_ap|_device|_device_ap]
  *   (0 = 256 for one struct, 512 for an ap[dp_sp] pair), "tlc_auto_tile" 1|0: with "tlc_tile_rows" 0 and one struct, take
  *   1024- or 512-row tiles instead when the largest 256-row tile needs more than 250 x lines and the larger tiles stage >= 99 %
- *   of the tiles (same y bits; measured in profiles/r03/tile_rows_sweep.txt),
+ *   of the tiles (same y bits; measured in profiles/r03/tile_rows_sweep.txt), "tlc_measure_tile" 1|0: structs of >= 2^20 padded rows get
+ *   the tile size that MEASURES fastest (plans for 256 / 512 / 1024 rows built on the device, three timed launches each, once per matrix
+ *   shape and process),
  *   "spmmv_variant" 0 (auto) | 1 (generic) | 2 (row-major, transposing X phase) | 3 (row-major, lane per row)
  *                   | 4 (single-wave block-plan tiles) | 5 (3 over the plan's tie-re-ordered copy) | 6 (four lanes per row, 64-byte rows)
  *                   | 8 (four lanes per row over the phased plan; what auto picks for 64-byte rows),

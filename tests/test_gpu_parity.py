@@ -294,6 +294,37 @@ def test_tile_rows_follow_the_lines_a_tile_needs(pkg, orc, torch_cuda):
         assert np.array_equal(y.cpu().numpy(), yo)
 
 
+def test_measured_tile_rows_on_a_large_struct(pkg, orc, torch_cuda):
+    """Structs of >= 2^20 padded rows: the rows per tile are measured (plans for 256 / 512 / 1024 rows built on the device, the kernel timed,
+    a larger tile kept when > 4 % ahead; uspmv_api.hip measured_tile_rows).  Whatever wins, the host and the device planner of the same
+    matrix agree (the choice is remembered per shape), the plans are identical, y has the reference's bits; "tlc_measure_tile" 0 gives the
+    rule-based 256 rows."""
+    t = torch_cuda
+    m = pkg.gen_stencil27(104, 104, 104)                      # 1 124 864 rows
+    s, a, xp = _prep(pkg, m, 32, 512, pkg.F64, make_x(m.n_rows))
+    assert s.n_rows_padded >= 1 << 20
+    yo = orc.spmv_scs(s.C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+    Ah = pkg.DeviceMatrix(s); Ah.optimize(s)
+    Ad = pkg.DeviceMatrix(s); Ad.optimize_device()
+    assert C_tile_rows(pkg, Ah) == C_tile_rows(pkg, Ad) and C_tile_rows(pkg, Ah) in (256, 512, 1024)
+    ph, pd = Ah.plan_download(), Ad.plan_download()
+    for k in ("tile_line_ptr", "tile_lines", "c16_ptrs", "col16"):
+        assert np.array_equal(ph[k], pd[k]), k
+    for A in (Ah, Ad):
+        y = t.full((s.n_rows_padded,), 3.0, dtype=t.float64, device="cuda")
+        pkg.spmv(A, _dev(t, xp), y)
+        assert np.array_equal(y.cpu().numpy(), yo)
+    pkg.set_tuning(tlc_measure_tile=0)
+    try:
+        A0 = pkg.DeviceMatrix(s); A0.optimize_device()
+    finally:
+        pkg.set_tuning(tlc_measure_tile=1)
+    assert C_tile_rows(pkg, A0) == 256
+    y = t.full((s.n_rows_padded,), 3.0, dtype=t.float64, device="cuda")
+    pkg.spmv(A0, _dev(t, xp), y)
+    assert np.array_equal(y.cpu().numpy(), yo)
+
+
 def test_device_plan_builder_matches_host_planner(pkg, orc, torch_cuda):
     """uspmv_dmat_optimize_device: the plan built on the GPU from the handle's arrays equals the host planner's
     (line lists, 16-bit indices) and the SpMV on it is bit-exact; also on handles made by convert_to_scs_device and

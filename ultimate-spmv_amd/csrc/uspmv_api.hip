@@ -190,6 +190,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "tlc")) g_tune.tlc = value != 0;
     else if (!strcmp(key, "rechunk")) g_tune.rechunk = value != 0;
     else if (!strcmp(key, "tlc_auto_tile")) g_tune.tlc_auto_tile = value != 0;
+    else if (!strcmp(key, "tlc_measure_tile")) g_tune.tlc_measure_tile = value != 0;
     else if (!strcmp(key, "tlc_tile_rows")) {
         if (value != 0 && value != 256 && value != 512 && value != 1024) return uspmv::fail(USPMV_ERR_INVALID, "tlc_tile_rows must be 0|256|512|1024");
         g_tune.tlc_tile_rows = value;
@@ -248,6 +249,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "rechunk")) *value = g_tune.rechunk;
     else if (!strcmp(key, "tlc_tile_rows")) *value = g_tune.tlc_tile_rows;
     else if (!strcmp(key, "tlc_auto_tile")) *value = g_tune.tlc_auto_tile;
+    else if (!strcmp(key, "tlc_measure_tile")) *value = g_tune.tlc_measure_tile;
     else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_get_tuning: unknown key '%s'", key);
     return USPMV_OK;
 }
@@ -398,6 +400,61 @@ static int plan_tile_rows(bool ap) { return g_tune.tlc_tile_rows ? g_tune.tlc_ti
 static bool tile_rows_grow(int rows, int lines_used) { return g_tune.tlc_auto_tile && g_tune.tlc_tile_rows == 0 && rows == 256 && lines_used > 250; }
 static bool tile_rows_accept(int64_t n_tiles, int64_t n_staged) { return n_staged * 100 >= n_tiles * 99; }
 
+static int device_plan_install_rows(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, int R, int64_t *n_tiles, int64_t *n_staged, const char *who);
+
+// For LARGE single structs the rows per tile are MEASURED (tuning tlc_measure_tile, default on; only when tlc_tile_rows is 0): the plan
+// is built on the device for 256, 512 and 1024 rows (two passes over the column indices each), the kernel timed three times on a zero
+// vector, and a larger tile kept when it is more than 4 % ahead of 256.  Why: which size wins depends on how far apart the x lines of
+// neighbouring tiles lie -- the 27-point stencil on 253^3 is fastest at 256 rows, the same stencil on 304^3 (planes of 739 instead of
+// 512 KB: more of the x lines miss the XCD's L2) at 512 (1.249 against 1.341 ms, profiles/r03/tile_rows_sweep.txt).  The choice is
+// remembered per (shape, size) for the life of the process, so the host and the device planner of one matrix agree.  0 = no opinion.
+static int measured_tile_rows(uspmv_dmat_t *A, int max_lines, const char *who) {
+    if (!g_tune.tlc_measure_tile || g_tune.tlc_tile_rows != 0 || A->alt || A->C > 256 || 256 % A->C != 0) return 0;
+    if (A->n_chunks * A->C < (int64_t)1 << 20) return 0;
+    struct Key { int64_t nc, ne, C; int dtype, ml; };
+    static std::vector<std::pair<Key, int>> seen;
+    for (auto &kv : seen)
+        if (kv.first.nc == A->n_chunks && kv.first.ne == A->n_elements && kv.first.C == A->C && kv.first.dtype == A->dtype && kv.first.ml == max_lines) return kv.second;
+    const size_t vsz = A->dtype == USPMV_F64 ? 8 : 4;
+    void *x = nullptr, *y = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int best = 0;
+    float t256 = 0, tbest = 0;
+    auto done = [&]() {
+        (void)hipFree(x); (void)hipFree(y);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (A->tlc) tlc_release(A);
+    };
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { done(); (void)hipGetLastError(); return 0; }
+    for (int R : {256, 512, 1024}) {
+        int64_t nt = 0, ns = 0;
+        if (device_plan_install_rows(A, nullptr, max_lines, R, &nt, &ns, who) != USPMV_OK || !A->tlc) { (void)hipGetLastError(); continue; }
+        if (!tile_rows_accept(nt, ns)) continue;
+        if (!x) {
+            const size_t xb = vsz * (size_t)std::max<int64_t>(A->tlc_x_len + 16, 16), yb = vsz * (size_t)std::max<int64_t>(A->n_chunks * A->C, 1);
+            if (hipMalloc(&x, xb) != hipSuccess || hipMalloc(&y, yb) != hipSuccess || hipMemset(x, 0, xb) != hipSuccess) { done(); (void)hipGetLastError(); return 0; }
+        }
+        float ms = 0;
+        bool ok = true;
+        for (int rep = 0; rep < 2 && ok; ++rep) {             // (first round warms up)
+            ok = hipEventRecord(e0, nullptr) == hipSuccess;
+            for (int k = 0; k < 3 && ok; ++k)
+                ok = (A->dtype == USPMV_F64 ? launch_spmv_tlc<double>(A, nullptr, (long)A->tlc_n_tiles, (const double *)x, (double *)y, nullptr)
+                                            : launch_spmv_tlc<float>(A, nullptr, (long)A->tlc_n_tiles, (const float *)x, (float *)y, nullptr)) == USPMV_OK;
+            ok = ok && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        }
+        if (!ok) { (void)hipGetLastError(); continue; }
+        if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] measured tile size: %d rows -> %.4f ms per SpMV (%lld of %lld tiles staged, %d lines at most)\n", R, ms / 3,
+                                             (long long)ns, (long long)nt, A->tlc_max_lines);
+        if (R == 256) { t256 = ms; best = 256; tbest = ms; }
+        else if (best == 0 || ms < (best == 256 ? 0.96f * t256 : tbest)) { best = R; tbest = ms; }
+    }
+    done();
+    seen.push_back({Key{A->n_chunks, A->n_elements, A->C, A->dtype, max_lines}, best});
+    return best;
+}
+
 int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
     if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: NULL argument");
     if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: layout-only struct; the plan builder needs the host column indices");
@@ -424,8 +481,9 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     const int cap = (int)(160 * 1024 / (16 * (s->dtype == USPMV_F64 ? 8 : 4)));
     if (max_lines > cap) max_lines = cap;
     uspmv_tlc_plan p;
-    if (int rc = uspmv_build_tlc_plan(s, nullptr, max_lines, plan_tile_rows(false), &p)) return rc;
-    if (p.valid && tile_rows_grow(p.tile_rows, p.max_lines_used))
+    const int R_meas = measured_tile_rows(A, max_lines, "uspmv_dmat_optimize");
+    if (int rc = uspmv_build_tlc_plan(s, nullptr, max_lines, R_meas ? R_meas : plan_tile_rows(false), &p)) return rc;
+    if (!R_meas && p.valid && tile_rows_grow(p.tile_rows, p.max_lines_used))
         for (int R : {1024, 512}) {
             uspmv_tlc_plan q;
             if (int rc = uspmv_build_tlc_plan(s, nullptr, max_lines, R, &q)) return rc;
@@ -479,10 +537,12 @@ static bool c16_offsets(const std::vector<int32_t> &cl, int64_t C, std::vector<u
 }
 
 // the tile-local-column plan of A (and of the pair A + B sharing one line list when B != nullptr), built on the device
-static int device_plan_install_rows(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, int R, int64_t *n_tiles, int64_t *n_staged, const char *who);
-
-// ... with the rows per tile chosen as uspmv_dmat_optimize chooses them (tile_rows_grow above)
+// ... with the rows per tile chosen as uspmv_dmat_optimize chooses them (measured_tile_rows / tile_rows_grow above)
 static int device_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, int64_t *n_tiles, int64_t *n_staged, const char *who) {
+    if (!B) {
+        const int ml = std::min(std::min(max_lines <= 0 ? 512 : max_lines, (int)(160 * 1024 / (16 * (A->dtype == USPMV_F64 ? 8 : 4)))), 4096);
+        if (const int R_meas = measured_tile_rows(A, ml, who)) return device_plan_install_rows(A, nullptr, max_lines, R_meas, n_tiles, n_staged, who);
+    }
     const int R0 = plan_tile_rows(B != nullptr);
     if (int rc = device_plan_install_rows(A, B, max_lines, R0, n_tiles, n_staged, who)) return rc;
     if (B || !A->tlc || !tile_rows_grow(R0, A->tlc_max_lines)) return USPMV_OK;

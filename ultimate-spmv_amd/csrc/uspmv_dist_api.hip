@@ -536,7 +536,15 @@ int uspmv_dist_create_from_coo_ex(const void *comm_id, int comm_rank, int comm_s
     if (!rc) rc = uspmv_permute_scs_cols(scs, o2n);
     if (!rc) rc = uspmv_dmat_upload(scs, &A);
     int64_t n_tiles = 0, n_staged = 0;
-    if (!rc && tlc) rc = uspmv_dmat_optimize(A, scs, 0, &n_tiles, &n_staged);
+    if (!rc && tlc) {
+        // (a rank's block keeps the 256-row tiles unless its lines ask for more: larger tiles measured level on a block of the 304^3 stencil
+        //  -- 0.1785 / 0.1791 / 0.1822 ms -- and a 512-row tile = a whole sigma window always holds a padded chunk, i.e. no interior tile is left)
+        int mt = 1;
+        (void)uspmv_get_tuning("tlc_measure_tile", &mt);
+        (void)uspmv_set_tuning("tlc_measure_tile", 0);
+        rc = uspmv_dmat_optimize(A, scs, 0, &n_tiles, &n_staged);
+        (void)uspmv_set_tuning("tlc_measure_tile", mt);
+    }
     int tile_rows = 0;
     if (!rc) rc = uspmv_dmat_tile_rows(A, &tile_rows);
     const int64_t n_local = wsa[rank + 1] - wsa[rank];
