@@ -294,6 +294,34 @@ def test_tile_rows_follow_the_lines_a_tile_needs(pkg, orc, torch_cuda):
         assert np.array_equal(y.cpu().numpy(), yo)
 
 
+def test_device_plan_builder_far_apart_column_clusters(pkg, orc, torch_cuda):
+    """Tiles whose columns form clusters millions of columns apart -- a KKT matrix large enough that states and multipliers lie more than
+    2^20 columns from each other (uspmv_gen_kkt N = 104), with the padding column as a third cluster: the device builder's bitmap works on
+    up to 16 windows of 4 096 lines wherever they lie (csrc/plan_kernels.hip), stages what the host planner stages, and builds the same
+    arrays.  (Before round 3 only clusters at either end of a tile's range were representable: the middle one left such tiles unstaged.)"""
+    t = torch_cuda
+    m = pkg.gen_kkt(104)
+    assert m.n_rows > (1 << 21)
+    pkg.set_tuning(tlc_measure_tile=0)                         # (compare the planners at the rule's tile size, not at a measured one)
+    try:
+        s, a, xp = _prep(pkg, m, 32, 512, pkg.F64, make_x(m.n_rows))
+        span = a["col_idxs"].reshape(-1)
+        assert int(span.max()) - int(span.min()) > (1 << 20)
+        Ah = pkg.DeviceMatrix(s); Ah.optimize(s)
+        Ad = pkg.DeviceMatrix(s); Ad.optimize_device()
+    finally:
+        pkg.set_tuning(tlc_measure_tile=1)
+    assert Ah.plan_info()[0] == 1 and Ah.tlc_staged * 100 >= Ah.tlc_tiles * 99
+    assert (Ad.tlc_tiles, Ad.tlc_staged) == (Ah.tlc_tiles, Ah.tlc_staged) and C_tile_rows(pkg, Ah) == C_tile_rows(pkg, Ad)
+    ph, pd = Ah.plan_download(), Ad.plan_download()
+    for k in ("tile_line_ptr", "tile_lines", "c16_ptrs", "col16"):
+        assert np.array_equal(ph[k], pd[k]), k
+    yo = orc.spmv_scs(s.C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+    y = t.full((s.n_rows_padded,), 3.0, dtype=t.float64, device="cuda")
+    pkg.spmv(Ad, _dev(t, xp), y)
+    assert np.array_equal(y.cpu().numpy(), yo)
+
+
 def test_measured_tile_rows_on_a_large_struct(pkg, orc, torch_cuda):
     """Structs of >= 2^20 padded rows: the rows per tile are measured (plans for 256 / 512 / 1024 rows built on the device, the kernel timed,
     a larger tile kept when > 4 % ahead; uspmv_api.hip measured_tile_rows).  Whatever wins, the host and the device planner of the same

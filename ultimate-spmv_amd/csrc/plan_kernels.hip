@@ -3,10 +3,13 @@
 // col_idxs, one 256-thread workgroup per tile (thread <-> row): the first counts a tile's distinct 16-element
 // x lines with a bitmap in LDS, the second -- after an exclusive scan of those counts on the host (n_tiles
 // integers) -- writes the sorted line list and the 16-bit local indices.  The bitmap covers 65 536 lines: the
-// tile's whole line range when it fits, else the 32 768 lines from its lowest and the 32 768 lines up to its
-// highest line (padding entries carry one far-away column, permute_scs_cols(0): the usual reason for a wide
-// range).  Tiles with lines in between are left unstaged (the host planner sorts those), which changes the plan,
-// never y; everywhere else the plan is identical to the host planner's.
+// tile's whole line range when it fits, else up to 16 WINDOWS of 4 096 lines (65 536 columns) each, wherever they lie -- the tile's
+// distinct windows are collected first (a 16-entry table in LDS, sorted), a line's bit is (its window's rank, line within the window),
+// so bit order is still line order.  That covers tiles whose columns form a few clusters far apart: the padding column 0 next to a
+// band anywhere in the matrix (permute_scs_cols(0)), and saddle-point (KKT) matrices whose rows reach into index ranges millions of
+// columns apart (round 3: before, only one cluster at either end of the range was representable and the KKT matrix of
+// uspmv_gen_kkt came out almost unstaged).  Tiles that need more than 16 windows are left unstaged (the host planner sorts those),
+// which changes the plan, never y; everywhere else the plan is identical to the host planner's.
 #include "uspmv_device.hpp"
 
 using namespace uspmv_dev;
@@ -15,76 +18,85 @@ namespace {
 
 constexpr int PLAN_BITS = 65536;            // lines a tile's bitmap covers
 constexpr int PLAN_WORDS = PLAN_BITS / 32;
-constexpr int PLAN_HALF = PLAN_BITS / 2;
+constexpr int WIN_SHIFT = 12, WIN_LINES = 1 << WIN_SHIFT, NWIN = PLAN_BITS / WIN_LINES;   // 16 windows of 4 096 lines
 
-// line -> bit (or -1: not representable) and back, for a tile with lowest / highest line lo / hi
-__device__ __forceinline__ int line_to_bit(int l, int lo, int hi) {
-    if (hi - lo < PLAN_BITS) return l - lo;
-    if (l - lo < PLAN_HALF) return l - lo;
-    if (hi - l < PLAN_HALF) return PLAN_BITS - 1 - (hi - l);
+// line -> bit (or -1: not representable) and back.  win == nullptr: the tile's whole range [lo, lo + PLAN_BITS) is the bitmap;
+// otherwise win[0 .. nwin) are the tile's window ids (line >> WIN_SHIFT), ascending
+__device__ __forceinline__ int line_to_bit(int l, int lo, const int *win, int nwin) {
+    if (!win) return l - lo;
+    const int w = l >> WIN_SHIFT;
+    for (int k = 0; k < nwin; ++k)
+        if (win[k] == w) return (k << WIN_SHIFT) | (l & (WIN_LINES - 1));
     return -1;
 }
-__device__ __forceinline__ int bit_to_line(int b, int lo, int hi) {
-    if (hi - lo < PLAN_BITS || b < PLAN_HALF) return lo + b;
-    return hi - (PLAN_BITS - 1 - b);
+__device__ __forceinline__ int bit_to_line(int b, int lo, const int *win) {
+    return win ? (win[b >> WIN_SHIFT] << WIN_SHIFT) | (b & (WIN_LINES - 1)) : lo + b;
 }
 
-// Marks the lines of the tile in bits[]; returns (lo line, line range) through LDS scalars.  range = 0: empty tile.
+// Marks the lines of the tile in bits[]; returns (lo line, hi line, window table) through LDS scalars.  *s_hi < 0: empty tile.
+// *s_nwin == 0: contiguous mode (the whole range fits the bitmap); > 0: window mode with s_win[0 .. *s_nwin) sorted.
 // (chunk_ptrs2 != nullptr: a second struct with the same row layout -- the sp part of an ap[dp_sp] pair -- marks the same bitmap)
 __device__ void tile_bitmap(const long n_chunks, const int C, const int *__restrict__ chunk_ptrs,
                             const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const long tile,
-                            unsigned *bits, int *s_lo, int *s_hi, int *s_maxcol, int *s_bad,
+                            unsigned *bits, int *s_lo, int *s_hi, int *s_maxcol, int *s_bad, int *s_win, int *s_nwin,
                             const int rpt, const int *__restrict__ chunk_ptrs2 = nullptr, const int *__restrict__ chunk_lengths2 = nullptr,
                             const int *__restrict__ col_idxs2 = nullptr) {
     // a tile is rpt * 256 rows: thread <-> rows tile*rpt*256 + h*256 + threadIdx.x, h < rpt
-    if (threadIdx.x == 0) { *s_lo = INT32_MAX; *s_hi = -1; *s_bad = 0; }
+    if (threadIdx.x == 0) { *s_lo = INT32_MAX; *s_hi = -1; *s_bad = 0; *s_nwin = 0; }
+    if (threadIdx.x < NWIN) s_win[threadIdx.x] = -1;
     for (int w = threadIdx.x; w < PLAN_WORDS; w += 256) bits[w] = 0u;
     __syncthreads();
-    int lo = INT32_MAX, hi = -1;
-    for (int h = 0; h < rpt; ++h) {
-        const long row = (tile * rpt + h) * 256 + threadIdx.x;
-        const long c = row / C;
-        const int i = (int)(row - c * C);
-        if (c >= n_chunks) continue;
-        const int cs = chunk_ptrs[c], L = chunk_lengths[c];
-        for (int j = 0; j < L; ++j) {
-            const int col = col_idxs[(long)cs + (long)j * C + i];
-            lo = min(lo, col); hi = max(hi, col);
-        }
-        if (chunk_ptrs2) {
-            const int cs2 = chunk_ptrs2[c], L2 = chunk_lengths2[c];
-            for (int j = 0; j < L2; ++j) {
-                const int col = col_idxs2[(long)cs2 + (long)j * C + i];
-                lo = min(lo, col); hi = max(hi, col);
+    // every entry of the tile, twice over: f(column)
+    auto for_each_col = [&](auto &&f) {
+        for (int h = 0; h < rpt; ++h) {
+            const long row = (tile * rpt + h) * 256 + threadIdx.x;
+            const long c = row / C;
+            const int i = (int)(row - c * C);
+            if (c >= n_chunks) continue;
+            const int cs = chunk_ptrs[c], L = chunk_lengths[c];
+            for (int j = 0; j < L; ++j) f(col_idxs[(long)cs + (long)j * C + i]);
+            if (chunk_ptrs2) {
+                const int cs2 = chunk_ptrs2[c], L2 = chunk_lengths2[c];
+                for (int j = 0; j < L2; ++j) f(col_idxs2[(long)cs2 + (long)j * C + i]);
             }
         }
-    }
+    };
+    int lo = INT32_MAX, hi = -1, last_w = -1;
+    bool over = false;
+    for_each_col([&](int col) {
+        lo = min(lo, col); hi = max(hi, col);
+        const int w = col >> (4 + WIN_SHIFT);
+        if (w != last_w) {                         // (consecutive entries of a row mostly share their window)
+            last_w = w;
+            bool placed = false;
+            for (int k = 0; k < NWIN && !placed; ++k) {
+                const int old = atomicCAS(&s_win[k], -1, w);
+                placed = old == -1 || old == w;
+            }
+            over |= !placed;
+        }
+    });
     if (hi >= 0) { atomicMin(s_lo, lo >> 4); atomicMax(s_hi, hi >> 4); atomicMax(s_maxcol, hi); }
+    if (over) *s_bad = 1;
     __syncthreads();
     const int tlo = *s_lo, thi = *s_hi;
     if (thi < 0) return;
-    bool bad = false;
-    for (int h = 0; h < rpt; ++h) {
-        const long row = (tile * rpt + h) * 256 + threadIdx.x;
-        const long c = row / C;
-        const int i = (int)(row - c * C);
-        if (c >= n_chunks) continue;
-        const int cs = chunk_ptrs[c], L = chunk_lengths[c];
-        for (int j = 0; j < L; ++j) {
-            const int b = line_to_bit(col_idxs[(long)cs + (long)j * C + i] >> 4, tlo, thi);
-            if (b < 0) bad = true;
-            else atomicOr(&bits[b >> 5], 1u << (b & 31));
-        }
-        if (chunk_ptrs2) {
-            const int cs2 = chunk_ptrs2[c], L2 = chunk_lengths2[c];
-            for (int j = 0; j < L2; ++j) {
-                const int b = line_to_bit(col_idxs2[(long)cs2 + (long)j * C + i] >> 4, tlo, thi);
-                if (b < 0) bad = true;
-                else atomicOr(&bits[b >> 5], 1u << (b & 31));
-            }
-        }
+    const bool contiguous = thi - tlo < PLAN_BITS;
+    if (threadIdx.x == 0 && !contiguous) {         // sort the table (<= 16 entries), count it
+        int n = 0;
+        while (n < NWIN && s_win[n] >= 0) ++n;
+        for (int a = 1; a < n; ++a) { const int v = s_win[a]; int b = a - 1; while (b >= 0 && s_win[b] > v) { s_win[b + 1] = s_win[b]; --b; } s_win[b + 1] = v; }
+        *s_nwin = n;
     }
-    if (bad) *s_bad = 1;
+    if (threadIdx.x == 0 && contiguous) *s_bad = 0;  // (the window table may have overflowed on a range that fits as a whole)
+    __syncthreads();
+    if (*s_bad) return;
+    const int nwin = *s_nwin;
+    const int *win = contiguous ? nullptr : s_win;
+    for_each_col([&](int col) {
+        const int b = line_to_bit(col >> 4, tlo, win, nwin);
+        atomicOr(&bits[b >> 5], 1u << (b & 31));
+    });
     __syncthreads();
 }
 
@@ -93,10 +105,10 @@ __global__ void __launch_bounds__(256) plan_count_lines(const long n_chunks, con
         int *__restrict__ n_lines, int *__restrict__ max_col, const int *__restrict__ chunk_ptrs2, const int *__restrict__ chunk_lengths2,
         const int *__restrict__ col_idxs2, const int rpt) {
     __shared__ unsigned bits[PLAN_WORDS];
-    __shared__ int s_lo, s_hi, s_cnt, s_maxcol, s_bad;
+    __shared__ int s_lo, s_hi, s_cnt, s_maxcol, s_bad, s_nwin, s_win[NWIN];
     if (threadIdx.x == 0) { s_cnt = 0; s_maxcol = 0; }
     const long tile = blockIdx.x;
-    tile_bitmap(n_chunks, C, chunk_ptrs, chunk_lengths, col_idxs, tile, bits, &s_lo, &s_hi, &s_maxcol, &s_bad, rpt, chunk_ptrs2, chunk_lengths2, col_idxs2);
+    tile_bitmap(n_chunks, C, chunk_ptrs, chunk_lengths, col_idxs, tile, bits, &s_lo, &s_hi, &s_maxcol, &s_bad, s_win, &s_nwin, rpt, chunk_ptrs2, chunk_lengths2, col_idxs2);
     int n = 0;
     if (s_hi >= 0 && !s_bad) {
         int cnt = 0;
@@ -118,13 +130,15 @@ __global__ void __launch_bounds__(256) plan_write(const long n_chunks, const int
         const unsigned *__restrict__ c16_ptrs2, unsigned short *__restrict__ col16_2, const int rpt) {
     __shared__ unsigned bits[PLAN_WORDS];
     __shared__ unsigned short rank0[PLAN_WORDS];   // set bits in the words before this one (< 4096)
-    __shared__ int s_lo, s_hi, s_dummy, s_bad;
+    __shared__ int s_lo, s_hi, s_dummy, s_bad, s_nwin, s_win[NWIN];
     __shared__ int wsum[256];
     const long tile = blockIdx.x;
     const int lp0 = tile_line_ptr[tile];
     if (tile_line_ptr[tile + 1] == lp0) return;   // unstaged or empty tile: col16 stays zero, the kernel gathers
     if (threadIdx.x == 0) s_dummy = 0;
-    tile_bitmap(n_chunks, C, chunk_ptrs, chunk_lengths, col_idxs, tile, bits, &s_lo, &s_hi, &s_dummy, &s_bad, rpt, chunk_ptrs2, chunk_lengths2, col_idxs2);
+    tile_bitmap(n_chunks, C, chunk_ptrs, chunk_lengths, col_idxs, tile, bits, &s_lo, &s_hi, &s_dummy, &s_bad, s_win, &s_nwin, rpt, chunk_ptrs2, chunk_lengths2, col_idxs2);
+    const int *win = s_nwin > 0 ? s_win : nullptr;
+    const int nwin = s_nwin;
     // exclusive prefix of the popcounts: 8 consecutive words per thread, then a block scan of the 256 partial sums
     constexpr int WPT = PLAN_WORDS / 256;
     int part = 0;
@@ -145,13 +159,13 @@ __global__ void __launch_bounds__(256) plan_write(const long n_chunks, const int
         int r = run;
         while (b) {                                 // the tile's sorted line list
             const int bit = __ffs(b) - 1;
-            tile_lines[lp0 + r++] = bit_to_line(w * 32 + bit, s_lo, s_hi);
+            tile_lines[lp0 + r++] = bit_to_line(w * 32 + bit, s_lo, win);
             b &= b - 1;
         }
         run += __popc(bits[w]);
     }
     __syncthreads();
-    const int tlo = s_lo, thi = s_hi;
+    const int tlo = s_lo;
     for (int h = 0; h < rpt; ++h) {
         const long row = (tile * rpt + h) * 256 + threadIdx.x;
         const long c = row / C;
@@ -161,7 +175,7 @@ __global__ void __launch_bounds__(256) plan_write(const long n_chunks, const int
         unsigned short *q = col16 + c16_ptrs[c];
         for (int j = 0; j < L; ++j) {
             const int col = col_idxs[(long)cs + (long)j * C + i];
-            const int l = line_to_bit(col >> 4, tlo, thi);
+            const int l = line_to_bit(col >> 4, tlo, win, nwin);
             const unsigned below = bits[l >> 5] & ((1u << (l & 31)) - 1u);
             const int pos = rank0[l >> 5] + __popc(below);
             q[(long)(j >> 2) * 4 * C + i * 4 + (j & 3)] = (unsigned short)((pos << 4) | (col & 15));
@@ -171,7 +185,7 @@ __global__ void __launch_bounds__(256) plan_write(const long n_chunks, const int
             unsigned short *q2 = col16_2 + c16_ptrs2[c];
             for (int j = 0; j < L2; ++j) {
                 const int col = col_idxs2[(long)cs2 + (long)j * C + i];
-                const int l = line_to_bit(col >> 4, tlo, thi);
+                const int l = line_to_bit(col >> 4, tlo, win, nwin);
                 const unsigned below = bits[l >> 5] & ((1u << (l & 31)) - 1u);
                 const int pos = rank0[l >> 5] + __popc(below);
                 q2[(long)(j >> 2) * 4 * C + i * 4 + (j & 3)] = (unsigned short)((pos << 4) | (col & 15));
