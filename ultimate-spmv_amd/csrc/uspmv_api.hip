@@ -404,7 +404,7 @@ static int device_plan_install_rows(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_li
 
 // For LARGE single structs the rows per tile are MEASURED (tuning tlc_measure_tile, default on; only when tlc_tile_rows is 0): the plan
 // is built on the device for 256, 512 and 1024 rows (two passes over the column indices each), the kernel timed three times on a zero
-// vector, and a larger tile kept when it is more than 4 % ahead of 256.  Why: which size wins depends on how far apart the x lines of
+// vector, and a larger tile kept when it is more than 3 % ahead of 256.  Why: which size wins depends on how far apart the x lines of
 // neighbouring tiles lie -- the 27-point stencil on 253^3 is fastest at 256 rows, the same stencil on 304^3 (planes of 739 instead of
 // 512 KB: more of the x lines miss the XCD's L2) at 512 (1.249 against 1.341 ms, profiles/r03/tile_rows_sweep.txt).  The choice is
 // remembered per (shape, size) for the life of the process, so the host and the device planner of one matrix agree.  0 = no opinion.
@@ -419,7 +419,7 @@ static int measured_tile_rows(uspmv_dmat_t *A, int max_lines, const char *who) {
     void *x = nullptr, *y = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int best = 0;
-    float t256 = 0, tbest = 0;
+    float tbest = 0;
     auto done = [&]() {
         (void)hipFree(x); (void)hipFree(y);
         if (e0) (void)hipEventDestroy(e0);
@@ -427,7 +427,10 @@ static int measured_tile_rows(uspmv_dmat_t *A, int max_lines, const char *who) {
         if (A->tlc) tlc_release(A);
     };
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { done(); (void)hipGetLastError(); return 0; }
-    for (int R : {256, 512, 1024}) {
+    float tmin[3] = {0, 0, 0};                                  // best time seen for 256 / 512 / 1024 rows (0: not usable)
+    for (int R : {256, 512, 1024, 256}) {                      // (256 once more at the end: the first candidate may have met a cold clock)
+        const int slot = R == 256 ? 0 : R == 512 ? 1 : 2;
+        if (slot == 0 && tmin[0] > 0 && !(tmin[1] > 0 && tmin[1] < 0.97f * tmin[0]) && !(tmin[2] > 0 && tmin[2] < 0.97f * tmin[0])) break;   // nothing to re-check
         int64_t nt = 0, ns = 0;
         if (device_plan_install_rows(A, nullptr, max_lines, R, &nt, &ns, who) != USPMV_OK || !A->tlc) { (void)hipGetLastError(); continue; }
         if (!tile_rows_accept(nt, ns)) continue;
@@ -447,8 +450,15 @@ static int measured_tile_rows(uspmv_dmat_t *A, int max_lines, const char *who) {
         if (!ok) { (void)hipGetLastError(); continue; }
         if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] measured tile size: %d rows -> %.4f ms per SpMV (%lld of %lld tiles staged, %d lines at most)\n", R, ms / 3,
                                              (long long)ns, (long long)nt, A->tlc_max_lines);
-        if (R == 256) { t256 = ms; best = 256; tbest = ms; }
-        else if (best == 0 || ms < (best == 256 ? 0.96f * t256 : tbest)) { best = R; tbest = ms; }
+        tmin[slot] = tmin[slot] > 0 ? std::min(tmin[slot], ms) : ms;
+    }
+    // 256 rows unless a larger tile is more than 3 % ahead of it (the faster of the two when both are)
+    if (tmin[0] > 0) {
+        best = 256; tbest = 0.97f * tmin[0];
+        if (tmin[1] > 0 && tmin[1] < tbest) { best = 512; tbest = tmin[1]; }
+        if (tmin[2] > 0 && tmin[2] < tbest) { best = 1024; tbest = tmin[2]; }
+    } else if (tmin[1] > 0 || tmin[2] > 0) {
+        best = tmin[1] > 0 && (tmin[2] <= 0 || tmin[1] <= tmin[2]) ? 512 : 1024;
     }
     done();
     seen.push_back({Key{A->n_chunks, A->n_elements, A->C, A->dtype, max_lines}, best});

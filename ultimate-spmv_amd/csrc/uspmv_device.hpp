@@ -143,7 +143,7 @@ struct Tuning {
     int tlc_auto_tile = 1;    // with tlc_tile_rows 0 and one struct: 1024- or 512-row tiles when the largest 256-row tile needs > 250 x lines
                               // (<= 16 waves per CU) and the larger tiles still stage >= 99 % of the tiles (profiles/r03/tile_rows_sweep.txt)
     int tlc_measure_tile = 1; // large single structs (>= 2^20 padded rows): build the plan for 256 / 512 / 1024 rows on the device, time the kernel, keep
-                              // a larger tile when it is > 4 % ahead (uspmv_api.hip measured_tile_rows; the 304^3 stencil: 512 rows, 7 % ahead)
+                              // a larger tile when it is > 3 % ahead (uspmv_api.hip measured_tile_rows; the 304^3 stencil: 512 rows, 7 % ahead)
     int tail_batch = 0;     // ragged tail of a chunk as one predicated batch
     int spmmv_unroll = 0;   // 0 = auto (256 bytes of X rows per lane and batch)
     int spmmv_lds_kb = 0;    // block plan: LDS budget per tile in KiB for the NEXT uspmv_dmat_optimize_block (0 = 80)
