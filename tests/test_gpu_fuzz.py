@@ -100,6 +100,9 @@ GENERATED = [   # (name, generator, C, sigma, f64[, what the automatic choices m
     ("banded 20000 x 140 +-9000 (sweep)", lambda pkg: pkg.gen_banded_random(20000, 140, 9000, magnitude_decades=8.0), 32, 512, True, dict(kind=2)),
     ("banded 20000 x 140 +-9000 sp", lambda pkg: pkg.gen_banded_random(20000, 140, 9000), 32, 512, False),
     ("banded 50000 x 12 +-300", lambda pkg: pkg.gen_banded_random(50000, 12, 300), 32, 1, True),
+    # 1.3 M rows: the padding column lies > 2^20 columns below the band of the last tiles (the device builder's window mode)
+    ("banded 1300000 x 5 +-100 (far padding column)", lambda pkg: pkg.gen_banded_random(1300000, 5, 100), 32, 512, True, dict(kind=1)),
+    ("banded 1300000 x 5 +-100 sp C64", lambda pkg: pkg.gen_banded_random(1300000, 5, 100), 64, 128, False, dict(kind=1)),
 ]
 
 
