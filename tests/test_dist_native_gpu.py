@@ -646,6 +646,42 @@ def test_cli_solve_mode_and_crs_across_real_ranks(pkg, orc, tmp_path):
     assert "data_type: float" in open(tmp_path / "spmv_bench.txt").read()
 
 
+def test_cli_rand_x_across_real_ranks(pkg, orc, tmp_path):
+    """-rand_x 1 | m across ranks as in the reference: min / max of |values| over the WHOLE matrix (rank 0 extracts and broadcasts,
+    code/utilities.hpp:2502-2540), then every rank draws the SAME default-seeded mt19937 sequence for its padded local vector (:880-912).
+    The expected x is rebuilt here from the generator's definition (numpy's legacy MT19937 stream = std::mt19937(5489); generate_canonical
+    = two draws; the product-sum fused, exact arithmetic in fractions), y from the oracle."""
+    from fractions import Fraction
+    tot = pkg.read_mtx(mtx_path("bcsstk13"))
+    n, P = tot.n_rows, 3
+    wsa = pkg.seg_work_sharing_arr(tot, "seg-nnz", P)
+    av = np.abs(tot.arrays()[2])
+    vmin, vmax = float(av.min()), float(av.max())
+    s = pkg.convert_to_scs(tot, 32, 512)
+    a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
+    raw = np.random.RandomState(5489).randint(0, 2 ** 32, size=2 * 1024, dtype=np.uint32).astype(np.float64)
+    u = (raw[0::2] + raw[1::2] * 4294967296.0) / 18446744073709551616.0            # generate_canonical<double, 53> on a 32-bit engine
+    seq = np.array([float(Fraction(float(x)) * Fraction(vmax - vmin) + Fraction(vmin)) for x in u])   # fma(u, max - min, min)
+    assert max(int(wsa[r + 1] - wsa[r]) for r in range(P)) <= seq.size
+    for rx, xg in (("1", np.concatenate([seq[:int(wsa[r + 1] - wsa[r])] for r in range(P)])), ("m", np.full(n, vmin + (vmax - vmin) / 2.0))):
+        xp = np.zeros(s.n_rows_padded); xp[:n] = pkg.apply_permutation(xg, a["new_to_old_idx"])
+        y = pkg.apply_permutation(orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp), a["old_to_new_idx"])[:n]
+        pre = str(tmp_path / ("y_rx" + rx))
+        procs = []
+        for rank in range(P):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(P), LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
+                       USPMV_JOB_ID=f"x{os.getpid()}{rx}", USPMV_HC_TIMEOUT="120")
+            env.pop("USPMV_LOOPBACK", None); env.pop("USPMV_DIST_X", None)
+            procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-mode", "s", "-rev", "1", "-rand_x", rx, "-seg_nnz",
+                                           "-comm_halos", "1", "-dump_y", pre], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=300)[0] for p in procs]
+        for p, o in zip(procs, outs):
+            assert p.returncode == 0, o
+        for rank in range(P):
+            got = np.fromfile(pre + f".{rank}", np.float64)
+            assert np.array_equal(got, y[wsa[rank]:wsa[rank + 1]]), (rx, rank, np.abs(got - y[wsa[rank]:wsa[rank + 1]]).max())
+
+
 def test_cli_loopback_graph_replay_with_ba_synch_and_check(pkg, tmp_path):
     """the captured step now also carries the per-step barrier (-ba_synch 1, the reference's default) and the self-check runs
     through the replayed graph"""

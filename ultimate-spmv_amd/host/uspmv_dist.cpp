@@ -34,6 +34,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cmath>
+#include <random>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -180,7 +182,7 @@ int uspmv_run_distributed(const DistConfig &c) {
     const bool setup_on_rccl = stk && !strcmp(stk, "rccl") && !host_exchange;
     if (comm_size == P && P > 1 && !setup_on_rccl) { CK(uspmv_hostcomm_transport(g.hc, &tr)); opt.transport = &tr; }
     CK(uspmv_dist_create_from_coo_ex(host_exchange ? nullptr : id, comm_rank, comm_size, rank, P, local, wsa.data(), c.C, c.sigma, c.sp ? USPMV_F32 : USPMV_F64, c.tlc ? 1 : 0, &opt, &D));
-    if (!c.check_y) { uspmv_coo_free(local); local = nullptr; }
+    // (the block's COO stays until the end: -rand_x reads its values, -step_form auto and -check_y run the self-check against it)
     hipStream_t st = nullptr;
     HK(hipStreamCreate(&st));
     CK(uspmv_dist_barrier(D, st));
@@ -217,8 +219,32 @@ int uspmv_run_distributed(const DistConfig &c) {
         std::vector<char> xo(vsz * (size_t)std::max<int64_t>(n_local, 1)), xp(vsz * (size_t)std::max<int64_t>(n_local, 1));
         const char *xk = getenv("USPMV_DIST_X");
         const bool ramp = xk && !strcmp(xk, "ramp");
+        // -rand_x 1 | m: min / max of |values| over the WHOLE matrix (every rank contributes its block; extract_matrix_min_mean_max +
+        // MPI_Bcast, code/utilities.hpp:2502-2540), then random_init's default-seeded engine -- the same sequence on every rank (:880-912),
+        // one draw per element of the padded local vector
+        double vmin = 1e308, vmax = 0;
+        if (c.random_init_x != '0') {
+            int64_t nz = 0;
+            const int32_t *ci = nullptr, *cj = nullptr;
+            const double *cv = nullptr;
+            { int64_t nr_ = 0, nc_ = 0; CK(uspmv_coo_dims(local, &nr_, &nc_, &nz)); }
+            CK(uspmv_coo_arrays(local, &ci, &cj, &cv));
+            for (int64_t k = 0; k < nz; ++k) { const double a = std::fabs(cv[k]); vmax = std::max(vmax, a); vmin = std::min(vmin, a); }
+            double neg_min = -vmin;
+            CK(uspmv_dist_allreduce_max(D, &vmax, st));
+            CK(uspmv_dist_allreduce_max(D, &neg_min, st));
+            vmin = -neg_min;
+        }
+        const double vmean = vmin + (vmax - vmin) / 2.0;
+        std::mt19937 engine;
+        auto draw = [&]() { return std::fma(std::generate_canonical<double, 53>(engine), vmax - vmin, vmin); };   // (fused like the reference's -O3 -march=native build, see uspmv_main.cpp)
         for (int v = 0; v < b; ++v) {
-            for (int64_t i = 0; i < n_local; ++i) put(xo, (size_t)i, ramp ? (1.0 + 1e-3 * (double)(i % 1000)) * (1.0 + v / 8.0) : 5.0);
+            for (int64_t i = 0; i < vec_len; ++i) {
+                double val = ramp ? (1.0 + 1e-3 * (double)(i % 1000)) * (1.0 + v / 8.0) : 5.0;
+                if (c.random_init_x == '1') val = c.sp ? (double)(float)draw() : draw();
+                else if (c.random_init_x == 'm') val = vmean;
+                if (i < n_local) put(xo, (size_t)i, val);
+            }
             CK(uspmv_apply_permutation(xp.data(), xo.data(), n2o, n_local, dtype));
             for (int64_t i = 0; i < n_local; ++i) put(hx, (size_t)(c.layout == USPMV_ROWWISE ? i * b + v : (int64_t)v * vec_len + i), get(xp, (size_t)i));
         }

@@ -19,6 +19,8 @@ struct DistConfig {
     // the padding-only tiles in front of the exchange; fused = pad in one launch (eager steps only); auto = time each for a few steps
     // on THIS machine, all ranks agreeing on the slowest rank's clock, and keep the fastest (all forms give the same bits).
     std::string step_form = "auto";
+    char random_init_x = '0';                  // -rand_x 0 | 1 | m: DefaultValues 5.0 | default-seeded mt19937 over [min, max] of |values| of the WHOLE matrix
+                                               // (rank 0 extracts, MPI_Bcast: code/utilities.hpp:2502-2540; the same sequence on every rank, :880-912) | their midpoint
     bool sp = false;                           // -sp: single precision matrix, vectors and exchange
     char mode = 'b';                           // -mode s: the reference's COMM-spmv-SWAP loop (code/main.cpp:528-607), -rev iterations, no timing
     unsigned long n_repetitions = 1;

@@ -414,7 +414,7 @@ int main(int argc, char **argv) {
         d.use_graph = c.use_graph != 0; d.print_comm_vol = c.print_comm_vol != 0; d.no_pack = c.no_pack != 0;
         d.no_overlap = getenv("USPMV_NO_OVERLAP") != nullptr;
         d.step_form = c.step_form;
-        d.mode = c.mode; d.n_repetitions = c.n_repetitions; d.dump_y = c.dump_y; d.sp = c.value_type == "sp";
+        d.mode = c.mode; d.n_repetitions = c.n_repetitions; d.dump_y = c.dump_y; d.sp = c.value_type == "sp"; d.random_init_x = c.random_init_x;
         d.bench_steps = c.bench_steps; d.bench_warmup = c.bench_warmup; d.check_y = c.check_y != 0; d.json = c.json;
         if (c.equilibrate) die("-equilibrate is a single-rank option in this round");
         // (-par_pack: on the device the send buffer is packed by one kernel either way, as in the reference's device branch, code/classes_structs.hpp:787-806)
