@@ -682,6 +682,45 @@ def test_cli_rand_x_across_real_ranks(pkg, orc, tmp_path):
             assert np.array_equal(got, y[wsa[rank]:wsa[rank + 1]]), (rx, rank, np.abs(got - y[wsa[rank]:wsa[rank + 1]]).max())
 
 
+def test_cli_equilibrate_across_real_ranks(pkg, orc, tmp_path):
+    """-equilibrate 1 across ranks: every rank scales ITS block (rows, then the columns of the row-scaled block) after the segmentation,
+    as the reference does (code/main.cpp:1117-1125 on local_mtx).  Expected: the blocks scaled one by one with numpy (division by the
+    row / column maxima: order-independent, exact), stacked, through the oracle's product."""
+    from ultimate_spmv_amd import binding as B
+    tot = pkg.read_mtx(mtx_path("bcsstk13"))
+    n, P = tot.n_rows, 3
+    wsa = pkg.seg_work_sharing_arr(tot, "seg-nnz", P)
+    I, J, V = (np.array(v) for v in tot.arrays())
+    Veq = V.copy()
+    for r in range(P):
+        sel = (I >= wsa[r]) & (I < wsa[r + 1])
+        v, ii, jj = Veq[sel], I[sel], J[sel]
+        rmax = np.zeros(n); np.maximum.at(rmax, ii, np.abs(v)); v = v / rmax[ii]
+        cmax = np.zeros(n); np.maximum.at(cmax, jj, np.abs(v)); v = v / cmax[jj]
+        Veq[sel] = v
+    eq = pkg.Coo.from_arrays(n, n, I, J, Veq)
+    s = pkg.convert_to_scs(eq, 32, 512)
+    a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
+    xg = np.concatenate([1.0 + 1e-3 * (np.arange(int(wsa[r + 1] - wsa[r])) % 1000) for r in range(P)])
+    xp = np.zeros(s.n_rows_padded); xp[:n] = pkg.apply_permutation(xg, a["new_to_old_idx"])
+    y = pkg.apply_permutation(orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp), a["old_to_new_idx"])[:n]
+    pre = str(tmp_path / "y_eq")
+    procs = []
+    for rank in range(P):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(P), LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
+                   USPMV_JOB_ID=f"e{os.getpid()}", USPMV_HC_TIMEOUT="120", USPMV_DIST_X="ramp")
+        env.pop("USPMV_LOOPBACK", None)
+        procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-mode", "s", "-rev", "1", "-equilibrate", "1", "-seg_nnz",
+                                       "-comm_halos", "1", "-check_y", "1", "-dump_y", pre], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert "y checked bitwise on every rank: ok" in outs[0]
+    for rank in range(P):
+        got = np.fromfile(pre + f".{rank}", np.float64)
+        assert np.array_equal(got, y[wsa[rank]:wsa[rank + 1]]), (rank, np.abs(got - y[wsa[rank]:wsa[rank + 1]]).max())
+
+
 def test_cli_loopback_graph_replay_with_ba_synch_and_check(pkg, tmp_path):
     """the captured step now also carries the per-step barrier (-ba_synch 1, the reference's default) and the self-check runs
     through the replayed graph"""

@@ -181,6 +181,24 @@ int uspmv_run_distributed(const DistConfig &c) {
     const char *stk = getenv("USPMV_SETUP_TRANSPORT");
     const bool setup_on_rccl = stk && !strcmp(stk, "rccl") && !host_exchange;
     if (comm_size == P && P > 1 && !setup_on_rccl) { CK(uspmv_hostcomm_transport(g.hc, &tr)); opt.transport = &tr; }
+    // -rand_x 1 | m: min / max of |values| over the WHOLE matrix, taken before any scaling (extract_matrix_min_mean_max on rank 0 +
+    // MPI_Bcast in the reference, code/main.cpp:1096, code/utilities.hpp:2502-2540; here every rank contributes its block)
+    double vmin = 1e308, vmax = 0;
+    if (c.random_init_x != '0') {
+        int64_t nr_ = 0, nc_ = 0, nz = 0;
+        const int32_t *ci = nullptr, *cj = nullptr;
+        const double *cv = nullptr;
+        CK(uspmv_coo_dims(local, &nr_, &nc_, &nz));
+        CK(uspmv_coo_arrays(local, &ci, &cj, &cv));
+        for (int64_t k = 0; k < nz; ++k) { const double a = std::fabs(cv[k]); vmax = std::max(vmax, a); vmin = std::min(vmin, a); }
+        double neg_min = -vmin;
+        CK(uspmv_hostcomm_allreduce_max_f64(g.hc, &vmax));
+        CK(uspmv_hostcomm_allreduce_max_f64(g.hc, &neg_min));
+        vmin = -neg_min;
+    }
+    // -equilibrate 1: every rank scales ITS block (rows, then columns of the row-scaled block), as the reference does after the
+    // segmentation (code/main.cpp:1117-1125 on local_mtx)
+    if (c.equilibrate) CK(uspmv_coo_equilibrate(local));
     CK(uspmv_dist_create_from_coo_ex(host_exchange ? nullptr : id, comm_rank, comm_size, rank, P, local, wsa.data(), c.C, c.sigma, c.sp ? USPMV_F32 : USPMV_F64, c.tlc ? 1 : 0, &opt, &D));
     // (the block's COO stays until the end: -rand_x reads its values, -step_form auto and -check_y run the self-check against it)
     hipStream_t st = nullptr;
@@ -222,19 +240,6 @@ int uspmv_run_distributed(const DistConfig &c) {
         // -rand_x 1 | m: min / max of |values| over the WHOLE matrix (every rank contributes its block; extract_matrix_min_mean_max +
         // MPI_Bcast, code/utilities.hpp:2502-2540), then random_init's default-seeded engine -- the same sequence on every rank (:880-912),
         // one draw per element of the padded local vector
-        double vmin = 1e308, vmax = 0;
-        if (c.random_init_x != '0') {
-            int64_t nz = 0;
-            const int32_t *ci = nullptr, *cj = nullptr;
-            const double *cv = nullptr;
-            { int64_t nr_ = 0, nc_ = 0; CK(uspmv_coo_dims(local, &nr_, &nc_, &nz)); }
-            CK(uspmv_coo_arrays(local, &ci, &cj, &cv));
-            for (int64_t k = 0; k < nz; ++k) { const double a = std::fabs(cv[k]); vmax = std::max(vmax, a); vmin = std::min(vmin, a); }
-            double neg_min = -vmin;
-            CK(uspmv_dist_allreduce_max(D, &vmax, st));
-            CK(uspmv_dist_allreduce_max(D, &neg_min, st));
-            vmin = -neg_min;
-        }
         const double vmean = vmin + (vmax - vmin) / 2.0;
         std::mt19937 engine;
         auto draw = [&]() { return std::fma(std::generate_canonical<double, 53>(engine), vmax - vmin, vmin); };   // (fused like the reference's -O3 -march=native build, see uspmv_main.cpp)

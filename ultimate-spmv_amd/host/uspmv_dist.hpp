@@ -21,6 +21,7 @@ struct DistConfig {
     std::string step_form = "auto";
     char random_init_x = '0';                  // -rand_x 0 | 1 | m: DefaultValues 5.0 | default-seeded mt19937 over [min, max] of |values| of the WHOLE matrix
                                                // (rank 0 extracts, MPI_Bcast: code/utilities.hpp:2502-2540; the same sequence on every rank, :880-912) | their midpoint
+    bool equilibrate = false;                  // -equilibrate 1: per-rank scaling of the block (code/main.cpp:1117-1125)
     bool sp = false;                           // -sp: single precision matrix, vectors and exchange
     char mode = 'b';                           // -mode s: the reference's COMM-spmv-SWAP loop (code/main.cpp:528-607), -rev iterations, no timing
     unsigned long n_repetitions = 1;

@@ -416,7 +416,7 @@ int main(int argc, char **argv) {
         d.step_form = c.step_form;
         d.mode = c.mode; d.n_repetitions = c.n_repetitions; d.dump_y = c.dump_y; d.sp = c.value_type == "sp"; d.random_init_x = c.random_init_x;
         d.bench_steps = c.bench_steps; d.bench_warmup = c.bench_warmup; d.check_y = c.check_y != 0; d.json = c.json;
-        if (c.equilibrate) die("-equilibrate is a single-rank option in this round");
+        d.equilibrate = c.equilibrate != 0;
         // (-par_pack: on the device the send buffer is packed by one kernel either way, as in the reference's device branch, code/classes_structs.hpp:787-806)
         return uspmv_run_distributed(d);   // every rank generates / receives only its row block
     }
