@@ -324,23 +324,32 @@ int uspmv_run_distributed(const DistConfig &c) {
         if (form == "auto") {
             std::vector<std::string> cand = {"overlap", "plain", "pad"};
             if (!c.use_graph) cand.push_back("fused");          // (a captured step never takes the one-launch form)
-            double best = 0;
-            for (const std::string &f : cand) {
-                CK(apply_form(f));
-                steps(10);
-                HK(hipStreamSynchronize(st));
-                CK(uspmv_dist_barrier(D, st));
-                auto t0 = std::chrono::steady_clock::now();
-                steps(40);
-                HK(hipStreamSynchronize(st));
-                CK(uspmv_dist_barrier(D, st));
-                double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 40 * 1e3;
-                CK(uspmv_dist_allreduce_max(D, &t, st));         // every rank sees the same numbers and takes the same decision
+            // (every collective the measurement uses once before anything is timed -- RCCL sets its channels up lazily, 40 ms the first time --
+            //  and two rounds over the candidates, the faster one counts: the first candidate must not pay for a cold start)
+            { double warm = 0; CK(uspmv_dist_barrier(D, st)); CK(uspmv_dist_allreduce_max(D, &warm, st)); }
+            std::vector<double> tms(cand.size(), 0.0);
+            for (int round = 0; round < 2; ++round)
+                for (size_t k = 0; k < cand.size(); ++k) {
+                    CK(apply_form(cand[k]));
+                    steps(10);
+                    HK(hipStreamSynchronize(st));
+                    CK(uspmv_dist_barrier(D, st));
+                    auto t0 = std::chrono::steady_clock::now();
+                    steps(40);
+                    HK(hipStreamSynchronize(st));
+                    CK(uspmv_dist_barrier(D, st));
+                    double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 40 * 1e3;
+                    CK(uspmv_dist_allreduce_max(D, &t, st));     // every rank sees the same numbers and takes the same decision
+                    tms[k] = round == 0 ? t : std::min(tms[k], t);
+                }
+            size_t kb = 0;
+            for (size_t k = 0; k < cand.size(); ++k) {
                 char buf[64];
-                snprintf(buf, sizeof buf, "%s\"%s\": %.6f", form_report.empty() ? "" : ", ", f.c_str(), t);
+                snprintf(buf, sizeof buf, "%s\"%s\": %.6f", form_report.empty() ? "" : ", ", cand[k].c_str(), tms[k]);
                 form_report += buf;
-                if (form == "auto" || t < best) { best = t; form = f; }
+                if (tms[k] < tms[kb]) kb = k;
             }
+            form = cand[kb];
         }
         CK(apply_form(form));
         // a form beyond the two plain ones is only kept if one step of it passes the bitwise self-check on every rank (the check is
