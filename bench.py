@@ -519,6 +519,9 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
             for _ in range(n):
                 d.spmv(x, y)
 
+    step_form = step_form_ms = None
+    if native and not args.no_overlap:            # the arrangement of the step that is fastest on THIS machine (collective; all forms give the same bits)
+        step_form, step_form_ms = d.autotune(x, y, use_graph=args.graph, local=loc, wsa=wsa)
     steps(args.warmup)
     sync()
     t0 = time.perf_counter()
@@ -578,6 +581,7 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
                   "local_kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(bytes_local),
                   "local_kernel_GBs": round(bytes_local / (k_ms * 1e-3) / 1e9, 1)},
         "setup_s": round(t_setup, 1), "y_checked": y_checked, "y_mismatches": y_bad, "native": bool(native),
+        "step_form": step_form, "step_form_candidates_ms": step_form_ms,
         "protocol": f"exactly {args.steps} steps between barriers after {args.warmup} warm-ups, slowest rank's clock; -ba_synch 0",
     }
     if native:

@@ -451,6 +451,16 @@ int uspmv_dist_comm_plan(const uspmv_dist_t *d, int64_t *n_send, const int64_t *
  * "diag_spmmv_part" 0|1|2 (diagnosis only: the two-part block-vector step runs both parts, its interior part, its boundary part),
  * "block_plan" b (block vectors: build the phased block plan for b columns on the rank's matrix, 0 drops it; see uspmv_dist_spmmv). */
 int uspmv_dist_set_option(uspmv_dist_t *d, const char *key, int value);
+/* How the single-vector step is arranged around the exchange: interior tiles during the exchange and boundary tiles after it | the
+ * exchange, then the whole matrix (the reference's order) | overlap with the padding-only tiles in front of the exchange ("pad_split") |
+ * that in one launch ("fused_step", eager steps only).  uspmv_dist_autotune times each for 2 x (10 + 40) steps on the machine at hand --
+ * COLLECTIVE: every rank calls it; the ranks agree on the slowest rank's clock -- sets the options of the fastest and returns it with
+ * the candidates' ms per step (0: not tried; negative: fastest but refused by the self-check).  With `local` and `wsa` (as for
+ * uspmv_dist_check, which it then runs) a pad / fused winner must pass the bitwise self-check on every rank or the faster of the first
+ * two takes over.  d_x keeps its local part (its halo tail and d_y are overwritten).  All arrangements give the same bits. */
+typedef enum { USPMV_STEP_OVERLAP = 0, USPMV_STEP_PLAIN = 1, USPMV_STEP_PAD = 2, USPMV_STEP_FUSED = 3 } uspmv_step_form;
+int uspmv_dist_autotune(uspmv_dist_t *d, void *d_x, void *d_y, int use_graph, const uspmv_coo_t *local, const int32_t *wsa, void *stream,
+                        int *form, double ms[4]);
 /* Self-check of the whole distributed path (partition, halo discovery, exchange plan, exchange, kernels) on the object's own
  * matrix: one step with x_global[j] = 1 + 1e-3 * (j mod 1000) -- every halo element differs from its neighbours, unlike the
  * benchmark's constant 5.0 -- and y of the local rows compared BITWISE with the rows' entry-ordered FMA chains evaluated on the

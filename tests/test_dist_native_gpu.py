@@ -161,6 +161,31 @@ def test_padding_tiles_run_with_the_interior_and_rerun_when_they_must(pkg, orc):
         d.close()
 
 
+def test_autotune_picks_a_form_and_keeps_the_bits(pkg, orc):
+    """uspmv_dist_autotune (loopback): every arrangement gets a time, the fastest is applied to the object (its options say so), x keeps its
+    local part, and a step afterwards still gives the oracle's rows -- eager steps and graph replay, with the self-check armed."""
+    import torch
+    torch.cuda.set_device(0)
+    P, shape, C, sigma = 2, (24, 24, 48), 32, 512
+    y_ref, nl = _global_reference(pkg, orc, shape, P, C, sigma)
+    counts = pkg.gen_stencil27_row_counts(*shape)
+    wsa = pkg.seg_from_row_counts(counts, "seg-rows", P)
+    rank = 1
+    loc = pkg.gen_stencil27(*shape, row_begin=int(wsa[rank]), row_end=int(wsa[rank + 1]))
+    d = pkg.DistNative(loc, wsa, C, sigma, rank, P, pkg.comm_unique_id(), comm_rank=0, comm_size=1)
+    for graph, forms in ((False, {"overlap", "plain", "pad", "fused"}), (True, {"overlap", "plain", "pad"})):
+        x = d.new_x(make_x(nl)); y = d.new_y()
+        x0 = x.clone()
+        form, ms = d.autotune(x, y, use_graph=graph, local=loc, wsa=wsa)
+        d.synchronize()
+        assert set(ms) == forms and form in forms and all(v > 0 for v in ms.values()), (form, ms)
+        assert ms[form] == min(ms.values())
+        assert torch.equal(x[:nl], x0[:nl])
+        d.run(x, y, 2, use_graph=graph); d.synchronize()
+        assert np.array_equal(d.y_to_original_order(y)[:nl], y_ref[wsa[rank]:wsa[rank + 1]]), (graph, form)
+    d.close()
+
+
 def test_native_block_vector_exchange_loopback_bitexact(pkg, orc):
     """uspmv_dist_spmmv: the halo exchange of b vectors in the reference's three message patterns (bulkvec / multivec / singlevec,
     code/classes_structs.hpp:875-924) + the SpMMV kernel, per column against the oracle's single-rank SpMV of the whole matrix."""

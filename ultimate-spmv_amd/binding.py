@@ -131,6 +131,7 @@ _SIGS = {
     "uspmv_dist_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dist_spmmv_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dist_pad_info": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "uspmv_dist_autotune": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _i32p, _vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "uspmv_dist_check_reference": (C.c_int, [_vp, _i32p, C.c_int, C.c_int, C.c_int, _vp]),
     "uspmv_dist_parts": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "uspmv_dist_set_overlap": (C.c_int, [_vp, C.c_int]),
@@ -668,6 +669,20 @@ class DistNative:
         self._order(X, Y)
         _ck(lib().uspmv_dist_spmmv(self.h, _dp(X), _dp(Y), int(b), int(layout), int(mode), int(bool(comm_halos)), self.stream.cuda_stream))
         return Y
+
+    STEP_FORMS = ("overlap", "plain", "pad", "fused")
+
+    def autotune(self, x, y, use_graph=False, local=None, wsa=None):
+        """Time the arrangements of the step on this machine and keep the fastest (uspmv_dist_autotune; COLLECTIVE: every rank calls it).
+        Returns (name of the chosen form, {form: ms per step}); with `local` (the block's Coo) and `wsa` a pad / fused winner must pass
+        the bitwise self-check."""
+        self._order(x, y)
+        form = C.c_int(0)
+        ms = (C.c_double * 4)()
+        w = None if wsa is None else np.ascontiguousarray(wsa, np.int32)
+        _ck(lib().uspmv_dist_autotune(self.h, _dp(x), _dp(y), int(bool(use_graph)), None if local is None else local.h,
+                                      None if w is None else w.ctypes.data_as(_i32p), self.stream.cuda_stream, C.byref(form), ms))
+        return self.STEP_FORMS[form.value], {self.STEP_FORMS[k]: float(ms[k]) for k in range(4) if ms[k] != 0}
 
     def pad_info(self):
         """dict(pad_tiles, real_boundary_tiles, pad_col, reruns) (uspmv_dist_pad_info)"""

@@ -24,6 +24,7 @@
 // ONE GPU, which is how the step runs with unequal seg-nnz blocks and asymmetric lists on a single-GPU box.
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <string>
 
 #include "uspmv_device.hpp"
@@ -739,6 +740,69 @@ int uspmv_dist_run(uspmv_dist_t *D, void *d_x, void *d_y, int n_steps, int use_g
     for (int k = 0; k < n_steps; ++k)
         if (int rc = step(D, d_x, d_y, main, true)) return rc;
     D->eager_steps += n_steps;
+    return USPMV_OK;
+}
+
+// How the step should be arranged around the exchange depends on what the exchange costs next to the kernel on the machine at hand
+// (one GPU cannot tell for real links): time the arrangements and keep the fastest.  Collective: every rank must call it; the ranks
+// agree on the slowest rank's clock through one all-reduce per measurement, so all take the same decision.
+int uspmv_dist_autotune(uspmv_dist_t *D, void *d_x, void *d_y, int use_graph, const uspmv_coo_t *local, const int32_t *wsa, void *stream, int *form,
+                        double ms[4]) {
+    if (!D || !d_x || !d_y || !form || !ms) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_autotune: NULL argument");
+    for (int k = 0; k < 4; ++k) ms[k] = 0;
+    *form = USPMV_STEP_OVERLAP;
+    if (D->P < 2) return USPMV_OK;
+    hipStream_t st = (hipStream_t)stream;
+    auto apply = [&](int f) -> int {
+        if (int rc = uspmv_dist_set_option(D, "overlap", f == USPMV_STEP_PLAIN ? 0 : 1)) return rc;
+        if (int rc = uspmv_dist_set_option(D, "pad_split", f == USPMV_STEP_PAD || f == USPMV_STEP_FUSED ? 1 : 0)) return rc;
+        return uspmv_dist_set_option(D, "fused_step", f == USPMV_STEP_FUSED ? 1 : 0);
+    };
+    std::vector<int> cand = {USPMV_STEP_OVERLAP, USPMV_STEP_PLAIN, USPMV_STEP_PAD};
+    if (!use_graph || D->host_exchange) cand.push_back(USPMV_STEP_FUSED);          // (a captured step never takes the one-launch form)
+    // every collective the measurement uses once before anything is timed (RCCL sets its channels up lazily, 40 ms the first time), and two
+    // rounds over the candidates of which the faster counts: the first candidate must not pay for a cold start
+    { double warm = 0; if (int rc = uspmv_dist_barrier(D, st)) return rc; if (int rc = uspmv_dist_allreduce_max(D, &warm, st)) return rc; }
+    for (int round = 0; round < 2; ++round)
+        for (int f : cand) {
+            if (int rc = apply(f)) return rc;
+            if (int rc = uspmv_dist_run(D, d_x, d_y, 10, use_graph, st)) return rc;
+            HIP_TRY(hipStreamSynchronize(st));
+            if (int rc = uspmv_dist_barrier(D, st)) return rc;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (int rc = uspmv_dist_run(D, d_x, d_y, 40, use_graph, st)) return rc;
+            HIP_TRY(hipStreamSynchronize(st));
+            if (int rc = uspmv_dist_barrier(D, st)) return rc;
+            double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 40 * 1e3;
+            if (int rc = uspmv_dist_allreduce_max(D, &t, st)) return rc;
+            ms[f] = round == 0 ? t : std::min(ms[f], t);
+        }
+    int best = cand[0];
+    for (int f : cand) if (ms[f] < ms[best]) best = f;
+    if (int rc = apply(best)) return rc;
+    // an arrangement beyond the two plain ones is only kept if one step of it passes the bitwise self-check on every rank (collective: all
+    // ranks reach the same verdict); otherwise the faster of overlap / plain takes over and ms[] of the rejected form is negated
+    if ((best == USPMV_STEP_PAD || best == USPMV_STEP_FUSED) && local && wsa) {
+        int64_t mm = 0;
+        DevBuf keep;                                            // (the check runs on its own x: put the caller's local part back afterwards)
+        const size_t xb = vsize(D) * (size_t)std::max<int64_t>(D->n_local, 1);
+        HIP_TRY(keep.alloc(xb));
+        HIP_TRY(hipMemcpyAsync(keep.p, d_x, xb, hipMemcpyDeviceToDevice, st));
+        const int rc_check = uspmv_dist_check(D, local, wsa, d_x, d_y, use_graph, stream, &mm, nullptr);
+        HIP_TRY(hipMemcpyAsync(d_x, keep.p, xb, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (rc_check) return rc_check;
+        std::vector<int64_t> all((size_t)std::max(D->P, D->comm_size), 0);
+        if (int rc = uspmv_dist_allgather_i64(D, mm, all.data(), stream)) return rc;
+        int64_t tot = 0;
+        for (int p = 0; p < (D->loopback ? 1 : D->comm_size); ++p) tot += all[(size_t)p];
+        if (tot) {
+            ms[best] = -ms[best];
+            best = ms[USPMV_STEP_PLAIN] < ms[USPMV_STEP_OVERLAP] ? USPMV_STEP_PLAIN : USPMV_STEP_OVERLAP;
+            if (int rc = apply(best)) return rc;
+        }
+    }
+    *form = best;
     return USPMV_OK;
 }
 

@@ -322,55 +322,21 @@ int uspmv_run_distributed(const DistConfig &c) {
     };
     if (P > 1 && comm_halos && b == 1 && !legacy_knobs) {
         if (form == "auto") {
-            std::vector<std::string> cand = {"overlap", "plain", "pad"};
-            if (!c.use_graph) cand.push_back("fused");          // (a captured step never takes the one-launch form)
-            // (every collective the measurement uses once before anything is timed -- RCCL sets its channels up lazily, 40 ms the first time --
-            //  and two rounds over the candidates, the faster one counts: the first candidate must not pay for a cold start)
-            { double warm = 0; CK(uspmv_dist_barrier(D, st)); CK(uspmv_dist_allreduce_max(D, &warm, st)); }
-            std::vector<double> tms(cand.size(), 0.0);
-            for (int round = 0; round < 2; ++round)
-                for (size_t k = 0; k < cand.size(); ++k) {
-                    CK(apply_form(cand[k]));
-                    steps(10);
-                    HK(hipStreamSynchronize(st));
-                    CK(uspmv_dist_barrier(D, st));
-                    auto t0 = std::chrono::steady_clock::now();
-                    steps(40);
-                    HK(hipStreamSynchronize(st));
-                    CK(uspmv_dist_barrier(D, st));
-                    double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 40 * 1e3;
-                    CK(uspmv_dist_allreduce_max(D, &t, st));     // every rank sees the same numbers and takes the same decision
-                    tms[k] = round == 0 ? t : std::min(tms[k], t);
-                }
-            size_t kb = 0;
-            for (size_t k = 0; k < cand.size(); ++k) {
+            static const char *names[4] = {"overlap", "plain", "pad", "fused"};
+            int best = USPMV_STEP_OVERLAP;
+            double tms[4];
+            CK(uspmv_dist_autotune(D, d_x, d_y, c.use_graph ? 1 : 0, local, wsa.data(), st, &best, tms));
+            for (int k = 0; k < 4; ++k) {
+                if (tms[k] == 0) continue;
                 char buf[64];
-                snprintf(buf, sizeof buf, "%s\"%s\": %.6f", form_report.empty() ? "" : ", ", cand[k].c_str(), tms[k]);
+                snprintf(buf, sizeof buf, "%s\"%s\": %.6f", form_report.empty() ? "" : ", ", names[k], std::fabs(tms[k]));
                 form_report += buf;
-                if (tms[k] < tms[kb]) kb = k;
+                if (tms[k] < 0) { form_report += ", \"rejected\": 1"; if (rank == 0) fprintf(stderr, "step form %s failed the self-check on this machine: not used\n", names[k]); }
             }
-            form = cand[kb];
+            form = names[best];
+            HK(hipMemcpy(d_x, hx.data(), hx.size(), hipMemcpyHostToDevice));
         }
         CK(apply_form(form));
-        // a form beyond the two plain ones is only kept if one step of it passes the bitwise self-check on every rank (the check is
-        // collective: all ranks see the same verdict); otherwise the faster of overlap / plain takes over
-        if (c.step_form == "auto" && (form == "pad" || form == "fused")) {
-            int64_t mm = 0;
-            CK(uspmv_dist_check(D, local, wsa.data(), d_x, d_y, c.use_graph ? 1 : 0, st, &mm, nullptr));
-            std::vector<int64_t> all((size_t)std::max(P, comm_size), 0);
-            CK(uspmv_dist_allgather_i64(D, mm, all.data(), st));
-            int64_t tot = 0;
-            for (int p = 0; p < (meta[8] ? 1 : comm_size); ++p) tot += all[(size_t)p];
-            HK(hipMemcpy(d_x, hx.data(), hx.size(), hipMemcpyHostToDevice));
-            if (tot) {
-                if (rank == 0) fprintf(stderr, "step form %s failed the self-check on this machine (%ld rows): not used\n", form.c_str(), (long)tot);
-                const size_t po = form_report.find("\"plain\": "), oo = form_report.find("\"overlap\": ");
-                const double tp = po == std::string::npos ? 0 : atof(form_report.c_str() + po + 9), to = oo == std::string::npos ? 0 : atof(form_report.c_str() + oo + 11);
-                form = (tp > 0 && tp < to) ? "plain" : "overlap";
-                form_report += ", \"rejected\": 1";
-                CK(apply_form(form));
-            }
-        }
     }
 
     // ---- timed region
