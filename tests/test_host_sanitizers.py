@@ -1,4 +1,5 @@
-"""AddressSanitizer + UBSan pass over the host data layer (reader, conversion, planners, halo set-up, cache): the
+"""AddressSanitizer + UBSan pass over the host data layer (reader, conversion, planners incl. the sweep and phased plans, halo set-up,
+chunk classes, the self-check's reference rows, graph partition, generators, host communicator, exchange plan, cache): the
 driver tools/sanitize_host.cpp is compiled together with host/*.cpp (no HIP) and run on the golden matrices.
 GPU sanitizers are not available on the test pool, so this is the sanitizer coverage of the product."""
 import os
@@ -14,7 +15,8 @@ PKG = os.path.join(ROOT, "ultimate-spmv_amd")
 def test_host_layer_is_clean_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "sanitize_host")
     srcs = [os.path.join(ROOT, "tools", "sanitize_host.cpp")] + [os.path.join(PKG, "host", f) for f in
-            ("mtx_io.cpp", "scs_convert.cpp", "halo_plan.cpp", "gen_matrix.cpp", "tlc_plan.cpp")]
+            ("mtx_io.cpp", "scs_convert.cpp", "halo_plan.cpp", "gen_matrix.cpp", "tlc_plan.cpp", "sweep_plan.cpp", "graph_partition.cpp",
+             "dist_check.cpp", "hostcomm.cpp", "comm_plan.cpp")]
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fopenmp", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "host")] + srcs + ["-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
