@@ -382,9 +382,11 @@ class stdout_to_stderr:
         return False
 
 
-def cli_measure(args, world, rank, scaling, grid, parents):
+def cli_measure(args, world, rank, scaling, grid, parents, host_exchange=False):
     """One N > 1 measurement by the `uspmv` harness: every rank starts it as a child process (this process has not touched the GPU),
-    rank 0's child writes the JSON report.  Returns (report dict | None, reason)."""
+    rank 0's child writes the JSON report.  Returns (report dict | None, reason).  host_exchange: the halo exchange staged through host
+    memory and the ranks' shared segment instead of RCCL (USPMV_EXCHANGE=host) -- the tier that still yields a native, checked number when
+    RCCL does not come up on the machine."""
     import subprocess
     import tempfile
     exe = os.path.join(ROOT, "ultimate-spmv_amd", "uspmv")
@@ -396,7 +398,11 @@ def cli_measure(args, world, rank, scaling, grid, parents):
     cmd = [exe, f"gen:{g}x{g}x{nz}", "scs", "-c", str(args.chunk), "-s", str(args.sigma), "-dp", "-" + args.seg.replace("-", "_"), "-comm_halos", "1",
            "-ba_synch", str(args.ba_synch), "-bench_steps", str(args.steps), "-bench_warmup", str(args.warmup), "-check_y", "1", "-json", js,
            "-tlc", "0" if args.no_tlc else "1", "-graph", "0" if args.no_graph else "1"]
-    env = dict(os.environ, OMP_NUM_THREADS=str(cores), USPMV_JOB_ID=f"bench{os.environ.get('MASTER_PORT', '0')}_{scaling}_{g}")
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), USPMV_JOB_ID=f"bench{os.environ.get('MASTER_PORT', '0')}_{scaling}_{g}{'_hx' if host_exchange else ''}")
+    if host_exchange:
+        env["USPMV_EXCHANGE"] = "host"
+    elif os.environ.get("USPMV_BENCH_SIMULATE_RCCL_FAILURE"):      # rehearsal of the second tier: the first tier's children fail at once
+        cmd = ["/bin/false"]
     if args.no_overlap:
         env["USPMV_NO_OVERLAP"] = "1"
     rc, out = -1, ""
@@ -432,6 +438,7 @@ def cli_result(args, rep, scaling, grid, world):
         "workload": (f"{klass} synthetic (27-pt stencil {g}x{g}x{nz}, n={rep['n_rows']}, nnz={rep['nnz']}) scs -c {args.chunk} -s {args.sigma} -dp "
                      f"-{args.seg.replace('-', '_')} -comm_halos 1"),
         "n_rows": rep["n_rows"], "nnz": rep["nnz"], "beta": None,
+        "exchange": rep.get("exchange"),
         "step": "uspmv child processes on the system RCCL: C++ uspmv_dist_run, " + ("hipGraph replay" if rep["graph_replay"] else "eager C++ steps"),
         "protocol": f"exactly {rep['steps']} steps between barriers after {rep['warmup']} warm-ups, slowest rank's clock; -ba_synch {rep['ba_synch']} "
                     f"(with -ba_synch {1 - rep['ba_synch']}: {rep['other_ba_synch_ms_per_step']:.5f} ms per step; 1 = the reference's default, a barrier behind every step, code/main.cpp:467)",
@@ -653,6 +660,17 @@ def main():
                         other = {"value": None, "scaling": second, "error": reason2 or "failed on another rank"}
             else:
                 reason = reason or "the uspmv child processes failed on another rank"
+                # second tier, still before this process touches the GPU: the same harness with the exchange staged through the host
+                # (no RCCL at all).  Slower per step, but a native, self-checked number; taken when it works, and said so in the line.
+                rep_h, reason_h = cli_measure(args, world, rank, first, grid1, parents, host_exchange=True)
+                good = int(parents.allgather(np.array([0 if (reason_h or (rank == 0 and rep_h is None)) else 1], np.int64)).min())
+                if good:
+                    reason = f"{reason}; measured with the halo exchange staged through host memory instead of RCCL"
+                    if rank == 0:
+                        res = cli_result(args, rep_h, first, grid1, world)
+                        res["step"] = res["step"].replace("on the system RCCL", "with the host-staged exchange (USPMV_EXCHANGE=host)")
+                else:
+                    reason = f"{reason}; host-staged retry: {reason_h or 'failed on another rank'}"
             parents.barrier()
             parents.close()
             use_cli = bool(good)
@@ -681,7 +699,7 @@ def main():
                 "config": {"workload": res["workload"], "C": args.chunk, "sigma": args.sigma, "n_rows": res["n_rows"], "nnz": res["nnz"], "beta": res["beta"],
                            "x": "5.0 (DefaultValues) in the timed steps; x_global[j] = 1 + 1e-3 (j mod 1000) in the checked step", "partition": args.seg,
                            "halo_overlap": (res.get("step_form") or ("plain" if args.no_overlap else "overlap")) != "plain", "step": res["step"], "protocol": res.get("protocol"),
-                           "step_form": res.get("step_form"), "step_form_candidates_ms": res.get("step_form_candidates_ms"),
+                           "step_form": res.get("step_form"), "step_form_candidates_ms": res.get("step_form_candidates_ms"), "exchange": res.get("exchange"),
                            "rank0": r0, "tuning": tuning, "versions": res.get("versions"), "cmd": res.get("cmd")},
                 "roofline": {"bound": "hbm", "achieved": r0["local_kernel_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(r0["local_kernel_GBs"] / HBM_PEAK_GBS, 4) if r0["local_kernel_GBs"] else None, "traffic": None,
