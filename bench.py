@@ -382,7 +382,7 @@ class stdout_to_stderr:
         return False
 
 
-def cli_measure(args, world, rank, scaling, grid, parents, host_exchange=False):
+def cli_measure(args, world, rank, scaling, grid, parents, host_exchange=False, eager=False):
     """One N > 1 measurement by the `uspmv` harness: every rank starts it as a child process (this process has not touched the GPU),
     rank 0's child writes the JSON report.  Returns (report dict | None, reason).  host_exchange: the halo exchange staged through host
     memory and the ranks' shared segment instead of RCCL (USPMV_EXCHANGE=host) -- the tier that still yields a native, checked number when
@@ -397,12 +397,12 @@ def cli_measure(args, world, rank, scaling, grid, parents, host_exchange=False):
     js = os.path.join(tmp, "report.json")
     cmd = [exe, f"gen:{g}x{g}x{nz}", "scs", "-c", str(args.chunk), "-s", str(args.sigma), "-dp", "-" + args.seg.replace("-", "_"), "-comm_halos", "1",
            "-ba_synch", str(args.ba_synch), "-bench_steps", str(args.steps), "-bench_warmup", str(args.warmup), "-check_y", "1", "-json", js,
-           "-tlc", "0" if args.no_tlc else "1", "-graph", "0" if args.no_graph else "1"]
-    env = dict(os.environ, OMP_NUM_THREADS=str(cores), USPMV_JOB_ID=f"bench{os.environ.get('MASTER_PORT', '0')}_{scaling}_{g}{'_hx' if host_exchange else ''}")
+           "-tlc", "0" if args.no_tlc else "1", "-graph", "0" if (args.no_graph or eager) else "1"]
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), USPMV_JOB_ID=f"bench{os.environ.get('MASTER_PORT', '0')}_{scaling}_{g}{'_hx' if host_exchange else ''}{'_e' if eager else ''}")
     if host_exchange:
         env["USPMV_EXCHANGE"] = "host"
-    elif os.environ.get("USPMV_BENCH_SIMULATE_RCCL_FAILURE"):      # rehearsal of the second tier: the first tier's children fail at once
-        cmd = ["/bin/false"]
+    elif os.environ.get("USPMV_BENCH_SIMULATE_RCCL_FAILURE") and (not eager or os.environ["USPMV_BENCH_SIMULATE_RCCL_FAILURE"] == "2"):
+        cmd = ["/bin/false"]                                       # rehearsal of the later tiers: these children fail at once
     if args.no_overlap:
         env["USPMV_NO_OVERLAP"] = "1"
     rc, out = -1, ""
@@ -660,17 +660,28 @@ def main():
                         other = {"value": None, "scaling": second, "error": reason2 or "failed on another rank"}
             else:
                 reason = reason or "the uspmv child processes failed on another rank"
-                # second tier, still before this process touches the GPU: the same harness with the exchange staged through the host
-                # (no RCCL at all).  Slower per step, but a native, self-checked number; taken when it works, and said so in the line.
-                rep_h, reason_h = cli_measure(args, world, rank, first, grid1, parents, host_exchange=True)
-                good = int(parents.allgather(np.array([0 if (reason_h or (rank == 0 and rep_h is None)) else 1], np.int64)).min())
-                if good:
-                    reason = f"{reason}; measured with the halo exchange staged through host memory instead of RCCL"
+                # still before this process touches the GPU: (a) the same children with eager steps (a capture of the RCCL group that goes
+                # wrong takes the child down with it, as torch's RCCL did in round 2); (b) the same harness with the exchange staged
+                # through the host (no RCCL at all) -- slower per step, but a native, self-checked number.  Said so in the line.
+                eager_ok = host_ok = 0
+                if not args.no_graph:
+                    rep_e, reason_e = cli_measure(args, world, rank, first, grid1, parents, eager=True)
+                    eager_ok = int(parents.allgather(np.array([0 if (reason_e or (rank == 0 and rep_e is None)) else 1], np.int64)).min())
+                if eager_ok:
+                    reason = f"{reason}; measured with eager steps instead of graph replay"
                     if rank == 0:
-                        res = cli_result(args, rep_h, first, grid1, world)
-                        res["step"] = res["step"].replace("on the system RCCL", "with the host-staged exchange (USPMV_EXCHANGE=host)")
+                        res = cli_result(args, rep_e, first, grid1, world)
                 else:
-                    reason = f"{reason}; host-staged retry: {reason_h or 'failed on another rank'}"
+                    rep_h, reason_h = cli_measure(args, world, rank, first, grid1, parents, host_exchange=True)
+                    host_ok = int(parents.allgather(np.array([0 if (reason_h or (rank == 0 and rep_h is None)) else 1], np.int64)).min())
+                    if host_ok:
+                        reason = f"{reason}; measured with the halo exchange staged through host memory instead of RCCL"
+                        if rank == 0:
+                            res = cli_result(args, rep_h, first, grid1, world)
+                            res["step"] = res["step"].replace("on the system RCCL", "with the host-staged exchange (USPMV_EXCHANGE=host)")
+                    else:
+                        reason = f"{reason}; host-staged retry: {reason_h or 'failed on another rank'}"
+                good = int(bool(eager_ok or host_ok))
             parents.barrier()
             parents.close()
             use_cli = bool(good)
