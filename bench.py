@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--no-second-line", action="store_true", help="N > 1: skip the other scaling mode's measurement")
     ap.add_argument("--in-process", action="store_true", help="N > 1: skip the uspmv child processes, run the C++ step inside this (torch) process")
     ap.add_argument("--ba-synch", type=int, default=0, choices=[0, 1], help="N > 1: per-step barrier of the headline protocol (the reference's default is 1; the other setting is timed too and reported)")
-    ap.add_argument("--child-timeout", type=float, default=1500.0, help="N > 1: seconds a uspmv child may take")
+    ap.add_argument("--child-timeout", type=float, default=420.0, help="N > 1: seconds a uspmv child may take (a healthy one needs well under a minute; three tiers of children may run)")
     ap.add_argument("--python-step", action="store_true", help="N > 1: round-1 path (torch.distributed all_to_all per step) instead of the C++ step")
     ap.add_argument("--seg", choices=["seg-nnz", "seg-rows"], default="seg-nnz")
     ap.add_argument("--no-overlap", action="store_true")
@@ -399,6 +399,7 @@ def cli_measure(args, world, rank, scaling, grid, parents, host_exchange=False, 
            "-ba_synch", str(args.ba_synch), "-bench_steps", str(args.steps), "-bench_warmup", str(args.warmup), "-check_y", "1", "-json", js,
            "-tlc", "0" if args.no_tlc else "1", "-graph", "0" if (args.no_graph or eager) else "1"]
     env = dict(os.environ, OMP_NUM_THREADS=str(cores), USPMV_JOB_ID=f"bench{os.environ.get('MASTER_PORT', '0')}_{scaling}_{g}{'_hx' if host_exchange else ''}{'_e' if eager else ''}")
+    env.setdefault("USPMV_HC_TIMEOUT", str(int(args.child_timeout)))     # (the children's rendezvous gives up with them, not an hour later)
     if host_exchange:
         env["USPMV_EXCHANGE"] = "host"
     elif os.environ.get("USPMV_BENCH_SIMULATE_RCCL_FAILURE") and (not eager or os.environ["USPMV_BENCH_SIMULATE_RCCL_FAILURE"] == "2"):
