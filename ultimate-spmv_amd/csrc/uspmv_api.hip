@@ -408,31 +408,43 @@ static int device_plan_install_rows(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_li
 // neighbouring tiles lie -- the 27-point stencil on 253^3 is fastest at 256 rows, the same stencil on 304^3 (planes of 739 instead of
 // 512 KB: more of the x lines miss the XCD's L2) at 512 (1.249 against 1.341 ms, profiles/r03/tile_rows_sweep.txt).  The choice is
 // remembered per (shape, size) for the life of the process, so the host and the device planner of one matrix agree.  0 = no opinion.
-static int measured_tile_rows(uspmv_dmat_t *A, int max_lines, const char *who) {
+static int measured_tile_rows(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, const char *who) {
     if (!g_tune.tlc_measure_tile || g_tune.tlc_tile_rows != 0 || A->alt || A->C > 256 || 256 % A->C != 0) return 0;
     if (A->n_chunks * A->C < (int64_t)1 << 20) return 0;
-    struct Key { int64_t nc, ne, C; int dtype, ml; };
+    if (B && (B->alt || B->C != A->C || B->n_chunks != A->n_chunks || A->dtype != USPMV_F64 || B->dtype != USPMV_F32)) return 0;
+    struct Key { int64_t nc, ne, ne2, C; int dtype, ml; };
     static std::vector<std::pair<Key, int>> seen;
+    const int64_t ne2 = B ? B->n_elements : -1;
     for (auto &kv : seen)
-        if (kv.first.nc == A->n_chunks && kv.first.ne == A->n_elements && kv.first.C == A->C && kv.first.dtype == A->dtype && kv.first.ml == max_lines) return kv.second;
+        if (kv.first.nc == A->n_chunks && kv.first.ne == A->n_elements && kv.first.ne2 == ne2 && kv.first.C == A->C && kv.first.dtype == A->dtype && kv.first.ml == max_lines)
+            return kv.second;
     const size_t vsz = A->dtype == USPMV_F64 ? 8 : 4;
     void *x = nullptr, *y = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int best = 0;
-    float tbest = 0;
     auto done = [&]() {
         (void)hipFree(x); (void)hipFree(y);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
         if (A->tlc) tlc_release(A);
+        if (B && B->tlc) tlc_release(B);
     };
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { done(); (void)hipGetLastError(); return 0; }
+    // the size to beat: 256 rows for one struct, 512 for an ap[dp_sp] pair (two entry streams per row, profiles/r02/ap_tile_rows.txt);
+    // it is timed first and once more at the end (the first candidate may have met a cold clock)
+    const int base = B ? 512 : 256;
+    const int order[4] = {base, base == 256 ? 512 : 256, 1024, base};
     float tmin[3] = {0, 0, 0};                                  // best time seen for 256 / 512 / 1024 rows (0: not usable)
-    for (int R : {256, 512, 1024, 256}) {                      // (256 once more at the end: the first candidate may have met a cold clock)
-        const int slot = R == 256 ? 0 : R == 512 ? 1 : 2;
-        if (slot == 0 && tmin[0] > 0 && !(tmin[1] > 0 && tmin[1] < 0.97f * tmin[0]) && !(tmin[2] > 0 && tmin[2] < 0.97f * tmin[0])) break;   // nothing to re-check
+    auto slot_of = [](int R) { return R == 256 ? 0 : R == 512 ? 1 : 2; };
+    for (int k = 0; k < 4; ++k) {
+        const int R = order[k], slot = slot_of(R), bs = slot_of(base);
+        if (k == 3) {                                           // re-check the base only when something is about to beat it
+            bool beaten = false;
+            for (int o = 0; o < 3; ++o) beaten |= o != bs && tmin[o] > 0 && tmin[bs] > 0 && tmin[o] < 0.97f * tmin[bs];
+            if (!beaten) break;
+        }
         int64_t nt = 0, ns = 0;
-        if (device_plan_install_rows(A, nullptr, max_lines, R, &nt, &ns, who) != USPMV_OK || !A->tlc) { (void)hipGetLastError(); continue; }
+        if (device_plan_install_rows(A, B, max_lines, R, &nt, &ns, who) != USPMV_OK || !A->tlc) { (void)hipGetLastError(); continue; }
         if (!tile_rows_accept(nt, ns)) continue;
         if (!x) {
             const size_t xb = vsz * (size_t)std::max<int64_t>(A->tlc_x_len + 16, 16), yb = vsz * (size_t)std::max<int64_t>(A->n_chunks * A->C, 1);
@@ -442,26 +454,29 @@ static int measured_tile_rows(uspmv_dmat_t *A, int max_lines, const char *who) {
         bool ok = true;
         for (int rep = 0; rep < 2 && ok; ++rep) {             // (first round warms up)
             ok = hipEventRecord(e0, nullptr) == hipSuccess;
-            for (int k = 0; k < 3 && ok; ++k)
-                ok = (A->dtype == USPMV_F64 ? launch_spmv_tlc<double>(A, nullptr, (long)A->tlc_n_tiles, (const double *)x, (double *)y, nullptr)
-                                            : launch_spmv_tlc<float>(A, nullptr, (long)A->tlc_n_tiles, (const float *)x, (float *)y, nullptr)) == USPMV_OK;
+            for (int l = 0; l < 3 && ok; ++l) {
+                if (B) ok = launch_spmv_ap(A, B, (const double *)x, nullptr, (double *)y, nullptr) == USPMV_OK;
+                else ok = (A->dtype == USPMV_F64 ? launch_spmv_tlc<double>(A, nullptr, (long)A->tlc_n_tiles, (const double *)x, (double *)y, nullptr)
+                                                 : launch_spmv_tlc<float>(A, nullptr, (long)A->tlc_n_tiles, (const float *)x, (float *)y, nullptr)) == USPMV_OK;
+            }
             ok = ok && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
         }
         if (!ok) { (void)hipGetLastError(); continue; }
-        if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] measured tile size: %d rows -> %.4f ms per SpMV (%lld of %lld tiles staged, %d lines at most)\n", R, ms / 3,
-                                             (long long)ns, (long long)nt, A->tlc_max_lines);
+        if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] measured tile size%s: %d rows -> %.4f ms per SpMV (%lld of %lld tiles staged, %d lines at most)\n", B ? " (ap pair)" : "",
+                                             R, ms / 3, (long long)ns, (long long)nt, A->tlc_max_lines);
         tmin[slot] = tmin[slot] > 0 ? std::min(tmin[slot], ms) : ms;
     }
-    // 256 rows unless a larger tile is more than 3 % ahead of it (the faster of the two when both are)
-    if (tmin[0] > 0) {
-        best = 256; tbest = 0.97f * tmin[0];
-        if (tmin[1] > 0 && tmin[1] < tbest) { best = 512; tbest = tmin[1]; }
-        if (tmin[2] > 0 && tmin[2] < tbest) { best = 1024; tbest = tmin[2]; }
-    } else if (tmin[1] > 0 || tmin[2] > 0) {
-        best = tmin[1] > 0 && (tmin[2] <= 0 || tmin[1] <= tmin[2]) ? 512 : 1024;
+    // the base size unless another one is more than 3 % ahead of it (the fastest of those that are)
+    {
+        const int bs = slot_of(base);
+        float tbest = tmin[bs] > 0 ? 0.97f * tmin[bs] : 1e30f;
+        best = tmin[bs] > 0 ? base : 0;
+        const int sizes[3] = {256, 512, 1024};
+        for (int o = 0; o < 3; ++o)
+            if (o != bs && tmin[o] > 0 && tmin[o] < tbest) { best = sizes[o]; tbest = tmin[o]; }
     }
     done();
-    seen.push_back({Key{A->n_chunks, A->n_elements, A->C, A->dtype, max_lines}, best});
+    seen.push_back({Key{A->n_chunks, A->n_elements, ne2, A->C, A->dtype, max_lines}, best});
     return best;
 }
 
@@ -491,7 +506,7 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     const int cap = (int)(160 * 1024 / (16 * (s->dtype == USPMV_F64 ? 8 : 4)));
     if (max_lines > cap) max_lines = cap;
     uspmv_tlc_plan p;
-    const int R_meas = measured_tile_rows(A, max_lines, "uspmv_dmat_optimize");
+    const int R_meas = measured_tile_rows(A, nullptr, max_lines, "uspmv_dmat_optimize");
     if (int rc = uspmv_build_tlc_plan(s, nullptr, max_lines, R_meas ? R_meas : plan_tile_rows(false), &p)) return rc;
     if (!R_meas && p.valid && tile_rows_grow(p.tile_rows, p.max_lines_used))
         for (int R : {1024, 512}) {
@@ -551,7 +566,10 @@ static bool c16_offsets(const std::vector<int32_t> &cl, int64_t C, std::vector<u
 static int device_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, int64_t *n_tiles, int64_t *n_staged, const char *who) {
     if (!B) {
         const int ml = std::min(std::min(max_lines <= 0 ? 512 : max_lines, (int)(160 * 1024 / (16 * (A->dtype == USPMV_F64 ? 8 : 4)))), 4096);
-        if (const int R_meas = measured_tile_rows(A, ml, who)) return device_plan_install_rows(A, nullptr, max_lines, R_meas, n_tiles, n_staged, who);
+        if (const int R_meas = measured_tile_rows(A, nullptr, ml, who)) return device_plan_install_rows(A, nullptr, max_lines, R_meas, n_tiles, n_staged, who);
+    } else {
+        const int ml = std::min(std::min(max_lines <= 0 ? 512 : max_lines, (int)(160 * 1024 / (16 * 8))), 1280);
+        if (const int R_meas = measured_tile_rows(A, B, ml, who)) return device_plan_install_rows(A, B, max_lines, R_meas, n_tiles, n_staged, who);
     }
     const int R0 = plan_tile_rows(B != nullptr);
     if (int rc = device_plan_install_rows(A, B, max_lines, R0, n_tiles, n_staged, who)) return rc;
@@ -1105,7 +1123,8 @@ int uspmv_dmat_optimize_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv_scs_t
     if (max_lines <= 0) max_lines = 512;
     if (max_lines > 1280) max_lines = 1280;
     uspmv_tlc_plan p;
-    if (int rc = uspmv_build_tlc_plan(s_dp, s_sp, max_lines, plan_tile_rows(true), &p)) return rc;
+    const int R_meas = measured_tile_rows(dp, sp, max_lines, "uspmv_dmat_optimize_ap");
+    if (int rc = uspmv_build_tlc_plan(s_dp, s_sp, max_lines, R_meas ? R_meas : plan_tile_rows(true), &p)) return rc;
     if (n_tiles) *n_tiles = p.n_tiles;
     if (n_staged) *n_staged = p.valid ? p.n_staged_tiles : 0;
     if (dp->sw) sw_release(dp);
