@@ -22,6 +22,12 @@
 // ids a rank asks block p for index p's rows, and the set-up refuses ids outside this block.
 // USPMV_EXCHANGE_HOST: the per-step exchange staged through host memory over the transport -- P real processes may then share
 // ONE GPU, which is how the step runs with unequal seg-nnz blocks and asymmetric lists on a single-GPU box.
+//
+// Round 3 additions in this file: optional arrangements of the step around the exchange ("pad_split": tiles that touch the halo only
+// through the reference's padding run before the exchange under a sign / finiteness guard; "fused_step": one launch whose boundary
+// tiles look once at an exchange counter and defer themselves otherwise), uspmv_dist_autotune (times the arrangements collectively and
+// keeps the fastest, self-checked), the block-vector step in two parts over marked chunk-length arrays (uspmv_dist_spmmv, also with
+// the phased block plan built on the rank's matrix), the block exchange staged through the host for real ranks on one GPU.
 #include <rccl/rccl.h>
 
 #include <chrono>
