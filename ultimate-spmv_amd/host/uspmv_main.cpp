@@ -415,7 +415,10 @@ int main(int argc, char **argv) {
         d.no_overlap = getenv("USPMV_NO_OVERLAP") != nullptr;
         d.step_form = c.step_form;
         d.mode = c.mode; d.n_repetitions = c.n_repetitions; d.dump_y = c.dump_y; d.sp = c.value_type == "sp"; d.random_init_x = c.random_init_x;
-        d.bench_steps = c.bench_steps; d.bench_warmup = c.bench_warmup; d.check_y = c.check_y != 0; d.json = c.json;
+        d.bench_steps = c.bench_steps; d.bench_warmup = c.bench_warmup; d.json = c.json;
+        // -validate (default 1) in solve mode: the reference gathers y and compares with MKL (code/write_results.hpp:442-556); across ranks
+        // here the bitwise self-check of one step plays that role, as -check_y 1 does in bench mode
+        d.check_y = c.check_y != 0 || (c.mode == 's' && c.validate_result != 0 && c.comm_halos != 0);
         d.equilibrate = c.equilibrate != 0;
         // (-par_pack: on the device the send buffer is packed by one kernel either way, as in the reference's device branch, code/classes_structs.hpp:787-806)
         return uspmv_run_distributed(d);   // every rank generates / receives only its row block
