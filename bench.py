@@ -54,7 +54,9 @@ def parse():
     ap.add_argument("--no-second-line", action="store_true", help="N > 1: skip the other scaling mode's measurement")
     ap.add_argument("--in-process", action="store_true", help="N > 1: skip the uspmv child processes, run the C++ step inside this (torch) process")
     ap.add_argument("--ba-synch", type=int, default=0, choices=[0, 1], help="N > 1: per-step barrier of the headline protocol (the reference's default is 1; the other setting is timed too and reported)")
-    ap.add_argument("--child-timeout", type=float, default=420.0, help="N > 1: seconds a uspmv child may take (a healthy one needs well under a minute; three tiers of children may run)")
+    ap.add_argument("--budget-s", type=float, default=480.0, help="N > 1: wall-clock budget of the WHOLE run (single-GPU reference, the tiers of uspmv children, the second scaling mode); when it ends the line is printed with value null and the reason")
+    ap.add_argument("--no-single-gpu-reference", action="store_true", help="N > 1, strong scaling: skip the single-rank child that times the same matrix on one GPU")
+    ap.add_argument("--step-form", default="auto", choices=["auto", "auto_all", "overlap", "plain", "pad", "fused"], help="N > 1: -step_form of the uspmv children (auto: overlap | plain timed on the machine, the faster kept)")
     ap.add_argument("--python-step", action="store_true", help="N > 1: round-1 path (torch.distributed all_to_all per step) instead of the C++ step")
     ap.add_argument("--seg", choices=["seg-nnz", "seg-rows"], default="seg-nnz")
     ap.add_argument("--no-overlap", action="store_true")
@@ -382,50 +384,163 @@ class stdout_to_stderr:
         return False
 
 
-def cli_measure(args, world, rank, scaling, grid, parents, host_exchange=False, eager=False):
-    """One N > 1 measurement by the `uspmv` harness: every rank starts it as a child process (this process has not touched the GPU),
-    rank 0's child writes the JSON report.  Returns (report dict | None, reason).  host_exchange: the halo exchange staged through host
-    memory and the ranks' shared segment instead of RCCL (USPMV_EXCHANGE=host) -- the tier that still yields a native, checked number when
-    RCCL does not come up on the machine."""
+class Parents:
+    """Agreement between the bench.py processes of one N > 1 run.  Self-launched (`python bench.py --gpus N`, no outer launcher): ONE
+    process, which starts all N `uspmv` rank children itself.  Under torch.distributed.run: N processes, each starting the child of its
+    own rank; they agree on every verdict through the library's host communicator (no torch, no GPU)."""
+
+    def __init__(self, pkg, rank, world, self_launch, timeout_s):
+        self.rank, self.world, self.self_launch = rank, world, self_launch
+        self.hc = None if self_launch else pkg.HostComm(f"benchparents{os.environ.get('MASTER_PORT', '0')}", rank, world, timeout_s=timeout_s)
+
+    def my_ranks(self):
+        return list(range(self.world)) if self.self_launch else [self.rank]
+
+    def allgather(self, v):
+        return [int(v)] if self.hc is None else self.hc.allgather(np.array([int(v)], np.int64)).ravel().tolist()
+
+    def close(self):
+        if self.hc is not None:
+            self.hc.barrier()
+            self.hc.close()
+            self.hc = None
+
+
+def _last_stage(text):
+    st = [ln.split("] ", 1)[1] for ln in text.splitlines() if ln.startswith("[uspmv stage] ")]
+    return st[-1] if st else "no stage reached"
+
+
+def run_children(cmd_of_rank, env_of_rank, ranks, timeout_s, tmp):
+    """Start one `uspmv` process per rank in `ranks`, wait until all have ended or `timeout_s` has passed, then terminate exactly the
+    processes started here that are still alive (their own sessions: SIGTERM, then SIGKILL).  Returns {rank: (rc, output tail, last stage)};
+    rc -9 = killed at the time limit."""
+    import signal
     import subprocess
+    procs, logs = {}, {}
+    for r in ranks:
+        logs[r] = open(os.path.join(tmp, f"rank{r}.log"), "w+")
+        try:
+            procs[r] = subprocess.Popen(cmd_of_rank(r), cwd=tmp, env=env_of_rank(r), stdout=logs[r], stderr=subprocess.STDOUT, start_new_session=True)
+        except OSError as e:
+            logs[r].write(f"cannot start: {e}\n")
+            procs[r] = None
+    t_end = time.time() + timeout_s
+    failed_at = None
+    while True:
+        alive = [r for r, p in procs.items() if p is not None and p.poll() is None]
+        if not alive:
+            break
+        bad = [r for r, p in procs.items() if p is None or (p.poll() is not None and p.returncode != 0)]
+        if bad and failed_at is None:
+            failed_at = time.time()        # a rank has failed: its peers notice through the communicator's failure flag; give them 20 s
+        if time.time() >= t_end or (failed_at is not None and time.time() - failed_at > 20):
+            for r in alive:
+                try:
+                    os.killpg(procs[r].pid, signal.SIGTERM)
+                except OSError:
+                    pass
+            time.sleep(3)
+            for r in alive:
+                if procs[r].poll() is None:
+                    try:
+                        os.killpg(procs[r].pid, signal.SIGKILL)
+                    except OSError:
+                        pass
+                    procs[r].wait()
+                    procs[r].returncode = -9
+            break
+        time.sleep(0.2)
+    out = {}
+    for r in ranks:
+        logs[r].flush(); logs[r].seek(0)
+        text = logs[r].read()
+        logs[r].close()
+        rc = -2 if procs[r] is None else procs[r].returncode
+        if rc is not None and rc < 0 and rc != -2:
+            rc = -9
+        out[r] = (rc, text[-1500:], _last_stage(text))
+    return out
+
+
+def cli_measure(args, parents, scaling, grid, timeout_s, host_exchange=False, eager=False):
+    """One N > 1 measurement by the `uspmv` harness: one child process per rank (the bench.py processes never touch the GPU), rank 0's child
+    writes the JSON report.  Returns (report dict | None on ranks other than the one holding rank 0, reason, stage the slowest child had
+    reached).  host_exchange: the halo exchange staged through host memory and the ranks' shared segment instead of RCCL
+    (USPMV_EXCHANGE=host) -- the tier that still yields a native, checked number when RCCL does not come up on the machine."""
     import tempfile
-    exe = os.path.join(ROOT, "ultimate-spmv_amd", "uspmv")
+    world, rank = parents.world, parents.rank
+    exe = os.environ.get("USPMV_BENCH_EXE") or os.path.join(ROOT, "ultimate-spmv_amd", "uspmv")     # (USPMV_BENCH_EXE: the launcher's CPU tests)
     g = grid
     nz = g * world if scaling == "weak" else g
-    cores = max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
+    cores = max(1, usable_cores() // max(1, world if parents.self_launch else int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
     tmp = tempfile.mkdtemp(prefix=f"uspmv_bench_r{rank}_")
     js = os.path.join(tmp, "report.json")
     cmd = [exe, f"gen:{g}x{g}x{nz}", "scs", "-c", str(args.chunk), "-s", str(args.sigma), "-dp", "-" + args.seg.replace("-", "_"), "-comm_halos", "1",
            "-ba_synch", str(args.ba_synch), "-bench_steps", str(args.steps), "-bench_warmup", str(args.warmup), "-check_y", "1", "-json", js,
-           "-tlc", "0" if args.no_tlc else "1", "-graph", "0" if (args.no_graph or eager) else "1"]
-    env = dict(os.environ, OMP_NUM_THREADS=str(cores), USPMV_JOB_ID=f"bench{os.environ.get('MASTER_PORT', '0')}_{scaling}_{g}{'_hx' if host_exchange else ''}{'_e' if eager else ''}")
-    env.setdefault("USPMV_HC_TIMEOUT", str(int(args.child_timeout)))     # (the children's rendezvous gives up with them, not an hour later)
-    if host_exchange:
-        env["USPMV_EXCHANGE"] = "host"
-    elif os.environ.get("USPMV_BENCH_SIMULATE_RCCL_FAILURE") and (not eager or os.environ["USPMV_BENCH_SIMULATE_RCCL_FAILURE"] == "2"):
-        cmd = ["/bin/false"]                                       # rehearsal of the later tiers: these children fail at once
-    if args.no_overlap:
-        env["USPMV_NO_OVERLAP"] = "1"
-    rc, out = -1, ""
-    try:
-        r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=args.child_timeout)
-        rc, out = r.returncode, (r.stdout + r.stderr)[-2000:]
-    except subprocess.TimeoutExpired:
-        rc, out = -9, "timed out"
-    except OSError as e:
-        rc, out = -2, str(e)
-    rcs = parents.allgather(np.array([rc], np.int64)).ravel().tolist()
+           "-tlc", "0" if args.no_tlc else "1", "-graph", "0" if (args.no_graph or eager) else "1", "-step_form", args.step_form]
+    job = f"bench{os.environ.get('MASTER_PORT', str(os.getppid() if not parents.self_launch else os.getpid()))}_{scaling}_{g}{'_hx' if host_exchange else ''}{'_e' if eager else ''}"
+
+    def env_of(r):
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores), USPMV_JOB_ID=job, USPMV_STAGES="1", RANK=str(r), WORLD_SIZE=str(world),
+                   LOCAL_RANK=str(r) if parents.self_launch else os.environ.get("LOCAL_RANK", str(r)))
+        env.setdefault("USPMV_HC_TIMEOUT", str(int(timeout_s)))     # (the children's rendezvous gives up with them, not an hour later)
+        if host_exchange:
+            env["USPMV_EXCHANGE"] = "host"
+        if args.no_overlap:
+            env["USPMV_NO_OVERLAP"] = "1"
+        return env
+
+    sim = os.environ.get("USPMV_BENCH_SIMULATE_RCCL_FAILURE")      # rehearsal of the later tiers: these children fail at once
+    fail_now = bool(sim) and not host_exchange and (not eager or sim == "2")
+    res = run_children(lambda r: ["/bin/false"] if fail_now else cmd, env_of, parents.my_ranks(), timeout_s, tmp)
+    mine_bad = max((1 if rc else 0) for rc, _, _ in res.values())
+    rcs = parents.allgather(mine_bad)
+    stages = "; ".join(f"rank {r}: rc {rc}, {stg}" for r, (rc, _, stg) in sorted(res.items()))
     if any(rcs):
-        sys.stderr.write(f"[bench rank {rank}] uspmv child exit codes {rcs}; rank {rank}: {out}\n")
-        return None, f"uspmv child processes failed (exit codes {rcs})"
+        for r, (rc, tail, _) in sorted(res.items()):
+            if rc:
+                sys.stderr.write(f"[bench] uspmv child of rank {r} ended with rc {rc}:\n{tail}\n")
+        hung = any(rc == -9 for rc, _, _ in res.values())
+        return None, ("uspmv child processes " + ("killed at the time limit of %.0f s" % timeout_s if hung else "failed") + f" ({stages})"), stages
     rep = None
-    if rank == 0:
+    if 0 in res:
         try:
             rep = json.load(open(js))
             rep["cmd"] = " ".join(cmd[1:])
         except (OSError, ValueError) as e:
-            return None, f"rank 0's report is unreadable: {e}"
-    return rep, ""
+            return None, f"rank 0's report is unreadable: {e}", stages
+    return rep, "", stages
+
+
+def single_gpu_reference(args, grid, timeout_s):
+    """The SAME matrix on ONE GPU (strong scaling's denominator): `uspmv gen:... scs -c 32 -s 512 -dp -bench_steps K -json` as a single-rank
+    child on GPU 0, all usable cores for its set-up, before any communicator exists.  Returns a dict (ms_per_step, ...) or {"error": ...}."""
+    import tempfile
+    exe = os.environ.get("USPMV_BENCH_EXE") or os.path.join(ROOT, "ultimate-spmv_amd", "uspmv")
+    tmp = tempfile.mkdtemp(prefix="uspmv_bench_single_")
+    js = os.path.join(tmp, "single.json")
+    cmd = [exe, f"gen:{grid}x{grid}x{grid}", "scs", "-c", str(args.chunk), "-s", str(args.sigma), "-dp", "-bench_steps", str(args.steps),
+           "-bench_warmup", str(args.warmup), "-json", js, "-tlc", "0" if args.no_tlc else "1"]
+
+    def env_of(_):
+        env = dict(os.environ, OMP_NUM_THREADS=str(usable_cores()))
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "USPMV_LOOPBACK", "USPMV_FORCE_DIST"):
+            env.pop(k, None)
+        return env
+
+    t0 = time.time()
+    rc, tail, _ = run_children(lambda r: cmd, env_of, [0], timeout_s, tmp)[0]
+    if rc:
+        return {"error": f"single-GPU child rc {rc}" + (" (killed at its time limit of %.0f s)" % timeout_s if rc == -9 else "") + f": {tail[-300:]}"}
+    try:
+        d = json.load(open(js))
+    except (OSError, ValueError) as e:
+        return {"error": f"single-GPU report unreadable: {e}"}
+    return {"ms_per_step": d["ms_per_step"], "kernel_ms": d["kernel_ms"], "gflops": d["gflops"], "n_rows": d["n_rows"], "nnz": d["nnz"],
+            "algorithmic_GBs": d["algorithmic_GBs"], "frac_of_8TBs": round(d["algorithmic_GBs"] / HBM_PEAK_GBS, 4),
+            "plan_tiles_planned": [d["plan_tiles_planned"], d["plan_tiles"]], "setup_s": d["setup_s"], "wall_s": round(time.time() - t0, 1),
+            "cmd": "uspmv " + " ".join(cmd[1:])}
 
 
 def cli_result(args, rep, scaling, grid, world):
@@ -434,12 +549,17 @@ def cli_result(args, rep, scaling, grid, world):
     klass = "nlpkkt240-class" if g == 304 else "nlpkkt200-class" if g == 253 else "stencil"
     r0 = rep["rank0"]
     k_ms = r0["local_kernel_ms"]
+    per_rank = []
+    for r in rep.get("per_rank", []):
+        r = dict(r)
+        r["local_kernel_GBs"] = round(r["algorithmic_bytes"] / (r["local_kernel_ms"] * 1e-3) / 1e9, 1) if r.get("local_kernel_ms") else None
+        per_rank.append(r)
     return {
         "value": round(rep["gflops"], 2), "ms_per_step": round(rep["ms_per_step"], 5), "scaling": scaling,
         "workload": (f"{klass} synthetic (27-pt stencil {g}x{g}x{nz}, n={rep['n_rows']}, nnz={rep['nnz']}) scs -c {args.chunk} -s {args.sigma} -dp "
                      f"-{args.seg.replace('-', '_')} -comm_halos 1"),
         "n_rows": rep["n_rows"], "nnz": rep["nnz"], "beta": None,
-        "exchange": rep.get("exchange"),
+        "exchange": rep.get("exchange"), "rccl_nranks": rep.get("rccl_nranks"), "ranks": rep.get("ranks"),
         "step": "uspmv child processes on the system RCCL: C++ uspmv_dist_run, " + ("hipGraph replay" if rep["graph_replay"] else "eager C++ steps"),
         "protocol": f"exactly {rep['steps']} steps between barriers after {rep['warmup']} warm-ups, slowest rank's clock; -ba_synch {rep['ba_synch']} "
                     f"(with -ba_synch {1 - rep['ba_synch']}: {rep['other_ba_synch_ms_per_step']:.5f} ms per step; 1 = the reference's default, a barrier behind every step, code/main.cpp:467)",
@@ -448,8 +568,117 @@ def cli_result(args, rep, scaling, grid, world):
         "rank0": {"n_local": r0["n_local"], "n_halo": r0["n_halo"], "n_send": r0["n_send"], "interior": r0["interior"], "boundary": r0["boundary"],
                   "tiles": r0["tiles"], "plan_kind": 1 if r0["tiles"] else 0, "local_kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(r0["algorithmic_bytes"]),
                   "local_kernel_GBs": round(r0["algorithmic_bytes"] / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None},
+        "per_rank": per_rank,
         "versions": rep["versions"], "cmd": "uspmv " + rep["cmd"],
     }
+
+
+def dist_bench(args, pkg, world, rank, self_launch, tuning):
+    """N > 1 (BASELINE config 5): the `uspmv` rank processes do everything on the GPUs; this process only starts them, keeps ONE wall-clock
+    budget over the whole run and prints ONE JSON line -- with "value": null and the reason when no tier produced a number in time.
+    Order: [strong scaling] the same matrix on one GPU (single-rank child) -> tier 1 graph replay on RCCL -> tier 2 eager steps on RCCL
+    (only when tier 1 got as far as its timed steps: a capture gone wrong takes the child down; a communicator that never came up would
+    not come up for eager steps either) -> tier 3 the exchange staged through host memory (no RCCL) -> the other scaling mode when at
+    least a third of the budget is left.  Every child is a fresh process; nothing that touched a GPU is ever re-used or re-exec'ed."""
+    t_start = time.time()
+    left = lambda: args.budget_s - (time.time() - t_start)
+    first = args.scaling or "strong"
+    second = "weak" if first == "strong" else "strong"
+    grid1 = args.grid or (304 if first == "strong" else 253)
+    grid2 = args.grid2 or (253 if second == "weak" else 304)
+    parents = Parents(pkg, rank, world, self_launch, timeout_s=args.budget_s + 60)
+    tiers, res, other, reason, single = [], None, None, "", None
+    lead = rank == 0
+    worth = lambda: left() > min(40.0, 0.15 * args.budget_s)                # (is there time for another tier?)
+    lead_says = lambda flag: bool(parents.allgather(int(bool(flag)))[0])    # (clock-dependent decisions are rank 0's: every parent takes the same road)
+
+    def tier(name, scaling, grid, share, **kw):
+        """(ok on every rank, report on the lead, reason, did every child get as far as its steps) -- the same verdicts on all parents"""
+        t0 = time.time()
+        tmo = max(1.0, min(max(20.0, left() * share), left() - 4.0))     # (never past the budget: 4 s are kept for ending the children)
+        rep, why, stages = cli_measure(args, parents, scaling, grid, tmo, **kw)
+        ok = bool(min(parents.allgather(0 if (why or (lead and rep is None)) else 1)))
+        steps_seen = bool(min(parents.allgather(int(any(k in stages for k in ("step form chosen", "timed region", "report written"))))))
+        tiers.append({"tier": name, "scaling": scaling, "ok": ok, "wall_s": round(time.time() - t0, 1), "time_limit_s": round(tmo, 1),
+                      **({} if ok else {"why": why or "failed on another rank"})})
+        return ok, (rep if ok else None), why or ("" if ok else "failed on another rank"), steps_seen
+
+    if first == "strong" and not args.no_single_gpu_reference:
+        if lead:
+            single = single_gpu_reference(args, grid1, max(1.0, min(0.3 * left(), 200.0)))
+        parents.allgather(0)                                         # (the other parents wait for rank 0's single-GPU child here)
+    ok, rep, why, steps_seen = tier("1: hipGraph replay, RCCL" if not args.no_graph else "1: eager steps, RCCL", first, grid1, 0.55)
+    if not ok:
+        reason = why
+        if not args.no_graph and steps_seen and lead_says(worth()):
+            ok, rep, why2, _ = tier("2: eager steps, RCCL", first, grid1, 0.5, eager=True)
+            reason += "; measured with eager steps instead of graph replay" if ok else f"; eager retry: {why2}"
+        if not ok and lead_says(worth()):
+            ok, rep, why3, _ = tier("3: exchange staged through host memory (no RCCL)", first, grid1, 0.85, host_exchange=True)
+            reason += "; measured with the halo exchange staged through host memory instead of RCCL" if ok else f"; host-staged retry: {why3}"
+        if not ok and not worth():
+            reason += "; the budget ended"
+    host_tier = False
+    if ok and lead:
+        res = cli_result(args, rep, first, grid1, world)
+        host_tier = rep.get("exchange") == "host"
+        if host_tier:
+            res["step"] = res["step"].replace("on the system RCCL", "with the host-staged exchange (USPMV_EXCHANGE=host)")
+    host_tier = bool(max(parents.allgather(int(host_tier))))
+    if ok and not args.no_second_line:
+        if lead_says(left() >= args.budget_s / 3.0):
+            ok2, rep2, why2, _ = tier("second line (" + second + " scaling)", second, grid2, 0.9, host_exchange=host_tier, eager=bool(args.no_graph))
+            if lead:
+                other = cli_result(args, rep2, second, grid2, world) if ok2 else {"value": None, "scaling": second, "error": why2}
+        elif lead:
+            other = {"value": None, "scaling": second, "error": f"skipped: {left():.0f} s of the {args.budget_s:.0f} s budget left (< 1/3)"}
+    parents.close()
+    if not lead:
+        return 0
+    out = {
+        "metric": "SpMV GFLOP/s (SELL-32-512 dp; achieved HBM GB/s in roofline)",
+        "value": res["value"] if res else None, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"] if res else None, "higher_is_better": True, "scaling": first, "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+    }
+    if res:
+        r0 = res["rank0"]
+        slow = max(res["per_rank"], key=lambda r: r.get("local_kernel_ms") or 0.0) if res["per_rank"] else None
+        out.update({
+            "y_checked": res.get("y_checked"), "y_mismatches": res.get("y_mismatches"),
+            "config": {"workload": res["workload"], "C": args.chunk, "sigma": args.sigma, "n_rows": res["n_rows"], "nnz": res["nnz"],
+                       "x": "5.0 (DefaultValues) in the timed steps; x_global[j] = 1 + 1e-3 (j mod 1000) in the checked step", "partition": args.seg,
+                       "halo_overlap": (res.get("step_form") or ("plain" if args.no_overlap else "overlap")) != "plain", "step": res["step"], "protocol": res.get("protocol"),
+                       "step_form": res.get("step_form"), "step_form_candidates_ms": res.get("step_form_candidates_ms"), "exchange": res.get("exchange"),
+                       "rccl_nranks": res.get("rccl_nranks"), "ranks": res.get("ranks"),
+                       "launcher": "bench.py started the uspmv rank processes itself" if self_launch else "torch.distributed.run ranks, each started its uspmv rank process",
+                       "rank0": r0, "per_rank": res["per_rank"], "tuning": tuning, "versions": res.get("versions"), "cmd": res.get("cmd")},
+            "roofline": {"bound": "hbm", "achieved": r0["local_kernel_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(r0["local_kernel_GBs"] / HBM_PEAK_GBS, 4) if r0["local_kernel_GBs"] else None, "traffic": None,
+                         "kernel": "rank 0's local SpMV (interior + boundary tiles, no exchange): " + ("scs_spmv_tlc<double,32>" if r0["plan_kind"] == 1 else "scs_spmv_rows<double,32,8>"),
+                         "kernel_ms": r0["local_kernel_ms"], "algorithmic_bytes_per_launch": r0["algorithmic_bytes"],
+                         "rank0_step_frac": round(r0["algorithmic_bytes"] / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "slowest_rank": None if not slow else {"rank": slow["rank"], "kernel_ms": slow["local_kernel_ms"], "achieved": slow["local_kernel_GBs"],
+                                                                "frac": round(slow["local_kernel_GBs"] / HBM_PEAK_GBS, 4) if slow["local_kernel_GBs"] else None}},
+        })
+        if first == "strong":
+            out["single_gpu_same_matrix"] = single
+            if single and "ms_per_step" in single:
+                out["speedup_vs_single_gpu"] = round(single["ms_per_step"] / res["ms_per_step"], 3)
+                out["strong_scaling_efficiency"] = round(single["ms_per_step"] / (world * res["ms_per_step"]), 4)
+    else:
+        out["error"] = reason or "no tier produced a number"
+        out["config"] = {"workload": f"27-pt stencil {grid1}^3 scs -c {args.chunk} -s {args.sigma} -dp -{args.seg.replace('-', '_')} -comm_halos 1", "tuning": tuning}
+        if single is not None:
+            out["single_gpu_same_matrix"] = single
+    if reason:
+        out["fallback_reason"] = reason
+    if other is not None:
+        out[second + "_scaling"] = {k: other.get(k) for k in ("value", "ms_per_step", "scaling", "workload", "step", "protocol", "y_checked", "y_mismatches", "rank0", "per_rank", "rccl_nranks", "error") if k in other}
+        out[second + "_scaling"]["unit"] = "GFLOP/s"
+    out["budget"] = {"budget_s": args.budget_s, "used_s": round(time.time() - t_start, 1), "tiers": tiers}
+    print(json.dumps(out), flush=True)
+    return 0 if res else 1
 
 
 def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
@@ -599,139 +828,111 @@ def run_distributed(args, pkg, B, torch, dist, dev, world, rank, scaling, grid):
     return res
 
 
+def in_process_distributed(args, pkg, world, rank, local_rank, tuning):
+    """--in-process / --python-step (explicit options, under torch.distributed.run only; NOT part of the default chain): the C++ step object
+    inside this torch process on torch's bundled RCCL, or the round-1 torch.distributed twin."""
+    import torch
+    import torch.distributed as dist
+    from ultimate_spmv_amd import binding as B
+    first = args.scaling or "strong"
+    second = "weak" if first == "strong" else "strong"
+    grid1 = args.grid or (304 if first == "strong" else 253)
+    grid2 = args.grid2 or (253 if second == "weak" else 304)
+    if os.environ.get("USPMV_BENCH_ONE_DEVICE"):   # rehearsal only: several ranks share GPU 0
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if os.environ.get("USPMV_BENCH_ONE_DEVICE"):
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # rehearsal: RCCL refuses duplicate GPUs
+    else:
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    res = run_distributed(args, pkg, B, torch, dist, dev, world, rank, first, grid1)
+    other = None if args.no_second_line else run_distributed(args, pkg, B, torch, dist, dev, world, rank, second, grid2)
+    if rank == 0:
+        r0 = res["rank0"]
+        twin = not res.get("native", True)
+        out = {
+            "metric": "SpMV GFLOP/s (SELL-32-512 dp; achieved HBM GB/s in roofline)",
+            "value": None if twin else res["value"], "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": first, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "y_checked": res.get("y_checked"), "y_mismatches": res.get("y_mismatches"),
+            "config": {"workload": res["workload"], "C": args.chunk, "sigma": args.sigma, "n_rows": res["n_rows"], "nnz": res["nnz"], "beta": res["beta"],
+                       "x": "5.0 (DefaultValues) in the timed steps; x_global[j] = 1 + 1e-3 (j mod 1000) in the checked step", "partition": args.seg,
+                       "halo_overlap": (res.get("step_form") or ("plain" if args.no_overlap else "overlap")) != "plain", "step": res["step"], "protocol": res.get("protocol"),
+                       "step_form": res.get("step_form"), "step_form_candidates_ms": res.get("step_form_candidates_ms"),
+                       "launcher": "torch.distributed.run ranks, the step inside the torch process (--in-process / --python-step)",
+                       "rank0": r0, "tuning": tuning},
+            "roofline": {"bound": "hbm", "achieved": r0["local_kernel_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(r0["local_kernel_GBs"] / HBM_PEAK_GBS, 4) if r0["local_kernel_GBs"] else None, "traffic": None,
+                         "kernel": "rank 0's local SpMV (interior + boundary tiles, no exchange): " + ("scs_spmv_tlc<double,32>" if r0["plan_kind"] == 1 else "scs_spmv_rows<double,32,8>"),
+                         "kernel_ms": r0["local_kernel_ms"], "algorithmic_bytes_per_launch": r0["algorithmic_bytes"],
+                         "rank0_step_frac": round(r0["algorithmic_bytes"] / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "setup_s": res.get("setup_s"),
+        }
+        if twin:
+            out["fallback_value"] = res["value"]
+        if other is not None:
+            out[second + "_scaling"] = {k: other.get(k) for k in ("value", "ms_per_step", "scaling", "workload", "step", "protocol", "y_checked", "y_mismatches", "rank0", "setup_s", "error") if k in other}
+            out[second + "_scaling"]["unit"] = "GFLOP/s"
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.pmc_child:
         return pmc_child(args)
+
+    # ================================================================== N > 1: BASELINE config 5 (strong) + the weak line
+    if args.gpus > 1 or world_env > 1 or os.environ.get("USPMV_BENCH_WORLD1"):
+        in_proc = args.in_process or args.python_step or args.graph or os.environ.get("USPMV_BENCH_WORLD1") or os.environ.get("USPMV_BENCH_ONE_DEVICE")
+        self_launch = world_env == 1 and not in_proc       # no outer launcher: this process starts the N rank processes itself
+        world = args.gpus if self_launch else world_env
+        if not self_launch and world != args.gpus:
+            args.gpus = world
+        set_omp_threads(max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+        import __graft_entry__ as ge
+        if not in_proc:
+            os.environ["USPMV_NO_TORCH"] = "1"             # this process never touches a GPU and never needs torch: the library binds to the system runtime
+        pkg = ge.load_package()
+        tuning = None
+        if in_proc:
+            if world_env == 1 and not os.environ.get("USPMV_BENCH_WORLD1"):
+                raise SystemExit("--in-process / --python-step / --graph need torch.distributed.run (one rank per GPU); the default N > 1 path does not")
+            for kv in filter(None, args.tune.split(",")):
+                k, v = kv.split("=")
+                pkg.set_tuning(**{k: int(v)})
+            tuning = {k: pkg.get_tuning(k) for k in ("unroll", "nontemporal", "xcd_remap", "block", "spmv_variant", "tlc")}
+            return in_process_distributed(args, pkg, world_env, rank, local_rank, tuning)
+        if args.tune:
+            sys.stderr.write("bench.py: --tune applies to in-process measurements only (the uspmv children run the library defaults)\n")
+        return dist_bench(args, pkg, world, 0 if self_launch else rank, self_launch, "library defaults (the uspmv rank processes)")
+
     traffic, traffic_note = None, "not measured"
-    if world == 1 and not args.mtx and not args.no_traffic:
+    if not args.mtx and not args.no_traffic:
         traffic, traffic_note = measure_traffic(args)      # child processes under rocprofv3, BEFORE this process touches the GPU
     import torch
-    import torch.distributed as dist
     import __graft_entry__ as ge
 
     pkg = ge.load_package()
     from ultimate_spmv_amd import binding as B
 
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1 and not os.environ.get("USPMV_BENCH_WORLD1"):
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    dist_path = world > 1 or bool(os.environ.get("USPMV_BENCH_WORLD1"))   # USPMV_BENCH_WORLD1: the N > 1 code path (C++ RCCL step object and all) rehearsed with ONE rank
-    if os.environ.get("USPMV_BENCH_ONE_DEVICE"):   # rehearsal only: several ranks share GPU 0
-        local_rank = 0
-    if not dist_path:      # (N > 1: the GPU is touched only after the uspmv child processes are done, and only as a fall-back)
-        torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # torchrun exports OMP_NUM_THREADS=1; the host set-up (generation, conversion, planning) is OpenMP code,
-    # so give every rank its share of the usable cores instead
-    set_omp_threads(max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    set_omp_threads(usable_cores())
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         pkg.set_tuning(**{k: int(v)})
     tuning = {k: pkg.get_tuning(k) for k in ("unroll", "nontemporal", "xcd_remap", "block", "spmv_variant", "tlc")}
-    if args.tune and dist_path and not (args.in_process or args.python_step):
-        sys.stderr.write("bench.py: --tune applies to in-process measurements only (the uspmv children run the library defaults)\n")
-
-    # ================================================================== N > 1: BASELINE config 5 (strong) + the weak line
-    if dist_path:
-        first = args.scaling or "strong"
-        second = "weak" if first == "strong" else "strong"
-        grid1 = args.grid or (304 if first == "strong" else 253)
-        grid2 = args.grid2 or (253 if second == "weak" else 304)
-        use_cli = not (args.in_process or args.python_step or args.graph or os.environ.get("USPMV_BENCH_WORLD1") or os.environ.get("USPMV_BENCH_ONE_DEVICE"))
-        res = other = None
-        reason = ""
-        if use_cli:   # the uspmv harness as child processes, BEFORE this process touches the GPU
-            parents = pkg.HostComm(f"benchparents{os.environ.get('MASTER_PORT', '0')}", rank, world, timeout_s=args.child_timeout + 600)
-            rep, reason = cli_measure(args, world, rank, first, grid1, parents)
-            good = int(parents.allgather(np.array([0 if (reason or (rank == 0 and rep is None)) else 1], np.int64)).min())
-            if good:
-                if rank == 0:
-                    res = cli_result(args, rep, first, grid1, world)
-                if not args.no_second_line:
-                    rep2, reason2 = cli_measure(args, world, rank, second, grid2, parents)
-                    good2 = int(parents.allgather(np.array([0 if (reason2 or (rank == 0 and rep2 is None)) else 1], np.int64)).min())
-                    if good2 and rank == 0:
-                        other = cli_result(args, rep2, second, grid2, world)
-                    elif rank == 0:
-                        other = {"value": None, "scaling": second, "error": reason2 or "failed on another rank"}
-            else:
-                reason = reason or "the uspmv child processes failed on another rank"
-                # still before this process touches the GPU: (a) the same children with eager steps (a capture of the RCCL group that goes
-                # wrong takes the child down with it, as torch's RCCL did in round 2); (b) the same harness with the exchange staged
-                # through the host (no RCCL at all) -- slower per step, but a native, self-checked number.  Said so in the line.
-                eager_ok = host_ok = 0
-                if not args.no_graph:
-                    rep_e, reason_e = cli_measure(args, world, rank, first, grid1, parents, eager=True)
-                    eager_ok = int(parents.allgather(np.array([0 if (reason_e or (rank == 0 and rep_e is None)) else 1], np.int64)).min())
-                if eager_ok:
-                    reason = f"{reason}; measured with eager steps instead of graph replay"
-                    if rank == 0:
-                        res = cli_result(args, rep_e, first, grid1, world)
-                else:
-                    rep_h, reason_h = cli_measure(args, world, rank, first, grid1, parents, host_exchange=True)
-                    host_ok = int(parents.allgather(np.array([0 if (reason_h or (rank == 0 and rep_h is None)) else 1], np.int64)).min())
-                    if host_ok:
-                        reason = f"{reason}; measured with the halo exchange staged through host memory instead of RCCL"
-                        if rank == 0:
-                            res = cli_result(args, rep_h, first, grid1, world)
-                            res["step"] = res["step"].replace("on the system RCCL", "with the host-staged exchange (USPMV_EXCHANGE=host)")
-                    else:
-                        reason = f"{reason}; host-staged retry: {reason_h or 'failed on another rank'}"
-                good = int(bool(eager_ok or host_ok))
-            parents.barrier()
-            parents.close()
-            use_cli = bool(good)
-        if not use_cli:   # in-process: the same C++ step under torch's RCCL (eager), then the torch.distributed twin
-            torch.cuda.set_device(local_rank)
-            dev = torch.device("cuda", local_rank)
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            if os.environ.get("USPMV_BENCH_ONE_DEVICE"):
-                dist.init_process_group("gloo", rank=rank, world_size=world)      # rehearsal: RCCL refuses duplicate GPUs
-            else:
-                with stdout_to_stderr():
-                    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            res = run_distributed(args, pkg, B, torch, dist, dev, world, rank, first, grid1)
-            if not args.no_second_line:
-                other = run_distributed(args, pkg, B, torch, dist, dev, world, rank, second, grid2)
-        if rank == 0:
-            r0 = res["rank0"]
-            twin = not use_cli and not res.get("native", True)
-            out = {
-                "metric": "SpMV GFLOP/s (SELL-32-512 dp; achieved HBM GB/s in roofline)",
-                "value": None if twin else res["value"], "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": first, "vs_baseline": None,
-                "dtype": "f64", "data": "synthetic",
-                "y_checked": res.get("y_checked"), "y_mismatches": res.get("y_mismatches"),
-                "config": {"workload": res["workload"], "C": args.chunk, "sigma": args.sigma, "n_rows": res["n_rows"], "nnz": res["nnz"], "beta": res["beta"],
-                           "x": "5.0 (DefaultValues) in the timed steps; x_global[j] = 1 + 1e-3 (j mod 1000) in the checked step", "partition": args.seg,
-                           "halo_overlap": (res.get("step_form") or ("plain" if args.no_overlap else "overlap")) != "plain", "step": res["step"], "protocol": res.get("protocol"),
-                           "step_form": res.get("step_form"), "step_form_candidates_ms": res.get("step_form_candidates_ms"), "exchange": res.get("exchange"),
-                           "rank0": r0, "tuning": tuning, "versions": res.get("versions"), "cmd": res.get("cmd")},
-                "roofline": {"bound": "hbm", "achieved": r0["local_kernel_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(r0["local_kernel_GBs"] / HBM_PEAK_GBS, 4) if r0["local_kernel_GBs"] else None, "traffic": None,
-                             "kernel": "rank 0's local SpMV (interior + boundary tiles, no exchange): " + ("scs_spmv_tlc<double,32>" if r0["plan_kind"] == 1 else "scs_spmv_rows<double,32,8>"),
-                             "kernel_ms": r0["local_kernel_ms"], "algorithmic_bytes_per_launch": r0["algorithmic_bytes"],
-                             "rank0_step_frac": round(r0["algorithmic_bytes"] / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                "setup_s": res.get("setup_s"),
-            }
-            if twin:
-                out["fallback_value"] = res["value"]
-            if reason:
-                out["fallback_reason"] = reason
-            if other is not None:
-                out[second + "_scaling"] = {k: other.get(k) for k in ("value", "ms_per_step", "scaling", "workload", "step", "protocol", "y_checked", "y_mismatches", "rank0", "setup_s", "error") if k in other}
-                out[second + "_scaling"]["unit"] = "GFLOP/s"
-            print(json.dumps(out), flush=True)
-        if not use_cli:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
 
     # ================================================================== N = 1: BASELINE config 2
     t_setup = time.time()
@@ -821,4 +1022,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -448,12 +448,14 @@ int uspmv_dist_comm_plan(const uspmv_dist_t *d, int64_t *n_send, const int64_t *
  *   the grid, each of which looks once whether the exchange has completed and otherwise defers itself to a small second launch behind
  *   the exchange; nothing spins.  0: interior launch, exchange, boundary launch),
  * "pad_split" 0|1 (default 0; 1: padding tiles run with the interior ones, see uspmv_dist_pad_info; 0: with the boundary tiles),
+ * "autotune_all" 0|1 (default 0: uspmv_dist_autotune times overlap | plain; 1: the pad / fused arrangements as well),
  * "diag_spmmv_part" 0|1|2 (diagnosis only: the two-part block-vector step runs both parts, its interior part, its boundary part),
  * "block_plan" b (block vectors: build the phased block plan for b columns on the rank's matrix, 0 drops it; see uspmv_dist_spmmv). */
 int uspmv_dist_set_option(uspmv_dist_t *d, const char *key, int value);
 /* How the single-vector step is arranged around the exchange: interior tiles during the exchange and boundary tiles after it | the
  * exchange, then the whole matrix (the reference's order) | overlap with the padding-only tiles in front of the exchange ("pad_split") |
- * that in one launch ("fused_step", eager steps only).  uspmv_dist_autotune times each for 2 x (10 + 40) steps on the machine at hand --
+ * that in one launch ("fused_step", eager steps only).  uspmv_dist_autotune times the first two (all four with "autotune_all" 1: the last
+ * two have never run next to an exchange between different GPUs) for 2 x (10 + 40) steps on the machine at hand --
  * COLLECTIVE: every rank calls it; the ranks agree on the slowest rank's clock -- sets the options of the fastest and returns it with
  * the candidates' ms per step (0: not tried; negative: fastest but refused by the self-check).  With `local` and `wsa` (as for
  * uspmv_dist_check, which it then runs) a pad / fused winner must pass the bitwise self-check on every rank or the faster of the first
@@ -474,6 +476,9 @@ int uspmv_dist_check_reference(const uspmv_coo_t *local, const int32_t *wsa, int
 /* HIP / RCCL versions this library was COMPILED against and the ones it RUNS on in this process:
  * v[0] HIP_VERSION (build), v[1] hipRuntimeGetVersion, v[2] NCCL_VERSION_CODE (build), v[3] ncclGetVersion. */
 int uspmv_runtime_versions(int v[4]);
+/* Ranks of the RCCL communicator the step's exchange runs on (ncclCommCount; the reference prints MPI_Comm_size, code/main.cpp:1838);
+ * 0 when the exchange is staged through the host (no communicator exists). */
+int uspmv_dist_comm_count(const uspmv_dist_t *d, int *n_ranks);
 /* meta[12] = n_local, n_halo, padded_vec_size, n_send, n_interior, n_boundary, ids_are_tiles, n_rows_padded, loopback,
  *            graph captured, graph launches so far, eager steps so far */
 int uspmv_dist_info(const uspmv_dist_t *d, int64_t meta[12]);

@@ -173,10 +173,12 @@ def test_autotune_picks_a_form_and_keeps_the_bits(pkg, orc):
     rank = 1
     loc = pkg.gen_stencil27(*shape, row_begin=int(wsa[rank]), row_end=int(wsa[rank + 1]))
     d = pkg.DistNative(loc, wsa, C, sigma, rank, P, pkg.comm_unique_id(), comm_rank=0, comm_size=1)
-    for graph, forms in ((False, {"overlap", "plain", "pad", "fused"}), (True, {"overlap", "plain", "pad"})):
+    assert d.comm_count() == 1                       # (loopback: a communicator of one rank)
+    for graph, every, forms in ((False, True, {"overlap", "plain", "pad", "fused"}), (True, True, {"overlap", "plain", "pad"}),
+                                (False, False, {"overlap", "plain"}), (True, False, {"overlap", "plain"})):
         x = d.new_x(make_x(nl)); y = d.new_y()
         x0 = x.clone()
-        form, ms = d.autotune(x, y, use_graph=graph, local=loc, wsa=wsa)
+        form, ms = d.autotune(x, y, use_graph=graph, local=loc, wsa=wsa, all_forms=every)
         d.synchronize()
         assert set(ms) == forms and form in forms and all(v > 0 for v in ms.values()), (form, ms)
         assert ms[form] == min(ms.values())
@@ -623,6 +625,46 @@ def test_cli_real_ranks_host_exchange_mtx_scatter_and_check(pkg, tmp_path):
     assert "seg_method: seg-nnz" in txt and "ba_synch: 1" in txt and "Per rank Elems Recvd" in txt
 
 
+def test_cli_config5_shaped_workload_three_real_ranks_seg_nnz(pkg, tmp_path):
+    """BASELINE config 5's shape on a workload larger than the goldens: `uspmv gen:96x96x96 scs -c 32 -s 512 -dp -seg_nnz -comm_halos 1
+    -check_y 1` as THREE real rank processes sharing the GPU with the exchange staged through the host.  (Block k of 8 of the 304^3 matrix
+    in RCCL loopback is impossible: seg-nnz blocks are unequal and loopback needs equal heights -- the set-up refuses it,
+    test_loopback_refuses_unequal_blocks_cleanly.)  Mirrors the reference's loop code/main.cpp:458-474 over
+    init/finalize_halo_exchange, code/classes_structs.hpp:857-995.  Every rank's row of the report is checked against the partition
+    rule, and y of every local row bitwise against the entry-ordered chains (uspmv_dist_check)."""
+    import json
+    g, P = 96, 3
+    counts = pkg.gen_stencil27_row_counts(g, g, g)
+    wsa = pkg.seg_from_row_counts(counts, "seg-nnz", P)
+    heights = np.diff(wsa)
+    assert len(set(heights.tolist())) > 1, "seg-nnz blocks of this workload are unequal"
+    js = str(tmp_path / "c5.json")
+    procs = []
+    for rank in range(P):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(P), LOCAL_RANK=str(rank), USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
+                   USPMV_JOB_ID=f"c5_{os.getpid()}", USPMV_HC_TIMEOUT="240", USPMV_STAGES="1", OMP_NUM_THREADS="4")
+        env.pop("USPMV_LOOPBACK", None)
+        procs.append(subprocess.Popen([EXE, f"gen:{g}x{g}x{g}", "scs", "-c", "32", "-s", "512", "-dp", "-seg_nnz", "-comm_halos", "1", "-ba_synch", "0",
+                                       "-bench_steps", "20", "-bench_warmup", "5", "-check_y", "1", "-json", js], cwd=tmp_path, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    rep = json.load(open(js))
+    assert rep["y_checked"] is True and rep["y_mismatches"] == 0 and rep["steps"] == 20 and rep["ranks"] == P
+    assert rep["exchange"] == "host" and rep["rccl_nranks"] == 0 and rep["n_rows"] == g ** 3 and rep["nnz"] == int(counts.sum())
+    assert rep["step_form"] in ("overlap", "plain") and set(rep["step_form_candidates_ms"]) == {"overlap", "plain"}
+    rows = rep["per_rank"]
+    assert [r["rank"] for r in rows] == list(range(P))
+    assert [r["n_local"] for r in rows] == heights.tolist()
+    assert sum(r["nnz"] for r in rows) == rep["nnz"]
+    # a slab of a 96^3 27-point stencil needs whole planes from its neighbours (+ the padding column 0 from rank 0, code/mpi_funcs.hpp:279-306)
+    assert rows[0]["n_halo"] >= g * g and rows[1]["n_halo"] >= 2 * g * g and rows[2]["n_halo"] >= g * g
+    assert all(r["local_kernel_ms"] > 0 and r["interior"] > 0 and r["boundary"] > 0 for r in rows)
+    assert rep["rank0"]["n_local"] == rows[0]["n_local"] and rep["rank0"]["n_halo"] == rows[0]["n_halo"]
+    assert "[uspmv stage] timed region done" in outs[0] and "[uspmv stage] report written" in outs[0]
+
+
 def test_cli_solve_mode_and_crs_across_real_ranks(pkg, orc, tmp_path):
     """`uspmv bcsstk13.mtx <scs -c 32 -s 512 | crs> <-dp | -sp> -mode s -rev 3 -seg_nnz` as three real rank processes (the multi-rank
     half of the reference's scripts/validate_master.sh): COMM - spmv - SWAP three times, every rank dumps y of its rows.  Each row is
@@ -763,7 +805,8 @@ def test_cli_loopback_graph_replay_with_ba_synch_and_check(pkg, tmp_path):
 
 def test_cli_step_forms_all_check_and_auto_picks_one(pkg, tmp_path):
     """-step_form: every arrangement of the step (overlap | plain | pad | fused) passes the bitwise self-check through the harness, and
-    auto times the candidates on this machine, reports them and keeps the fastest (graph replay: without the one-launch form)."""
+    auto times overlap | plain on this machine, reports them and keeps the fastest; auto_all adds the speculative pad / fused forms
+    (graph replay: without the one-launch form)."""
     import json
     import subprocess
     env = dict(os.environ, USPMV_LOOPBACK="4", USPMV_LOOPBACK_RANK="2", USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID="sf")
@@ -777,9 +820,10 @@ def test_cli_step_forms_all_check_and_auto_picks_one(pkg, tmp_path):
         assert rep["step_form"] == form and rep["y_checked"] is True and rep["y_mismatches"] == 0, rep
         assert rep["overlap"] == (form != "plain") and rep["graph_replay"] == bool(graph)
         assert f"step form: {form}" in r.stdout
-    for graph, cands in ((1, {"overlap", "plain", "pad"}), (0, {"overlap", "plain", "pad", "fused"})):
-        js = tmp_path / f"auto{graph}.json"
-        r = subprocess.run(base + ["-graph", str(graph), "-json", str(js)], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    for graph, sf, cands in ((1, "auto_all", {"overlap", "plain", "pad"}), (0, "auto_all", {"overlap", "plain", "pad", "fused"}),
+                             (1, "auto", {"overlap", "plain"}), (0, "auto", {"overlap", "plain"})):
+        js = tmp_path / f"{sf}{graph}.json"
+        r = subprocess.run(base + ["-graph", str(graph), "-step_form", sf, "-json", str(js)], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         rep = json.load(open(js))
         assert set(rep["step_form_candidates_ms"]) == cands and rep["step_form"] in cands, rep

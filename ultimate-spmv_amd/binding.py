@@ -131,6 +131,7 @@ _SIGS = {
     "uspmv_dist_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dist_spmmv_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dist_pad_info": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "uspmv_dist_comm_count": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "uspmv_dist_autotune": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _i32p, _vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "uspmv_dist_check_reference": (C.c_int, [_vp, _i32p, C.c_int, C.c_int, C.c_int, _vp]),
     "uspmv_dist_parts": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
@@ -672,11 +673,18 @@ class DistNative:
 
     STEP_FORMS = ("overlap", "plain", "pad", "fused")
 
-    def autotune(self, x, y, use_graph=False, local=None, wsa=None):
+    def comm_count(self):
+        """ranks of the RCCL communicator the exchange runs on (ncclCommCount); 0 with the host-staged exchange"""
+        n = C.c_int(0)
+        _ck(lib().uspmv_dist_comm_count(self.h, C.byref(n)))
+        return n.value
+
+    def autotune(self, x, y, use_graph=False, local=None, wsa=None, all_forms=False):
         """Time the arrangements of the step on this machine and keep the fastest (uspmv_dist_autotune; COLLECTIVE: every rank calls it).
-        Returns (name of the chosen form, {form: ms per step}); with `local` (the block's Coo) and `wsa` a pad / fused winner must pass
-        the bitwise self-check."""
+        Candidates: overlap | plain; all_forms adds pad (and fused for eager steps).  Returns (name of the chosen form, {form: ms per
+        step}); with `local` (the block's Coo) and `wsa` a pad / fused winner must pass the bitwise self-check."""
         self._order(x, y)
+        _ck(lib().uspmv_dist_set_option(self.h, b"autotune_all", int(bool(all_forms))))
         form = C.c_int(0)
         ms = (C.c_double * 4)()
         w = None if wsa is None else np.ascontiguousarray(wsa, np.int32)

@@ -39,6 +39,7 @@ struct uspmv_dist {
     int rank = 0, P = 1, comm_rank = 0, comm_size = 1;
     bool loopback = false, overlap = true, tiles = false, owns_setup = false, no_pack = false, ba_synch = false, host_exchange = false;
     bool diag_skip_exchange = false;
+    bool autotune_all = false;        // uspmv_dist_autotune also times the speculative arrangements (pad, fused); off: overlap | plain only
     int diag_spmmv_part = 0;          // diagnosis: the two-part block-vector step runs only its interior (1) or boundary (2) part
     int capture_mode = hipStreamCaptureModeRelaxed;
     ncclComm_t comm = nullptr;
@@ -640,6 +641,7 @@ int uspmv_dist_set_option(uspmv_dist_t *D, const char *key, int value) {
     else if (k == "ba_synch") { if ((value != 0) != D->ba_synch) drop_graph(D); D->ba_synch = value != 0; }
     else if (k == "fused_step") { if ((value != 0) != D->fused) drop_graph(D); D->fused = value != 0; }
     else if (k == "pad_split") { if ((value != 0) != D->pad_split) drop_graph(D); D->pad_split = value != 0; }
+    else if (k == "autotune_all") D->autotune_all = value != 0;
     else if (k == "diag_spmmv_part") {
         if (value < 0 || value > 2) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_option: diag_spmmv_part is 0 (both), 1 (interior only) or 2 (boundary only)");
         D->diag_spmmv_part = value;
@@ -666,6 +668,13 @@ int uspmv_dist_set_option(uspmv_dist_t *D, const char *key, int value) {
     }
     else if (k == "diag_skip_exchange") { drop_graph(D); D->diag_skip_exchange = value != 0; }
     else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_set_option: unknown key '%s'", key);
+    return USPMV_OK;
+}
+
+int uspmv_dist_comm_count(const uspmv_dist_t *D, int *n_ranks) {
+    if (!D || !n_ranks) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dist_comm_count: NULL argument");
+    *n_ranks = 0;                                                   // (host-staged exchange: no RCCL communicator exists)
+    if (D->comm) NCCL_TRY(ncclCommCount(D->comm, n_ranks));
     return USPMV_OK;
 }
 
@@ -764,8 +773,14 @@ int uspmv_dist_autotune(uspmv_dist_t *D, void *d_x, void *d_y, int use_graph, co
         if (int rc = uspmv_dist_set_option(D, "pad_split", f == USPMV_STEP_PAD || f == USPMV_STEP_FUSED ? 1 : 0)) return rc;
         return uspmv_dist_set_option(D, "fused_step", f == USPMV_STEP_FUSED ? 1 : 0);
     };
-    std::vector<int> cand = {USPMV_STEP_OVERLAP, USPMV_STEP_PLAIN, USPMV_STEP_PAD};
-    if (!use_graph || D->host_exchange) cand.push_back(USPMV_STEP_FUSED);          // (a captured step never takes the one-launch form)
+    // Candidates: the two arrangements every run has executed (overlap | plain).  The padding-tile and one-launch forms have only ever
+    // run next to an exchange on the SAME GPU (loopback / host-staged), where they measured slower; they are timed only on request
+    // ("autotune_all" 1, -step_form auto_all) until a run with real peers has shown what they are worth.
+    std::vector<int> cand = {USPMV_STEP_OVERLAP, USPMV_STEP_PLAIN};
+    if (D->autotune_all) {
+        cand.push_back(USPMV_STEP_PAD);
+        if (!use_graph || D->host_exchange) cand.push_back(USPMV_STEP_FUSED);      // (a captured step never takes the one-launch form)
+    }
     // every collective the measurement uses once before anything is timed (RCCL sets its channels up lazily, 40 ms the first time), and two
     // rounds over the candidates of which the faster counts: the first candidate must not pay for a cold start
     { double warm = 0; if (int rc = uspmv_dist_barrier(D, st)) return rc; if (int rc = uspmv_dist_allreduce_max(D, &warm, st)) return rc; }

@@ -61,6 +61,13 @@ Ctx g;
 #define CK(call) do { int rc_ = (call); if (rc_ != USPMV_OK) die(std::string(#call) + ": " + uspmv_last_error()); } while (0)
 #define HK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) die(std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
+// USPMV_STAGES=1: one line on stderr per stage a rank reaches -- a launcher that has to kill a hung run (bench.py --gpus N) can say
+// WHERE it hung (communicator creation, set-up, the timed steps ...), and whether a later tier is worth trying
+void stage(const char *what) {
+    static const bool on = getenv("USPMV_STAGES") != nullptr;
+    if (on) { fprintf(stderr, "[uspmv stage] %s (rank %d)\n", what, g.rank); fflush(stderr); }
+}
+
 int env_int(const char *a, const char *b, int dflt) {
     const char *v = getenv(a);
     if (!v && b) v = getenv(b);
@@ -110,7 +117,9 @@ int uspmv_run_distributed(const DistConfig &c) {
     CK(uspmv_set_device(local_rank % ndev));  // device = my_rank % num_devices (code/main.cpp:1838-1842)
 
     // ---- the ranks meet (MPI_Init's part); the RCCL id travels through the host communicator
+    stage("device set, waiting for the other ranks");
     CK(uspmv_hostcomm_create(job_key().c_str(), comm_rank, comm_size, (double)env_int("USPMV_HC_TIMEOUT", nullptr, 3600), &g.hc));
+    stage("ranks met");
     uint64_t nonce = 0;
     CK(uspmv_hostcomm_info(g.hc, nullptr, nullptr, &nonce));
     unsigned char id[USPMV_COMM_ID_BYTES] = {0};
@@ -174,6 +183,7 @@ int uspmv_run_distributed(const DistConfig &c) {
         }
     }
 
+    stage("matrix block built");
     // ---- the distributed object: convert, halo discovery, upload, plan, exchange plan, communicator (init_local_structs + collect_comm_info)
     uspmv_dist_t *D = nullptr;
     uspmv_transport_t tr{};
@@ -201,9 +211,11 @@ int uspmv_run_distributed(const DistConfig &c) {
     if (c.equilibrate) CK(uspmv_coo_equilibrate(local));
     CK(uspmv_dist_create_from_coo_ex(host_exchange ? nullptr : id, comm_rank, comm_size, rank, P, local, wsa.data(), c.C, c.sigma, c.sp ? USPMV_F32 : USPMV_F64, c.tlc ? 1 : 0, &opt, &D));
     // (the block's COO stays until the end: -rand_x reads its values, -step_form auto and -check_y run the self-check against it)
+    stage("step object created (communicator up)");
     hipStream_t st = nullptr;
     HK(hipStreamCreate(&st));
     CK(uspmv_dist_barrier(D, st));
+    stage("first collective done");
     if (c.no_overlap) CK(uspmv_dist_set_option(D, "overlap", 0));
     if (const char *fs = getenv("USPMV_FUSED_STEP")) CK(uspmv_dist_set_option(D, "fused_step", atoi(fs) != 0));
     if (const char *ps = getenv("USPMV_PAD_SPLIT")) CK(uspmv_dist_set_option(D, "pad_split", atoi(ps) != 0));   // (A/B of the padding tiles, tools/ab_dist_step.sh)
@@ -321,10 +333,11 @@ int uspmv_run_distributed(const DistConfig &c) {
         return uspmv_dist_set_option(D, "fused_step", f == "fused" ? 1 : 0);
     };
     if (P > 1 && comm_halos && b == 1 && !legacy_knobs) {
-        if (form == "auto") {
+        if (form == "auto" || form == "auto_all") {
             static const char *names[4] = {"overlap", "plain", "pad", "fused"};
             int best = USPMV_STEP_OVERLAP;
             double tms[4];
+            CK(uspmv_dist_set_option(D, "autotune_all", form == "auto_all"));   // (pad / fused: timed on request only, see uspmv_dist_autotune)
             CK(uspmv_dist_autotune(D, d_x, d_y, c.use_graph ? 1 : 0, local, wsa.data(), st, &best, tms));
             for (int k = 0; k < 4; ++k) {
                 if (tms[k] == 0) continue;
@@ -339,6 +352,7 @@ int uspmv_run_distributed(const DistConfig &c) {
         CK(apply_form(form));
     }
 
+    stage("step form chosen");
     // ---- timed region
     int n_iter = 2;
     double runtime = 0, runtime_other = 0;
@@ -382,6 +396,7 @@ int uspmv_run_distributed(const DistConfig &c) {
         n_iter /= 2;
     }
     const double perf = (double)nnz_g * 2.0 * b / (runtime / n_iter) / 1e9;
+    stage("timed region done");
 
     // ---- this rank's kernel alone (interior + boundary without the exchange), HIP events on the step's stream
     double kernel_ms = 0;
@@ -418,6 +433,15 @@ int uspmv_run_distributed(const DistConfig &c) {
     CK(uspmv_dist_allgather_i64(D, n_halo, halos.data(), st));
     CK(uspmv_dist_allgather_i64(D, n_send, sends.data(), st));
     CK(uspmv_dist_info(D, meta));
+    // every rank's row of the report (the reference gathers its per-rank numbers on rank 0 too, code/main.cpp:809-1062)
+    const double my_bytes = n_el * (vsz + 4.0) + 8.0 * n_chunks + (double)vsz * b * (n_local + n_halo) + (double)vsz * b * n_pad;
+    const int n_rep = meta[8] ? 1 : comm_size;
+    const char *rank_keys[9] = {"n_local", "n_halo", "n_send", "interior", "boundary", "n_elements", "nnz", "algorithmic_bytes", "local_kernel_ns"};
+    const int64_t rank_vals[9] = {n_local, n_halo, n_send, meta[4], meta[5], n_el, sm[7], (int64_t)my_bytes, (int64_t)(kernel_ms * 1e6)};
+    std::vector<std::vector<int64_t>> rank_rows(9, std::vector<int64_t>((size_t)std::max(P, comm_size), 0));
+    for (int k = 0; k < 9; ++k) CK(uspmv_dist_allgather_i64(D, rank_vals[k], rank_rows[(size_t)k].data(), st));
+    int rccl_nranks = 0;
+    CK(uspmv_dist_comm_count(D, &rccl_nranks));
     int ver[4] = {0, 0, 0, 0};
     CK(uspmv_runtime_versions(ver));
     const char *protocol = c.bench_steps > 0 ? "fixed steps between barriers" : "reference bench loop (doubling batches)";
@@ -454,6 +478,17 @@ int uspmv_run_distributed(const DistConfig &c) {
                    b, (long)bm[0], (long)bm[1], bm[2] ? "yes" : "no", (long)bm[4], (long)bm[3]);
         }
         if (!c.json.empty()) {
+            std::string per_rank = "[";
+            for (int p = 0; p < n_rep; ++p) {
+                per_rank += p ? ", {" : "{";
+                char kv[96];
+                snprintf(kv, sizeof kv, "\"rank\": %d", p);
+                per_rank += kv;
+                for (int k = 0; k < 8; ++k) { snprintf(kv, sizeof kv, ", \"%s\": %ld", rank_keys[k], (long)rank_rows[(size_t)k][(size_t)p]); per_rank += kv; }
+                snprintf(kv, sizeof kv, ", \"local_kernel_ms\": %.6f}", (double)rank_rows[8][(size_t)p] * 1e-6);
+                per_rank += kv;
+            }
+            per_rank += "]";
             char js[3072];
             snprintf(js, sizeof js,
                      "{\"gflops\": %.4f, \"ms_per_step\": %.6f, \"steps\": %d, \"warmup\": %d, \"runtime_s\": %.6f, \"ranks\": %d, \"loopback\": %s, "
@@ -461,16 +496,18 @@ int uspmv_run_distributed(const DistConfig &c) {
                      "\"eager_steps\": %ld, \"overlap\": %s, \"step_form\": \"%s\", \"step_form_candidates_ms\": {%s}, \"other_ba_synch_ms_per_step\": %.6f, \"y_checked\": %s, \"y_mismatches\": %ld, \"y_checksum_rank0\": %.17g, "
                      "\"rank0\": {\"n_local\": %ld, \"n_halo\": %ld, \"n_send\": %ld, \"interior\": %ld, \"boundary\": %ld, \"tiles\": %s, \"n_elements\": %ld, "
                      "\"n_chunks\": %ld, \"n_rows_padded\": %ld, \"algorithmic_bytes\": %.0f, \"local_kernel_ms\": %.6f}, "
-                     "\"versions\": {\"hip_build\": %d, \"hip_runtime\": %d, \"rccl_build\": %d, \"rccl_runtime\": %d}}",
+                     "\"rccl_nranks\": %d, \"versions\": {\"hip_build\": %d, \"hip_runtime\": %d, \"rccl_build\": %d, \"rccl_runtime\": %d}",
                      perf, runtime / n_iter * 1e3, n_iter, warm, runtime, P, meta[8] ? "true" : "false", host_exchange ? "host" : "rccl", (long)n_rows_g, (long)nnz_g,
                      protocol, c.ba_synch && c.comm_halos ? 1 : 0, meta[9] ? "true" : "false", (long)meta[10], (long)meta[11], form == "plain" ? "false" : "true", form.c_str(), form_report.c_str(), runtime_other / n_iter * 1e3,
                      mism_total < 0 ? "null" : mism_total == 0 ? "true" : "false", (long)mism_total, checksum, (long)n_local, (long)n_halo, (long)n_send,
                      (long)meta[4], (long)meta[5], meta[6] ? "true" : "false", (long)n_el, (long)n_chunks, (long)n_pad, bytes, kernel_ms,
-                     ver[0], ver[1], ver[2], ver[3]);
-            if (c.json == "-") printf("%s\n", js);
-            else { std::ofstream jf(c.json); jf << js << std::endl; }
+                     rccl_nranks, ver[0], ver[1], ver[2], ver[3]);
+            const std::string full = std::string(js) + ", \"per_rank\": " + per_rank + "}";
+            if (c.json == "-") printf("%s\n", full.c_str());
+            else { std::ofstream jf(c.json); jf << full << std::endl; }
         }
     }
+    stage("report written");
     CK(uspmv_dist_barrier(D, st));
     (void)hipFree(d_x); (void)hipFree(d_y);
     uspmv_dist_free(D);

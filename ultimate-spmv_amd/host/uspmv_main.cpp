@@ -17,6 +17,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -77,7 +78,7 @@ void usage() {
             "  -equilibrate <0|1> -ap_threshold_1 <float> -ap_threshold_2 <float> -dropout <0|1>\n"
             "  -dropout_threshold <float> -block_vec_layout <colwise|rowwise> -tlc <0|1> -graph <0|1> -dump_y <file>\n"
             "  -mpi_mode <singlevec|multivec|bulkvec>\n"
-            "  multi-rank runs: -bench_steps <int> -bench_warmup <int> -check_y <0|1> -json <file|-> -step_form <auto|overlap|plain|pad|fused>\n"
+            "  multi-rank runs: -bench_steps <int> -bench_warmup <int> -check_y <0|1> -json <file|-> -step_form <auto|auto_all|overlap|plain|pad|fused>\n"
             "  -seg_metis [-part_file <file>]: graph partition (built-in level-set partitioner, or part ids from a gpmetis-style file)\n");
 }
 
@@ -124,7 +125,7 @@ Config parse(int argc, char **argv) {
         else if (a == "-bench_warmup") { c.bench_warmup = atoi(need(i)); if (c.bench_warmup < 0) die("bench_warmup must be >= 0."); }
         else if (a == "-check_y") c.check_y = atoi(need(i));
         else if (a == "-json") c.json = need(i);
-        else if (a == "-step_form") { c.step_form = need(i); if (c.step_form != "auto" && c.step_form != "overlap" && c.step_form != "plain" && c.step_form != "pad" && c.step_form != "fused") die("step_form must be auto, overlap, plain, pad or fused."); }
+        else if (a == "-step_form") { c.step_form = need(i); if (c.step_form != "auto" && c.step_form != "auto_all" && c.step_form != "overlap" && c.step_form != "plain" && c.step_form != "pad" && c.step_form != "fused") die("step_form must be auto, auto_all, overlap, plain, pad or fused."); }
         else if (a == "-block_vec_layout") { std::string v = need(i); if (v == "colwise") c.layout = USPMV_COLWISE; else if (v == "rowwise") c.layout = USPMV_ROWWISE; else die("block_vec_layout must be colwise or rowwise."); }
         else { usage(); die("unknown argument: " + a); }
     }
@@ -203,6 +204,7 @@ template <typename VT>
 int run(const Config &c, uspmv_coo_t *coo) {
     const int dtype = sizeof(VT) == 8 ? USPMV_F64 : USPMV_F32;
     const bool ap = c.value_type == "ap[dp_sp]";
+    const auto t_start = std::chrono::steady_clock::now();
     int64_t n_rows, n_cols, nnz;
     ck(uspmv_coo_dims(coo, &n_rows, &n_cols, &nnz), "uspmv_coo_dims");
     const double *vals; ck(uspmv_coo_arrays(coo, nullptr, nullptr, &vals), "uspmv_coo_arrays");
@@ -274,11 +276,31 @@ int run(const Config &c, uspmv_coo_t *coo) {
     r.y = dev_alloc<VT>((size_t)b * ld);
     hk(hipMemcpy(r.x, hx.data(), sizeof(VT) * hx.size(), hipMemcpyHostToDevice), "hipMemcpy x");
 
+    const auto t_setup_end = std::chrono::steady_clock::now();
     if (c.kernel_format == "scs") printf("C = %ld => %s SCS Sp%sV kernel selected (gfx950)\n", c.chunk_size, ap ? "ap[dp_sp]" : "one-precision", b > 1 ? "MM" : "M");
     else printf("CRS Sp%sV kernel selected (gfx950)\n", b > 1 ? "MM" : "M");
 
     double perf = 0, runtime = 0; int n_iter = 0;
-    if (c.mode == 'b') {
+    float kernel_ms = 0.f;
+    if (c.mode == 'b' && c.bench_steps > 0) {
+        // -bench_steps K [-bench_warmup W]: exactly K launches between two synchronisations, wall clock and HIP events (the protocol
+        // bench.py asks the multi-rank harness for; here it yields the one-GPU time of the same matrix for the strong-scaling line)
+        const int warm = c.bench_warmup >= 0 ? c.bench_warmup : WARM_UP_REPS;
+        for (int k = 0; k < warm; ++k) r.exec();
+        hk(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        hipEvent_t e0, e1;
+        hk(hipEventCreate(&e0), "hipEventCreate"); hk(hipEventCreate(&e1), "hipEventCreate");
+        const auto t0 = std::chrono::steady_clock::now();
+        hk(hipEventRecord(e0, nullptr), "hipEventRecord");
+        for (int k = 0; k < c.bench_steps; ++k) r.exec();
+        hk(hipEventRecord(e1, nullptr), "hipEventRecord");
+        hk(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        hk(hipEventElapsedTime(&kernel_ms, e0, e1), "hipEventElapsedTime");
+        kernel_ms /= (float)c.bench_steps;
+        n_iter = c.bench_steps;
+        perf = (double)nnz * 2.0 * b / (runtime / n_iter) / 1e9;
+    } else if (c.mode == 'b') {
         for (int k = 0; k < WARM_UP_REPS; ++k) r.exec();
         hk(hipDeviceSynchronize(), "hipDeviceSynchronize");
         hipEvent_t e0, e1;
@@ -389,6 +411,22 @@ int run(const Config &c, uspmv_coo_t *coo) {
     printf("Total Gflops: %.4f   (%d iterations in %.4f s, %.6f ms per SpMV)\n", perf, n_iter, runtime, t_iter * 1e3);
     printf("Achieved GB/s: %.1f   (%.1f %% of the %.0f GB/s HBM3E roofline; algorithmic bytes %.0f per SpMV)\n", gbs,
            100.0 * gbs / HBM_PEAK_GBS, HBM_PEAK_GBS, bytes);
+    if (!c.json.empty()) {   // -json <file|->: the single-rank twin of the multi-rank report
+        int64_t pi[3] = {0, 0, 0};
+        int pk = 0;
+        (void)uspmv_dmat_plan_info(r.A, &pk, &pi[1], &pi[2]);
+        pi[0] = pk;
+        char js[1024];
+        snprintf(js, sizeof js,
+                 "{\"gflops\": %.4f, \"ms_per_step\": %.6f, \"kernel_ms\": %.6f, \"steps\": %d, \"warmup\": %d, \"runtime_s\": %.6f, \"ranks\": 1, "
+                 "\"n_rows\": %ld, \"nnz\": %ld, \"n_elements\": %ld, \"n_chunks\": %ld, \"n_rows_padded\": %ld, \"algorithmic_bytes\": %.0f, "
+                 "\"algorithmic_GBs\": %.1f, \"plan_kind\": %ld, \"plan_tiles\": %ld, \"plan_tiles_planned\": %ld, \"setup_s\": %.2f}",
+                 perf, t_iter * 1e3, (double)kernel_ms, n_iter, c.bench_steps > 0 ? (c.bench_warmup >= 0 ? c.bench_warmup : WARM_UP_REPS) : WARM_UP_REPS, runtime,
+                 (long)n_rows, (long)nnz, (long)n_el, (long)n_chunks, (long)n_pad, bytes, gbs, (long)pi[0], (long)pi[1], (long)pi[2],
+                 std::chrono::duration<double>(t_setup_end - t_start).count());
+        if (c.json == "-") printf("%s\n", js);
+        else { std::ofstream jf(c.json); jf << js << std::endl; }
+    }
     return 0;
 }
 
