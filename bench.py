@@ -630,6 +630,8 @@ def dist_bench(args, pkg, world, rank, self_launch, tuning):
             ok2, rep2, why2, _ = tier("second line (" + second + " scaling)", second, grid2, 0.9, host_exchange=host_tier, eager=bool(args.no_graph))
             if lead:
                 other = cli_result(args, rep2, second, grid2, world) if ok2 else {"value": None, "scaling": second, "error": why2}
+                if ok2 and rep2.get("exchange") == "host":
+                    other["step"] = other["step"].replace("on the system RCCL", "with the host-staged exchange (USPMV_EXCHANGE=host)")
         elif lead:
             other = {"value": None, "scaling": second, "error": f"skipped: {left():.0f} s of the {args.budget_s:.0f} s budget left (< 1/3)"}
     parents.close()
@@ -674,7 +676,7 @@ def dist_bench(args, pkg, world, rank, self_launch, tuning):
     if reason:
         out["fallback_reason"] = reason
     if other is not None:
-        out[second + "_scaling"] = {k: other.get(k) for k in ("value", "ms_per_step", "scaling", "workload", "step", "protocol", "y_checked", "y_mismatches", "rank0", "per_rank", "rccl_nranks", "error") if k in other}
+        out[second + "_scaling"] = {k: other.get(k) for k in ("value", "ms_per_step", "scaling", "workload", "step", "exchange", "protocol", "y_checked", "y_mismatches", "rank0", "per_rank", "rccl_nranks", "error") if k in other}
         out[second + "_scaling"]["unit"] = "GFLOP/s"
     out["budget"] = {"budget_s": args.budget_s, "used_s": round(time.time() - t_start, 1), "tiers": tiers}
     print(json.dumps(out), flush=True)
