@@ -67,7 +67,9 @@ def parse():
     ap.add_argument("--tune", default="", help="key=value,... forwarded to uspmv_set_tuning")
     ap.add_argument("--no-tlc", action="store_true", help="skip the tile-local-column plan (plain gather kernel)")
     ap.add_argument("--no-traffic", action="store_true", help="N = 1: do not run the two rocprofv3 PMC child passes (roofline.traffic then comes from profiles/traffic.json)")
-    ap.add_argument("--other-configs", default="3,4b", help="N = 1: further BASELINE configurations measured after the headline and reported under \"other_configs\" (3 = Queen_4147-class SpMMV b = 8, both layouts; 4b = HV15R-class ap[dp_sp] and dp); \"\" = none")
+    ap.add_argument("--other-configs", default="3,4b,2k,5one", help="N = 1: further configurations measured after the headline and reported under \"other_configs\" (3 = Queen_4147-class SpMMV b = 8, both layouts; 4b = HV15R-class ap[dp_sp] and dp; 2k = nlpkkt200-class KKT matrix; 5one = config 5's 304^3 matrix on one GPU); \"\" = none")
+    ap.add_argument("--kkt", type=int, default=200, help="config 2k: grid edge N of uspmv_gen_kkt")
+    ap.add_argument("--grid5", type=int, default=304, help="config 5one: stencil grid edge")
     ap.add_argument("--grid3", type=int, default=111, help="config 3: nodes per edge (3 dof per node)")
     ap.add_argument("--n4b", type=int, default=2017169, help="config 4b: rows")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -102,27 +104,33 @@ def set_omp_threads(n):
         pass
 
 
-def cpu_baseline(scs_arrays, C, n_chunks, nnz, x, seconds):
+def cpu_baseline(scs_arrays, C, n_chunks, nnz, x, seconds, x_check=None, y_gpu_check=None):
     """Reference CPU kernel timed on the host cores (rank 0, N = 1): the genuine scs_impl_cpu<32>
-    from oracle/_ref when present (kind "reference"), else the oracle's C port (kind "port")."""
+    from oracle/_ref when present (kind "reference"), else the oracle's C port (kind "port").
+    x_check / y_gpu_check: a non-uniform x and the GPU's y for it -- the CPU kernel's y for the same x is compared bitwise (the checker's
+    role; returned as the second value, None when not asked for)."""
     from oracle import refshim
     a = scs_arrays
     cores = usable_cores()
     set_omp_threads(cores)
+    same = None
     if refshim.available("colwise"):
         kind = "reference"
         L = refshim.lib("colwise")
         y = np.zeros(n_chunks * C)
         xx = np.ascontiguousarray(x)
 
-        def run():
-            L.ref_spmv_omp_scs_adv_f64(C, n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xx, y)
+        def run(xv=xx):
+            L.ref_spmv_omp_scs_adv_f64(C, n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xv, y)
+            return y
     else:
         kind = "port"
         from oracle import oracle as orc
 
-        def run():
-            orc.spmv_scs(C, n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], x)
+        def run(xv=x):
+            return orc.spmv_scs(C, n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xv)
+    if x_check is not None:
+        same = bool(np.array_equal(np.asarray(run(np.ascontiguousarray(x_check))), y_gpu_check))
     run(); run()
     reps, t0 = 0, time.perf_counter()
     while True:
@@ -132,7 +140,7 @@ def cpu_baseline(scs_arrays, C, n_chunks, nnz, x, seconds):
             break
     return {"value": round(2.0 * nnz * reps / el / 1e9, 3), "unit": "GFLOP/s", "cores": cores, "kind": kind,
             "sample": f"whole matrix, {reps} SpMVs of spmv_omp_scs_adv<C=32,double> in {el:.1f} s, "
-                      f"OMP threads = {cores}"}
+                      f"OMP threads = {cores}"}, same
 
 
 def vendor_baseline(grid):
@@ -182,24 +190,66 @@ def _cpu_leg(flops, fn_ref, fn_port, y_cpu, y_gpu, seconds, name):
 
 def other_configs(pkg, B, torch, args, which):
     """BASELINE configs 3 (Queen_4147-class, -block_vec_size 8, both block-vector layouts) and 4b (HV15R-class banded-random matrix of
-    SURVEY 8(d), ap[dp_sp] and plain dp) under the driver's clock: set-up, the timed kernel (HIP events on its stream, whole
-    uspmv_spmmv / uspmv_spmv_ap / uspmv_spmv call), the algorithmic-byte roofline of SURVEY 8(d) and the reference CPU kernel of the
-    same configuration, whose result is compared bitwise with the GPU's."""
+    SURVEY 8(d), ap[dp_sp] and plain dp), plus 2k (the KKT-structured member of the nlpkkt200 class) and 5one (config 5's 304^3 matrix on
+    ONE GPU: the strong-scaling denominator) under the driver's clock.  Per configuration: set-up, W warm-up + K wall-clock steps like the
+    headline's ("ms_per_step"), the kernel's average over the same number of launches by HIP events on its stream ("kernel_ms"), the
+    algorithmic-byte roofline of SURVEY 8(d) and the reference CPU kernel of the same configuration, whose result is compared bitwise
+    with the GPU's."""
     from oracle import refshim
     from oracle import oracle as orc       # cpu_baseline leg: the port stands in when oracle/_ref did not travel
     t = torch
-    reps = max(10, min(args.steps, 50))
+    K, W = max(args.steps, 50), 30         # (short loops behind seconds of host work measure the GPU's clock ramp, see DESIGN 7)
     res = []
 
-    def line(config, workload, kernel, ms, byts, flops, same, cpu, setup, extra=None):
-        d = {"config": config, "workload": workload, "kernel": kernel, "kernel_ms": round(ms, 5), "ms_per_step": round(ms, 5),
-             "value": round(flops / ms / 1e6, 1), "unit": "GFLOP/s",
-             "roofline": {"bound": "hbm", "achieved": round(byts / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(byts / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(byts)},
+    def measure(call, kind, **kw):
+        """(wall-clock ms per step over K steps after W warm-ups, HIP-event ms per launch over K launches)"""
+        for _ in range(W):
+            call()
+        t.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            call()
+        t.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / K * 1e3
+        return wall, B.time_launches(kind, K, **kw)
+
+    def line(config, workload, kernel, wall_ms, k_ms, byts, flops, same, cpu, setup, extra=None):
+        d = {"config": config, "workload": workload, "kernel": kernel, "kernel_ms": round(k_ms, 5), "ms_per_step": round(wall_ms, 5), "steps": K, "warmup": W,
+             "value": round(flops / wall_ms / 1e6, 1), "unit": "GFLOP/s",
+             "roofline": {"bound": "hbm", "achieved": round(byts / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(byts / k_ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(byts)},
              "bitexact_vs_reference_cpu": same, "cpu_baseline": cpu, "setup_s": round(setup, 1)}
         if extra:
             d.update(extra)
         res.append(d)
+
+    def ramp(s, a):
+        xp = np.zeros(s.n_rows_padded)
+        xp[:s.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(s.n_rows) % 1000), a["new_to_old_idx"])
+        return xp
+
+    def spmv_config(config, workload, coo):
+        """one struct, SELL-32-512 dp, default plan: uspmv_spmv"""
+        t0 = time.time()
+        s = pkg.convert_to_scs(coo, 32, 512, B.F64)
+        a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
+        A = pkg.DeviceMatrix(s, tlc=True)
+        xp = ramp(s, a)
+        x = t.from_numpy(xp).cuda(); y = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
+        pkg.spmv(A, x, y)
+        t.cuda.synchronize()
+        setup = time.time() - t0
+        wall, k_ms = measure(lambda: pkg.spmv(A, x, y), 0, A=A, x=x, y=y)
+        byts = s.n_elements * 12 + 8 * s.n_chunks + 8 * (s.n_rows + s.n_rows_padded)
+        yc = np.zeros(s.n_rows_padded)
+        fr = (lambda: refshim.lib("colwise").ref_spmv_omp_scs_adv_f64(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp, yc)) if refshim.available("colwise") else None
+        fp = lambda: orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+        cpu, same = _cpu_leg(2.0 * s.nnz, fr or fp, fp, yc, y.cpu().numpy(), args.cpu_seconds / 3, "spmv_omp_scs_adv<C=32,double>")
+        kind, ntile, nplan = A.plan_info()
+        line(config, workload + " scs -c 32 -s 512 -dp", {2: "scs_spmv_sweep<double> (column-window sweep)", 1: "scs_spmv_tlc<double,32>", 0: "scs_spmv_rows<double,32,8>"}[kind],
+             wall, k_ms, byts, 2.0 * s.nnz, same, cpu, setup, {"plan_kind": kind, "plan_tiles_planned": [nplan, ntile], "rows_per_tile": (s.n_rows_padded // ntile) if ntile else None})
+        del A, s, a, x, y
+        t.cuda.empty_cache()
 
     if "3" in which:
         t0 = time.time()
@@ -211,7 +261,7 @@ def other_configs(pkg, B, torch, args, which):
         del coo
         b, ld = 8, s.n_rows_padded
         A = pkg.DeviceMatrix(s, block_tlc=b)
-        xp = np.zeros(ld); xp[:s.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(s.n_rows) % 1000), a["new_to_old_idx"])
+        xp = ramp(s, a)
         byts = s.n_elements * 12 + 8 * s.n_chunks + b * 8 * s.n_rows + b * 8 * s.n_rows_padded
         setup = time.time() - t0
         for lay, nm in ((B.COLWISE, "colwise"), (B.ROWWISE, "rowwise")):
@@ -225,7 +275,7 @@ def other_configs(pkg, B, torch, args, which):
             dX = t.from_numpy(X).cuda(); dY = t.zeros(b * ld, dtype=t.float64, device="cuda")
             pkg.spmmv(A, dX, dY, b, ld, lay)
             t.cuda.synchronize()
-            ms = B.time_launches(5, reps, A=A, x=dX, y=dY, b=b, ld=ld, layout=lay)
+            wall, k_ms = measure(lambda: pkg.spmmv(A, dX, dY, b, ld, lay), 5, A=A, x=dX, y=dY, b=b, ld=ld, layout=lay)
             Yc = np.zeros(b * ld)
             var = "rowwise" if lay == B.ROWWISE else "colwise"
             fr = (lambda: refshim.lib(var).ref_block_spmv_omp_scs_general_f64(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, Yc, b, ld)) if refshim.available(var) else None
@@ -234,7 +284,7 @@ def other_configs(pkg, B, torch, args, which):
             kind = A.plan_info()[0]
             line(f"3 ({nm})", f"Queen_4147-class synthetic (27-pt stencil {g}^3 x 3 dof, n={s.n_rows}, nnz={nnz}) scs -c 32 -s 512 -dp -block_vec_size 8, {nm} X / Y",
                  "uspmv_spmmv: scs_spmmv_quadph<double,8> (phased block plan)" + (" behind block_vector_to_rowmajor" if lay == B.COLWISE else ""),
-                 ms, byts, 2.0 * nnz * b, same, cpu, setup, {"block_plan_tiles": [A.block_staged, A.block_tiles], "plan_kind": kind})
+                 wall, k_ms, byts, 2.0 * nnz * b, same, cpu, setup, {"block_plan_tiles": [A.block_staged, A.block_tiles], "plan_kind": kind})
             del dX, dY
         del A, s, a
         t.cuda.empty_cache()
@@ -249,12 +299,12 @@ def other_configs(pkg, B, torch, args, which):
         da, sa = ds.arrays(), ss.arrays()
         Ad, As = pkg.DeviceMatrix(ds), pkg.DeviceMatrix(ss)
         nt_, ns_ = pkg.optimize_ap(Ad, As, ds, ss)
-        xp = np.zeros(ds.n_rows_padded); xp[:ds.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(ds.n_rows) % 1000), da["new_to_old_idx"])
+        xp = ramp(ds, da)
         x = t.from_numpy(xp).cuda(); y = t.zeros(ds.n_rows_padded, dtype=t.float64, device="cuda")
         pkg.spmv_ap(Ad, As, x, y)
         t.cuda.synchronize()
         setup = time.time() - t0
-        ms = B.time_launches(4, reps, A=Ad, B=As, x=x, y=y)
+        wall, k_ms = measure(lambda: pkg.spmv_ap(Ad, As, x, y), 4, A=Ad, B=As, x=x, y=y)
         byts = 12 * ds.n_elements + 8 * ss.n_elements + 16 * ds.n_chunks + 8 * (ds.n_rows + ds.n_rows_padded)
         ycpu = np.zeros(ds.n_rows_padded); yspc = np.zeros(ds.n_rows_padded, np.float32); xspc = xp.astype(np.float32)
         fr = (lambda: refshim.lib("colwise").ref_spmv_omp_scs_ap_adv(32, ds.n_chunks, da["chunk_ptrs"], da["chunk_lengths"], da["col_idxs"], da["values"], xp, ycpu,
@@ -265,30 +315,22 @@ def other_configs(pkg, B, torch, args, which):
         kind, ntile, nplan = Ad.plan_info()
         wl = f"HV15R-class synthetic (banded-random n={coo.n_rows}, 140 entries per row within +-50000, |a_ij| log-uniform over 10 decades, nnz={coo.nnz})"
         line("4b (ap[dp_sp])", wl + " scs -c 32 -s 512 -ap[dp_sp] -ap_threshold_1 1e-3",
-             {2: "scs_spmv_sweep<double,AP> (column-window sweep)", 1: "scs_spmv_ap_tlc", 0: "scs_spmv_ap_rows"}[kind], ms, byts, 2.0 * coo.nnz, same, cpu, setup,
+             {2: "scs_spmv_sweep<double,AP> (column-window sweep)", 1: "scs_spmv_ap_tlc", 0: "scs_spmv_ap_rows"}[kind], wall, k_ms, byts, 2.0 * coo.nnz, same, cpu, setup,
              {"dp_nnz": dp.nnz, "sp_nnz": sp.nnz, "dp_elements": ds.n_elements, "sp_elements": ss.n_elements, "plan_kind": kind, "plan_tiles_planned": [nplan, ntile]})
-        del Ad, As, ds, ss, da, sa, dp, sp
+        del Ad, As, ds, ss, da, sa, dp, sp, x, y
         t.cuda.empty_cache()
-        t0 = time.time()
-        s = pkg.convert_to_scs(coo, 32, 512, B.F64)
-        a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
-        A = pkg.DeviceMatrix(s, tlc=True)
-        xp = np.zeros(s.n_rows_padded); xp[:s.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(s.n_rows) % 1000), a["new_to_old_idx"])
-        x = t.from_numpy(xp).cuda(); y = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
-        pkg.spmv(A, x, y)
-        t.cuda.synchronize()
-        setup = time.time() - t0
-        ms = B.time_launches(0, reps, A=A, x=x, y=y)
-        byts = s.n_elements * 12 + 8 * s.n_chunks + 8 * (s.n_rows + s.n_rows_padded)
-        yc = np.zeros(s.n_rows_padded)
-        fr = (lambda: refshim.lib("colwise").ref_spmv_omp_scs_adv_f64(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp, yc)) if refshim.available("colwise") else None
-        fp = lambda: orc.spmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
-        cpu, same = _cpu_leg(2.0 * s.nnz, fr or fp, fp, yc, y.cpu().numpy(), args.cpu_seconds / 3, "spmv_omp_scs_adv<C=32,double>")
-        kind, ntile, nplan = A.plan_info()
-        line("4b (dp)", wl + " scs -c 32 -s 512 -dp", {2: "scs_spmv_sweep<double> (column-window sweep)", 1: "scs_spmv_tlc<double,32>", 0: "scs_spmv_rows<double,32,8>"}[kind],
-             ms, byts, 2.0 * s.nnz, same, cpu, setup, {"plan_kind": kind, "plan_tiles_planned": [nplan, ntile]})
-        del A, s, a, coo
-        t.cuda.empty_cache()
+        spmv_config("4b (dp)", wl, coo)
+        del coo
+    if "2k" in which:
+        N = args.kkt
+        coo = pkg.gen_kkt(N)
+        spmv_config("2k", f"nlpkkt200-class KKT [H A^T; A 0] synthetic (uspmv_gen_kkt N={N}: n={coo.n_rows}, nnz={coo.nnz}, rows of 5-28 entries in two index ranges N^3 apart)", coo)
+        del coo
+    if "5one" in which:
+        g = args.grid5
+        coo = pkg.gen_stencil27(g, g, g)
+        spmv_config("5one", f"nlpkkt240-class synthetic (27-pt stencil {g}^3, n={coo.n_rows}, nnz={coo.nnz}) on ONE GPU (config 5's matrix: the strong-scaling denominator)", coo)
+        del coo
     return res
 
 
@@ -356,7 +398,85 @@ def measure_traffic(args):
                      f"+ --pmc WRITE_SIZE {write_kib:.0f} KiB, separate passes, kernel trace only")
 
 
-def stream_rates(B, torch, dev):
+def gpu_state(card=None):
+    """Clocks, power and temperatures of the GPU as the amdgpu driver publishes them in sysfs (no HIP call, nothing is changed): the level
+    of every pp_dpm_* clock that is active right now, the hwmon sensors (power, power cap, temperatures incl. the HBM's, frequencies).
+    `card`: /sys/class/drm/cardN/device; default: the first card that has pp_dpm_sclk."""
+    import glob
+    if card is None:
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        if not cards:
+            return {"error": "no amdgpu sysfs (pp_dpm_sclk) visible"}
+        card = os.path.dirname(cards[0])
+    out = {"card": card.split("/")[4], "pci": os.path.basename(os.path.realpath(card))}
+    for f in sorted(glob.glob(os.path.join(card, "pp_dpm_*"))):
+        try:
+            lines = [ln.strip() for ln in open(f).read().splitlines() if ln.strip()]
+        except OSError:
+            continue
+        act = [ln for ln in lines if ln.endswith("*")]
+        out[os.path.basename(f)[7:]] = {"active": act[0].rstrip("* ").split(": ")[-1] if act else None, "top": lines[-1].rstrip("* ").split(": ")[-1] if lines else None}
+    for f in sorted(glob.glob(os.path.join(card, "hwmon", "hwmon*", "*"))):
+        name = os.path.basename(f)
+        if not (name.endswith("_input") or name.endswith("_average") or name.endswith("_cap") or name.endswith("_label") or name.endswith("_cap_max")):
+            continue
+        try:
+            v = open(f).read().strip()
+            out["hwmon_" + name] = int(v) if v.lstrip("-").isdigit() else v
+        except (OSError, ValueError):
+            pass
+    return out
+
+
+def card_of_device(torch, idx):
+    """/sys/class/drm/cardN/device of HIP device `idx` (by PCI address; a box shows the sysfs of every GPU of its host), or None"""
+    import glob
+    try:
+        p = torch.cuda.get_device_properties(idx)
+        bus = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        c = sorted(glob.glob(f"/sys/bus/pci/devices/{bus}/drm/card[0-9]*"))
+        return os.path.join("/sys/class/drm", os.path.basename(c[0]), "device") if c else None
+    except (AttributeError, RuntimeError, OSError):
+        return None
+
+
+class GpuStateSampler:
+    """Samples gpu_state() every `period` seconds in a thread while a measurement runs (sysfs reads only)."""
+
+    def __init__(self, card=None, period=0.02):
+        import threading
+        self.card = card
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append(gpu_state(self.card))
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._t.join(timeout=2)
+        return False
+
+    def summary(self):
+        """per key: the distinct values seen (clock levels) or min / max (sensors)"""
+        agg = {}
+        for smp in self.samples:
+            for k, v in smp.items():
+                if isinstance(v, dict):
+                    agg.setdefault(k, set()).add(v.get("active"))
+                elif isinstance(v, int):
+                    lo, hi = agg.get(k, (v, v))
+                    agg[k] = (min(lo, v), max(hi, v))
+        return {"samples": len(self.samples), **{k: (sorted(x for x in v if x) if isinstance(v, set) else list(v)) for k, v in agg.items()}}
+
+
+def stream_rates(B, torch, dev, x_elems=0, plane=0, line=0, rows=256):
     n = 1 << 27  # 1 GiB per array
     sa = torch.empty(n, dtype=torch.float64, device=dev)
     sb = torch.ones(2 * n, dtype=torch.float64, device=dev)
@@ -365,7 +485,20 @@ def stream_rates(B, torch, dev):
     copy = 16.0 * n / (B.time_launches(1, 20, x=sb, y=sa, n=n) * 1e-3) / 1e9
     triad = 24.0 * n / (B.time_launches(2, 20, x=sb, y=sa, n=n) * 1e-3) / 1e9
     read = 8.0 * n / (B.time_launches(3, 20, x=sb, y=part, n=n) * 1e-3) / 1e9
-    return {"copy": round(copy, 1), "triad": round(triad, 1), "read": round(read, 1)}
+    out = {"copy": round(copy, 1), "triad": round(triad, 1), "read": round(read, 1)}
+    if x_elems >= 4096:
+        # second yardstick: the x traffic of the tile-local-column kernel without its matrix stream -- one workgroup per 256-row tile, mapped
+        # to the XCDs like the kernel's tiles, reads the nine runs of x lines its rows touch (uspmv_stream_gather_lines): a vector of
+        # x_elems doubles, every line wanted by ~9 workgroups, ~3 of them far apart in launch order.  L2 / fabric, not HBM streaming.
+        tiles = (x_elems + rows - 1) // rows
+        part2 = torch.empty(4 * tiles, dtype=torch.float64, device=dev)
+        gbytes = tiles * 9 * (((rows + 2 + 15) // 16 + 1) * 128)
+        B.time_launches(6, 3, x=sb, y=part2, n=x_elems, ld=plane, b=line, layout=rows)
+        ms = B.time_launches(6, 50, x=sb, y=part2, n=x_elems, ld=plane, b=line, layout=rows)
+        out["x_line_gather"] = round(gbytes / (ms * 1e-3) / 1e9, 1)
+        out["x_line_gather_note"] = (f"{tiles} workgroups x 9 runs of x lines ({gbytes / 1e9:.2f} GB asked for, vector of {8 * x_elems / 1e6:.0f} MB, plane stride {plane}, "
+                                     f"line stride {line}) in {ms:.4f} ms")
+    return out
 
 
 class stdout_to_stderr:
@@ -958,7 +1091,26 @@ def main():
     bytes_local = s.n_elements * 12 + 8 * s.n_chunks + 8 * s.n_rows + 8 * s.n_rows_padded
     t_setup = time.time() - t_setup
 
-    # ------------------------------------------------------------------ timed region
+    # ------------------------------------------------------------------ one checked launch on a NON-uniform x (a constant would hide a permutation
+    #                                                                    error): its y is compared bitwise with the CPU kernel's further down
+    x_check = np.zeros(s.n_rows_padded)
+    x_check[:s.n_rows] = pkg.apply_permutation(1.0 + 1e-3 * (np.arange(s.n_rows) % 1000), a["new_to_old_idx"])
+    xc = torch.from_numpy(x_check).to(dev)
+    B.spmv(A, xc, y)
+    torch.cuda.synchronize(dev)
+    y_gpu_check = y.cpu().numpy().copy()
+    del xc
+    card = card_of_device(torch, local_rank)
+    state_idle = gpu_state(card)
+
+    # ------------------------------------------------------------------ dominant kernel, HIP events on its stream (first: 100 launches also bring
+    #                                                                    the GPU out of the power state the host-side set-up left it in)
+    reps = 100
+    with GpuStateSampler(card) as smp:
+        k_ms = B.time_launches(0, reps, A=A, x=x, y=y)
+    state_load = smp.summary()
+
+    # ------------------------------------------------------------------ timed region: W warm-up steps, then EXACTLY K steps
     for _ in range(args.warmup):
         B.spmv(A, x, y)
     torch.cuda.synchronize(dev)
@@ -970,11 +1122,9 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * total_nnz / (ms_per_step * 1e-3) / 1e9
 
-    # ------------------------------------------------------------------ dominant kernel, HIP events on its stream
-    reps = max(10, min(args.steps, 100))
-    k_ms = B.time_launches(0, reps, A=A, x=x, y=y)
     achieved = bytes_local / (k_ms * 1e-3) / 1e9
-    stream = stream_rates(B, torch, dev)
+    g_ = args.grid or 253
+    stream = stream_rates(B, torch, dev, x_elems=0 if args.mtx else s.n_rows, plane=g_ * g_, line=g_)
     kind, n_tiles, n_planned = A.plan_info()
     kname = {0: "scs_spmv_rows<double,32,8>", 1: "scs_spmv_tlc<double,32>", 2: "scs_spmv_sweep<double>"}[kind if pkg.get_tuning("tlc") else 0]
     if traffic is None and not args.mtx:
@@ -1007,9 +1157,15 @@ def main():
                      "frac_physical_of_stream_read": None if not traffic else round(traffic / (k_ms * 1e-3) / 1e9 / stream["read"], 4)},
         "setup_s": round(t_setup, 1),
     }
+    out["gpu_state"] = {"idle_before_timing": state_idle, "during_the_kernel_timing": state_load,
+                        "note": "amdgpu sysfs (pp_dpm_* active levels, hwmon sensors in their native units: microwatts, millidegrees, Hz), read only"}
+    out["order"] = "set-up, one checked launch, HIP-event timing of the kernel (100 launches), W warm-up steps, K timed steps, stream yardsticks, CPU baseline, other configs"
     if not args.no_cpu_baseline:
         a = s.arrays()
-        out["cpu_baseline"] = cpu_baseline(a, s.C, s.n_chunks, s.nnz, x.cpu().numpy(), args.cpu_seconds)
+        out["cpu_baseline"], same = cpu_baseline(a, s.C, s.n_chunks, s.nnz, x.cpu().numpy(), args.cpu_seconds, x_check=x_check, y_gpu_check=y_gpu_check)
+        out["bitexact_vs_reference_cpu"] = same
+        out["bitexact_note"] = ("one launch on x_i = 1 + 1e-3 (i mod 1000) (permuted), y of all n_rows_padded rows compared bitwise with the y of " +
+                                ("the reference's spmv_omp_scs_adv<32> (oracle/_ref)" if out["cpu_baseline"]["kind"] == "reference" else "the oracle's C port") + " for the same x")
     if not args.no_vendor_baseline and not args.mtx:
         out["vendor_baseline"] = vendor_baseline(args.grid or 253)
     which = [w for w in args.other_configs.split(",") if w]

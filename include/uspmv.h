@@ -529,9 +529,13 @@ void uspmv_dist_free(uspmv_dist_t *d);
 int uspmv_stream_copy(double *d_a, const double *d_b, int64_t n, void *stream);
 int uspmv_stream_triad(double *d_a, const double *d_b, const double *d_c, double s, int64_t n, void *stream);
 int uspmv_stream_read(const double *d_b, int64_t n, double *d_partial, void *stream);
+/* Second yardstick next to the streams: the x traffic of the tile-local-column SpMV without its matrix stream.  ceil(n / rows) workgroups,
+ * mapped to the XCDs like the kernel's tiles ("xcd_remap"), each read the nine runs of x lines a `rows`-row tile of a 27-point stencil
+ * with the given plane / line strides touches (16-byte loads).  d_partial: 4 * ceil(n / rows) doubles.  *bytes = bytes gathered. */
+int uspmv_stream_gather_lines(const double *d_x, int64_t n, int64_t plane, int64_t line, int rows, double *d_partial, void *stream, int64_t *bytes);
 /* Time `reps` back-to-back launches of one entry point with HIP events on `stream`;
  * what: 0 spmv(A,x,y) 1 stream_copy 2 stream_triad 3 stream_read 4 spmv_ap(A,B,x,y)
- *       5 spmmv(A,X,Y,b,ld,layout).  Two untimed launches precede the timed ones; returns the average milliseconds per launch.
+ *       5 spmmv(A,X,Y,b,ld,layout) 6 stream_gather_lines(x, n, plane = ld, line = b, rows = layout).  Two untimed launches precede the timed ones; returns the average milliseconds per launch.
  * For the STREAM kinds d_x is the source (n doubles; 2n for the triad: b = d_x, c = d_x + n) and d_y
  * the destination (n doubles; 8192 for the read kernel's partial sums). */
 int uspmv_time_launches(int what, int reps, const uspmv_dmat_t *A, const uspmv_dmat_t *B, const void *d_x,

@@ -167,6 +167,7 @@ _SIGS = {
     "uspmv_stream_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
     "uspmv_stream_triad": (C.c_int, [_vp, _vp, _vp, C.c_double, _i64, _vp]),
     "uspmv_stream_read": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "uspmv_stream_gather_lines": (C.c_int, [_vp, _i64, _i64, _i64, C.c_int, _vp, _vp, C.POINTER(_i64)]),
     "uspmv_time_launches": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _i64, C.c_int, _i64, C.c_int, _vp,
                                       C.POINTER(C.c_double)]),
 }

@@ -114,6 +114,30 @@ __global__ void stream_read_kernel(const double2 *__restrict__ b, const long n2,
     if ((threadIdx.x & 63) == 0) partial[((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6] = acc;
 }
 
+// Second yardstick (what the tile-local-column kernel asks of the cache hierarchy beyond a stream): as many workgroups as the SpMV has
+// tiles, mapped to the XCDs like its tiles, each reading the x lines a `rows`-row tile of a 27-point stencil touches -- nine runs of
+// rows + 2 elements (rounded out to whole 128-byte lines) at the offsets {-plane, 0, +plane} + {-line, 0, +line} around its own rows --
+// with the plain 16-byte loads of the kernel's staging phase.  Every element of x is asked for by ~9 workgroups, ~3 of them far apart
+// in launch order (the neighbouring planes): what comes from the XCD's L2, what from the fabric, is exactly the SpMV's x traffic,
+// without its matrix stream.  Reported as gathered bytes per second.
+__global__ void __launch_bounds__(256) stream_gather_lines_kernel(const double2 *__restrict__ x, const long n, const long plane, const long line,
+                                                                  const int rows, const int xcd_remap, double *__restrict__ partial) {
+    const unsigned tile = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+    const long base = (long)tile * rows;
+    double acc = 0.0;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy) {
+            long lo = base + dz * plane + dy * line - 1, hi = base + rows + dz * plane + dy * line + 1;
+            lo = lo < 0 ? 0 : (lo & ~15L);
+            hi = hi > n ? n : hi;
+            hi = (hi + 15) & ~15L;
+            if (hi > (n & ~15L)) hi = n & ~15L;
+            for (long i = lo / 2 + threadIdx.x; i < hi / 2; i += 256) { const double2 v = x[i]; acc += v.x + v.y; }
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) partial[(long)blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
+}
 
 }  // namespace
 
@@ -1743,6 +1767,18 @@ int uspmv_stream_read(const double *b, int64_t n, double *partial, void *stream)
     return USPMV_OK;
 }
 
+int uspmv_stream_gather_lines(const double *x, int64_t n, int64_t plane, int64_t line, int rows, double *partial, void *stream, int64_t *bytes) {
+    if (!x || !partial || n < 4096 || rows < 16 || rows > 4096 || plane < 0 || line < 0)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_stream_gather_lines: bad argument (partial needs 4 * ceil(n / rows) doubles)");
+    if (int rc = require_device()) return rc;
+    const long tiles = (long)((n + rows - 1) / rows);
+    hipLaunchKernelGGL(stream_gather_lines_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, (const double2 *)x, (long)n, (long)plane, (long)line, rows,
+                       g_tune.xcd_remap, partial);
+    HIP_TRY(hipGetLastError());
+    if (bytes) *bytes = tiles * 9 * (int64_t)(((rows + 2 + 15) / 16 + 1) * 128);   // (nine runs of whole lines per tile; the ends of the vector ask for a little less)
+    return USPMV_OK;
+}
+
 int uspmv_time_launches(int what, int reps, const uspmv_dmat_t *A, const uspmv_dmat_t *B, const void *d_x, void *d_y,
                         int64_t n, int b, int64_t ld, int layout, void *stream, double *avg_ms) {
     if (reps < 1 || !avg_ms) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_time_launches: bad argument");
@@ -1761,6 +1797,7 @@ int uspmv_time_launches(int what, int reps, const uspmv_dmat_t *A, const uspmv_d
             case 3: rc = uspmv_stream_read((const double *)d_x, n, (double *)d_y, stream); break;
             case 4: rc = uspmv_spmv_ap(A, B, (const double *)d_x, (double *)d_y, stream); break;
             case 5: rc = uspmv_spmmv(A, d_x, d_y, b, ld, layout, stream); break;
+            case 6: rc = uspmv_stream_gather_lines((const double *)d_x, n, ld, (int64_t)b, layout, (double *)d_y, stream, nullptr); break;
             default: rc = uspmv::fail(USPMV_ERR_INVALID, "uspmv_time_launches: unknown kind %d", what);
         }
     }
