@@ -67,6 +67,9 @@ int uspmv_read_mtx(const char *path, uspmv_coo_t **out);
  * expanded, row-sorted -- written / read back verbatim, so that later runs skip the text parse. */
 int uspmv_coo_save(const uspmv_coo_t *m, const char *path);
 int uspmv_coo_load(const char *path, uspmv_coo_t **out);
+/* MatrixMarket writer (the reference only reads; used to produce inputs): coordinate real general, or -- symmetric != 0 -- the entries
+ * with column <= row under a "symmetric" banner, which uspmv_read_mtx / read_mtx expand again.  17 significant digits. */
+int uspmv_coo_write_mtx(const uspmv_coo_t *m, const char *path, int symmetric);
 /* -equilibrate 1 of a one-precision run: equilibrate_matrix (code/utilities.hpp:2667-2685), in place.  (With
  * ap[dp_sp] the reference indexes two empty vectors here, code/main.cpp:1143-1153 -- undefined behaviour, not offered.) */
 int uspmv_coo_equilibrate(uspmv_coo_t *m);
@@ -143,6 +146,28 @@ int uspmv_dmat_upload(const uspmv_scs_t *s, uspmv_dmat_t **out);
  * must be sorted by row (uspmv_read_mtx and the generators produce that order). */
 int uspmv_convert_to_scs_device(const uspmv_coo_t *m, int64_t C, int64_t sigma, int dtype, const int32_t *fixed_permutation,
                                 int permute_cols, uspmv_scs_t **layout, uspmv_dmat_t **out);
+/* The same from DEVICE-resident COO arrays (d_I, d_J: int32, d_V: double; entries sorted by row, order inside a row = summation order):
+ * nothing but O(n_rows) integers ever leaves the device.  Row populations by a run-boundary kernel (code/utilities.hpp:1901-1903), chunk
+ * lengths by a per-chunk maximum and chunk_ptrs by a device scan (:1949-1966), the scatter as above (:2013-2036).  The sigma-window
+ * ordering (:1930-1941) in one of two ways:
+ *   USPMV_SORT_HOST          the reference's std::sort (same pair type, same comparator) on the host over the row COUNTS only -- 4 bytes
+ *                            per row down, 4 up; every array bit-identical to uspmv_convert_to_scs incl. the tie order of the unstable sort;
+ *   USPMV_SORT_DEVICE_STABLE a stable rank per window on the device (sigma <= 8192): rows of equal length keep their original order.
+ *                            chunk_lengths, chunk_ptrs and y in ORIGINAL row order are bit-identical to the reference's; the order of
+ *                            equal-length rows inside a window, hence old_to_new_idx and the row order of y_permuted, differs.
+ * d_fixed_permutation (device, n_rows entries, may be NULL) as fixed_permutation above.  d_old_to_new / d_new_to_old (device, n_rows
+ * int32 each, may be NULL) receive the struct's permutations for uspmv_apply_permutation_dev; *layout (may be NULL) a host struct
+ * without entries as above.  Works on `stream`; returns when the handle is complete. */
+/* diagnosis: device addresses of {tile-local-column indices, x-line lists, line pointers, index offsets, values, col_idxs, chunk_ptrs,
+ * chunk_lengths} of the struct the SpMV kernels read (tools/placement_probe.py) */
+int uspmv_dmat_plan_addresses(const uspmv_dmat_t *m, uint64_t addr[8]);
+/* meta[4] = C, n_chunks, n_elements, dtype of a device handle (one without a host struct has nothing else to ask) */
+int uspmv_dmat_meta(const uspmv_dmat_t *m, int64_t meta[4]);
+enum { USPMV_SORT_HOST = 0, USPMV_SORT_DEVICE_STABLE = 1 };
+int uspmv_convert_to_scs_device_from_arrays(const int32_t *d_I, const int32_t *d_J, const double *d_V, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                                            int64_t C, int64_t sigma, int dtype, const int32_t *d_fixed_permutation, int permute_cols,
+                                            int sort_mode, void *stream, uspmv_scs_t **layout, int32_t *d_old_to_new, int32_t *d_new_to_old,
+                                            uspmv_dmat_t **out);
 /* copies of the device arrays of a handle (any pointer may be NULL): n_chunks+1, n_chunks, n_elements, n_elements */
 int uspmv_dmat_download(const uspmv_dmat_t *m, int32_t *chunk_ptrs, int32_t *chunk_lengths, int32_t *col_idxs, void *values);
 /* Wrap arrays that already live in HBM (owned by the caller, e.g. a framework allocator). */

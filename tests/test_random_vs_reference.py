@@ -169,3 +169,52 @@ def test_partition_and_halo_discovery_match_reference(pkg, seed, n, P, method, C
         for p in range(P):
             assert np.array_equal(plan.recv_idxs_of(p), recv_ref[p]), (r, p)
         assert np.array_equal(s.arrays()["col_idxs"], rs.arrays()["col_idxs"]), r
+
+
+def _same_coo(pkg, path):
+    a = pkg.read_mtx(path)
+    r = refshim.RefMtx.read(path)
+    I, J, V = a.arrays()
+    rI, rJ, rV = r.arrays()
+    assert (a.n_rows, a.nnz) == (r.n_rows, r.nnz)
+    assert np.array_equal(I, rI) and np.array_equal(J, rJ) and np.array_equal(V.view(np.uint64), rV.view(np.uint64))
+    return a
+
+
+def test_read_mtx_number_spellings_like_the_reference(pkg, tmp_path):
+    """uspmv_read_mtx parses plain decimals with std::from_chars and everything else with strtod; the reference reads every value with
+    fscanf("%lg") (code/mmio.h:132-263).  Spellings on either side of that split must give the same bits."""
+    vals = ["1", "-1", "+1.5", "1.", ".5", "-.5e-3", "1e400", "-1e400", "1e-400", "4.9406564584124654e-324", "1.7976931348623157e308",
+            "0.1", "0.30000000000000004", "123456789012345678901234567890", "0x1p3", "-0x1.8p-2", "inf", "-inf", "INF", "1E5", "1e+05",
+            "00012.5", "-0", "0", "2.2250738585072011e-308", "9007199254740993", "5e-324", "1.0000000000000002"]
+    n = len(vals)
+    p = tmp_path / "spellings.mtx"
+    with open(p, "w") as f:
+        f.write(f"%%MatrixMarket matrix coordinate real general\n% odd spellings\n{n} {n} {n}\n")
+        for i, v in enumerate(vals):
+            f.write(f"{i + 1}   {(i * 7) % n + 1}\t{v}\n")
+    _same_coo(pkg, str(p))
+
+
+def test_read_mtx_large_symmetric_file_parallel_path(pkg, tmp_path):
+    """A file large enough for the multi-threaded parse and the two-pass stable bucket sort (>= 1 MiB of entries, more rows than one
+    bucket): identical COO -- same expansion order, same order inside every row -- as the reference's read_mtx; also with more lines
+    than the header announces, and through our own writer."""
+    rng = np.random.default_rng(77)
+    n, k = 30000, 120000
+    I = rng.integers(0, n, k); J = rng.integers(0, n, k)
+    lo = np.maximum(I, J); hi = np.minimum(I, J)
+    V = rng.standard_normal(k) * 10.0 ** rng.integers(-8, 8, k)
+    p = tmp_path / "big_sym.mtx"
+    with open(p, "w") as f:
+        f.write(f"%%MatrixMarket matrix coordinate real symmetric\n{n} {n} {k - 5}\n")       # (five surplus lines at the end)
+        for a, b, v in zip(lo, hi, V):
+            f.write(f"{a + 1} {b + 1} {float(v)!r}\n")
+    assert p.stat().st_size > (1 << 20)
+    a = _same_coo(pkg, str(p))
+    q = tmp_path / "rewritten.mtx"
+    a.write_mtx(str(q), symmetric=False)
+    b = pkg.read_mtx(str(q))
+    for u, w in zip(a.arrays(), b.arrays()):
+        assert np.array_equal(u, w)
+    _same_coo(pkg, str(q))

@@ -50,6 +50,7 @@ _SIGS = {
     "uspmv_version": (C.c_char_p, []),
     "uspmv_read_mtx": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "uspmv_coo_save": (C.c_int, [_vp, C.c_char_p]),
+    "uspmv_coo_write_mtx": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "uspmv_coo_load": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "uspmv_coo_equilibrate": (C.c_int, [_vp]),
     "uspmv_coo_create": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
@@ -131,6 +132,10 @@ _SIGS = {
     "uspmv_dist_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dist_spmmv_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dist_pad_info": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "uspmv_convert_to_scs_device_from_arrays": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, C.c_int, C.c_int, _vp,
+                                                          C.POINTER(_vp), _vp, _vp, C.POINTER(_vp)]),
+    "uspmv_dmat_plan_addresses": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "uspmv_dmat_meta": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dist_comm_count": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "uspmv_dist_autotune": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _i32p, _vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "uspmv_dist_check_reference": (C.c_int, [_vp, _i32p, C.c_int, C.c_int, C.c_int, _vp]),
@@ -249,6 +254,10 @@ class Coo:
         h = _vp()
         _ck(lib().uspmv_coo_load(os.fsencode(path), C.byref(h)))
         return cls(h)
+
+    def write_mtx(self, path, symmetric=False):
+        """MatrixMarket file of this matrix (uspmv_coo_write_mtx)"""
+        _ck(lib().uspmv_coo_write_mtx(self.h, os.fsencode(path), int(bool(symmetric))))
 
     def arrays(self):
         """(I, J, values) as numpy views borrowed from the library (valid while self lives)."""
@@ -933,6 +942,36 @@ def convert_to_scs_device(coo, C_, sigma, dtype=F64, fixed_permutation=None, per
     _ck(lib().uspmv_convert_to_scs_device(coo.h, C_, sigma, dtype, _np_ptr(fp), int(bool(permute_cols)), C.byref(hs), C.byref(hA)))
     s = Scs(hs)
     return s, DeviceMatrix(s, device, _handle=hA)
+
+
+SORT_HOST, SORT_DEVICE_STABLE = 0, 1
+
+
+def convert_to_scs_device_from_arrays(d_I, d_J, d_V, n_rows, n_cols, C_, sigma, dtype=F64, fixed_permutation=None, permute_cols=True,
+                                      sort=SORT_HOST, want_layout=True, stream=None):
+    """convert_to_scs (+ permute_scs_cols) from DEVICE-resident COO arrays (torch int32 / int32 / float64 tensors, entries sorted by row):
+    returns (layout-only Scs or None, DeviceMatrix, old_to_new, new_to_old) -- the permutations as int32 device tensors."""
+    import torch
+    assert d_I.dtype == torch.int32 and d_J.dtype == torch.int32 and d_V.dtype == torch.float64 and d_I.is_cuda
+    nnz = int(d_I.numel())
+    o2n = torch.empty(n_rows, dtype=torch.int32, device=d_I.device)
+    n2o = torch.empty(n_rows, dtype=torch.int32, device=d_I.device)
+    hs, hA = _vp(), _vp()
+    _ck(lib().uspmv_convert_to_scs_device_from_arrays(_dp(d_I), _dp(d_J), _dp(d_V), n_rows, n_cols, nnz, C_, sigma, dtype,
+                                                      None if fixed_permutation is None else _dp(fixed_permutation), int(bool(permute_cols)), int(sort),
+                                                      _stream_ptr(stream), C.byref(hs) if want_layout else None, _dp(o2n), _dp(n2o), C.byref(hA)))
+    if want_layout:
+        s = Scs(hs)
+        return s, DeviceMatrix(s, d_I.device, _handle=hA), o2n, n2o
+
+    class _Meta:      # what DeviceMatrix needs to know about a handle that has no host struct
+        pass
+    m = (_i64 * 4)()
+    _ck(lib().uspmv_dmat_meta(hA, m))
+    s = _Meta()
+    s.C, s.n_chunks, s.n_elements, s.dtype = int(m[0]), int(m[1]), int(m[2]), int(m[3])
+    s.n_rows, s.n_rows_padded, s.nnz = n_rows, s.n_chunks * s.C, nnz
+    return None, DeviceMatrix(s, d_I.device, _handle=hA), o2n, n2o
 
 
 def dmat_download(A):

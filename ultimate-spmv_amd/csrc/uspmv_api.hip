@@ -141,6 +141,20 @@ __global__ void __launch_bounds__(256) stream_gather_lines_kernel(const double2 
 
 }  // namespace
 
+namespace uspmv_dev {
+// the O(nnz) scatter of convert_to_scs for callers in other files (csrc/convert_kernels.hip)
+int launch_scs_fill(int dtype, long nnz, int C, int n_rows, const int *I, const int *J, const double *V, const int *row_start, const int *row_map,
+                    const int *perm, const int *chunk_ptrs, int *col_idxs, void *values, hipStream_t st) {
+    const unsigned grid = (unsigned)((nnz + 255) / 256);
+    if (dtype == USPMV_F64)
+        hipLaunchKernelGGL(scs_fill_kernel<double>, dim3(grid), dim3(256), 0, st, nnz, C, n_rows, I, J, V, row_start, row_map, perm, chunk_ptrs, col_idxs, (double *)values);
+    else
+        hipLaunchKernelGGL(scs_fill_kernel<float>, dim3(grid), dim3(256), 0, st, nnz, C, n_rows, I, J, V, row_start, row_map, perm, chunk_ptrs, col_idxs, (float *)values);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+}  // namespace uspmv_dev
+
 // ============================================================================================ C ABI
 extern "C" {
 
@@ -173,7 +187,10 @@ int uspmv_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "nontemporal")) g_tune.nontemporal = value != 0;
     else if (!strcmp(key, "xcd_remap")) {
         if (value < 0 || value > 65536) return uspmv::fail(USPMV_ERR_INVALID, "xcd_remap must be 0, 1 or a group size <= 65536");
-        g_tune.xcd_remap = value;
+        g_tune.xcd_remap = (g_tune.xcd_remap & ~0xFFFFF) | value;
+    } else if (!strcmp(key, "xcd_stagger")) {     // XCD k starts its group value*k tiles in (remap_block); 0 = all XCDs in step
+        if (value < 0 || value > 2047) return uspmv::fail(USPMV_ERR_INVALID, "xcd_stagger must be in [0, 2047]");
+        g_tune.xcd_remap = (g_tune.xcd_remap & 0xFFFFF) | (value << 20);
     } else if (!strcmp(key, "ablate")) g_tune.ablate = value;
     else if (!strcmp(key, "spmmv_prefetch")) g_tune.spmmv_prefetch = value != 0;
     else if (!strcmp(key, "spmmv_swizzle")) g_tune.spmmv_swizzle = value != 0;
@@ -237,7 +254,8 @@ int uspmv_get_tuning(const char *key, int *value) {
     if (!key || !value) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_get_tuning: NULL argument");
     if (!strcmp(key, "unroll")) *value = g_tune.unroll;
     else if (!strcmp(key, "nontemporal")) *value = g_tune.nontemporal;
-    else if (!strcmp(key, "xcd_remap")) *value = g_tune.xcd_remap;
+    else if (!strcmp(key, "xcd_remap")) *value = g_tune.xcd_remap & 0xFFFFF;
+    else if (!strcmp(key, "xcd_stagger")) *value = g_tune.xcd_remap >> 20;
     else if (!strcmp(key, "block")) *value = g_tune.block;
     else if (!strcmp(key, "spmv_variant")) *value = g_tune.spmv_variant;
     else if (!strcmp(key, "csr_lanes")) *value = g_tune.csr_lanes;
@@ -386,6 +404,21 @@ int uspmv_convert_to_scs_device(const uspmv_coo_t *m, int64_t C, int64_t sigma, 
     }
     *layout = s;
     *out = A;
+    return USPMV_OK;
+}
+
+int uspmv_dmat_plan_addresses(const uspmv_dmat_t *A, uint64_t addr[8]) {
+    if (!A || !addr) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_plan_addresses: NULL argument");
+    const uspmv_dmat *M = A->alt ? A->alt : A;
+    addr[0] = (uint64_t)(uintptr_t)M->tlc_col16; addr[1] = (uint64_t)(uintptr_t)M->tlc_lines; addr[2] = (uint64_t)(uintptr_t)M->tlc_line_ptr;
+    addr[3] = (uint64_t)(uintptr_t)M->tlc_c16_ptrs; addr[4] = (uint64_t)(uintptr_t)M->values; addr[5] = (uint64_t)(uintptr_t)M->col_idxs;
+    addr[6] = (uint64_t)(uintptr_t)M->chunk_ptrs; addr[7] = (uint64_t)(uintptr_t)M->chunk_lengths;
+    return USPMV_OK;
+}
+
+int uspmv_dmat_meta(const uspmv_dmat_t *A, int64_t meta[4]) {
+    if (!A || !meta) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_meta: NULL argument");
+    meta[0] = A->C; meta[1] = A->n_chunks; meta[2] = A->n_elements; meta[3] = A->dtype;
     return USPMV_OK;
 }
 

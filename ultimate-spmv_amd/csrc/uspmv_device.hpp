@@ -131,7 +131,7 @@ struct Tuning {
     // defaults = fastest of the interleaved sweep on the nlpkkt200-class matrix (profiles/r01_sweep253.txt)
     int unroll = 8;
     int nontemporal = 1;
-    int xcd_remap = 256;  // groups of 256 consecutive workgroups per XCD (profiles/r01/sweepH.txt)
+    int xcd_remap = 256;  // groups of 256 consecutive workgroups per XCD (profiles/r01/sweepH.txt); bits 20+: the stagger (remap_block)
     int block = 256;
     int spmv_variant = 0;
     int csr_lanes = 0;  // 0 = choose from average row length
@@ -295,7 +295,13 @@ __device__ __forceinline__ float quad_bcast(float v) { return __int_as_float(qua
 // mode G >= 2: groups of G consecutive logical blocks per XCD, the 8 groups of a super-block
 // of 8*G blocks being processed concurrently (keeps all XCDs inside one moving DRAM window while
 // neighbouring blocks -- which share x lines -- share an L2).
+// Bits 20+ of `mode` (tuning "xcd_stagger" S): XCD k starts its group S*k blocks in, wrapping around -- the eight XCDs, which move
+// through their groups in step, then no longer touch addresses that differ by exact multiples of the group's byte size (256 tiles x 2 KB
+// of y = 512 KiB: eight write streams 2^19 bytes apart land on whatever memory channels the physical address bits above 2^19 select --
+// the same few, or all different, by the luck of the process's physical pages: profiles/r04/placement_*.txt).
 __device__ __forceinline__ unsigned remap_block(unsigned b, unsigned nb, int mode) {
+    const unsigned S = (unsigned)mode >> 20;
+    mode &= 0xFFFFF;
     if (mode == 0 || nb < 16) return b;
     if (mode == 1) {
         const unsigned xcd = b & 7u, q = nb >> 3, r = nb & 7u;
@@ -306,6 +312,9 @@ __device__ __forceinline__ unsigned remap_block(unsigned b, unsigned nb, int mod
     const unsigned full = (nb / SG) * SG;
     if (b >= full) return b;
     const unsigned sup = b / SG, rem = b - sup * SG;
-    return sup * SG + (rem & 7u) * G + (rem >> 3);
+    const unsigned xcd = rem & 7u;
+    unsigned pos = (rem >> 3) + S * xcd;
+    if (S) pos %= G;
+    return sup * SG + xcd * G + pos;
 }
 

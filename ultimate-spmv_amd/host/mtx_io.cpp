@@ -17,7 +17,14 @@
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
+#include <charconv>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <memory>
+#include <string>
+#include <vector>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -28,30 +35,132 @@ namespace {
 
 thread_local std::string g_last_error;
 
-struct Slurp {
+struct Slurp {   // the file mapped read-only (+ one readable byte behind it: files whose size is a multiple of the page size get a private copy)
     char *p = nullptr;
-    size_t n = 0;
-    ~Slurp() { free(p); }
+    size_t n = 0, mapped = 0;
+    bool heap = false;
+    ~Slurp() { if (heap) free(p); else if (p) munmap(p, mapped); }
+};
+
+// scratch array on anonymous memory with transparent huge pages asked for: 2 MiB pages take 512 times fewer page faults than 4 KiB ones
+// (eight parsing threads faulting in one address space serialise on the kernel's mm lock) and keep hundreds of write streams in the TLB
+template <typename T> struct HugeBuf {
+    T *p = nullptr;
+    size_t cap = 0, n = 0;
+    HugeBuf() = default;
+    HugeBuf(const HugeBuf &) = delete;
+    HugeBuf &operator=(const HugeBuf &) = delete;
+    ~HugeBuf() { release(); }
+    void release() { if (p) munmap(p, bytes()); p = nullptr; cap = n = 0; }
+    size_t bytes() const { return ((cap * sizeof(T) + (2u << 20) - 1) / (2u << 20)) * (2u << 20); }
+    bool alloc(size_t elems) {
+        release();
+        cap = elems ? elems : 1;
+        void *m = mmap(nullptr, bytes(), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (m == MAP_FAILED) { cap = 0; return false; }
+        (void)madvise(m, bytes(), MADV_HUGEPAGE);
+        p = (T *)m;
+        return true;
+    }
+    void push(T v) { p[n++] = v; }
 };
 
 bool slurp(const char *path, Slurp &s) {
-    FILE *f = fopen(path, "rb");
-    if (!f) return false;
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    if (sz < 0) { fclose(f); return false; }
-    s.p = (char *)malloc((size_t)sz + 1);
-    if (!s.p) { fclose(f); return false; }
-    s.n = fread(s.p, 1, (size_t)sz, f);
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st{};
+    if (fstat(fd, &st) != 0 || st.st_size < 0) { close(fd); return false; }
+    s.n = (size_t)st.st_size;
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    if (s.n > 0 && s.n % page != 0) {           // the tail of the last page reads as zeros: a terminator for strtol / strtod
+        void *m = mmap(nullptr, s.n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        if (m != MAP_FAILED) {
+            (void)madvise(m, s.n, MADV_SEQUENTIAL);
+            s.p = (char *)m; s.mapped = s.n;
+            close(fd);
+            return true;
+        }
+    }
+    s.p = (char *)malloc(s.n + 1);
+    if (!s.p) { close(fd); return false; }
+    s.heap = true;
+    size_t got = 0;
+    while (got < s.n) {
+        const ssize_t r = read(fd, s.p + got, s.n - got);
+        if (r <= 0) break;
+        got += (size_t)r;
+    }
+    s.n = got;
     s.p[s.n] = 0;
-    fclose(f);
+    close(fd);
     return true;
 }
 
-std::string lower(std::string s) {
-    for (auto &c : s) c = (char)tolower((unsigned char)c);
-    return s;
+// decimal -> double, correctly rounded like the reference's fscanf("%lg") / strtod.  Fast path for plain decimal tokens "[-]ddd[.ddd][e[+-]dd]"
+// with at most 19 significant digits: the digits as one 64-bit integer m (exact in x87 extended precision, 64-bit significand), times or
+// divided by an exactly representable power of ten 10^k, k <= 27 -- ONE rounding to 64 bits, the true value within half a unit of the
+// last place -- then rounded to double.  That second rounding can only differ from a direct one when the 64-bit value sits at a midpoint
+// between two doubles (low 11 bits 0x400; 0x3ff and 0x401 are refused as well): those tokens, and everything else (more digits, larger
+// exponents, hex floats, '+', inf / nan), go to strtod.  (libstdc++ 11's std::from_chars<double> is strtod behind a locale switch: slower.)
+inline bool parse_double(char *&q, char *e, double &v) {
+    while (q < e && (*q == ' ' || *q == '\t')) ++q;
+    const char *s = q;
+    bool neg = false;
+    if (s < e && *s == '-') { neg = true; ++s; }
+    uint64_t m = 0;
+    int nd = 0, frac = 0;
+    bool any = false, ok = true;
+    while (s < e && *s >= '0' && *s <= '9') { any = true; if (nd < 19) { m = m * 10 + (uint64_t)(*s - '0'); nd += (m != 0); } else ok = false; ++s; }
+    if (s < e && *s == '.') {
+        ++s;
+        while (s < e && *s >= '0' && *s <= '9') {
+            any = true;
+            if (nd < 19) { m = m * 10 + (uint64_t)(*s - '0'); nd += (m != 0); ++frac; }
+            else if (*s != '0') ok = false;                   // (zeros behind the 19th significant digit change nothing)
+            ++s;
+        }
+    }
+    int ex = 0;
+    if (any && s < e && (*s == 'e' || *s == 'E')) {
+        const char *t = s + 1;
+        bool eneg = false;
+        if (t < e && (*t == '+' || *t == '-')) { eneg = *t == '-'; ++t; }
+        if (t < e && *t >= '0' && *t <= '9') {
+            int x = 0;
+            while (t < e && *t >= '0' && *t <= '9') { if (x < 100000) x = x * 10 + (*t - '0'); ++t; }
+            ex = eneg ? -x : x;
+            s = t;
+        }
+    }
+    // the token must end here: anything glued to it ('x' of a hex float, a 'd' exponent, "nan(...)") is strtod's business
+    if (any && ok && (s >= e || *s == ' ' || *s == '\t' || *s == '\n' || *s == '\r' || *s == 0)) {
+        const int k = ex - frac;
+        if (m == 0) { v = neg ? -0.0 : 0.0; q = (char *)s; return true; }
+        if (k >= -27 && k <= 27) {
+            static const long double P10[28] = {1e0L, 1e1L, 1e2L, 1e3L, 1e4L, 1e5L, 1e6L, 1e7L, 1e8L, 1e9L, 1e10L, 1e11L, 1e12L, 1e13L, 1e14L, 1e15L, 1e16L,
+                                                1e17L, 1e18L, 1e19L, 1e20L, 1e21L, 1e22L, 1e23L, 1e24L, 1e25L, 1e26L, 1e27L};
+            long double x = (long double)m;                   // exact: m < 2^64
+            bool ambiguous = false;
+            if (k != 0) {
+                x = k > 0 ? x * P10[k] : x / P10[-k];         // one rounding to 64 bits
+                uint64_t sig;
+                memcpy(&sig, &x, 8);                          // x87 extended: the low 8 bytes are the explicit 64-bit significand
+                const unsigned low = (unsigned)(sig & 0x7FF);
+                ambiguous = low >= 0x3FF && low <= 0x401;
+            }
+            if (!ambiguous) {
+                v = (double)x;                                // (k == 0: the one and only rounding, ties to even like strtod)
+                if (neg) v = -v;
+                q = (char *)s;
+                return true;
+            }
+        }
+    }
+    char *r2;
+    v = strtod(q, &r2);
+    if (r2 == q) return false;
+    q = r2;
+    return true;
 }
 
 }  // namespace
@@ -164,8 +273,57 @@ int uspmv_coo_load(const char *path, uspmv_coo_t **out) {
     return USPMV_OK;
 }
 
+// MatrixMarket writer (no reference counterpart: the reference only reads; tools/mtx_scale_probe.py and the tests write inputs with it).
+// symmetric != 0: only entries with column <= row are written under a "symmetric" banner -- the reader expands them again.
+// Values are printed with 17 significant digits, so a general file read back gives the same doubles.
+int uspmv_coo_write_mtx(const uspmv_coo_t *m, const char *path, int symmetric) {
+    if (!m || !path) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_coo_write_mtx: NULL argument");
+    FILE *f = fopen(path, "wb");
+    if (!f) return uspmv::fail(USPMV_ERR_IO, "uspmv_coo_write_mtx: cannot create '%s'", path);
+    int64_t stored = m->nnz;
+    if (symmetric) {
+        stored = 0;
+#pragma omp parallel for reduction(+ : stored) schedule(static)
+        for (int64_t k = 0; k < m->nnz; ++k) stored += m->J[(size_t)k] <= m->I[(size_t)k];
+    }
+    bool ok = fprintf(f, "%%%%MatrixMarket matrix coordinate real %s\n%lld %lld %lld\n", symmetric ? "symmetric" : "general", (long long)m->n_rows,
+                      (long long)m->n_cols, (long long)stored) > 0;
+    constexpr int64_t BLK = 1 << 22;                        // entries formatted per round (every thread its piece, written in order)
+    for (int64_t b0 = 0; b0 < m->nnz && ok; b0 += BLK) {
+        const int64_t b1 = std::min(b0 + BLK, m->nnz);
+        int nt = 1;
+#ifdef _OPENMP
+        nt = omp_get_max_threads();
+#endif
+        std::vector<std::string> piece((size_t)nt);
+#pragma omp parallel num_threads(nt)
+        {
+            int t = 0;
+#ifdef _OPENMP
+            t = omp_get_thread_num();
+#endif
+            const int64_t per = (b1 - b0 + nt - 1) / nt, k0 = b0 + t * per, k1 = std::min(k0 + per, b1);
+            std::string &out = piece[(size_t)t];
+            out.reserve((size_t)std::max<int64_t>(k1 - k0, 0) * 40);
+            char line[96];
+            for (int64_t k = k0; k < k1; ++k) {
+                if (symmetric && m->J[(size_t)k] > m->I[(size_t)k]) continue;
+                const int n = snprintf(line, sizeof line, "%d %d %.17g\n", m->I[(size_t)k] + 1, m->J[(size_t)k] + 1, m->values[(size_t)k]);
+                out.append(line, (size_t)n);
+            }
+        }
+        for (const std::string &o : piece) ok = ok && (o.empty() || fwrite(o.data(), 1, o.size(), f) == o.size());
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return uspmv::fail(USPMV_ERR_IO, "uspmv_coo_write_mtx: write to '%s' failed", path);
+    return USPMV_OK;
+}
+
 int uspmv_read_mtx(const char *path, uspmv_coo_t **out) {
     if (!path || !out) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_read_mtx: NULL argument");
+    const bool verbose = getenv("USPMV_VERBOSE") != nullptr;
+    double t_last = omp_get_wtime();
+    auto lap = [&](const char *what) { if (verbose) { const double t = omp_get_wtime(); fprintf(stderr, "[uspmv] read_mtx: %-28s %.2f s\n", what, t - t_last); t_last = t; } };
     Slurp s;
     if (!slurp(path, s)) return uspmv::fail(USPMV_ERR_IO, "uspmv_read_mtx: cannot open '%s'", path);
     char *p = s.p, *end = s.p + s.n;
@@ -212,8 +370,6 @@ int uspmv_read_mtx(const char *path, uspmv_coo_t **out) {
     // into one piece per thread at line boundaries; pieces are parsed in parallel and concatenated in
     // file order, so the result is identical to a sequential fscanf loop (the reference
     // parses 7.6e8 entries with one fscanf each on rank 0).
-    std::vector<int32_t> ru, cu;
-    std::vector<double> vu;
     {
         int nth = 1;
 #ifdef _OPENMP
@@ -228,16 +384,17 @@ int uspmv_read_mtx(const char *path, uspmv_coo_t **out) {
             while (q < end && *q != '\n') ++q;
             cut[(size_t)t] = q < end ? q + 1 : end;
         }
-        std::vector<std::vector<int32_t>> pr((size_t)nth), pc((size_t)nth);
-        std::vector<std::vector<double>> pv((size_t)nth);
+        std::vector<HugeBuf<int32_t>> pr((size_t)nth), pc((size_t)nth);
+        std::vector<HugeBuf<double>> pv((size_t)nth);
         std::vector<long> n_parsed((size_t)nth, 0);
         std::vector<int> err((size_t)nth, 0);
 #pragma omp parallel for schedule(static, 1) num_threads(nth)
         for (int t = 0; t < nth; ++t) {
             char *q = cut[(size_t)t], *e = cut[(size_t)t + 1];
             auto &R = pr[(size_t)t]; auto &Cc = pc[(size_t)t]; auto &V = pv[(size_t)t];
-            const size_t guess = (size_t)(e - q) / 12 + 16;
-            R.reserve(guess * (symmetric ? 2 : 1)); Cc.reserve(guess * (symmetric ? 2 : 1)); V.reserve(guess * (symmetric ? 2 : 1));
+            // upper bound of the entries of this piece: the shortest line is "1 1\n" (pattern) / "1 1 1\n" (only touched pages become real)
+            const size_t bound = ((size_t)(e - q) / (pattern ? 4 : 6) + 2) * (symmetric ? 2 : 1);
+            if (!R.alloc(bound) || !Cc.alloc(bound) || !V.alloc(bound)) { err[(size_t)t] = 3; continue; }
             while (q < e) {
                 while (q < e && (*q == ' ' || *q == '\t' || *q == '\r' || *q == '\n')) ++q;
                 if (q >= e) break;
@@ -249,61 +406,112 @@ int uspmv_read_mtx(const char *path, uspmv_coo_t **out) {
                 if (r2 == q) { err[(size_t)t] = 1; break; }
                 q = r2;
                 double v = 0.01;  // pattern matrices (code/mmio.h:195-203)
-                if (!pattern) {
-                    v = strtod(q, &r2);
-                    if (r2 == q) { err[(size_t)t] = 1; break; }
-                    q = r2;
-                }
+                if (!pattern && !parse_double(q, e, v)) { err[(size_t)t] = 1; break; }
                 if (r < 1 || r > M || c < 1 || c > N) { err[(size_t)t] = 2; break; }
-                R.push_back((int32_t)(r - 1)); Cc.push_back((int32_t)(c - 1)); V.push_back(v);
-                if (symmetric && r != c) { R.push_back((int32_t)(c - 1)); Cc.push_back((int32_t)(r - 1)); V.push_back(v); }
+                R.push((int32_t)(r - 1)); Cc.push((int32_t)(c - 1)); V.push(v);
+                if (symmetric && r != c) { R.push((int32_t)(c - 1)); Cc.push((int32_t)(r - 1)); V.push(v); }
                 ++n_parsed[(size_t)t];
             }
         }
+        lap("parse");
         long total = 0;
         for (int t = 0; t < nth; ++t) {
+            if (err[(size_t)t] == 3) return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_read_mtx: out of memory");
             if (err[(size_t)t] == 2) return uspmv::fail(USPMV_ERR_IO, "uspmv_read_mtx: an entry lies outside the %ldx%ld matrix", M, N);
             if (err[(size_t)t]) return uspmv::fail(USPMV_ERR_IO, "uspmv_read_mtx: malformed entry line");
             total += n_parsed[(size_t)t];
         }
         if (total < NZ) return uspmv::fail(USPMV_ERR_IO, "uspmv_read_mtx: premature end of file (%ld of %ld entries)", total, NZ);
-        // keep exactly the first NZ entries of the file (what the reference's counted loop reads)
-        ru.reserve((size_t)NZ * (symmetric ? 2 : 1)); cu.reserve(ru.capacity()); vu.reserve(ru.capacity());
+        // keep exactly the first NZ entries of the file (what the reference's counted loop reads): per piece, how many of its (expanded)
+        // elements count.  A file with more lines than the header announces is cut inside the piece that crosses NZ.
+        std::vector<size_t> keep((size_t)nth, 0);
         long seen = 0;
         for (int t = 0; t < nth; ++t) {
-            const auto &R = pr[(size_t)t]; const auto &Cc = pc[(size_t)t]; const auto &V = pv[(size_t)t];
-            if (seen + n_parsed[(size_t)t] <= NZ) {
-                ru.insert(ru.end(), R.begin(), R.end()); cu.insert(cu.end(), Cc.begin(), Cc.end()); vu.insert(vu.end(), V.begin(), V.end());
-                seen += n_parsed[(size_t)t];
-            } else {  // file holds more lines than the header announces: take entries until NZ is reached
-                size_t k = 0;
-                while (seen < NZ && k < R.size()) {
-                    const bool pair = symmetric && k + 1 < R.size() && R[k] == Cc[k + 1] && Cc[k] == R[k + 1] && R[k] != Cc[k];
-                    ru.push_back(R[k]); cu.push_back(Cc[k]); vu.push_back(V[k]); ++k;
-                    if (pair) { ru.push_back(R[k]); cu.push_back(Cc[k]); vu.push_back(V[k]); ++k; }
-                    ++seen;
+            const int32_t *R = pr[(size_t)t].p, *Cc = pc[(size_t)t].p;
+            const size_t rn = pr[(size_t)t].n;
+            if (seen + n_parsed[(size_t)t] <= NZ) { keep[(size_t)t] = rn; seen += n_parsed[(size_t)t]; continue; }
+            size_t k = 0;
+            while (seen < NZ && k < rn) {
+                const bool pair = symmetric && k + 1 < rn && R[k] == Cc[k + 1] && Cc[k] == R[k + 1] && R[k] != Cc[k];
+                k += pair ? 2 : 1;
+                ++seen;
+            }
+            keep[(size_t)t] = k;
+            break;
+        }
+        size_t tot = 0;
+        for (int t = 0; t < nth; ++t) tot += keep[(size_t)t];
+        if (tot > (size_t)INT32_MAX)
+            return uspmv::fail(USPMV_ERR_OVERFLOW, "uspmv_read_mtx: expanded nnz exceeds the 32-bit index type");
+
+        // ---- stable sort by row (code/utilities.hpp:2139-2146, :2278), in parallel and in two passes instead of one serial counting sort
+        //      with 2e8 cache-missing scatters: (1) the pieces, in file order, are distributed stably over NB buckets of consecutive rows
+        //      (per-piece bucket histograms -> every piece knows where its share of a bucket starts: sequential writes into NB streams);
+        //      (2) every bucket -- a few thousand rows, cache-resident -- is counting-sorted by row on its own, stably, into its final place.
+        const int64_t nnz = (int64_t)tot;
+        int shift = 0;
+        while (((int64_t)(M - 1) >> shift) >= 512) ++shift;      // (<= 512 buckets: 3 x 512 write streams stay inside the second-level TLB)
+        const int64_t NB = ((int64_t)(M - 1) >> shift) + 1;
+        std::vector<std::vector<int64_t>> hist((size_t)nth, std::vector<int64_t>((size_t)NB, 0));
+#pragma omp parallel for schedule(static, 1) num_threads(nth)
+        for (int t = 0; t < nth; ++t) {
+            const int32_t *R = pr[(size_t)t].p;
+            int64_t *h = hist[(size_t)t].data();
+            for (size_t k = 0; k < keep[(size_t)t]; ++k) h[R[k] >> shift]++;
+        }
+        lap("bucket histograms");
+        std::vector<int64_t> bstart((size_t)NB + 1, 0);
+        {
+            int64_t run = 0;
+            for (int64_t b = 0; b < NB; ++b) {
+                bstart[(size_t)b] = run;
+                for (int t = 0; t < nth; ++t) { const int64_t c = hist[(size_t)t][(size_t)b]; hist[(size_t)t][(size_t)b] = run; run += c; }
+            }
+            bstart[(size_t)NB] = run;
+        }
+        HugeBuf<int32_t> trb, tcb;
+        HugeBuf<double> tvb;
+        if (!trb.alloc((size_t)nnz) || !tcb.alloc((size_t)nnz) || !tvb.alloc((size_t)nnz)) return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_read_mtx: out of memory");
+        int32_t *tr = trb.p, *tc = tcb.p;
+        double *tv = tvb.p;
+#pragma omp parallel for schedule(static, 1) num_threads(nth)
+        for (int t = 0; t < nth; ++t) {
+            const int32_t *R = pr[(size_t)t].p, *Cc = pc[(size_t)t].p;
+            const double *V = pv[(size_t)t].p;
+            int64_t *h = hist[(size_t)t].data();
+            for (size_t k = 0; k < keep[(size_t)t]; ++k) {
+                const int64_t d = h[R[k] >> shift]++;
+                tr[(size_t)d] = R[k]; tc[(size_t)d] = Cc[k]; tv[(size_t)d] = V[k];
+            }
+            pr[(size_t)t].release(); pc[(size_t)t].release(); pv[(size_t)t].release();
+        }
+        lap("distribute over buckets");
+        auto *m = new uspmv_coo;
+        m->n_rows = M; m->n_cols = N; m->nnz = nnz;
+        m->I.resize((size_t)nnz); m->J.resize((size_t)nnz); m->values.resize((size_t)nnz);
+        lap("allocate the result");
+#pragma omp parallel
+        {
+            std::vector<int64_t> cnt((size_t)1 << shift);
+#pragma omp for schedule(dynamic, 8)
+            for (int64_t b = 0; b < NB; ++b) {
+                const int64_t k0 = bstart[(size_t)b], k1 = bstart[(size_t)b + 1];
+                const int32_t r0 = (int32_t)(b << shift);
+                const int64_t nr = std::min<int64_t>((int64_t)1 << shift, M - r0);
+                std::fill(cnt.begin(), cnt.begin() + nr, 0);
+                for (int64_t k = k0; k < k1; ++k) cnt[(size_t)(tr[(size_t)k] - r0)]++;
+                int64_t run = k0;
+                for (int64_t r = 0; r < nr; ++r) { const int64_t c = cnt[(size_t)r]; cnt[(size_t)r] = run; run += c; }
+                for (int64_t k = k0; k < k1; ++k) {
+                    const int64_t d = cnt[(size_t)(tr[(size_t)k] - r0)]++;
+                    m->I[(size_t)d] = tr[(size_t)k]; m->J[(size_t)d] = tc[(size_t)k]; m->values[(size_t)d] = tv[(size_t)k];
                 }
-                break;
             }
         }
+        lap("sort inside the buckets");
+        *out = m;
+        return USPMV_OK;
     }
-    if (ru.size() > (size_t)INT32_MAX)
-        return uspmv::fail(USPMV_ERR_OVERFLOW, "uspmv_read_mtx: expanded nnz exceeds the 32-bit index type");
-
-    // ---- stable sort by row == counting sort
-    int64_t nnz = (int64_t)ru.size();
-    std::vector<int64_t> start((size_t)M + 1, 0);
-    for (int64_t k = 0; k < nnz; ++k) start[(size_t)ru[k] + 1]++;
-    for (long r = 0; r < M; ++r) start[(size_t)r + 1] += start[(size_t)r];
-    auto *m = new uspmv_coo;
-    m->n_rows = M; m->n_cols = N; m->nnz = nnz;
-    m->I.resize((size_t)nnz); m->J.resize((size_t)nnz); m->values.resize((size_t)nnz);
-    for (int64_t k = 0; k < nnz; ++k) {
-        int64_t d = start[(size_t)ru[k]]++;
-        m->I[(size_t)d] = ru[k]; m->J[(size_t)d] = cu[k]; m->values[(size_t)d] = vu[k];
-    }
-    *out = m;
-    return USPMV_OK;
 }
 
 }  // extern "C"
