@@ -234,7 +234,7 @@ int uspmv_coo_equilibrate(uspmv_coo_t *m) {
     if (!m) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_coo_equilibrate: NULL matrix");
     const int64_t nnz = m->nnz;
     for (int pass = 0; pass < 2; ++pass) {
-        const std::vector<int32_t> &idx = pass == 0 ? m->I : m->J;
+        const uspmv_ivec &idx = pass == 0 ? m->I : m->J;
         std::vector<double> mx((size_t)std::max<int64_t>(pass == 0 ? m->n_rows : m->n_cols, 1), 0.0);
 #pragma omp parallel
         {

@@ -4,16 +4,32 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <memory>
+#include <utility>
 #include <vector>
 
 #include "uspmv.h"
 
 // COO matrix, 0-based, entries stable-sorted by row when produced by uspmv_read_mtx
 // (role of MtxData<double,int>, reference code/classes_structs.hpp:1169-1238).
+// allocator whose resize() leaves new elements uninitialised: the three arrays of a large COO are first touched by the threads that fill
+// them (a value-initialising resize is a serial 3 GB memset for 2e8 entries, host/mtx_io.cpp)
+template <class T> struct uspmv_noinit_alloc : std::allocator<T> {
+    template <class U> struct rebind { using other = uspmv_noinit_alloc<U>; };
+    uspmv_noinit_alloc() = default;
+    template <class U> uspmv_noinit_alloc(const uspmv_noinit_alloc<U> &) {}
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+        else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+using uspmv_ivec = std::vector<int32_t, uspmv_noinit_alloc<int32_t>>;
+using uspmv_dvec = std::vector<double, uspmv_noinit_alloc<double>>;
+
 struct uspmv_coo {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
-    std::vector<int32_t> I, J;
-    std::vector<double> values;
+    uspmv_ivec I, J;
+    uspmv_dvec values;
 };
 
 // SELL-C-sigma matrix on the host (role of ScsData<VT,int>, code/classes_structs.hpp:1313-1339).
