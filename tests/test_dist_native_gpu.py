@@ -861,3 +861,28 @@ def test_cli_seg_metis_real_ranks(pkg, tmp_path):
         assert rep["rank0"]["n_local"] == int(sizes[0])
         assert "seg-metis: METIS is not linked" in outs[0]
     assert "seg_method: seg-metis" in open(tmp_path / "spmv_bench.txt").read()
+    # The self-check runs in the PERMUTED numbering (a wrong symmetric permutation would still pass it): dump y with the ramp x, put it
+    # back into the original numbering with <prefix>.perm and compare with the single-rank product of the ORIGINAL matrix -- the
+    # permutation keeps the entry order inside a row, so every row's FMA chain is the same and the comparison is bitwise.
+    from oracle import oracle as orc
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID=f"mp{os.getpid()}",
+                   USPMV_HC_TIMEOUT="120", USPMV_DIST_X="ramp", USPMV_DUMP_Y=str(tmp_path / "ymetis"))
+        env.pop("USPMV_LOOPBACK", None)
+        procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-seg_metis", "-comm_halos", "1", "-bench_steps", "1", "-bench_warmup", "0"],
+                                      cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p_ in procs:
+        o = p_.communicate(timeout=300)[0]
+        assert p_.returncode == 0, o
+    perm = np.fromfile(tmp_path / "ymetis.perm", np.int32)
+    assert np.array_equal(np.sort(perm), np.arange(m.n_rows))
+    _, wsa, _ = pkg.apply_partition(m, 3, part)
+    y_new = np.concatenate([np.fromfile(tmp_path / f"ymetis.{r}") for r in range(3)])
+    x_new = np.concatenate([1.0 + 1e-3 * (np.arange(int(wsa[r + 1] - wsa[r])) % 1000) for r in range(3)])     # USPMV_DIST_X=ramp: per rank, local numbering
+    x_orig = np.empty(m.n_rows); x_orig[perm] = x_new
+    I, J, V = m.arrays()
+    s1 = pkg.convert_to_scs(m, 1, 1, pkg.F64)                                                             # (C = 1, sigma = 1: rows in original order, chains in entry order)
+    a1 = s1.arrays()
+    y_orig = orc.spmv_scs(1, s1.n_chunks, a1["chunk_ptrs"], a1["chunk_lengths"], a1["col_idxs"], a1["values"], x_orig)[:m.n_rows]
+    assert np.array_equal(y_new, y_orig[perm])

@@ -95,8 +95,10 @@ def main():
             env["LD_PRELOAD"] = "/opt/rocm/lib/libamdhip64.so.7:/opt/rocm/lib/librccl.so.1"
         print(f"\n================ variant {v}", flush=True)
         try:
-            r = subprocess.run(["timeout", "-k", "10", "180", sys.executable, os.path.abspath(__file__), "--child", "preload_child" if v == "preload" else v],
-                               env=env, capture_output=True, text=True, timeout=240)
+            # (no `timeout` wrapper: with LD_PRELOAD it would carry the HIP / RCCL runtime and then exec python -- an exec hop from a process
+            #  with the GPU runtime loaded, which this pool forbids; subprocess.run's own timeout ends a hung child)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "preload_child" if v == "preload" else v],
+                               env=env, capture_output=True, text=True, timeout=200)
             out = (r.stdout + r.stderr)
             keep = [ln for ln in out.splitlines() if not ln.startswith("  File ") and "site-packages" not in ln]
             print("\n".join(keep[-60:]))

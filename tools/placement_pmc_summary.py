@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """per counter: mean over the fast (even) and slow (odd) launches of the LAST 8 scs_spmv_tlc dispatches of every pass under <dir>/g*/"""
 import collections, csv, glob, sys
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "scs_spmv_tlc"
 for d in sorted(glob.glob(sys.argv[1] + "/g*")):
     rows = collections.defaultdict(list)
     for f in sorted(glob.glob(d + "/**/*_counter_collection.csv", recursive=True)):
         for r in csv.DictReader(open(f)):
-            if "scs_spmv_tlc" in r["Kernel_Name"]:
+            if KERNEL in r["Kernel_Name"]:
                 rows[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
     for c, v in sorted(rows.items()):
         v = sorted(v)[-8:]

@@ -6,6 +6,7 @@
 
 using namespace uspmv_dev;
 
+namespace uspmv_dev { thread_local int tl_measure_off = 0; }
 namespace uspmv_dev {
 
 Tuning g_tune;
@@ -466,6 +467,11 @@ static int device_plan_install_rows(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_li
 // 512 KB: more of the x lines miss the XCD's L2) at 512 (1.249 against 1.341 ms, profiles/r03/tile_rows_sweep.txt).  The choice is
 // remembered per (shape, size) for the life of the process, so the host and the device planner of one matrix agree.  0 = no opinion.
 static int measured_tile_rows(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, const char *who) {
+    if (uspmv_dev::tl_measure_off > 0) return 0;
+    // one measurement at a time, and the verdict table only read / written under the lock (the verdict is keyed on the struct's shape and
+    // size, not its content: two matrices with equal counts share it -- the price of host and device planner of ONE matrix agreeing)
+    static std::mutex mtx;
+    std::lock_guard<std::mutex> lock(mtx);
     if (!g_tune.tlc_measure_tile || g_tune.tlc_tile_rows != 0 || A->alt || A->C > 256 || 256 % A->C != 0) return 0;
     if (A->n_chunks * A->C < (int64_t)1 << 20) return 0;
     if (B && (B->alt || B->C != A->C || B->n_chunks != A->n_chunks || A->dtype != USPMV_F64 || B->dtype != USPMV_F32)) return 0;

@@ -97,6 +97,10 @@ struct uspmv_dmat {
 
 namespace uspmv_dev {
 
+// "do not MEASURE the rows per tile" (tlc_measure_tile) for the planner calls of the current thread, as a scope
+extern thread_local int tl_measure_off;
+struct MeasureOff { MeasureOff() { ++tl_measure_off; } ~MeasureOff() { --tl_measure_off; } };
+
 // One-launch distributed step (csrc/uspmv_dist_api.hip): the tile list of a step is [early | late | conditional | early].  Early entries
 // (interior + padding tiles) run at once.  A late entry (a tile with real halo references) looks ONCE at the exchange counter: if the
 // exchange of this step has completed it proceeds (acquire), otherwise it appends its position to the step's deferred list and

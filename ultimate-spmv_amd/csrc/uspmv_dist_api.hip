@@ -311,7 +311,7 @@ int step_fused(uspmv_dist *D, void *d_x, void *d_y, hipStream_t main) {
 // The RCCL group stays on the CALLER's stream on purpose: when the step is captured, that is the capture's origin stream.  Under
 // the HIP 7.0 / RCCL 2.26 pair that torch bundles, hipStreamEndCapture crashes if an RCCL p2p group was captured on a stream that
 // JOINED the capture through an event, while the same group on the origin stream, and kernels on joined streams, capture fine
-// (profiles/r03/graph_capture_diag.txt; the system's HIP 7.2 / RCCL 2.27 takes either form).  Same DAG, same overlap.
+// (profiles/r03/graph_capture_diag_before_fix.txt / _after_fix.txt; the system's HIP 7.2 / RCCL 2.27 takes either form).  Same DAG, same overlap.
 int step(uspmv_dist *D, void *d_x, void *d_y, hipStream_t main, bool comm_halos) {
     if (D->P == 1 || !comm_halos) return uspmv_spmv(D->A, d_x, d_y, main);
     if (!D->overlap) {
@@ -547,11 +547,8 @@ int uspmv_dist_create_from_coo_ex(const void *comm_id, int comm_rank, int comm_s
     if (!rc && tlc) {
         // (a rank's block keeps the 256-row tiles unless its lines ask for more: larger tiles measured level on a block of the 304^3 stencil
         //  -- 0.1785 / 0.1791 / 0.1822 ms -- and a 512-row tile = a whole sigma window always holds a padded chunk, i.e. no interior tile is left)
-        int mt = 1;
-        (void)uspmv_get_tuning("tlc_measure_tile", &mt);
-        (void)uspmv_set_tuning("tlc_measure_tile", 0);
+        uspmv_dev::MeasureOff no_measure;                     // (this thread's planner calls only: no global tuning state is flipped)
         rc = uspmv_dmat_optimize(A, scs, 0, &n_tiles, &n_staged);
-        (void)uspmv_set_tuning("tlc_measure_tile", mt);
     }
     int tile_rows = 0;
     if (!rc) rc = uspmv_dmat_tile_rows(A, &tile_rows);
@@ -960,7 +957,13 @@ uspmv_dist::BlockPlan *block_plan(uspmv_dist *D, int b, int layout, int mode) {
             bp.d_unpack.push_back(d_u);
         }
     }
-    if (e != hipSuccess) { uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dist_spmmv: %s", hipGetErrorString(e)); return nullptr; }
+    if (e != hipSuccess) {   // nothing of a half-built plan stays behind (every failed call would leak it again)
+        (void)hipFree(bp.d_src); (void)hipFree(bp.d_send); (void)hipFree(bp.d_recv);
+        for (int32_t *u : bp.d_unpack) (void)hipFree(u);
+        (void)hipGetLastError();
+        uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dist_spmmv: %s", hipGetErrorString(e));
+        return nullptr;
+    }
     D->block_plans.push_back(bp);
     return &D->block_plans.back();
 }

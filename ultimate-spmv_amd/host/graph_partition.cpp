@@ -30,7 +30,7 @@ Graph build_graph(const uspmv_coo *m) {
     std::vector<int64_t> deg((size_t)n + 1, 0);
     for (int64_t k = 0; k < m->nnz; ++k) {
         const int32_t i = m->I[(size_t)k], j = m->J[(size_t)k];
-        if (i == j || j >= n) continue;
+        if (i == j || j >= n || j < 0 || i < 0 || i >= n) continue;   // (entries outside the square are no edges; uspmv_graph_partition refuses them up front)
         ++deg[(size_t)i + 1]; ++deg[(size_t)j + 1];
     }
     for (int64_t i = 0; i < n; ++i) deg[(size_t)i + 1] += deg[(size_t)i];
@@ -38,7 +38,7 @@ Graph build_graph(const uspmv_coo *m) {
     std::vector<int64_t> pos(deg.begin(), deg.end() - 1);
     for (int64_t k = 0; k < m->nnz; ++k) {
         const int32_t i = m->I[(size_t)k], j = m->J[(size_t)k];
-        if (i == j || j >= n) continue;
+        if (i == j || j >= n || j < 0 || i < 0 || i >= n) continue;   // (entries outside the square are no edges; uspmv_graph_partition refuses them up front)
         raw[(size_t)pos[(size_t)i]++] = j; raw[(size_t)pos[(size_t)j]++] = i;
     }
     g.ptr.assign((size_t)n + 1, 0);
@@ -92,6 +92,10 @@ int uspmv_graph_partition(const uspmv_coo_t *m, int P, int32_t *part) {
     if (m->n_rows != m->n_cols) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_graph_partition: the matrix must be square");
     const int64_t n = m->n_rows;
     if (n == 0) return USPMV_OK;
+    for (int64_t k = 0; k < m->nnz; ++k)
+        if (m->I[(size_t)k] < 0 || m->I[(size_t)k] >= n || m->J[(size_t)k] < 0 || m->J[(size_t)k] >= n)
+            return uspmv::fail(USPMV_ERR_INVALID, "uspmv_graph_partition: entry %lld (%d, %d) lies outside the %lld x %lld matrix", (long long)k, m->I[(size_t)k],
+                               m->J[(size_t)k], (long long)n, (long long)n);
     const Graph g = build_graph(m);
     std::vector<char> seen((size_t)n, 0);
     std::vector<int32_t> order;
@@ -111,7 +115,7 @@ int uspmv_graph_partition(const uspmv_coo_t *m, int P, int32_t *part) {
     // boundary refinement: a vertex moves to the part that holds most of its neighbours when that lowers the cut and keeps every part
     // within 3 % (at least one vertex) of the mean
     const int64_t slack = std::max<int64_t>(1, n * 3 / (100 * (int64_t)P));
-    const int64_t lo = n / P - slack, hi = (n + P - 1) / P + slack;
+    const int64_t lo = std::max<int64_t>(1, n / P - slack), hi = (n + P - 1) / P + slack;   // (lo >= 1: refinement never empties a part)
     std::vector<int32_t> cnt((size_t)P, 0), touched;
     for (int pass = 0; pass < 4 && P > 1; ++pass) {
         int64_t moved = 0;

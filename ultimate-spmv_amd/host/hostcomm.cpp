@@ -284,6 +284,9 @@ int uspmv_hostcomm_alltoallv(uspmv_hostcomm_t *h, const void *send, const int64_
         }
         if (int rc = hc_barrier(h)) return rc;
     }
+    // every send buffer empty: no window round, so nothing has separated the peers' reads of this rank's offset table from the next
+    // call's write to it -- close the table phase here (a rank running ahead would otherwise change table(me) under a slower reader)
+    if (hi <= 0) if (int rc = hc_barrier(h)) return rc;
     return USPMV_OK;
 }
 

@@ -29,7 +29,8 @@
 // ranks may share one GPU (unequal seg-nnz blocks included).
 // USPMV_DIST_X=ramp sets x_local[i] = 1 + 1e-3 * (i mod 1000) in ORIGINAL local row order on every rank (the default is the
 // reference's constant 5.0); USPMV_DUMP_Y=<prefix> writes y of the local rows in original order to <prefix>.<rank> (raw
-// doubles) after one step.  tests/test_dist_native_gpu.py checks that output against the oracle.
+// doubles) after one step (with -seg_metis also <prefix>.perm: permuted row r = original row perm[r]).  tests/test_dist_native_gpu.py
+// checks that output against the oracle.
 #include <hip/hip_runtime_api.h>
 #include <unistd.h>
 
@@ -129,7 +130,7 @@ int uspmv_run_distributed(const DistConfig &c) {
     }
 
     // ---- this rank's row block (and nothing else)
-    std::vector<int32_t> wsa((size_t)P + 1, 0);
+    std::vector<int32_t> wsa((size_t)P + 1, 0), metis_perm;
     uspmv_coo_t *local = nullptr;
     int64_t n_rows_g = 0, nnz_g = 0;
     const int seg = c.seg_nnz ? USPMV_SEG_NNZ : USPMV_SEG_ROWS;
@@ -156,7 +157,8 @@ int uspmv_run_distributed(const DistConfig &c) {
                 if (!c.part_file.empty()) CK(uspmv_read_partition(c.part_file.c_str(), n_rows_g, P, part.data()));
                 else CK(uspmv_graph_partition(total, P, part.data()));
                 uspmv_coo_t *permuted = nullptr;
-                CK(uspmv_coo_apply_partition(total, P, part.data(), &permuted, wsa.data(), nullptr));
+                metis_perm.resize((size_t)n_rows_g);             // new row r = old row perm[r]: kept, so that dumped results can be mapped back
+                CK(uspmv_coo_apply_partition(total, P, part.data(), &permuted, wsa.data(), metis_perm.data()));
                 uspmv_coo_free(total);
                 total = permuted;
                 printf("seg-metis: METIS is not linked; rows partitioned by %s\n", c.part_file.empty() ? "the built-in level-set partitioner" : c.part_file.c_str());
@@ -284,6 +286,9 @@ int uspmv_run_distributed(const DistConfig &c) {
             CK(uspmv_apply_permutation(yo.data() + vsz * (size_t)v * n_local, col.data(), o2n, n_local, dtype));
         }
         publish(std::string(dump) + "." + std::to_string(rank), yo.data(), vsz * (size_t)n_local * b);
+        // -seg_metis: the blocks are blocks of the PERMUTED matrix; <prefix>.perm (int32 per row: permuted row r = original row perm[r])
+        // lets the reader put the gathered y back into the original numbering
+        if (!metis_perm.empty()) publish(std::string(dump) + ".perm", metis_perm.data(), 4 * metis_perm.size());
     }
 
     // ---- solve mode (-mode s): COMM - spmv - SWAP, -rev times (code/main.cpp:528-607; the last swap is undone by reading y), y of the
@@ -300,6 +305,7 @@ int uspmv_run_distributed(const DistConfig &c) {
             HK(hipMemcpy(hy.data(), sy, vsz * (size_t)n_pad, hipMemcpyDeviceToHost));
             CK(uspmv_apply_permutation(yo.data(), hy.data(), o2n, n_local, dtype));
             publish(c.dump_y + "." + std::to_string(rank), yo.data(), vsz * (size_t)n_local);
+            if (!metis_perm.empty()) publish(c.dump_y + ".perm", metis_perm.data(), 4 * metis_perm.size());
         }
         int64_t mm = -1, tot = -1;
         if (c.check_y && comm_halos) {
