@@ -285,6 +285,16 @@ def other_configs(pkg, B, torch, args, which):
             line(f"3 ({nm})", f"Queen_4147-class synthetic (27-pt stencil {g}^3 x 3 dof, n={s.n_rows}, nnz={nnz}) scs -c 32 -s 512 -dp -block_vec_size 8, {nm} X / Y",
                  "uspmv_spmmv: scs_spmmv_quadph<double,8> (phased block plan)" + (" behind block_vector_to_rowmajor" if lay == B.COLWISE else ""),
                  wall, k_ms, byts, 2.0 * nnz * b, same, cpu, setup, {"block_plan_tiles": [A.block_staged, A.block_tiles], "plan_kind": kind})
+            if lay == B.COLWISE:
+                # the reference's bench loop multiplies the SAME X every iteration (code/main.cpp:458-519): re-laid out once
+                pkg.spmmv_x_prepared(A, dX, b, ld)
+                dY.zero_()
+                wall2, k2 = measure(lambda: pkg.spmmv(A, dX, dY, b, ld, lay), 5, A=A, x=dX, y=dY, b=b, ld=ld, layout=lay)
+                same2 = bool(np.array_equal(dY.cpu().numpy(), Yc))
+                pkg.spmmv_x_release(A)
+                line("3 (colwise, X prepared)", f"the same, X unchanged between the calls (uspmv_spmmv_x_prepared: the column-major X re-laid out once, not per call)",
+                     "uspmv_spmmv: scs_spmmv_quadph<double,8> (phased block plan), column-major Y", wall2, k2, byts, 2.0 * nnz * b, same2,
+                     {"note": "see 3 (colwise)"}, setup, {"plan_kind": kind})
             del dX, dY
         del A, s, a
         t.cuda.empty_cache()

@@ -263,6 +263,14 @@ int uspmv_spmv_chunks(const uspmv_dmat_t *A, const int32_t *d_chunk_ids, int64_t
  * semantics = block_spmv_omp_scs_general (code/kernels.hpp:306-398).  ld = vec_length of the
  * colwise layout (ignored for rowwise). */
 int uspmv_spmmv(const uspmv_dmat_t *A, const void *d_X, void *d_Y, int b, int64_t ld, int layout, void *stream);
+/* Column-major block vectors whose X does NOT change between calls -- the reference's bench loop multiplies the same X in every
+ * iteration (code/main.cpp:458-519): re-lay X out into the handle's row-major workspace once, now.  Until uspmv_spmmv_x_release, every
+ * uspmv_spmmv(m, d_X, ..., b, ld, USPMV_COLWISE) with THIS pointer, b and ld skips its re-layout pass (another X, b or ld takes the
+ * per-call re-layout as before and overwrites the workspace: call again afterwards).  The caller promises that the CONTENTS of X are
+ * unchanged since this call; a caller that writes X (solve mode: x <- y) must call again or release.  Widths without a re-layout pass
+ * (b not in {2, 4, 8, 16}) return USPMV_OK and skip nothing. */
+int uspmv_spmmv_x_prepared(const uspmv_dmat_t *m, const void *d_X, int block_vec_size, int64_t ld, void *stream);
+int uspmv_spmmv_x_release(const uspmv_dmat_t *m);
 /* Adaptive precision dp+sp.  Replaces execute_two_prec -> spmv_gpu_ap_scs_adv_launcher
  * (code/classes_structs.hpp:1037-1075, code/ap_kernels.hpp:821-953); numerics follow the CPU
  * kernel scs_ap_impl_cpu (code/ap_kernels.hpp:24-82): both parts accumulated in double from the

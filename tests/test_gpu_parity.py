@@ -994,3 +994,39 @@ def test_device_block_plan_builder_equals_host_planner(pkg, orc, torch_cuda):
             assert digests[0][0] == digests[1][0], (C, sigma, code, [k for k in range(8) if digests[0][0][k] != digests[1][0][k]])
     finally:
         pkg.set_tuning(block_plan_device=1)
+
+
+def test_spmmv_column_major_x_prepared_once(pkg, orc, torch_cuda):
+    """uspmv_spmmv_x_prepared: a caller whose column-major X does not change between calls (the reference's bench loop, code/main.cpp:458-519)
+    pays the re-layout once.  Same bits as the per-call form; another X falls back to the per-call pass (and gives ITS result); after that
+    the first X is right again; release ends it."""
+    t = torch_cuda
+    m = pkg.gen_stencil27(12, 11, 10, dof=3)
+    s, a, xp = _prep(pkg, m, 32, 512, pkg.F64, make_x(m.n_rows))
+    for b in (8, 4, 3):
+        A = pkg.DeviceMatrix(s, block_tlc=b if b == 8 else 0)
+        ld = s.n_rows_padded
+        X1 = np.concatenate([xp * (1.0 + v / 8.0) for v in range(b)]); X2 = np.concatenate([xp * (2.0 - v / 16.0) for v in range(b)])
+        d1, d2 = _dev(t, X1), _dev(t, X2)
+        Y = t.zeros(b * ld, dtype=t.float64, device="cuda")
+        ref = {}
+        for nm, d in (("1", d1), ("2", d2)):
+            pkg.spmmv(A, d, Y, b, ld, pkg.COLWISE); t.cuda.synchronize()
+            ref[nm] = Y.clone()
+            Yo = orc.spmmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], d.cpu().numpy(), b, ld, False)
+            assert np.array_equal(ref[nm].cpu().numpy(), Yo)
+        pkg.spmmv_x_prepared(A, d1, b, ld)
+        for _ in range(3):
+            Y.zero_(); pkg.spmmv(A, d1, Y, b, ld, pkg.COLWISE); t.cuda.synchronize()
+            assert t.equal(Y, ref["1"]), b
+        Y.zero_(); pkg.spmmv(A, d2, Y, b, ld, pkg.COLWISE); t.cuda.synchronize()
+        assert t.equal(Y, ref["2"]), b
+        Y.zero_(); pkg.spmmv(A, d1, Y, b, ld, pkg.COLWISE); t.cuda.synchronize()
+        assert t.equal(Y, ref["1"]), b
+        pkg.spmmv_x_prepared(A, d2, b, ld)
+        d2.mul_(1.0)                                          # (contents unchanged)
+        Y.zero_(); pkg.spmmv(A, d2, Y, b, ld, pkg.COLWISE); t.cuda.synchronize()
+        assert t.equal(Y, ref["2"]), b
+        pkg.spmmv_x_release(A)
+        Y.zero_(); pkg.spmmv(A, d2, Y, b, ld, pkg.ROWWISE if False else pkg.COLWISE); t.cuda.synchronize()
+        assert t.equal(Y, ref["2"]), b

@@ -12,6 +12,6 @@ The directory name contains a hyphen (repository convention), so import it throu
 from .binding import (  # noqa: F401
     COLWISE, F32, F64, ROWWISE, SEG_NNZ, SEG_ROWS, Coo, DeviceMatrix, HaloPlan, Scs, UspmvError, apply_permutation,
     build_library, convert_to_scs, convert_to_scs_device, convert_to_scs_device_from_arrays, SORT_HOST, SORT_DEVICE_STABLE, device_count, dmat_download, gen_banded_random, graph_partition, read_partition, apply_partition, gen_kkt, gen_kkt_row_counts, gen_stencil27, get_tuning, lib, library_path, optimize_ap, optimize_device_ap, optimize_sweep_ap, pack_send_buf,
-    partition_precisions, permute_scs_cols, read_mtx, seg_work_sharing_arr, seg_local_coo, set_tuning, spmmv, spmv, spmv_ap,
+    partition_precisions, permute_scs_cols, read_mtx, seg_work_sharing_arr, seg_local_coo, set_tuning, spmmv_x_prepared, spmmv_x_release, spmmv, spmv, spmv_ap,
     spmv_chunks, spmv_tiles, uspmv_csr_gpu, uspmv_scs_gpu, DistNative, HostComm, CommPlan, Transport, DistOptions, EXCHANGE_HOST, EXCHANGE_RCCL, runtime_versions, dist_check_reference, comm_unique_id, seg_from_row_counts, gen_stencil27_row_counts,
 )

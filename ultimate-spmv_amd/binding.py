@@ -135,6 +135,8 @@ _SIGS = {
     "uspmv_convert_to_scs_device_from_arrays": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, C.c_int, C.c_int, _vp,
                                                           C.POINTER(_vp), _vp, _vp, C.POINTER(_vp)]),
     "uspmv_dmat_plan_addresses": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "uspmv_spmmv_x_prepared": (C.c_int, [_vp, _vp, C.c_int, _i64, _vp]),
+    "uspmv_spmmv_x_release": (C.c_int, [_vp]),
     "uspmv_dmat_meta": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dist_comm_count": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "uspmv_dist_autotune": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _i32p, _vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
@@ -972,6 +974,15 @@ def convert_to_scs_device_from_arrays(d_I, d_J, d_V, n_rows, n_cols, C_, sigma, 
     s.C, s.n_chunks, s.n_elements, s.dtype = int(m[0]), int(m[1]), int(m[2]), int(m[3])
     s.n_rows, s.n_rows_padded, s.nnz = n_rows, s.n_chunks * s.C, nnz
     return None, DeviceMatrix(s, d_I.device, _handle=hA), o2n, n2o
+
+
+def spmmv_x_prepared(A, X, b, ld, stream=None):
+    """column-major X unchanged between calls: re-lay it out once (uspmv_spmmv_x_prepared); spmmv_x_release(A) ends it"""
+    _ck(lib().uspmv_spmmv_x_prepared(A.h, _dp(X), int(b), int(ld), _stream_ptr(stream)))
+
+
+def spmmv_x_release(A):
+    _ck(lib().uspmv_spmmv_x_release(A.h))
 
 
 def dmat_download(A):

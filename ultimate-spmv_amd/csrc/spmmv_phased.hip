@@ -84,6 +84,20 @@ __global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, con
     // XLINE: local index (line << LS | row in line) -> LDS byte offset of (line, column 0, row in line)
     auto lds_off = [](unsigned ix) -> unsigned { return XLINE ? (((ix >> LS) << (7 + LB)) | ((ix & ((1u << LS) - 1u)) << LVS)) : ix; };
     int g0 = p0 < p1 ? ph_g0[p0] : 0, lp = p0 < p1 ? ph_list_ptr[p0] : 0;
+    // LISTAHEAD (row-major X only): the X-row list of phase ph + 1 is requested together with the X rows and the matrix entries of phase
+    // ph, so that a phase costs ONE dependent round trip (list of the first phase -> {X rows, entries, next list} per phase) instead of
+    // two (list -> X rows + entries).  At eight workgroups per CU the waves spend half their cycles waiting (profiles/r03/pmc_cfg3.txt),
+    // and cutting the X re-fetch from the fabric by half changes nothing (profiles/r04/pmc_xcd_cfg3): the kernel is bound by these waits.
+    constexpr bool LISTAHEAD = XM == 0 && !(ABL & 16);
+    int xr_cur[MAXP];
+    if constexpr (LISTAHEAD) {
+        const int np_first = p0 < p1 ? (ph_list_ptr[p0 + 1] - lp) << 2 : 0;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const int pp = (wave + 4 * k) * 64 + lane;
+            xr_cur[k] = pp < np_first ? xrows[lp + (pp >> 2)] : -1;
+        }
+    }
     for (int ph = p0; ph < p1; ++ph) {
         const int g1 = ph + 1 < p1 ? ph_g0[ph + 1] : 0x7fffffff;
         const int lp1 = ph_list_ptr[ph + 1];
@@ -121,11 +135,16 @@ __global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, con
         } else if constexpr (!XCOL) {
             // ---- the list entries this lane needs for its DMA pieces (piece p = (wave + 4k)*64 + lane <-> list entry p >> 2)
             int xr[MAXP];
+            if constexpr (LISTAHEAD) {
 #pragma unroll
-            for (int k = 0; k < MAXP; ++k) {
-                const int pp = (wave + 4 * k) * 64 + lane;
-                xr[k] = -1;
-                if (!(ABL & 16) && pp < np) xr[k] = xrows[lp + (pp >> 2)];
+                for (int k = 0; k < MAXP; ++k) xr[k] = xr_cur[k];     // (requested one phase ago)
+            } else {
+#pragma unroll
+                for (int k = 0; k < MAXP; ++k) {
+                    const int pp = (wave + 4 * k) * 64 + lane;
+                    xr[k] = -1;
+                    if (!(ABL & 16) && pp < np) xr[k] = xrows[lp + (pp >> 2)];
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (ph > p0) __syncthreads();                    // every wave is through with the previous phase's rows
@@ -134,6 +153,15 @@ __global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, con
             for (int k = 0; k < MAXP; ++k)
                 if (!(ABL & 1) && xr[k] >= 0)
                     __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(X + (long)xr[k] * B + q * VW), (lds_void_t *)(tlc_smem + (wave + 4 * k) * 1024), 16, 0, 0);
+            if constexpr (LISTAHEAD) {
+                // ---- ... and the list of the NEXT phase (it lands with the entries below: no round trip of its own)
+                const int np_next = ph + 1 < p1 ? (ph_list_ptr[ph + 2] - lp1) << 2 : 0;
+#pragma unroll
+                for (int k = 0; k < MAXP; ++k) {
+                    const int pp = (wave + 4 * k) * 64 + lane;
+                    xr_cur[k] = pp < np_next ? xrows[lp1 + (pp >> 2)] : -1;
+                }
+            }
         } else {
             // ---- column-major X: thread <-> list entry (MAXP*64/256 entries per thread), its B elements loaded column by column
             constexpr int EPT = MAXP / 4;                    // list entries per thread (cap rows / 256 threads)

@@ -1648,6 +1648,27 @@ int uspmv_spmmv(const uspmv_dmat_t *A, const void *d_X, void *d_Y, int b, int64_
     return launch_spmmv<float>(A, (const float *)d_X, (float *)d_Y, b, (long)ld, layout, (hipStream_t)stream);
 }
 
+int uspmv_spmmv_x_prepared(const uspmv_dmat_t *A, const void *d_X, int b, int64_t ld, void *stream) {
+    if (int rc = check_dmat(A, "uspmv_spmmv_x_prepared")) return rc;
+    if (!d_X || b < 1 || ld < A->n_chunks * A->C) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_spmmv_x_prepared: bad argument");
+    if (int rc = require_device()) return rc;
+    if (A->alt && g_tune.rechunk) A = A->alt;
+    A->xprep_ptr = nullptr;
+    const int rc = A->dtype == USPMV_F64 ? prepare_x<double>(A, (const double *)d_X, b, (long)ld, (hipStream_t)stream)
+                                         : prepare_x<float>(A, (const float *)d_X, b, (long)ld, (hipStream_t)stream);
+    if (rc > 0) return USPMV_OK;                              // (this width / alignment has no re-layout pass: nothing to prepare, nothing skipped)
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int uspmv_spmmv_x_release(const uspmv_dmat_t *A) {
+    if (int rc = check_dmat(A, "uspmv_spmmv_x_release")) return rc;
+    A->xprep_ptr = nullptr;
+    if (A->alt) A->alt->xprep_ptr = nullptr;
+    return USPMV_OK;
+}
+
 static int spmv_ap_impl(const uspmv_dmat_t *dp, const uspmv_dmat_t *sp, const double *d_x, const float *d_x_sp,
                         double *d_y, void *stream, const char *who) {
     if (int rc = check_dmat(dp, who)) return rc;

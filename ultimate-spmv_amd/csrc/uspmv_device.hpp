@@ -25,6 +25,10 @@ struct uspmv_dmat {
     // on demand, released with the handle.  Not thread-safe per handle, like the reference's kernel object.
     mutable void *ws = nullptr;
     mutable size_t ws_bytes = 0;
+    // uspmv_spmmv_x_prepared: the workspace holds the re-laid-out copy of THIS column-major X (b, ld; form 1 plain / 2 sigma permutation undone)
+    mutable const void *xprep_ptr = nullptr;
+    mutable int xprep_b = 0, xprep_form = 0;
+    mutable long xprep_ld = 0;
     // SpMMV in two parts (the halo overlap of uspmv_dist_spmmv, csrc/uspmv_dist_api.hip): chunk-length arrays in which the chunks of the
     // OTHER part carry USPMV_SKIP_LEN -- a kernel that meets it leaves those rows of Y alone.  [order][part - 1]: order 0 = the caller's
     // row order (gather kernels), order 1 = the phased plan's tie-re-ordered rows (scs_spmmv_quadph), classified per 64-row plan tile.
@@ -209,6 +213,8 @@ template <typename VT>
 int launch_csr(long n_rows, long nnz_hint, const int *rp, const int *ci, const VT *va, const VT *x, VT *y, hipStream_t st);  // spmv_kernels.hip
 template <typename VT>
 int launch_spmmv(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int layout, hipStream_t st);            // spmmv_kernels.hip
+template <typename VT>
+int prepare_x(const uspmv_dmat *A, const VT *X, int b, long ld, hipStream_t st);                                    // spmmv_kernels.hip
 // phased block plan, 64-byte X rows (spmmv_phased.hip); false: no plan / schedule on the handle or it does not fit the compiled shapes
 // xmode: 0 = row-major X, 1 = column-major X assembled through registers, 2 = column-major X staged by 128-byte lines (line plan)
 bool spmmv_phased(const uspmv_dmat *A, const double *X, double *Y, long ld, bool ycol, int xmode, hipStream_t st);

@@ -54,7 +54,8 @@ struct Config {  // subset of the reference's Config (code/classes_structs.hpp:4
     int vec_mode = USPMV_BULKVEC;  // -mpi_mode: message pattern of the block-vector halo exchange (a make knob in the reference, Makefile / config.mk)
     std::string step_form = "auto";
     int bench_steps = 0, bench_warmup = -1, check_y = 0;   // multi-rank: -bench_steps K / -bench_warmup W (fixed-count protocol), -check_y 1
-    std::string json;                                       // multi-rank: -json <file|->
+    std::string json;                                       // -json <file|->
+    int x_prepared = 1;                                     // -x_prepared 0|1: bench mode, column-major block vectors: re-lay X out once (1) or per call (0)
     std::string part_file;                                  // -seg_metis: part ids from this file (one per row, gpmetis format) instead of the built-in partitioner
 };
 
@@ -78,7 +79,8 @@ void usage() {
             "  -equilibrate <0|1> -ap_threshold_1 <float> -ap_threshold_2 <float> -dropout <0|1>\n"
             "  -dropout_threshold <float> -block_vec_layout <colwise|rowwise> -tlc <0|1> -graph <0|1> -dump_y <file>\n"
             "  -mpi_mode <singlevec|multivec|bulkvec>\n"
-            "  multi-rank runs: -bench_steps <int> -bench_warmup <int> -check_y <0|1> -json <file|-> -step_form <auto|auto_all|overlap|plain|pad|fused>\n"
+            "  -bench_steps <int> -bench_warmup <int> -json <file|-> (fixed-count protocol, JSON report)  -x_prepared <0|1> (bench mode, column-major block vectors: X re-laid out once)\n"
+            "  multi-rank runs: -check_y <0|1> -step_form <auto|auto_all|overlap|plain|pad|fused>\n"
             "  -seg_metis [-part_file <file>]: graph partition (built-in level-set partitioner, or part ids from a gpmetis-style file)\n");
 }
 
@@ -125,6 +127,7 @@ Config parse(int argc, char **argv) {
         else if (a == "-bench_warmup") { c.bench_warmup = atoi(need(i)); if (c.bench_warmup < 0) die("bench_warmup must be >= 0."); }
         else if (a == "-check_y") c.check_y = atoi(need(i));
         else if (a == "-json") c.json = need(i);
+        else if (a == "-x_prepared") c.x_prepared = atoi(need(i));
         else if (a == "-step_form") { c.step_form = need(i); if (c.step_form != "auto" && c.step_form != "auto_all" && c.step_form != "overlap" && c.step_form != "plain" && c.step_form != "pad" && c.step_form != "fused") die("step_form must be auto, auto_all, overlap, plain, pad or fused."); }
         else if (a == "-block_vec_layout") { std::string v = need(i); if (v == "colwise") c.layout = USPMV_COLWISE; else if (v == "rowwise") c.layout = USPMV_ROWWISE; else die("block_vec_layout must be colwise or rowwise."); }
         else { usage(); die("unknown argument: " + a); }
@@ -282,6 +285,9 @@ int run(const Config &c, uspmv_coo_t *coo) {
 
     double perf = 0, runtime = 0; int n_iter = 0;
     float kernel_ms = 0.f;
+    // bench mode multiplies the SAME block vector in every iteration (code/main.cpp:458-519): a column-major X is re-laid out once
+    // (uspmv_spmmv_x_prepared) instead of per call; -x_prepared 0 keeps the per-call pass.  Solve mode writes x every revision: never.
+    if (c.mode == 'b' && b > 1 && c.layout == USPMV_COLWISE && c.x_prepared) ck(uspmv_spmmv_x_prepared(r.A, r.x, b, ld, nullptr), "uspmv_spmmv_x_prepared");
     if (c.mode == 'b' && c.bench_steps > 0) {
         // -bench_steps K [-bench_warmup W]: exactly K launches between two synchronisations, wall clock and HIP events (the protocol
         // bench.py asks the multi-rank harness for; here it yields the one-GPU time of the same matrix for the strong-scaling line)
