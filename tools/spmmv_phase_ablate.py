@@ -16,8 +16,9 @@ b, ld = 8, s.n_rows_padded
 X = torch.rand(b * ld, dtype=torch.float64, device="cuda"); Y = torch.zeros_like(X)
 A = pkg.DeviceMatrix(s, block_tlc=b)
 names = {0: "full kernel", 1: "no X staging", 2: "no arithmetic", 4: "no value loads", 8: "no index loads", 17: "no list, no X staging",
-         14: "list + X staging only", 3: "list + matrix stream only", 19: "matrix stream only (no list)"}
-for var, abls in ((8, (0, 1, 2, 4, 8, 17, 14, 3, 19)),):
+         14: "list + X staging only", 3: "list + matrix stream only", 19: "matrix stream only (no list)",
+         64: "X staging of CONSECUTIVE rows (same count, whole lines)", 78: "list + staging of consecutive rows only"}
+for var, abls in ((8, (0, 1, 2, 4, 8, 17, 14, 3, 19, 64, 78)),):
     pkg.set_tuning(spmmv_variant=var)
     for abl in abls:
         pkg.set_tuning(ablate=abl)

@@ -84,20 +84,10 @@ __global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, con
     // XLINE: local index (line << LS | row in line) -> LDS byte offset of (line, column 0, row in line)
     auto lds_off = [](unsigned ix) -> unsigned { return XLINE ? (((ix >> LS) << (7 + LB)) | ((ix & ((1u << LS) - 1u)) << LVS)) : ix; };
     int g0 = p0 < p1 ? ph_g0[p0] : 0, lp = p0 < p1 ? ph_list_ptr[p0] : 0;
-    // LISTAHEAD (row-major X only): the X-row list of phase ph + 1 is requested together with the X rows and the matrix entries of phase
-    // ph, so that a phase costs ONE dependent round trip (list of the first phase -> {X rows, entries, next list} per phase) instead of
-    // two (list -> X rows + entries).  At eight workgroups per CU the waves spend half their cycles waiting (profiles/r03/pmc_cfg3.txt),
-    // and cutting the X re-fetch from the fabric by half changes nothing (profiles/r04/pmc_xcd_cfg3): the kernel is bound by these waits.
-    constexpr bool LISTAHEAD = XM == 0 && !(ABL & 16);
-    int xr_cur[MAXP];
-    if constexpr (LISTAHEAD) {
-        const int np_first = p0 < p1 ? (ph_list_ptr[p0 + 1] - lp) << 2 : 0;
-#pragma unroll
-        for (int k = 0; k < MAXP; ++k) {
-            const int pp = (wave + 4 * k) * 64 + lane;
-            xr_cur[k] = pp < np_first ? xrows[lp + (pp >> 2)] : -1;
-        }
-    }
+    // (Built and measured level in round 4, then removed: the X-row list of phase ph + 1 requested together with the X rows and entries of
+    //  phase ph -- one dependent round trip per phase instead of two, at 72 instead of 64 registers: 0.7468 against 0.7486 ms.  Neither the
+    //  list's round trip nor the bytes the X staging takes from the fabric -- halved by a tile -> XCD group of plane/8, PMC-confirmed --
+    //  bound this kernel: profiles/r04/spmmv_listahead_timing.txt, pmc_xcd_cfg3/summary.txt.)
     for (int ph = p0; ph < p1; ++ph) {
         const int g1 = ph + 1 < p1 ? ph_g0[ph + 1] : 0x7fffffff;
         const int lp1 = ph_list_ptr[ph + 1];
@@ -135,16 +125,14 @@ __global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, con
         } else if constexpr (!XCOL) {
             // ---- the list entries this lane needs for its DMA pieces (piece p = (wave + 4k)*64 + lane <-> list entry p >> 2)
             int xr[MAXP];
-            if constexpr (LISTAHEAD) {
 #pragma unroll
-                for (int k = 0; k < MAXP; ++k) xr[k] = xr_cur[k];     // (requested one phase ago)
-            } else {
-#pragma unroll
-                for (int k = 0; k < MAXP; ++k) {
-                    const int pp = (wave + 4 * k) * 64 + lane;
-                    xr[k] = -1;
-                    if (!(ABL & 16) && pp < np) xr[k] = xrows[lp + (pp >> 2)];
-                }
+            for (int k = 0; k < MAXP; ++k) {
+                const int pp = (wave + 4 * k) * 64 + lane;
+                xr[k] = -1;
+                if (!(ABL & 16) && pp < np) xr[k] = xrows[lp + (pp >> 2)];
+                // measurement only (ablate 64): the same number of X rows, but CONSECUTIVE ones -- whole 128-byte lines, 1 KiB per wave
+                // instruction -- instead of the list's: what the staging would cost if only its bytes counted, not its requests
+                if ((ABL & 64) && pp < np) xr[k] = (int)(((long)tile * 97 + (pp >> 2)) % (ld > 1024 ? ld - 1024 : 1));
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (ph > p0) __syncthreads();                    // every wave is through with the previous phase's rows
@@ -153,15 +141,6 @@ __global__ void __launch_bounds__(256) scs_spmmv_quadph(const long n_chunks, con
             for (int k = 0; k < MAXP; ++k)
                 if (!(ABL & 1) && xr[k] >= 0)
                     __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(X + (long)xr[k] * B + q * VW), (lds_void_t *)(tlc_smem + (wave + 4 * k) * 1024), 16, 0, 0);
-            if constexpr (LISTAHEAD) {
-                // ---- ... and the list of the NEXT phase (it lands with the entries below: no round trip of its own)
-                const int np_next = ph + 1 < p1 ? (ph_list_ptr[ph + 2] - lp1) << 2 : 0;
-#pragma unroll
-                for (int k = 0; k < MAXP; ++k) {
-                    const int pp = (wave + 4 * k) * 64 + lane;
-                    xr_cur[k] = pp < np_next ? xrows[lp1 + (pp >> 2)] : -1;
-                }
-            }
         } else {
             // ---- column-major X: thread <-> list entry (MAXP*64/256 entries per thread), its B elements loaded column by column
             constexpr int EPT = MAXP / 4;                    // list entries per thread (cap rows / 256 threads)
@@ -310,7 +289,7 @@ void launch_spmmv_quadph_m(const uspmv_dmat *A, const VT *X, VT *Y, long ld, boo
         if (g_tune.ablate >= 1 && !xcol && !ycol) {   // measurement only
 #define QH_ABL(N) case N: hipLaunchKernelGGL((scs_spmmv_quadph<VT, IT, B, true, false, CT, 8, MAXP, 0, N>), dim3((unsigned)A->pb_n_tiles), dim3(256), lds, st, \
                            QH_ARGS(A->pb_ph_ptr, A->pb_g0, A->pb_list_ptr, A->pb_xrows, A->pb_col16)); break;
-            switch (g_tune.ablate) { QH_ABL(1) QH_ABL(2) QH_ABL(4) QH_ABL(8) QH_ABL(17) QH_ABL(14) QH_ABL(3) QH_ABL(19) QH_ABL(32) default: break; }
+            switch (g_tune.ablate) { QH_ABL(1) QH_ABL(2) QH_ABL(4) QH_ABL(8) QH_ABL(17) QH_ABL(14) QH_ABL(3) QH_ABL(19) QH_ABL(32) QH_ABL(64) QH_ABL(78) default: break; }
 #undef QH_ABL
             return;
         }
