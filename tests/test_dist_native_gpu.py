@@ -886,3 +886,33 @@ def test_cli_seg_metis_real_ranks(pkg, tmp_path):
     a1 = s1.arrays()
     y_orig = orc.spmv_scs(1, s1.n_chunks, a1["chunk_ptrs"], a1["chunk_lengths"], a1["col_idxs"], a1["values"], x_orig)[:m.n_rows]
     assert np.array_equal(y_new, y_orig[perm])
+
+
+def test_bench_launcher_starts_real_rank_processes_and_reports_every_rank(pkg, tmp_path):
+    """`python3 bench.py --gpus 2` with NO outer launcher, the real `uspmv` harness on the GPU(s) of this box: the bench process starts
+    the two rank processes itself, keeps its budget and prints one JSON line.  On a one-GPU box RCCL refuses two ranks on one device
+    (tier 1 fails cleanly, tier 3 -- exchange staged through host memory -- measures); on a multi-GPU box tier 1 measures.  Either way:
+    y of every local row checked bitwise, every rank's row in the line, the one-GPU time of the same matrix and the efficiency."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "USPMV_LOOPBACK", "USPMV_EXCHANGE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--grid", "72", "--grid2", "48",
+                        "--budget-s", "300"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=400)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["value"] > 0 and d["n_gpus"] == 2 and d["scaling"] == "strong" and d["y_checked"] is True and d["y_mismatches"] == 0
+    assert "itself" in c["launcher"] and [x["rank"] for x in c["per_rank"]] == [0, 1]
+    assert sum(x["n_local"] for x in c["per_rank"]) == 72 ** 3 == c["n_rows"]
+    assert all(x["local_kernel_ms"] > 0 and x["n_halo"] >= 72 * 72 for x in c["per_rank"])
+    if c["exchange"] == "host":          # one GPU: the communicator was refused, and the line says so
+        assert c["rccl_nranks"] == 0 and "fallback_reason" in d and [t["ok"] for t in d["budget"]["tiers"]][:2] == [False, True]
+    else:                                # several GPUs: the production path
+        assert c["exchange"] == "rccl" and c["rccl_nranks"] == 2 and d["budget"]["tiers"][0]["ok"] is True
+    s1 = d["single_gpu_same_matrix"]
+    assert s1["n_rows"] == 72 ** 3 and s1["ms_per_step"] > 0
+    assert d["strong_scaling_efficiency"] == pytest.approx(s1["ms_per_step"] / (2 * d["ms_per_step"]), rel=1e-3)
+    assert d["weak_scaling"]["value"] > 0 and d["weak_scaling"]["y_checked"] is True
+    assert d["budget"]["used_s"] < 300
