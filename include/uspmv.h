@@ -222,6 +222,13 @@ int uspmv_dmat_block_plan_info(const uspmv_dmat_t *m, int64_t meta[10]);
  * local indices, the group-major values, the row map (tests: a plan built on the device equals the host planner's) */
 int uspmv_dmat_block_plan_digest(const uspmv_dmat_t *m, uint64_t digest[8]);
 
+/* Block vectors with 64-byte X rows (dp b = 8, sp b = 16): the column-window sweep plan for block vectors.  A tile of 1 024 - 4 096 rows
+ * walks the windows of 2^wlog X rows its rows touch, each staged in LDS once per tile (the phased plan above stages every X row once per
+ * slot range: 11.9 against ~5 rows per matrix row on a 3-dof 27-point stencil), a lane owning whole rows; column-major X and Y are taken
+ * as they are, without a re-layout pass.  Installed only when every tile qualifies (rows column-sorted at window granularity); uspmv_spmmv
+ * then prefers it.  wlog / tile_rows 0 = defaults.  *n_sweep < *n_tiles: not installed.  Same bits as every other path. */
+int uspmv_dmat_optimize_block_sweep(uspmv_dmat_t *m, const uspmv_scs_t *s, int block_vec_size, int wlog, int tile_rows, int64_t *n_tiles, int64_t *n_sweep);
+
 /* The block plan for a handle without a host struct (uspmv_dmat_wrap): the device arrays are copied to the host once and the plan is
  * built there.  No permutation is known then: ties of the sigma sort are ordered by first column instead of by original row. */
 int uspmv_dmat_optimize_block_device(uspmv_dmat_t *m, int block_vec_size, int64_t *n_tiles, int64_t *n_staged);

@@ -27,9 +27,11 @@ if mode == "fail" or (mode == "rccl_down" and world > 1 and not host):
     sys.stderr.write("ERROR: made to fail\n")
     sys.exit(1)
 stage("step object created (communicator up)")
-stage("step form chosen")
+stage("first collective done")
+stage("timing the step forms")
 if mode == "capture_crash" and world > 1 and opt.get("-graph") == "1" and not host:
     os.abort()
+stage("step form chosen")
 stage("timed region done")
 steps, warm = int(opt.get("-bench_steps", 5)), int(opt.get("-bench_warmup", 2))
 g = [int(v) for v in a[0][4:].split("x")]

@@ -135,6 +135,7 @@ _SIGS = {
     "uspmv_convert_to_scs_device_from_arrays": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, C.c_int, C.c_int, _vp,
                                                           C.POINTER(_vp), _vp, _vp, C.POINTER(_vp)]),
     "uspmv_dmat_plan_addresses": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "uspmv_dmat_optimize_block_sweep": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_spmmv_x_prepared": (C.c_int, [_vp, _vp, C.c_int, _i64, _vp]),
     "uspmv_spmmv_x_release": (C.c_int, [_vp]),
     "uspmv_dmat_meta": (C.c_int, [_vp, C.POINTER(_i64)]),
@@ -844,6 +845,13 @@ class DeviceMatrix:
         self.block_tiles = self.block_staged = 0
         if block_tlc:
             self.optimize_block(scs, block_tlc)
+
+    def optimize_block_sweep(self, scs, b, wlog=0, tile_rows=0):
+        """Block-vector column-window sweep plan for 64-byte X rows (uspmv_dmat_optimize_block_sweep); returns (n_tiles, n_sweep_tiles):
+        installed iff they are equal."""
+        a, n = _i64(), _i64()
+        _ck(lib().uspmv_dmat_optimize_block_sweep(self.h, scs.h, int(b), int(wlog), int(tile_rows), C.byref(a), C.byref(n)))
+        return a.value, n.value
 
     def optimize_device(self, max_lines=0):
         """Build the tile-local-column plan on the device from the handle's own arrays (uspmv_dmat_optimize_device)."""

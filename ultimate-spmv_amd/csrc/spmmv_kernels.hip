@@ -837,6 +837,14 @@ int relayout_x(const uspmv_dmat *A, const VT *X, long ld, hipStream_t st, int *f
 // scratch and Y written column-major directly by the kernel.
 template <typename VT, int B>
 int spmmv_fast(const uspmv_dmat *A, const VT *X, VT *Y, long ld, int layout, hipStream_t st) {
+    if constexpr (B * (int)sizeof(VT) == 64) {
+        // the block-vector window sweep, when the handle carries its plan (uspmv_dmat_optimize_block_sweep): both layouts straight from
+        // the caller's vectors -- column-major X is staged column by column, no re-layout pass
+        if (A->bw && (g_tune.spmmv_variant == 0 || g_tune.spmmv_variant == 9) && !g_tune.ablate) {
+            const int rc = launch_spmmv_sweep<VT>(A, X, Y, B, ld, layout == USPMV_COLWISE, layout == USPMV_COLWISE, st);
+            if (rc <= 0) return rc;
+        }
+    }
     if (layout == USPMV_ROWWISE) {
         launch_spmmv_rowmajor<VT, B>(A, X, Y, ld, false, st);
         return USPMV_OK;

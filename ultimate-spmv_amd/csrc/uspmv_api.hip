@@ -224,7 +224,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_tile_rows")) g_tune.spmmv_tile_rows = value == 64 ? 64 : value == 32 ? 32 : 0;
     else if (!strcmp(key, "spmmv_lds_kb")) g_tune.spmmv_lds_kb = value < 0 ? 0 : value;
     else if (!strcmp(key, "spmmv_variant")) {
-        if (value < 0 || value > 8 || value == 7) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0..6 or 8");
+        if (value < 0 || value > 9 || value == 7) return uspmv::fail(USPMV_ERR_INVALID, "spmmv_variant must be 0..6, 8 or 9 (9: the block-vector window sweep only)");
         g_tune.spmmv_variant = value;
     }
     else if (!strcmp(key, "tail_batch")) g_tune.tail_batch = value != 0;
@@ -1458,8 +1458,71 @@ int uspmv_dmat_optimize_sweep_ap(uspmv_dmat_t *dp, uspmv_dmat_t *sp, const uspmv
     return sweep_plan_install(dp, sp, s_dp, s_sp, wlog, tile_rows, n_tiles, n_sweep, "uspmv_dmat_optimize_sweep_ap");
 }
 
+static void bw_release(uspmv_dmat_t *A) {
+    (void)hipFree(A->bw_tile_ids); (void)hipFree(A->bw_win_ptr); (void)hipFree(A->bw_wins); (void)hipFree(A->bw_pad); (void)hipFree(A->bw_cnt_off);
+    (void)hipFree(A->bw_wave_off); (void)hipFree(A->bw_cnt); (void)hipFree(A->bw_vals); (void)hipFree(A->bw_idx);
+    A->bw_tile_ids = A->bw_win_ptr = A->bw_wins = A->bw_pad = nullptr; A->bw_cnt_off = nullptr; A->bw_wave_off = nullptr; A->bw_cnt = nullptr;
+    A->bw_vals = nullptr; A->bw_idx = nullptr;
+    A->bw = false; A->bw_n_tiles = A->bw_all_tiles = 0; A->bw_b = 0;
+}
+
+// The block-vector column-window sweep plan (host/sweep_plan.cpp: uspmv_build_block_sweep_plan; kernel csrc/spmmv_sweep.hip) for 64-byte X
+// rows.  Installed only when EVERY tile sweeps (rows column-sorted at window granularity, staging within "spmmv_sweep_max_stage" bytes
+// per non-zero); otherwise the handle keeps whatever block plan it has.  wlog / tile_rows 0 = defaults (2^11 rows = 128 KiB windows, one
+// buffer; 4 096-row tiles, fewer when the matrix is small).
+int uspmv_dmat_optimize_block_sweep(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_vec_size, int wlog, int tile_rows, int64_t *n_tiles, int64_t *n_sweep) {
+    if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block_sweep: NULL argument");
+    if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block_sweep: layout-only struct; the plan builder needs the host entries");
+    if (A->C != s->C || A->n_chunks != s->n_chunks || A->dtype != s->dtype)
+        return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block_sweep: handle and host struct do not describe the same matrix");
+    if (int rc = require_device()) return rc;
+    if (A->bw) bw_release(A);
+    if (n_tiles) *n_tiles = 0;
+    if (n_sweep) *n_sweep = 0;
+    const size_t vsz = s->dtype == USPMV_F64 ? 8 : 4;
+    if ((size_t)block_vec_size * vsz != 64) return USPMV_OK;                 // the kernel is written for 64-byte X rows
+    // defaults: the largest window (2^11 rows = 128 KiB, one buffer) and 4 096-row tiles measured best on the Queen_4147-class matrix
+    // (0.998 / 1.016 ms row- / column-wise; 2^9-row windows with two buffers 1.26 / 1.29: profiles/r04/spmmv_sweep_probe.txt)
+    if (wlog <= 0) wlog = 11;
+    if (((size_t)1 << wlog) * 64 > 160 * 1024) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize_block_sweep: a window of 2^%d rows does not fit the LDS", wlog);
+    if (tile_rows <= 0) {
+        tile_rows = 4096;
+        while (tile_rows > 1024 && s->n_chunks * s->C / tile_rows < 384) tile_rows /= 2;   // (at least ~1.5 tiles per CU)
+    }
+    uspmv_block_sweep_plan p;
+    const double max_stage = g_tune.sweep_max_stage > 0 ? (double)g_tune.sweep_max_stage : 24.0;
+    if (int rc = uspmv_build_block_sweep_plan(s, wlog, tile_rows, 64, max_stage, &p)) return rc;
+    if (n_tiles) *n_tiles = p.n_tiles;
+    if (n_sweep) *n_sweep = p.valid ? p.n_sweep_tiles : 0;
+    if (getenv("USPMV_VERBOSE"))
+        fprintf(stderr, "[uspmv] block sweep plan: tile_rows=%d wlog=%d tiles=%lld sweep=%lld rest_chunks=%zu elements=%zu windows staged=%lld (%.2f X rows per matrix row) cnt_bytes=%zu\n",
+                p.tile_rows, p.wlog, (long long)p.n_tiles, (long long)p.n_sweep_tiles, p.rest_chunks.size(), p.idx.size(), (long long)p.windows_staged,
+                (double)p.windows_staged * (double)((int64_t)1 << p.wlog) / (double)std::max<int64_t>(s->n_chunks * s->C, 1), p.cnt.size());
+    if (!p.valid || p.n_sweep_tiles != p.n_tiles || !p.rest_chunks.empty()) return USPMV_OK;
+    hipError_t e = hipSuccess;
+    auto up = [&](const void *h, size_t bytes, void **d) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(d, bytes ? bytes : 4);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+    };
+    up(p.tile_ids.data(), p.tile_ids.size() * 4, (void **)&A->bw_tile_ids);
+    up(p.t_win_ptr.data(), p.t_win_ptr.size() * 4, (void **)&A->bw_win_ptr);
+    up(p.wins.data(), p.wins.size() * 4, (void **)&A->bw_wins);
+    up(p.t_cnt_off.data(), p.t_cnt_off.size() * 8, (void **)&A->bw_cnt_off);
+    up(p.wave_off.data(), p.wave_off.size() * 4, (void **)&A->bw_wave_off);
+    up(p.cnt.data(), p.cnt.size(), (void **)&A->bw_cnt);
+    up(vsz == 8 ? (const void *)p.vals_f64.data() : (const void *)p.vals_f32.data(), p.idx.size() * vsz, &A->bw_vals);
+    up(p.idx.data(), p.idx.size() * 2, (void **)&A->bw_idx);
+    up(p.pad_col.data(), p.pad_col.size() * 4, (void **)&A->bw_pad);
+    if (e != hipSuccess) { bw_release(A); (void)hipGetLastError(); return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize_block_sweep: %s", hipGetErrorString(e)); }
+    A->bw = true; A->bw_tile_rows = p.tile_rows; A->bw_wlog = p.wlog; A->bw_b = block_vec_size;
+    A->bw_n_tiles = p.n_sweep_tiles; A->bw_all_tiles = p.n_tiles; A->bw_x_rows = p.x_rows_min; A->bw_windows = p.windows_staged;
+    return USPMV_OK;
+}
+
 void uspmv_dmat_free(uspmv_dmat_t *A) {
     if (!A) return;
+    if (A->bw) bw_release(A);
     if (A->sw) sw_release(A);
     if (A->alt) { uspmv_dmat_free(A->alt); A->alt = nullptr; }
     if (A->tlc) tlc_release(A);

@@ -83,6 +83,17 @@ struct uspmv_dmat {
     int64_t pu_n_phases = 0, pu_n_perm = 0;
     int32_t *pu_ph_ptr = nullptr, *pu_g0 = nullptr, *pu_list_ptr = nullptr, *pu_xrows = nullptr, *pu_perm = nullptr;
     uint8_t *pu_col8 = nullptr;
+    // block-vector column-window sweep plan (uspmv_build_block_sweep_plan, csrc/spmmv_sweep.hip): 64-byte X rows, windows of 2^bw_wlog X rows,
+    // per tile the list of windows its rows touch
+    bool bw = false;
+    int bw_tile_rows = 2048, bw_wlog = 9, bw_b = 0;
+    int64_t bw_n_tiles = 0, bw_all_tiles = 0, bw_x_rows = 0, bw_windows = 0;
+    int32_t *bw_tile_ids = nullptr, *bw_win_ptr = nullptr, *bw_wins = nullptr, *bw_pad = nullptr;
+    uint64_t *bw_cnt_off = nullptr;
+    uint32_t *bw_wave_off = nullptr;
+    uint8_t *bw_cnt = nullptr;
+    void *bw_vals = nullptr;
+    uint16_t *bw_idx = nullptr;
     // column-window sweep plan (host/sweep_plan.cpp, uspmv_dmat_optimize_sweep[_ap]); the _b arrays are the sp part of
     // an ap[dp_sp] pair and live on the dp handle, the sp handle only carries the plan id
     bool sw = false;
@@ -213,6 +224,8 @@ template <typename VT>
 int launch_csr(long n_rows, long nnz_hint, const int *rp, const int *ci, const VT *va, const VT *x, VT *y, hipStream_t st);  // spmv_kernels.hip
 template <typename VT>
 int launch_spmmv(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, int layout, hipStream_t st);            // spmmv_kernels.hip
+template <typename VT>
+int launch_spmmv_sweep(const uspmv_dmat *A, const VT *X, VT *Y, int b, long ld, bool xcol, bool ycol, hipStream_t st);   // spmmv_sweep.hip; false-y: USPMV_OK when launched, > 0 when the plan does not apply
 template <typename VT>
 int prepare_x(const uspmv_dmat *A, const VT *X, int b, long ld, hipStream_t st);                                    // spmmv_kernels.hip
 // phased block plan, 64-byte X rows (spmmv_phased.hip); false: no plan / schedule on the handle or it does not fit the compiled shapes

@@ -339,6 +339,7 @@ int uspmv_run_distributed(const DistConfig &c) {
         return uspmv_dist_set_option(D, "fused_step", f == "fused" ? 1 : 0);
     };
     if (P > 1 && comm_halos && b == 1 && !legacy_knobs) {
+        stage("timing the step forms");                       // (the first captured / eager steps run in here)
         if (form == "auto" || form == "auto_all") {
             static const char *names[4] = {"overlap", "plain", "pad", "fused"};
             int best = USPMV_STEP_OVERLAP;

@@ -96,6 +96,28 @@ struct uspmv_sweep_plan {
 int uspmv_build_sweep_plan(const uspmv_scs *s, const uspmv_scs *s2, int wlog, int tile_rows, double max_stage_bytes_per_nnz,
                            uspmv_sweep_plan *plan);   // host/sweep_plan.cpp
 
+// Block-vector column-window sweep plan (host copy; host/sweep_plan.cpp, csrc/spmmv_sweep.hip): like uspmv_sweep_plan, but the windows
+// are windows of X ROWS (2^wlog rows of block_vec_size values each) and a tile lists only the windows its rows TOUCH -- the rows of a
+// 3-D grid matrix reach into three plane-sized index ranges far apart, and staging the gaps between them would cost more than it saves
+struct uspmv_block_sweep_plan {
+    bool valid = false;
+    int tile_rows = 2048, wlog = 9;
+    int64_t n_tiles = 0, n_sweep_tiles = 0, x_rows_min = 0, windows_staged = 0;
+    std::vector<int32_t> tile_ids;       // per sweep tile: tile number
+    std::vector<int32_t> t_win_ptr;      // n_sweep_tiles + 1: the tile's windows in `wins`
+    std::vector<int32_t> wins;           // window ids, ascending per tile
+    std::vector<uint64_t> t_cnt_off;     // per sweep tile: offset of its (windows x tile_rows) count bytes
+    std::vector<uint32_t> wave_off;      // per (sweep tile, wave): first element of the wave's compacted stream
+    std::vector<uint8_t> cnt;            // [tile][window of the tile][row]: entries of the row in the window
+    std::vector<uint16_t> idx;           // X row - first row of the window
+    std::vector<double> vals_f64;
+    std::vector<float> vals_f32;
+    std::vector<int32_t> pad_col;        // per (sweep tile, row): column of the stripped trailing padding, -1 = none
+    std::vector<int32_t> rest_chunks;    // chunks of the tiles that do not sweep
+};
+int uspmv_build_block_sweep_plan(const uspmv_scs *s, int wlog, int tile_rows, int row_bytes, double max_stage_bytes_per_nnz,
+                                 uspmv_block_sweep_plan *plan);   // host/sweep_plan.cpp
+
 // Phased block plan (host copy), see host/tlc_plan.cpp
 struct uspmv_phased_plan {
     bool valid = false;
