@@ -1134,6 +1134,20 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * total_nnz / (ms_per_step * 1e-3) / 1e9
 
+    # ------------------------------------------------------------------ what y's placement alone is worth in THIS process: the same
+    #                                                                    kernel, matrix and x, four more output vectors (fresh allocations, all held)
+    placement = None
+    try:
+        ys = [torch.zeros(s.n_rows_padded, dtype=torch.float64, device=dev) for _ in range(3)]
+        raw = torch.zeros(s.n_rows_padded * 8 + (2 << 20), dtype=torch.uint8, device=dev)
+        ys.append(raw[1 << 20:(1 << 20) + s.n_rows_padded * 8].view(torch.float64))                 # one that starts 1 MiB behind a 2 MiB boundary
+        placement = {"kernel_ms_per_output_vector": [round(B.time_launches(0, 30, A=A, x=x, y=yy), 5) for yy in [y] + ys],
+                     "note": "same kernel, matrix and x; y = the line's own vector, three more fresh allocations, one placed 1 MiB behind a 2 MiB boundary "
+                             "(informational: value / roofline use the first)"}
+        del ys, raw
+    except Exception as e:      # noqa: BLE001 -- an informational extra must not cost the line
+        placement = {"error": f"{type(e).__name__}: {e}"}
+
     achieved = bytes_local / (k_ms * 1e-3) / 1e9
     g_ = args.grid or 253
     stream = stream_rates(B, torch, dev, x_elems=0 if args.mtx else s.n_rows, plane=g_ * g_, line=g_)
@@ -1171,6 +1185,7 @@ def main():
     }
     out["gpu_state"] = {"idle_before_timing": state_idle, "during_the_kernel_timing": state_load,
                         "note": "amdgpu sysfs (pp_dpm_* active levels, hwmon sensors in their native units: microwatts, millidegrees, Hz), read only"}
+    out["y_placement"] = placement
     out["order"] = "set-up, one checked launch, HIP-event timing of the kernel (100 launches), W warm-up steps, K timed steps, stream yardsticks, CPU baseline, other configs"
     if not args.no_cpu_baseline:
         a = s.arrays()
