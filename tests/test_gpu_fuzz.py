@@ -147,6 +147,27 @@ def check_every_setup(pkg, orc, t, rng, m, C, sigma, f64, tag, expect=None):
     lay, A3 = pkg.convert_to_scs_device(m, C, sigma, code)
     assert np.array_equal(lay.arrays()["old_to_new_idx"], a["old_to_new_idx"]), tag
     check_spmv(A3, "device conversion"); A3.optimize_device(); check_spmv(A3, "device conversion + device plan")
+    # ---- the conversion from DEVICE-resident COO arrays: the reference's tie order (every array bit-identical), and the stable device
+    #      ordering (another tie order: compared through y in ORIGINAL row order, which does not depend on it)
+    I_, J_, V_ = m.arrays()
+    if np.all(np.diff(I_) >= 0):
+        dI, dJ, dV = _dev(t, np.array(I_)), _dev(t, np.array(J_)), _dev(t, np.array(V_))
+        lay6, A6, o2n6, n2o6 = pkg.convert_to_scs_device_from_arrays(dI, dJ, dV, n, n_cols, C, sigma, code)
+        d6 = pkg.dmat_download(A6)
+        for k in ("chunk_ptrs", "chunk_lengths", "col_idxs", "values"):
+            assert np.array_equal(d6[k], a[k]), tag + ("conversion from device arrays", k)
+        assert np.array_equal(o2n6.cpu().numpy(), a["old_to_new_idx"]), tag
+        check_spmv(A6, "conversion from device arrays"); A6.optimize_device(); check_spmv(A6, "conversion from device arrays + device plan")
+        if min(sigma, s.n_rows_padded) <= 8192:
+            lay7, A7, o2n7, n2o7 = pkg.convert_to_scs_device_from_arrays(dI, dJ, dV, n, n_cols, C, sigma, code, sort=pkg.SORT_DEVICE_STABLE)
+            assert np.array_equal(lay7.arrays()["chunk_ptrs"], a["chunk_ptrs"]) and np.array_equal(lay7.arrays()["chunk_lengths"], a["chunk_lengths"]), tag
+            x7 = t.zeros(max(ld, n_cols), dtype=tdt, device="cuda"); x7[o2n7.long()] = _dev(t, xo)
+            y7 = t.full((ld,), 3.0, dtype=tdt, device="cuda")
+            A7.optimize_device()
+            pkg.spmv(A7, x7, y7)
+            xs_ = np.zeros(max(ld, n_cols), ndt); xs_[a["old_to_new_idx"]] = xo           # (scatter form: right even where the reference's tie order parks a real row behind n_rows)
+            want7 = orc.spmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xs_)[a["old_to_new_idx"]]
+            assert np.array_equal(y7[o2n7.long()].cpu().numpy(), want7), tag + ("stable device ordering",)
     if 256 % C == 0:
         A4 = pkg.DeviceMatrix(s)
         try:
@@ -167,6 +188,14 @@ def check_every_setup(pkg, orc, t, rng, m, C, sigma, f64, tag, expect=None):
     handles = [("no plan", pkg.DeviceMatrix(s))]
     Ab = pkg.DeviceMatrix(s); Ab.optimize_block(s, b); handles.append(("host block plan", Ab))
     Ad = pkg.DeviceMatrix(s); Ad.optimize_block_device(b); handles.append(("device block plan", Ad))
+    if b * (8 if f64 else 4) == 64 and 64 % C == 0:          # 64-byte X rows: the block-vector window sweep, where every tile qualifies
+        Aw = pkg.DeviceMatrix(s)
+        try:
+            ntw, nsw = Aw.optimize_block_sweep(s, b, wlog=int(rng.choice([9, 10, 11])), tile_rows=int(rng.choice([1024, 2048, 4096])))
+        except pkg.UspmvError:
+            ntw, nsw = 1, 0
+        if ntw == nsw:
+            handles.append(("block window sweep", Aw))
     if expect.get("phased"):
         assert Ab.block_plan_info()["phased_plan"] == 1 and Ad.block_plan_info()["phased_plan"] == 1, tag + (Ab.block_plan_info(), Ad.block_plan_info())
     for lay_code, rowwise in ((pkg.COLWISE, False), (pkg.ROWWISE, True)):
@@ -185,6 +214,13 @@ def check_every_setup(pkg, orc, t, rng, m, C, sigma, f64, tag, expect=None):
             else:
                 for v in range(b):
                     assert np.array_equal(got[v * ld:v * ld + s.n_rows_padded], wantb[v * ld:v * ld + s.n_rows_padded]), tag + (what, "colwise", b, v)
+                # the same X again, re-laid out once (uspmv_spmmv_x_prepared): same bits
+                dXp = _dev(t, X)
+                pkg.spmmv_x_prepared(H, dXp, b, ld)
+                Y2 = t.full((b * ld,), 3.0, dtype=tdt, device="cuda")
+                pkg.spmmv(H, dXp, Y2, b, ld, lay_code)
+                pkg.spmmv_x_release(H)
+                assert t.equal(Y2, Y), tag + (what, "colwise, X prepared", b)
 
     # ---- adaptive precision pair (dp struct sorted on its own, sp struct placed with its permutation): plain, host plan, device plan
     if code == pkg.F64 and n >= C:
