@@ -129,6 +129,20 @@ def _coll_worker(rank, world, q, job, slot):
         got = hc.alltoallv(send, sc, rc)
         want = np.concatenate([np.array([qq * 1000 + rank * 10 + k for k in range(rc[qq])], np.float64) for qq in range(world)] or [np.zeros(0)])
         assert np.array_equal(got, want)
+        # an all-EMPTY all-to-all-v straight before non-empty ones, many times, with one rank running late: a rank that left the empty call
+        # early must not rewrite its offset table under a peer that still reads it (the table phase is closed by a barrier)
+        import time
+        for it in range(40):
+            if rank == it % world:
+                time.sleep(0.002)
+            e = hc.alltoallv(np.zeros(0, np.float64), [0] * world, [0] * world)
+            assert e.size == 0
+            sc2 = [(rank + qq + it) % 3 for qq in range(world)]
+            rc2 = [(qq + rank + it) % 3 for qq in range(world)]
+            send2 = np.concatenate([np.full(sc2[qq], rank * 100 + qq + it, np.float64) for qq in range(world)] or [np.zeros(0)])
+            got2 = hc.alltoallv(send2, sc2, rc2)
+            want2 = np.concatenate([np.full(rc2[qq], qq * 100 + rank + it, np.float64) for qq in range(world)] or [np.zeros(0)])
+            assert np.array_equal(got2, want2), (it, got2, want2)
         assert hc.allreduce_max(float(rank)) == float(world - 1)
         hc.barrier()
         hc.close()

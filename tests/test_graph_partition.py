@@ -91,3 +91,27 @@ def test_partition_file_and_edge_cases(pkg, tmp_path):
     p2 = pkg.graph_partition(mm, 2)
     assert np.bincount(p2).tolist() == [n, n]
     assert np.all(pkg.graph_partition(m, 1) == 0)
+
+
+def test_tiny_graphs_never_lose_a_part_and_malformed_entries_are_refused(pkg):
+    """with n < 2 P the refinement's lower bound n / P - slack was 0 and a vertex could leave a part of size one; entries
+    outside the square indexed the degree array out of bounds."""
+    for n, P in ((5, 4), (7, 4), (3, 3), (9, 8), (2, 2)):
+        I = np.arange(n - 1, dtype=np.int32); J = I + 1
+        rows = np.concatenate([I, J, np.arange(n, dtype=np.int32)]); cols = np.concatenate([J, I, np.arange(n, dtype=np.int32)])
+        order = np.argsort(rows, kind="stable")
+        m = pkg.Coo.from_arrays(n, n, rows[order], cols[order], np.ones(rows.size))
+        part = pkg.graph_partition(m, P)
+        assert part.min() >= 0 and part.max() < P
+        sizes = np.bincount(part, minlength=P)
+        assert sizes.min() >= 1, (n, P, sizes)
+    import ctypes
+    from ultimate_spmv_amd import binding as B
+    # a handle whose arrays were tampered with after creation (uspmv_coo_create itself refuses such entries)
+    m = pkg.Coo.from_arrays(4, 4, [0, 1, 2, 3], [1, 2, 3, 0], [1.0, 1.0, 1.0, 1.0])
+    Ip, Jp, Vp = B._i32p(), B._i32p(), B._f64p()
+    assert B.lib().uspmv_coo_arrays(m.h, ctypes.byref(Ip), ctypes.byref(Jp), ctypes.byref(Vp)) == 0
+    Jp[2] = 9
+    part = np.zeros(4, np.int32)
+    rc = B.lib().uspmv_graph_partition(m.h, 2, part.ctypes.data_as(B._i32p))
+    assert rc != 0 and b"outside" in B.lib().uspmv_last_error()
