@@ -720,8 +720,8 @@ def dist_bench(args, pkg, world, rank, self_launch, tuning):
     """N > 1 (BASELINE config 5): the `uspmv` rank processes do everything on the GPUs; this process only starts them, keeps ONE wall-clock
     budget over the whole run and prints ONE JSON line -- with "value": null and the reason when no tier produced a number in time.
     Order: [strong scaling] the same matrix on one GPU (single-rank child) -> tier 1 graph replay on RCCL -> tier 2 eager steps on RCCL
-    (only when tier 1's communicator came up and carried a collective: a capture gone wrong takes the child down; a communicator that
-    never came up would not come up for eager steps either) -> tier 3 the exchange staged through host memory (no RCCL) -> the other scaling mode when at
+    (only when one eager step of tier 1 completed on every rank: a capture gone wrong takes the child down; an exchange that does not
+    work eagerly would not work in tier 2 either) -> tier 3 the exchange staged through host memory (no RCCL) -> the other scaling mode when at
     least a third of the budget is left.  Every child is a fresh process; nothing that touched a GPU is ever re-used or re-exec'ed."""
     t_start = time.time()
     left = lambda: args.budget_s - (time.time() - t_start)
@@ -741,9 +741,9 @@ def dist_bench(args, pkg, world, rank, self_launch, tuning):
         tmo = max(1.0, min(max(20.0, left() * share), left() - 4.0))     # (never past the budget: 4 s are kept for ending the children)
         rep, why, stages = cli_measure(args, parents, scaling, grid, tmo, **kw)
         ok = bool(min(parents.allgather(0 if (why or (lead and rep is None)) else 1)))
-        # (did the communicator come up and carry a collective?  Then a failure later on -- graph capture inside the step-form timing or the
-        #  timed steps -- is what the eager tier is for; if not, eager steps would meet the same communicator and the tier is skipped)
-        steps_seen = bool(min(parents.allgather(int(any(k in stages for k in ("first collective done", "timing the step forms", "step form chosen", "timed region", "report written"))))))
+        # (did one EAGER step with its exchange complete on every rank?  Then a failure later on -- graph capture inside the step-form timing
+        #  or the timed steps -- is what the eager tier is for; if not, eager steps would fail the same way and the tier is skipped)
+        steps_seen = bool(min(parents.allgather(int(any(k in stages for k in ("first eager step done", "timing the step forms", "step form chosen", "timed region", "report written"))))))
         tiers.append({"tier": name, "scaling": scaling, "ok": ok, "wall_s": round(time.time() - t0, 1), "time_limit_s": round(tmo, 1),
                       **({} if ok else {"why": why or "failed on another rank"})})
         return ok, (rep if ok else None), why or ("" if ok else "failed on another rank"), steps_seen

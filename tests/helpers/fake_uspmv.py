@@ -28,6 +28,7 @@ if mode == "fail" or (mode == "rccl_down" and world > 1 and not host):
     sys.exit(1)
 stage("step object created (communicator up)")
 stage("first collective done")
+stage("first eager step done")
 stage("timing the step forms")
 if mode == "capture_crash" and world > 1 and opt.get("-graph") == "1" and not host:
     os.abort()

@@ -329,6 +329,14 @@ int uspmv_run_distributed(const DistConfig &c) {
         return tot > 0 ? 3 : 0;
     }
 
+    // ---- one EAGER step before anything is captured or timed: whoever has to kill a hung run can tell "the exchange itself does not work"
+    //      (no point in an eager retry) from "the exchange works, its capture / replay does not" (USPMV_STAGES, bench.py's tiers)
+    if (c.mode == 'b' && P > 1 && comm_halos && b == 1) {
+        CK(uspmv_dist_spmv(D, d_x, d_y, comm_halos, st));
+        HK(hipStreamSynchronize(st));
+        stage("first eager step done");
+    }
+
     // ---- the arrangement of the step (-step_form): fixed, or the fastest of the candidates on this machine
     std::string form = c.step_form, form_report;
     const bool legacy_knobs = c.no_overlap || getenv("USPMV_PAD_SPLIT") || getenv("USPMV_FUSED_STEP");
