@@ -203,7 +203,25 @@ public:
         if (optimise) uspmv_detail::check(uspmv_dmat_optimize_device(d.h_, 0, nullptr, nullptr), "uspmv_dmat_optimize_device");
         return d;
     }
+    // the same from COO arrays that already live in HBM (d_I, d_J: int; d_V: double; entries sorted by row): nothing but O(n_rows)
+    // integers leaves the device.  stable_ties = false: the reference's std::sort tie order (every array as convert_to_scs gives it);
+    // true: rows of equal length keep their original order (ordering on the device; y in original row order is the same either way).
+    // d_perm / d_inv_perm (device, n_rows ints each, may be null) receive old_to_new_idx / new_to_old_idx.
+    static DeviceScs from_device_coo(const int *d_I, const int *d_J, const double *d_V, ST n_rows, ST n_cols, ST nnz, ST C, ST sigma,
+                                     bool single_precision, int *d_perm, int *d_inv_perm, bool stable_ties = false, bool optimise = true,
+                                     void *stream = nullptr) {
+        DeviceScs d;
+        uspmv_detail::check(uspmv_convert_to_scs_device_from_arrays(d_I, d_J, d_V, n_rows, n_cols, nnz, C, sigma, single_precision ? USPMV_F32 : USPMV_F64,
+                                                                    nullptr, 1, stable_ties ? USPMV_SORT_DEVICE_STABLE : USPMV_SORT_HOST, stream, nullptr,
+                                                                    d_perm, d_inv_perm, &d.h_), "uspmv_convert_to_scs_device_from_arrays");
+        d.n_rows_padded_ = ((n_rows + C - 1) / C) * C;
+        if (optimise) uspmv_detail::check(uspmv_dmat_optimize_device(d.h_, 0, nullptr, nullptr), "uspmv_dmat_optimize_device");
+        return d;
+    }
     void spmv(const void *d_x, void *d_y, void *stream = nullptr) const { uspmv_detail::check(uspmv_spmv(h_, d_x, d_y, stream), "uspmv_spmv"); }
+    // a column-major X that does not change between calls (a bench loop): re-laid out once, until x_released() or another X
+    void x_prepared(const void *d_X, int b, ST ld, void *stream = nullptr) const { uspmv_detail::check(uspmv_spmmv_x_prepared(h_, d_X, b, ld, stream), "uspmv_spmmv_x_prepared"); }
+    void x_released() const { uspmv_detail::check(uspmv_spmmv_x_release(h_), "uspmv_spmmv_x_release"); }
     void spmmv(const void *d_X, void *d_Y, int b, ST ld, bool rowwise, void *stream = nullptr) const {
         uspmv_detail::check(uspmv_spmmv(h_, d_X, d_Y, b, ld, rowwise ? USPMV_ROWWISE : USPMV_COLWISE, stream), "uspmv_spmmv");
     }

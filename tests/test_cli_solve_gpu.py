@@ -57,3 +57,30 @@ def test_solve_mode_grid_against_reference_goldens(pkg, tmp_path):
             assert np.all(np.abs(got - want) <= tol * np.abs(want).max()), (name, dt, rx)
             n_tol += 1
     assert seen_sigma == set(SIGMAS) and n_exact >= 120 and n_tol == 12
+
+
+def test_solve_mode_with_the_conversion_on_the_device(pkg, tmp_path):
+    """-convert device | device_stable: convert_to_scs + permute_scs_cols run on the device from the COO arrays in HBM
+    (uspmv_convert_to_scs_device_from_arrays), the plan is built there too.  Same goldens, bit for bit -- the stable tie order changes the
+    permuted numbering, not y in original row order; bench mode and block vectors run as well."""
+    g = golden("solve.npz")
+    n = 0
+    for name, fmt, C, sg, dt, rx in _cases():
+        if fmt != "scs" or (C, sg) not in ((32, 64), (16, 32), (4, 3), (64, 2), (8, 8), (10, 10), (32, 16), (64, 64), (16, 4), (4, 1)):
+            continue
+        for conv in ("device", "device_stable"):
+            yf = str(tmp_path / "y.bin")
+            args = [EXE, mtx_path(name), fmt, "-c", str(C), "-s", str(sg), "-mode", "s", "-rev", "3", "-rand_x", str(rx), "-dp" if dt == "f64" else "-sp",
+                    "-validate", "0", "-dump_y", yf, "-convert", conv]
+            r = subprocess.run(args, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0 and "convert_to_scs on the device" in r.stdout, (args, r.stdout, r.stderr)
+            want = g[f"{name}_{fmt}_C{C}_s{sg}_{dt}_r{rx}"]
+            assert np.array_equal(np.fromfile(yf, want.dtype), want), (name, C, sg, dt, rx, conv)
+            n += 1
+    assert n >= 12
+    for extra in ([], ["-block_vec_size", "4"], ["-sp", "-block_vec_size", "8"]):
+        r = subprocess.run([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-mode", "b", "-bench_time", "0.05", "-convert", "device_stable"] + extra,
+                           cwd=tmp_path, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "Total Gflops" in r.stdout, (extra, r.stdout, r.stderr)
+    r = subprocess.run([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-ap[dp_sp]", "-ap_threshold_1", "1", "-convert", "device"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "one-precision" in (r.stdout + r.stderr)

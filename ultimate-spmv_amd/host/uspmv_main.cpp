@@ -55,6 +55,7 @@ struct Config {  // subset of the reference's Config (code/classes_structs.hpp:4
     std::string step_form = "auto";
     int bench_steps = 0, bench_warmup = -1, check_y = 0;   // multi-rank: -bench_steps K / -bench_warmup W (fixed-count protocol), -check_y 1
     std::string json;                                       // -json <file|->
+    std::string convert = "host";                           // -convert host|device|device_stable: where convert_to_scs runs (device: from the COO arrays in HBM)
     int x_prepared = 1;                                     // -x_prepared 0|1: bench mode, column-major block vectors: re-lay X out once (1) or per call (0)
     std::string part_file;                                  // -seg_metis: part ids from this file (one per row, gpmetis format) instead of the built-in partitioner
 };
@@ -80,6 +81,7 @@ void usage() {
             "  -dropout_threshold <float> -block_vec_layout <colwise|rowwise> -tlc <0|1> -graph <0|1> -dump_y <file>\n"
             "  -mpi_mode <singlevec|multivec|bulkvec>\n"
             "  -bench_steps <int> -bench_warmup <int> -json <file|-> (fixed-count protocol, JSON report)  -x_prepared <0|1> (bench mode, column-major block vectors: X re-laid out once)\n"
+            "  -convert <host|device|device_stable> (where convert_to_scs runs; device_stable: ties of the sigma sort in original order)\n"
             "  multi-rank runs: -check_y <0|1> -step_form <auto|auto_all|overlap|plain|pad|fused>\n"
             "  -seg_metis [-part_file <file>]: graph partition (built-in level-set partitioner, or part ids from a gpmetis-style file)\n");
 }
@@ -128,6 +130,7 @@ Config parse(int argc, char **argv) {
         else if (a == "-check_y") c.check_y = atoi(need(i));
         else if (a == "-json") c.json = need(i);
         else if (a == "-x_prepared") c.x_prepared = atoi(need(i));
+        else if (a == "-convert") { c.convert = need(i); if (c.convert != "host" && c.convert != "device" && c.convert != "device_stable") die("convert must be host, device or device_stable."); }
         else if (a == "-step_form") { c.step_form = need(i); if (c.step_form != "auto" && c.step_form != "auto_all" && c.step_form != "overlap" && c.step_form != "plain" && c.step_form != "pad" && c.step_form != "fused") die("step_form must be auto, auto_all, overlap, plain, pad or fused."); }
         else if (a == "-block_vec_layout") { std::string v = need(i); if (v == "colwise") c.layout = USPMV_COLWISE; else if (v == "rowwise") c.layout = USPMV_ROWWISE; else die("block_vec_layout must be colwise or rowwise."); }
         else { usage(); die("unknown argument: " + a); }
@@ -137,6 +140,8 @@ Config parse(int argc, char **argv) {
         die("Row-wise block vector layout selected, but block vector width is 1.\n Please choose colwise block vector layout if using SpMV.");
     bool ap = c.value_type.rfind("ap[", 0) == 0;
     if (c.block_vec_size > 1 && ap) die("SpMMV is not yet implemented for AP kernels.");
+    if (c.convert != "host" && ap) die("-convert device needs a one-precision run (-dp or -sp).");
+    if (c.convert != "host" && uspmv_dist_requested()) die("-convert device is a single-rank option (every rank of a multi-rank run converts its block on the host).");
     if (c.seg_method == "seg-metis" && !uspmv_dist_requested()) die("seg-metis selected, but this is a single-rank run (the partition only matters across ranks).");
     if (c.seg_method == "seg-metis" && c.matrix_file_name.rfind("gen:", 0) == 0) die("seg-metis needs the whole matrix on rank 0: use a .mtx file (generated matrices are built per rank).");
     if (c.value_type == "hp" || c.value_type == "ap[sp_hp]" || c.value_type == "ap[dp_hp]" || c.value_type == "ap[dp_sp_hp]")
@@ -217,6 +222,7 @@ int run(const Config &c, uspmv_coo_t *coo) {
 
     // ---- format conversion (init_local_structs, code/main.cpp:1128-1221, :1308)
     uspmv_scs_t *scs = nullptr, *scs_sp = nullptr;
+    uspmv_dmat_t *device_A = nullptr;          // -convert device*: the handle the device-side conversion made
     uspmv_coo_t *coo_dp = nullptr, *coo_sp = nullptr;
     int64_t meta[8], meta_sp[8] = {0};
     const int32_t *o2n, *n2o;
@@ -230,6 +236,22 @@ int run(const Config &c, uspmv_coo_t *coo) {
         ck(uspmv_permute_scs_cols(scs, o2n), "uspmv_permute_scs_cols");
         ck(uspmv_permute_scs_cols(scs_sp, o2n), "uspmv_permute_scs_cols");
         ck(uspmv_scs_meta(scs_sp, meta_sp), "uspmv_scs_meta");
+    } else if (c.convert != "host") {
+        // -convert device | device_stable: the COO arrays go to HBM once and convert_to_scs + permute_scs_cols run there
+        // (uspmv_convert_to_scs_device_from_arrays; device: the reference's std::sort tie order, computed on the host from the row counts;
+        // device_stable: ties in original order, nothing but the layout comes back).  `scs` is then a struct WITHOUT entries.
+        const int32_t *ci_ = nullptr, *cj_ = nullptr;
+        ck(uspmv_coo_arrays(coo, &ci_, &cj_, nullptr), "uspmv_coo_arrays");
+        int32_t *dI = dev_alloc<int32_t>((size_t)nnz), *dJ = dev_alloc<int32_t>((size_t)nnz);
+        double *dV = dev_alloc<double>((size_t)nnz);
+        hk(hipMemcpy(dI, ci_, 4 * (size_t)nnz, hipMemcpyHostToDevice), "hipMemcpy I");
+        hk(hipMemcpy(dJ, cj_, 4 * (size_t)nnz, hipMemcpyHostToDevice), "hipMemcpy J");
+        hk(hipMemcpy(dV, vals, 8 * (size_t)nnz, hipMemcpyHostToDevice), "hipMemcpy V");
+        ck(uspmv_convert_to_scs_device_from_arrays(dI, dJ, dV, n_rows, n_cols, nnz, c.chunk_size, c.sigma, dtype, nullptr, 1,
+                                                   c.convert == "device_stable" ? USPMV_SORT_DEVICE_STABLE : USPMV_SORT_HOST, nullptr, &scs, nullptr, nullptr, &device_A),
+           "uspmv_convert_to_scs_device_from_arrays");
+        (void)hipFree(dI); (void)hipFree(dJ); (void)hipFree(dV);
+        ck(uspmv_scs_arrays(scs, nullptr, nullptr, nullptr, nullptr, &o2n, &n2o), "uspmv_scs_arrays");
     } else {
         ck(uspmv_convert_to_scs(coo, c.chunk_size, c.sigma, dtype, nullptr, &scs), "uspmv_convert_to_scs");
         ck(uspmv_scs_arrays(scs, nullptr, nullptr, nullptr, nullptr, &o2n, &n2o), "uspmv_scs_arrays");
@@ -262,17 +284,20 @@ int run(const Config &c, uspmv_coo_t *coo) {
     }
     Run r;
     r.b = b; r.ld = ld; r.layout = c.layout; r.ap = ap;
-    ck(uspmv_dmat_upload(scs, &r.A), "uspmv_dmat_upload");
+    if (device_A) { r.A = device_A; printf("convert_to_scs on the device from the COO arrays in HBM (%s)\n", c.convert == "device_stable" ? "stable tie order" : "the reference's tie order"); }
+    else ck(uspmv_dmat_upload(scs, &r.A), "uspmv_dmat_upload");
     if (ap) ck(uspmv_dmat_upload(scs_sp, &r.A_sp), "uspmv_dmat_upload");
     if (c.kernel_format != "scs") ck(uspmv_dmat_set_crs(r.A, 1), "uspmv_dmat_set_crs");
     if (c.tlc && (b == 1 || (!ap && c.chunk_size < 32 && 32 % c.chunk_size == 0))) {   // b > 1: for the internal C = 32 re-chunking of narrow chunks / crs
         int64_t nt = 0, ns = 0;
         if (ap) ck(uspmv_dmat_optimize_ap(r.A, r.A_sp, scs, scs_sp, 0, &nt, &ns), "uspmv_dmat_optimize_ap");
+        else if (device_A) ck(uspmv_dmat_optimize_device(r.A, 0, &nt, &ns), "uspmv_dmat_optimize_device");   // (no host entries: the plan is built on the device too)
         else ck(uspmv_dmat_optimize(r.A, scs, 0, &nt, &ns), "uspmv_dmat_optimize");
         printf("tile-local-column plan: %ld of %ld tiles staged in LDS\n", (long)ns, (long)nt);
     } else if (c.tlc && b > 1 && !ap && (size_t)b * sizeof(VT) <= 32) {   // block plan pays for rows of <= 32 bytes
         int64_t nt = 0, ns = 0;
-        ck(uspmv_dmat_optimize_block(r.A, scs, b, &nt, &ns), "uspmv_dmat_optimize_block");
+        if (device_A) ck(uspmv_dmat_optimize_block_device(r.A, b, &nt, &ns), "uspmv_dmat_optimize_block_device");
+        else ck(uspmv_dmat_optimize_block(r.A, scs, b, &nt, &ns), "uspmv_dmat_optimize_block");
         if (nt) printf("block plan: %ld of %ld tiles staged in LDS\n", (long)ns, (long)nt);
     }
     r.x = dev_alloc<VT>((size_t)b * ld);
