@@ -37,16 +37,37 @@ def _cases():
     return sorted(set(out))
 
 
+def _harness_runs(tmp_path, jobs, workers=4):
+    """jobs: [(key, args without the -dump_y file)] -> {key: (CompletedProcess, y file)}; `workers` harness processes at a time (each is a
+    process of its own on the GPU: start-up dominates its cost; the pool stays below the box's limit of concurrent GPU processes)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(job):
+        k, (key, args) = job
+        d = tmp_path / f"run{k}"
+        d.mkdir()
+        yf = str(d / "y.bin")
+        env = dict(os.environ, OMP_NUM_THREADS="2", OMP_WAIT_POLICY="passive")       # (tiny matrices: keep the pool from oversubscribing the cores)
+        return key, (subprocess.run(args + ["-dump_y", yf], cwd=d, env=env, capture_output=True, text=True, timeout=180), yf)
+
+    with ThreadPoolExecutor(workers) as ex:
+        return dict(ex.map(one, enumerate(jobs)))
+
+
 def test_solve_mode_grid_against_reference_goldens(pkg, tmp_path):
     g = golden("solve.npz")
     seen_sigma = set()
     n_exact = n_tol = 0
-    for name, fmt, C, sg, dt, rx in _cases():
-        yf = str(tmp_path / "y.bin")
-        args = [EXE, mtx_path(name), fmt] + (["-c", str(C), "-s", str(sg)] if fmt == "scs" else []) + \
-               ["-mode", "s", "-rev", "3", "-rand_x", str(rx), "-dp" if dt == "f64" else "-sp", "-validate", "0", "-dump_y", yf]
-        r = subprocess.run(args, cwd=tmp_path, capture_output=True, text=True, timeout=120)
-        assert r.returncode == 0 and "3 revision(s) done" in r.stdout, (args, r.stdout, r.stderr)
+    jobs = []
+    for case in _cases():
+        name, fmt, C, sg, dt, rx = case
+        jobs.append((case, [EXE, mtx_path(name), fmt] + (["-c", str(C), "-s", str(sg)] if fmt == "scs" else []) +
+                     ["-mode", "s", "-rev", "3", "-rand_x", str(rx), "-dp" if dt == "f64" else "-sp", "-validate", "0"]))
+    done = _harness_runs(tmp_path, jobs)
+    for case in _cases():
+        name, fmt, C, sg, dt, rx = case
+        r, yf = done[case]
+        assert r.returncode == 0 and "3 revision(s) done" in r.stdout, (case, r.stdout, r.stderr)
         want = g[f"{name}_{fmt}_C{C}_s{sg}_{dt}_r{rx}"]
         got = np.fromfile(yf, want.dtype)
         if fmt == "scs":
@@ -64,20 +85,19 @@ def test_solve_mode_with_the_conversion_on_the_device(pkg, tmp_path):
     (uspmv_convert_to_scs_device_from_arrays), the plan is built there too.  Same goldens, bit for bit -- the stable tie order changes the
     permuted numbering, not y in original row order; bench mode and block vectors run as well."""
     g = golden("solve.npz")
-    n = 0
+    jobs = []
     for name, fmt, C, sg, dt, rx in _cases():
         if fmt != "scs" or (C, sg) not in ((32, 64), (16, 32), (4, 3), (64, 2), (8, 8), (10, 10), (32, 16), (64, 64), (16, 4), (4, 1)):
             continue
         for conv in ("device", "device_stable"):
-            yf = str(tmp_path / "y.bin")
-            args = [EXE, mtx_path(name), fmt, "-c", str(C), "-s", str(sg), "-mode", "s", "-rev", "3", "-rand_x", str(rx), "-dp" if dt == "f64" else "-sp",
-                    "-validate", "0", "-dump_y", yf, "-convert", conv]
-            r = subprocess.run(args, cwd=tmp_path, capture_output=True, text=True, timeout=120)
-            assert r.returncode == 0 and "convert_to_scs on the device" in r.stdout, (args, r.stdout, r.stderr)
-            want = g[f"{name}_{fmt}_C{C}_s{sg}_{dt}_r{rx}"]
-            assert np.array_equal(np.fromfile(yf, want.dtype), want), (name, C, sg, dt, rx, conv)
-            n += 1
-    assert n >= 12
+            jobs.append(((name, fmt, C, sg, dt, rx, conv), [EXE, mtx_path(name), fmt, "-c", str(C), "-s", str(sg), "-mode", "s", "-rev", "3", "-rand_x", str(rx),
+                                                            "-dp" if dt == "f64" else "-sp", "-validate", "0", "-convert", conv]))
+    assert len(jobs) >= 12
+    for key, (r, yf) in _harness_runs(tmp_path, jobs).items():
+        name, fmt, C, sg, dt, rx, conv = key
+        assert r.returncode == 0 and "convert_to_scs on the device" in r.stdout, (key, r.stdout, r.stderr)
+        want = g[f"{name}_{fmt}_C{C}_s{sg}_{dt}_r{rx}"]
+        assert np.array_equal(np.fromfile(yf, want.dtype), want), key
     for extra in ([], ["-block_vec_size", "4"], ["-sp", "-block_vec_size", "8"]):
         r = subprocess.run([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-mode", "b", "-bench_time", "0.05", "-convert", "device_stable"] + extra,
                            cwd=tmp_path, capture_output=True, text=True, timeout=120)

@@ -301,7 +301,7 @@ def test_cli_distributed_loopback_dumps_the_right_y(pkg, orc, tmp_path):
     for rank in range(P):
         pre = str(tmp_path / f"y{rank}")
         env = dict(os.environ, USPMV_LOOPBACK=str(P), USPMV_LOOPBACK_RANK=str(rank), USPMV_DIST_X="ramp", USPMV_DUMP_Y=pre,
-                   USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID=f"t{rank}")
+                   USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID=f"t{rank}", OMP_NUM_THREADS=os.environ.get("USPMV_TEST_OMP", "4"), OMP_WAIT_POLICY="passive")
         env.pop("WORLD_SIZE", None); env.pop("RANK", None)
         r = subprocess.run([EXE, "gen:24x24x24", "scs", "-c", "32", "-s", "512", "-seg_rows", "-comm_halos", "1", "-bench_time", "0.05",
                             "-print_comm_vol", "1"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
@@ -313,7 +313,7 @@ def test_cli_distributed_loopback_dumps_the_right_y(pkg, orc, tmp_path):
     assert "with 2 RCCL ranks" in txt and "seg_method: seg-rows" in txt and "Per rank Elems Recvd" in txt
     # block vectors through the harness: -block_vec_size 2 -mpi_mode multivec, vector v = ramp * (1 + v/8)
     pre = str(tmp_path / "Y")
-    env = dict(os.environ, USPMV_LOOPBACK="2", USPMV_LOOPBACK_RANK="1", USPMV_DIST_X="ramp", USPMV_DUMP_Y=pre, USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID="tb")
+    env = dict(os.environ, USPMV_LOOPBACK="2", USPMV_LOOPBACK_RANK="1", USPMV_DIST_X="ramp", USPMV_DUMP_Y=pre, USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID="tb", OMP_NUM_THREADS=os.environ.get("USPMV_TEST_OMP", "4"), OMP_WAIT_POLICY="passive")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
     r = subprocess.run([EXE, "gen:24x24x24", "scs", "-c", "32", "-s", "512", "-seg_rows", "-comm_halos", "1", "-bench_time", "0.05", "-block_vec_size", "2",
                         "-mpi_mode", "multivec"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
@@ -350,6 +350,7 @@ from conftest import GOLDEN, mtx_path
 def _hx_worker(rank, world, q, job, case):
     try:
         sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ.setdefault("OMP_NUM_THREADS", "4"); os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # (several rank processes share the box's cores)
         import torch
         import __graft_entry__ as ge
         pkg = ge.load_package()
@@ -437,6 +438,7 @@ def test_native_step_real_ranks_unequal_seg_nnz_blocks(pkg, case, world):
 def _fuzz_worker(rank, world, q, job, n_cases, seed0):
     try:
         sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ.setdefault("OMP_NUM_THREADS", "4"); os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # (several rank processes share the box's cores)
         import torch
         import __graft_entry__ as ge
         pkg = ge.load_package()
@@ -606,7 +608,7 @@ def test_cli_real_ranks_host_exchange_mtx_scatter_and_check(pkg, tmp_path):
     procs = []
     for rank in range(4):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="4", LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
-                   USPMV_JOB_ID=f"c{os.getpid()}", USPMV_HC_TIMEOUT="120")
+                   USPMV_JOB_ID=f"c{os.getpid()}", USPMV_HC_TIMEOUT="120", OMP_NUM_THREADS=os.environ.get("USPMV_TEST_OMP", "4"), OMP_WAIT_POLICY="passive")
         env.pop("USPMV_LOOPBACK", None)
         procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-seg_nnz", "-comm_halos", "1", "-bench_steps", "5",
                                        "-bench_warmup", "2", "-check_y", "1", "-json", js, "-print_comm_vol", "1"], cwd=tmp_path, env=env,
@@ -687,7 +689,7 @@ def test_cli_solve_mode_and_crs_across_real_ranks(pkg, orc, tmp_path):
             procs = []
             for rank in range(P):
                 env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(P), LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
-                           USPMV_JOB_ID=f"s{os.getpid()}{fmt[0]}{prec}", USPMV_HC_TIMEOUT="120", USPMV_DIST_X="ramp")
+                           USPMV_JOB_ID=f"s{os.getpid()}{fmt[0]}{prec}", USPMV_HC_TIMEOUT="120", USPMV_DIST_X="ramp", OMP_NUM_THREADS=os.environ.get("USPMV_TEST_OMP", "4"), OMP_WAIT_POLICY="passive")
                 env.pop("USPMV_LOOPBACK", None)
                 procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13")] + fmt + [prec, "-mode", "s", "-rev", "3", "-seg_nnz", "-comm_halos", "1", "-check_y", "1",
                                                "-dump_y", pre], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -702,7 +704,7 @@ def test_cli_solve_mode_and_crs_across_real_ranks(pkg, orc, tmp_path):
     procs = []
     for rank in range(P):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(P), LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
-                   USPMV_JOB_ID=f"b{os.getpid()}", USPMV_HC_TIMEOUT="120")
+                   USPMV_JOB_ID=f"b{os.getpid()}", USPMV_HC_TIMEOUT="120", OMP_NUM_THREADS=os.environ.get("USPMV_TEST_OMP", "4"), OMP_WAIT_POLICY="passive")
         env.pop("USPMV_LOOPBACK", None)
         procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-sp", "-seg_nnz", "-comm_halos", "1", "-bench_steps", "5",
                                        "-bench_warmup", "2", "-check_y", "1"], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -737,7 +739,7 @@ def test_cli_rand_x_across_real_ranks(pkg, orc, tmp_path):
         procs = []
         for rank in range(P):
             env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(P), LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
-                       USPMV_JOB_ID=f"x{os.getpid()}{rx}", USPMV_HC_TIMEOUT="120")
+                       USPMV_JOB_ID=f"x{os.getpid()}{rx}", USPMV_HC_TIMEOUT="120", OMP_NUM_THREADS=os.environ.get("USPMV_TEST_OMP", "4"), OMP_WAIT_POLICY="passive")
             env.pop("USPMV_LOOPBACK", None); env.pop("USPMV_DIST_X", None)
             procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-mode", "s", "-rev", "1", "-rand_x", rx, "-seg_nnz",
                                            "-comm_halos", "1", "-dump_y", pre], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -775,7 +777,7 @@ def test_cli_equilibrate_across_real_ranks(pkg, orc, tmp_path):
     procs = []
     for rank in range(P):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(P), LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
-                   USPMV_JOB_ID=f"e{os.getpid()}", USPMV_HC_TIMEOUT="120", USPMV_DIST_X="ramp")
+                   USPMV_JOB_ID=f"e{os.getpid()}", USPMV_HC_TIMEOUT="120", USPMV_DIST_X="ramp", OMP_NUM_THREADS=os.environ.get("USPMV_TEST_OMP", "4"), OMP_WAIT_POLICY="passive")
         env.pop("USPMV_LOOPBACK", None)
         procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-mode", "s", "-rev", "1", "-equilibrate", "1", "-seg_nnz",
                                        "-comm_halos", "1", "-check_y", "1", "-dump_y", pre], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -791,7 +793,7 @@ def test_cli_equilibrate_across_real_ranks(pkg, orc, tmp_path):
 def test_cli_loopback_graph_replay_with_ba_synch_and_check(pkg, tmp_path):
     """the captured step now also carries the per-step barrier (-ba_synch 1, the reference's default) and the self-check runs
     through the replayed graph"""
-    env = dict(os.environ, USPMV_LOOPBACK="2", USPMV_LOOPBACK_RANK="1", USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID=f"g{os.getpid()}")
+    env = dict(os.environ, USPMV_LOOPBACK="2", USPMV_LOOPBACK_RANK="1", USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID=f"g{os.getpid()}", OMP_NUM_THREADS=os.environ.get("USPMV_TEST_OMP", "4"), OMP_WAIT_POLICY="passive")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
     for ba in ("1", "0"):
         r = subprocess.run([EXE, "gen:24x24x24", "scs", "-c", "32", "-s", "512", "-seg_rows", "-comm_halos", "1", "-bench_time", "0.05", "-ba_synch", ba,
@@ -809,7 +811,7 @@ def test_cli_step_forms_all_check_and_auto_picks_one(pkg, tmp_path):
     (graph replay: without the one-launch form)."""
     import json
     import subprocess
-    env = dict(os.environ, USPMV_LOOPBACK="4", USPMV_LOOPBACK_RANK="2", USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID="sf")
+    env = dict(os.environ, USPMV_LOOPBACK="4", USPMV_LOOPBACK_RANK="2", USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID="sf", OMP_NUM_THREADS=os.environ.get("USPMV_TEST_OMP", "4"), OMP_WAIT_POLICY="passive")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
     base = [EXE, "gen:32x32x64", "scs", "-c", "32", "-s", "512", "-seg_rows", "-comm_halos", "1", "-bench_steps", "20", "-bench_warmup", "3", "-check_y", "1"]
     for form, graph in (("overlap", 1), ("plain", 1), ("pad", 1), ("pad", 0), ("fused", 0)):
@@ -848,7 +850,7 @@ def test_cli_seg_metis_real_ranks(pkg, tmp_path):
         procs = []
         for rank in range(3):
             env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path),
-                       USPMV_JOB_ID=f"m{os.getpid()}_{len(extra)}", USPMV_HC_TIMEOUT="120")
+                       USPMV_JOB_ID=f"m{os.getpid()}_{len(extra)}", USPMV_HC_TIMEOUT="120", OMP_NUM_THREADS=os.environ.get("USPMV_TEST_OMP", "4"), OMP_WAIT_POLICY="passive")
             env.pop("USPMV_LOOPBACK", None)
             procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-seg_metis", "-comm_halos", "1", "-bench_steps", "3",
                                            "-bench_warmup", "1", "-check_y", "1", "-json", js] + extra, cwd=tmp_path, env=env,
@@ -868,7 +870,7 @@ def test_cli_seg_metis_real_ranks(pkg, tmp_path):
     procs = []
     for rank in range(3):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK="0", USPMV_EXCHANGE="host", USPMV_ID_DIR=str(tmp_path), USPMV_JOB_ID=f"mp{os.getpid()}",
-                   USPMV_HC_TIMEOUT="120", USPMV_DIST_X="ramp", USPMV_DUMP_Y=str(tmp_path / "ymetis"))
+                   USPMV_HC_TIMEOUT="120", USPMV_DIST_X="ramp", USPMV_DUMP_Y=str(tmp_path / "ymetis"), OMP_NUM_THREADS=os.environ.get("USPMV_TEST_OMP", "4"), OMP_WAIT_POLICY="passive")
         env.pop("USPMV_LOOPBACK", None)
         procs.append(subprocess.Popen([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-seg_metis", "-comm_halos", "1", "-bench_steps", "1", "-bench_warmup", "0"],
                                       cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
