@@ -33,6 +33,24 @@ def _cycle_handles(pkg, t, m):
     lay, Ad = pkg.convert_to_scs_device(m, 32, 512, pkg.F64)
     Ad.optimize_device(); pkg.spmv(Ad, x, y)
     del Ad, lay
+    # round 4: conversion from device arrays (both orderings), block-vector window sweep, prepared X
+    I_, J_, V_ = m.arrays()
+    dI, dJ, dV = (t.from_numpy(np.array(v)).cuda() for v in (I_, J_, V_))
+    for mode in (pkg.SORT_HOST, pkg.SORT_DEVICE_STABLE):
+        lay2, A2, o2n, n2o = pkg.convert_to_scs_device_from_arrays(dI, dJ, dV, m.n_rows, m.n_cols, 32, 512, pkg.F64, sort=mode, want_layout=mode == pkg.SORT_HOST)
+        A2.optimize_device(); pkg.spmv(A2, x, y)
+        del A2, lay2, o2n, n2o
+    del dI, dJ, dV
+    X = t.ones(8 * s.n_rows_padded, dtype=t.float64, device="cuda"); Y = t.zeros_like(X)
+    Aw = pkg.DeviceMatrix(s)
+    Aw.optimize_block_sweep(s, 8, wlog=9, tile_rows=1024)
+    Ab = pkg.DeviceMatrix(s); Ab.optimize_block(s, 8)
+    for A in (Aw, Ab):
+        pkg.spmmv_x_prepared(A, X, 8, s.n_rows_padded)
+        for lay_ in (pkg.COLWISE, pkg.ROWWISE):
+            pkg.spmmv(A, X, Y, 8, s.n_rows_padded, lay_)
+        pkg.spmmv_x_release(A)
+    del Aw, Ab, A, X, Y
     dp, sp = pkg.partition_precisions(m, 1e-1)
     ds = pkg.convert_to_scs(dp, 32, 512, pkg.F64)
     perm = ds.arrays()["old_to_new_idx"].copy()
