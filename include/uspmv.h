@@ -218,6 +218,8 @@ int uspmv_dmat_plan_info(const uspmv_dmat_t *m, int *kind, int64_t *n_tiles, int
  * block vectors staged by 128-byte lines, no re-layout pass), tiles, phases of the phased plan, phases of the line plan, X rows the
  * line plan stages, one-byte indices, index part built on the device, most X rows of a phase */
 int uspmv_dmat_block_plan_info(const uspmv_dmat_t *m, int64_t meta[10]);
+/* X rows the phased block plan stages per product (sum of its phases' lists; 0 without such a plan) */
+int uspmv_dmat_block_plan_staged(const uspmv_dmat_t *m, int64_t *rows_staged);
 /* FNV-1a digests of the phased block plan's device arrays: phase pointers, first groups, list pointers, X-row lists, index offsets,
  * local indices, the group-major values, the row map (tests: a plan built on the device equals the host planner's) */
 int uspmv_dmat_block_plan_digest(const uspmv_dmat_t *m, uint64_t digest[8]);

@@ -549,9 +549,9 @@ def test_spmmv_block_plan_bitexact(pkg, orc, torch_cuda):
                         Y.fill_(-3.0)
                         pkg.spmmv(A16, _dev(t, X), Y, b, ld, lay)
                         assert t.equal(Y, Y0), (name, C, code, b, rowwise, "idx16")
-                        pkg.set_tuning(spmmv_reorder=2)                  # ... and over clustered rows (breadth-first balls per tile)
+                        pkg.set_tuning(spmmv_reorder=2)                  # ... and over clustered rows (balls over all slots instead of the default's flat patches)
                         Acl = pkg.DeviceMatrix(s, block_tlc=b)
-                        pkg.set_tuning(spmmv_reorder=1)
+                        pkg.set_tuning(spmmv_reorder=4)
                         for var in (8, 6, 4):
                             pkg.set_tuning(spmmv_variant=var)
                             Y.fill_(-3.0)
@@ -965,8 +965,11 @@ def test_spmmv_line_plan_column_major_without_relayout(pkg, orc, torch_cuda):
 def test_device_block_plan_builder_equals_host_planner(pkg, orc, torch_cuda):
     """uspmv_dmat_optimize_block_device with the plan built entirely on the device (csrc/block_plan_kernels.hip: row order, phases, X-row
     lists, one-byte indices, group-major values) against the same entry point planning the index part on the host ("block_plan_device" 0):
-    every plan array bit for bit (digests of the device arrays), and Y against the oracle, both layouts."""
+    every plan array bit for bit (digests of the device arrays), and Y against the oracle, both layouts.  The device builder undoes the
+    ties and fills every phase to the brim, so the host planner is asked for the same ("spmmv_reorder" 1, "spmmv_phase_dp" 0; its own
+    defaults -- flat row patches, cuts by dynamic programming -- are checked in test_block_plan_row_patches_and_dp_cuts)."""
     t = torch_cuda
+    pkg.set_tuning(spmmv_reorder=1, spmmv_phase_dp=0)
     cases = [(pkg.gen_stencil27(20, 18, 16, dof=3), 32, 512, pkg.F64, 8), (pkg.gen_stencil27(20, 18, 16, dof=3), 32, 1, pkg.F64, 8),
              (pkg.gen_stencil27(16, 15, 14, dof=2), 64, 64, pkg.F64, 8), (pkg.gen_stencil27(14, 13, 12, dof=3), 32, 512, pkg.F32, 16),
              (pkg.read_mtx(mtx_path("bcsstk13")), 32, 512, pkg.F64, 8), (pkg.read_mtx(mtx_path("impcol_e")), 64, 64, pkg.F32, 16),
@@ -993,7 +996,47 @@ def test_device_block_plan_builder_equals_host_planner(pkg, orc, torch_cuda):
             assert digests[0][1] == digests[1][1], (C, sigma, digests[0][1], digests[1][1])
             assert digests[0][0] == digests[1][0], (C, sigma, code, [k for k in range(8) if digests[0][0][k] != digests[1][0][k]])
     finally:
-        pkg.set_tuning(block_plan_device=1)
+        pkg.set_tuning(block_plan_device=1, spmmv_reorder=4, spmmv_phase_dp=24)
+
+
+def test_block_plan_row_patches_and_dp_cuts(pkg, orc, torch_cuda):
+    """The host planner's row orders (0 as is | 1 ties undone | 2 balls | 4 flat patches, the default) x phase cuts (0 greedy | 24 | 200: dynamic
+    programming) on mesh, file and banded-random matrices, with and without sigma sorting / column permutation, handles with and without
+    the host struct's permutation: both layouts bit-identical to the oracle, every plan a phased one-byte plan, and on the 3-dof mesh the
+    default stages at most 0.85 of the X rows the ties-undone / greedy plan does."""
+    t = torch_cuda
+    cases = [("mesh3", pkg.gen_stencil27(24, 22, 20, dof=3), 32, 512, pkg.F64, 8), ("mesh3 s1", pkg.gen_stencil27(20, 18, 16, dof=3), 32, 1, pkg.F64, 8),
+             ("mesh2 C64", pkg.gen_stencil27(16, 15, 14, dof=2), 64, 128, pkg.F64, 8), ("mesh3 sp", pkg.gen_stencil27(14, 13, 12, dof=3), 32, 512, pkg.F32, 16),
+             ("bcsstk13", pkg.read_mtx(mtx_path("bcsstk13")), 32, 512, pkg.F64, 8), ("impcol_e", pkg.read_mtx(mtx_path("impcol_e")), 32, 64, pkg.F64, 8),
+             ("banded", pkg.gen_banded_random(20000, 40, 3000), 32, 512, pkg.F64, 8)]
+    staged = {}
+    try:
+        for name, coo, C, sigma, code, b in cases:
+            s, a, xp = _prep(pkg, coo, C, sigma, code, make_x(coo.n_rows))
+            ld = s.n_rows_padded
+            Yo = {rw: orc.spmmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], block_x(xp, ld, b, ld, rw), b, ld, bool(rw)) for rw in (0, 1)}
+            for reorder in (0, 1, 2, 4):
+                for dp in (0, 24, 200):
+                    for structless in (0, 1):
+                        if structless and (reorder in (0, 2) or dp == 200): continue
+                        pkg.set_tuning(spmmv_reorder=reorder, spmmv_phase_dp=dp, block_plan_device=0)
+                        A = pkg.DeviceMatrix(s)
+                        if structless: A.optimize_block_device(b)      # (arrays copied back, no permutation known: ties ordered by first column)
+                        else: A.optimize_block(s, b)
+                        info = A.block_plan_info()
+                        assert info["phased_plan"] == 1 and info["idx8"] == 1 and info["device_built"] == 0, (name, reorder, dp, info)
+                        if not structless: staged[(name, reorder, dp)] = info["rows_staged"]
+                        for rw in (0, 1):
+                            Y = t.full((b * ld,), -3.0, dtype=A.torch_dtype, device="cuda")
+                            pkg.spmmv(A, _dev(t, block_x(xp, ld, b, ld, rw)), Y, b, ld, pkg.ROWWISE if rw else pkg.COLWISE)
+                            assert np.array_equal(Y.cpu().numpy(), Yo[rw]), (name, reorder, dp, structless, rw)
+                        del A
+        assert staged[("mesh3", 4, 24)] <= 0.85 * staged[("mesh3", 1, 0)], staged
+        for name, *_ in cases:                                  # the dynamic programme never stages more than the greedy cuts + its per-phase allowance
+            for reorder in (0, 1, 2, 4):
+                assert staged[(name, reorder, 24)] <= staged[(name, reorder, 0)] * 1.02 + 64, (name, reorder, staged)
+    finally:
+        pkg.set_tuning(block_plan_device=1, spmmv_reorder=4, spmmv_phase_dp=24)
 
 
 def test_spmmv_column_major_x_prepared_once(pkg, orc, torch_cuda):

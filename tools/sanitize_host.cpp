@@ -38,6 +38,11 @@ int main(int argc, char **argv) {
                     CK(uspmv_build_phased_plan(moved ? &r : s, 256, 8, &pp, dt == USPMV_F64 ? 4 : 5));
                     uspmv_scs r2; std::vector<int32_t> rm2;
                     if (uspmv_scs_reorder_rows(s, 2, &r2, &rm2) < 0) return 1;
+                    uspmv_scs r4; std::vector<int32_t> rm4;                 // the default: flat patches + cuts by dynamic programming
+                    const int moved4 = uspmv_scs_reorder_rows(s, 4, &r4, &rm4);
+                    if (moved4 < 0) return 1;
+                    CK(uspmv_build_phased_plan(moved4 ? &r4 : s, 256, 8, &pp, 0, 24));
+                    CK(uspmv_build_phased_plan(moved4 ? &r4 : s, 512, 8, &pp, 0, 200));
                 }
                 uspmv_scs_free(s);
             }

@@ -96,6 +96,7 @@ _SIGS = {
     "uspmv_dmat_plan_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_block_plan_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dmat_block_plan_digest": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "uspmv_dmat_block_plan_staged": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dmat_optimize_sweep_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_sweep_plan_digest": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(_i64)]),
     "uspmv_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp]),
@@ -916,7 +917,11 @@ class DeviceMatrix:
         m = (_i64 * 10)()
         _ck(lib().uspmv_dmat_block_plan_info(self.h, m))
         keys = ("list_plan", "phased_plan", "line_plan", "tiles", "phases", "line_phases", "line_rows_staged", "idx8", "device_built", "max_rows")
-        return dict(zip(keys, [int(v) for v in m]))
+        d = dict(zip(keys, [int(v) for v in m]))
+        n = _i64()
+        _ck(lib().uspmv_dmat_block_plan_staged(self.h, C.byref(n)))
+        d["rows_staged"] = n.value
+        return d
 
     def optimize_block_device(self, block_vec_size):
         """The block plan from the handle's device arrays alone (uspmv_dmat_optimize_block_device)."""

@@ -195,7 +195,10 @@ int uspmv_set_tuning(const char *key, int value) {
     } else if (!strcmp(key, "ablate")) g_tune.ablate = value;
     else if (!strcmp(key, "spmmv_prefetch")) g_tune.spmmv_prefetch = value != 0;
     else if (!strcmp(key, "spmmv_swizzle")) g_tune.spmmv_swizzle = value != 0;
-    else if (!strcmp(key, "spmmv_reorder")) g_tune.spmmv_reorder = value < 0 ? 0 : value > 2 ? 2 : (int)value;
+    else if (!strcmp(key, "spmmv_reorder")) g_tune.spmmv_reorder = value < 0 ? 0 : value > 4 ? 4 : (int)value;
+    else if (!strcmp(key, "spmmv_brick_stride")) g_tune.spmmv_brick_stride = value < 0 ? 0 : (long)value;
+    else if (!strcmp(key, "spmmv_brick_lines")) g_tune.spmmv_brick_lines = value < 1 ? 1 : (int)value;
+    else if (!strcmp(key, "spmmv_phase_dp")) g_tune.spmmv_phase_dp = value < 0 ? 0 : (int)value;
     else if (!strcmp(key, "spmmv_phased")) g_tune.spmmv_phased = value != 0;
     else if (!strcmp(key, "spmmv_xcol")) g_tune.spmmv_xcol = value != 0;
     else if (!strcmp(key, "spmmv_ycol_nt")) g_tune.spmmv_ycol_nt = value != 0;
@@ -264,6 +267,9 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_prefetch")) *value = g_tune.spmmv_prefetch;
     else if (!strcmp(key, "spmmv_swizzle")) *value = g_tune.spmmv_swizzle;
     else if (!strcmp(key, "spmmv_reorder")) *value = g_tune.spmmv_reorder;
+    else if (!strcmp(key, "spmmv_brick_stride")) *value = g_tune.spmmv_brick_stride;
+    else if (!strcmp(key, "spmmv_brick_lines")) *value = g_tune.spmmv_brick_lines;
+    else if (!strcmp(key, "spmmv_phase_dp")) *value = g_tune.spmmv_phase_dp;
     else if (!strcmp(key, "spmmv_phased")) *value = g_tune.spmmv_phased;
     else if (!strcmp(key, "spmmv_xcol")) *value = g_tune.spmmv_xcol;
     else if (!strcmp(key, "spmmv_ycol_nt")) *value = g_tune.spmmv_ycol_nt;
@@ -907,13 +913,14 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
     uspmv_tlc_plan p;
     uspmv_scs r;                       // private copy with the sigma sort's ties undone (only kept when rows moved)
     std::vector<int32_t> row_map;
-    const bool moved = g_tune.spmmv_reorder && uspmv_scs_reorder_rows(s, g_tune.spmmv_reorder == 2 ? 2 : 1, &r, &row_map) == 1;
-    // 64-byte rows: the phased plan over the same (tie-re-ordered) entries -- what uspmv_spmmv runs by default.  When the phased kernel
+    const bool moved = g_tune.spmmv_reorder && (g_tune.spmmv_reorder == 3 ? uspmv_scs_reorder_bricks(s, g_tune.spmmv_brick_stride, g_tune.spmmv_brick_lines, &r, &row_map)
+                                                                          : uspmv_scs_reorder_rows(s, g_tune.spmmv_reorder == 2 ? 2 : g_tune.spmmv_reorder == 4 ? 4 : 1, &r, &row_map)) == 1;
+    // 64-byte rows: the phased plan over the same (re-ordered) entries -- what uspmv_spmmv runs by default.  When the phased kernel
     // can take it (at most 512 rows per phase), the one-list-per-tile plan of the older kernels and its column-major copy of the entries
     // (8 + 6 bytes per non-zero of HBM, a second or two of planning) are only built on request ("spmmv_list_plan" 1).
     uspmv_phased_plan pp;
     if (row_bytes == 64 && tile_rows == 64 && g_tune.spmmv_phased)
-        if (int rc = uspmv_build_phased_plan(moved ? &r : s, g_tune.spmmv_phase_rows, 8, &pp)) return rc;
+        if (int rc = uspmv_build_phased_plan(moved ? &r : s, g_tune.spmmv_phase_rows, 8, &pp, 0, g_tune.spmmv_phase_dp)) return rc;
     const bool phased_ok = pp.valid && pp.ngp <= 8 && (pp.max_rows_used * 4 + 255) / 256 <= 8;
     // ... and once more with LINE lists for column-major block vectors (no re-layout pass over X): kept when no phase needs more
     // than 256 rows' worth of lines and the lines staged stay below twice the rows the row plan stages
@@ -944,7 +951,7 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
         const int64_t nr = s->n_rows;
 #pragma omp parallel for schedule(static)
         for (int64_t k = 0; k < (int64_t)src->col_idxs.size(); ++k) { const int32_t c = src->col_idxs[(size_t)k]; u.col_idxs[(size_t)k] = c < nr ? n2o[c] : c; }
-        if (int rc = uspmv_build_phased_plan(&u, 256, 8, &pu)) return rc;
+        if (int rc = uspmv_build_phased_plan(&u, 256, 8, &pu, 0, g_tune.spmmv_phase_dp)) return rc;
         if (pu.valid && (pu.max_rows_used > 256 || pu.ngp > 8)) pu.valid = false;
     }
     const bool list_plan = !phased_ok || g_tune.spmmv_list_plan;
@@ -1054,7 +1061,7 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
     }
     if (pp.valid && pu.valid) { A->pu = true; A->pu_max_rows = pu.max_rows_used; A->pu_n_phases = pu.n_phases; A->pu_n_perm = s->n_rows; }
     if (pp.valid && pl.valid) { A->pl = true; A->pl_shift = pl.line_shift; A->pl_max_rows = pl.max_rows_used; A->pl_n_phases = pl.n_phases; A->pl_rows_staged = (int64_t)pl.xrows.size() << pl.line_shift; }
-    if (pp.valid) { A->pb = true; A->pb_cap_rows = pp.cap_rows; A->pb_ngp = pp.ngp; A->pb_max_rows = pp.max_rows_used; A->pb_n_tiles = pp.n_tiles; A->pb_n_phases = pp.n_phases; }
+    if (pp.valid) { A->pb = true; A->pb_cap_rows = pp.cap_rows; A->pb_ngp = pp.ngp; A->pb_max_rows = pp.max_rows_used; A->pb_n_tiles = pp.n_tiles; A->pb_n_phases = pp.n_phases; A->pb_rows_staged = (int64_t)pp.xrows.size(); }
     if (list_plan && p.valid) { A->bt = true; A->bt_tile_rows = p.tile_rows; A->bt_max_rows = p.max_lines_used; A->bt_n_tiles = p.n_tiles; A->bt_staged = p.n_staged_tiles; }
     return USPMV_OK;
 }
@@ -1066,7 +1073,7 @@ static int block_plan_install_device(uspmv_dmat_t *A, int block_vec_size, int64_
     const size_t vsz = A->dtype == USPMV_F64 ? 8 : 4;
     const size_t row_bytes = (size_t)block_vec_size * vsz;
     if (row_bytes != 64 || (A->C != 32 && A->C != 64) || !g_tune.spmmv_phased || g_tune.spmmv_phase_rows != 256 || g_tune.spmmv_list_plan ||
-        g_tune.spmmv_reorder != 1 || !g_tune.spmmv_idx8 || g_tune.spmmv_tile_rows == 32 || g_tune.spmmv_xline || !g_tune.block_plan_device) return 1;
+        (g_tune.spmmv_reorder != 1 && g_tune.spmmv_reorder != 4) || !g_tune.spmmv_idx8 || g_tune.spmmv_tile_rows == 32 || g_tune.spmmv_xline || !g_tune.block_plan_device) return 1;
     const int64_t C = A->C, nc = A->n_chunks, n_pad = nc * C, nt = (n_pad + 63) / 64;
     if (A->bt || A->pb) bt_release(A);
     std::vector<int32_t> cl((size_t)nc);
@@ -1132,7 +1139,7 @@ static int block_plan_install_device(uspmv_dmat_t *A, int block_vec_size, int64_
     if (!rc) { e = hipMemcpy(&max_rows, d_max, 4, hipMemcpyDeviceToHost); if (e != hipSuccess) return fail_out("plan kernels"); }
     (void)hipFree(d_changed); (void)hipFree(d_tph); (void)hipFree(d_tl);
     if (rc) { bt_release(A); return rc; }
-    A->pb = true; A->pb_idx8 = true; A->pb_device_built = true; A->pb_cap_rows = 256; A->pb_ngp = 8; A->pb_max_rows = max_rows; A->pb_n_tiles = nt; A->pb_n_phases = n_ph;
+    A->pb = true; A->pb_idx8 = true; A->pb_device_built = true; A->pb_cap_rows = 256; A->pb_ngp = 8; A->pb_max_rows = max_rows; A->pb_n_tiles = nt; A->pb_n_phases = n_ph; A->pb_rows_staged = n_list;
     if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] phased block plan (device builder): tiles=%lld phases=%lld rows_total=%lld max_rows=%d rows %s\n",
                                          (long long)nt, (long long)n_ph, (long long)n_list, max_rows, changed ? "re-ordered" : "in the caller's order");
     return USPMV_OK;
@@ -1680,6 +1687,13 @@ int uspmv_dmat_block_plan_digest(const uspmv_dmat_t *A0, uint64_t digest[8]) {
     if (!rc) rc = fnv(A->pb_values, (size_t)tot16 * vsz, &digest[6]);
     if (!rc) rc = fnv(A->bt_row_map, A->bt_row_map ? nc * (size_t)A->C * 4 : 0, &digest[7]);
     return rc;
+}
+
+int uspmv_dmat_block_plan_staged(const uspmv_dmat_t *A, int64_t *rows_staged) {
+    if (!A || !rows_staged) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_block_plan_staged: NULL argument");
+    const uspmv_dmat_t *M = (A->alt && g_tune.rechunk) ? A->alt : A;
+    *rows_staged = M->pb ? M->pb_rows_staged : 0;
+    return USPMV_OK;
 }
 
 int uspmv_dmat_block_plan_info(const uspmv_dmat_t *A, int64_t meta[10]) {

@@ -60,7 +60,7 @@ struct uspmv_dmat {
     // phased block plan (uspmv_build_phased_plan; 64-byte X rows): per tile a run of phases, each with its own X-row list
     bool pb = false;
     int pb_cap_rows = 0, pb_ngp = 0, pb_max_rows = 0;
-    int64_t pb_n_tiles = 0, pb_n_phases = 0;
+    int64_t pb_n_tiles = 0, pb_n_phases = 0, pb_rows_staged = 0;
     int32_t *pb_ph_ptr = nullptr, *pb_g0 = nullptr, *pb_list_ptr = nullptr, *pb_xrows = nullptr;
     void *pb_values = nullptr;          // the entries again, GROUP-major like pb_col16 ([chunk][group of four slots][row][slot % 4])
     uint32_t *pb_c16_ptrs = nullptr;
@@ -200,8 +200,15 @@ struct Tuning {
     int spmmv_phase_rows = 256;  // ... X rows per phase (256 | 512)
     int spmmv_list_plan = 0;   // NEXT optimize_block: also build the one-list-per-tile plan (variants 4 / 5 / 6) when the phased kernel can take the matrix
     int spmmv_idx8 = 1;        // NEXT optimize_block: one-byte phase-local indices when every phase lists <= 256 rows
-    int spmmv_reorder = 1;  // block plan's private copy of the entries: 1 = rows of equal-length chunks of a sigma window back in original order,
-                            // 2 = rows re-dealt to the tiles as breadth-first balls of the matrix graph (fewer X rows per tile, scattered y rows), 0 = as is
+    int spmmv_reorder = 4;  // block plan's private copy of the entries (host planner): 1 = rows of equal-length chunks of a sigma window back in original order;
+                            // 4 = on top of that, rows re-dealt to the tiles as FLAT patches of the matrix graph (grown along the slots of one phase
+                            // around the diagonal: 7.9 instead of 11.9 staged X rows per row on config 3; kept only where a sample of tiles
+                            // confirms it); 2 = the same with balls over all slots (fewer distinct X rows per tile, but more per phase); 0 = as is.
+                            // The device-side builder (handles without a host struct) always does 1.
+    long spmmv_brick_stride = 0;  // spmmv_reorder 3 (measurement aid): rows of a mesh line in ORIGINAL numbering; tiles = flat bricks of spmmv_brick_lines lines
+    int spmmv_brick_lines = 4;
+    int spmmv_phase_dp = 24;  // NEXT optimize_block (host planner): > 0 = phase cuts by dynamic programming (least staged rows + this many rows' worth per
+                              // phase), 0 = every phase filled to the brim (what the device-side builder does)
     int spmmv_variant = 0;  // 0 = auto (= 3 where a B-specialised kernel exists); 1 = generic kernel; 2 = row-major with transposing X phase; 3 = row-major, lane per row
 };
 extern Tuning g_tune;   // uspmv_api.hip

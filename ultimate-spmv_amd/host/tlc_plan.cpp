@@ -16,6 +16,9 @@
 // reads the four indices of its next four slots with a single 8-byte load.
 #include <algorithm>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <omp.h>
 
 #include "uspmv_internal.hpp"
 
@@ -197,90 +200,190 @@ int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *o) {
 // chunk length or pointer, so the plan's private copy of the entries puts them back in original-row order
 // inside every run of equal-length chunks of a window; row_map[new position] = position in the caller's
 // struct (= where y goes).  Per-row slot order is untouched, hence the same FMA chain per (row, column).
-// Row CLUSTERING for the block plan (mode 2 of uspmv_scs_reorder_rows).  The X rows a 64-row tile stages are the union of its
+// Row CLUSTERING for the block plan (modes 2 and 4 of uspmv_scs_reorder_rows).  The X rows a 64-row tile stages are the union of its
 // rows' columns; for a matrix from a 2-D / 3-D mesh a tile of 64 CONSECUTIVE rows is a line segment of the mesh and touches
 // ~10 X rows per row, a compact patch of the mesh about 6.  Rows may be exchanged freely between positions that sit in chunks of
 // equal length (nothing about the chunk structure changes, every row keeps its own padded slot sequence -> same FMA chain), so the
-// tiles are re-filled greedily: a tile takes the next unassigned row of its chunk-length class and grows a breadth-first ball
-// around it over rows of the same class (the matrix' own column indices are the graph).  row_map[new position] = position in the
-// caller's struct.  Serial, O(elements).
-static void cluster_row_map(const uspmv_scs *s, std::vector<int32_t> *row_map) {
+// tiles are re-filled greedily: a tile takes the next unassigned row of its chunk-length class (in the order of `base`: ties undone)
+// and grows a breadth-first ball around it over rows of the same class (the matrix' own column indices are the graph).
+// flat (mode 4): the ball grows only along the slots AROUND THE DIAGONAL that one phase of the plan can hold (32 slots at most, an
+// equal share of the row when it needs several phases) -- for column-sorted rows of a mesh those are the neighbours whose own rows
+// share X rows with this one IN THE SAME PHASES, so for a 3-D mesh the balls come out as patches of one plane (three phases, each
+// staging one plane's patch) instead of 3 x 3 x 3 blocks (each phase staging three planes' worth).  Rows of one phase: all slots.
+// row_map[new position] = position in the caller's struct.  O(elements); the matrix is cut into segments of whole sigma windows that
+// are clustered independently (in parallel; a ball does not cross a segment's end).
+static void cluster_row_map(const uspmv_scs *s, const std::vector<int32_t> &base, int64_t window_chunks, std::vector<int32_t> *row_map, bool flat) {
     const int64_t C = s->C, nc = s->n_chunks, n_pad = nc * C;
+    const int64_t T = std::max<int64_t>(1, 64 / C);
+    int64_t seg_chunks = std::max<int64_t>(window_chunks, T);
+    while (seg_chunks * C < 65536) seg_chunks *= 2;
+    const int64_t n_seg = (nc + seg_chunks - 1) / seg_chunks;
+    std::vector<char> assigned((size_t)n_pad, 0);
+    std::vector<int32_t> stamp((size_t)n_pad, -1), cnt((size_t)n_pad, 0);
+#pragma omp parallel
+    {
+        std::vector<int32_t> cls_rows;
+        std::vector<std::pair<int32_t, int32_t>> heap;      // (rows of the tile pointing at u, -u)
+        std::vector<int64_t> cls_begin, cursor;
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t sg = 0; sg < n_seg; ++sg) {
+            const int64_t cA = sg * seg_chunks, cB = std::min(nc, cA + seg_chunks), lo = cA * C, hi = cB * C;
+            int32_t max_len = 0;
+            for (int64_t c = cA; c < cB; ++c) max_len = std::max(max_len, s->chunk_lengths[(size_t)c]);
+            // the segment's rows of every class in `base` order, and a cursor to the first one that may still be unassigned
+            cls_begin.assign((size_t)max_len + 2, 0);
+            for (int64_t c = cA; c < cB; ++c) cls_begin[(size_t)s->chunk_lengths[(size_t)c] + 1] += C;
+            for (size_t l = 0; l + 1 < cls_begin.size(); ++l) cls_begin[l + 1] += cls_begin[l];
+            cls_rows.resize((size_t)(hi - lo));
+            cursor.assign(cls_begin.begin(), cls_begin.end() - 1);
+            for (int64_t c = cA; c < cB; ++c) {
+                const int32_t l = s->chunk_lengths[(size_t)c];
+                for (int64_t i = 0; i < C; ++i) cls_rows[(size_t)cursor[(size_t)l]++] = base[(size_t)(c * C + i)];
+            }
+            cursor.assign(cls_begin.begin(), cls_begin.end() - 1);
+            int32_t blob = 0;
+            for (int64_t c0 = cA; c0 < cB;) {
+                const int64_t tile_end = std::min(cB, (c0 / T + 1) * T);
+                int64_t c1 = c0 + 1;
+                const int32_t l = s->chunk_lengths[(size_t)c0];
+                while (c1 < tile_end && s->chunk_lengths[(size_t)c1] == l) ++c1;
+                const int64_t need = (c1 - c0) * C;
+                int32_t *out = row_map->data() + c0 * C;
+                if (l == 0) {                                    // empty chunks: rows stay where `base` has them
+                    for (int64_t k = 0; k < need; ++k) { out[k] = base[(size_t)(c0 * C + k)]; assigned[(size_t)out[k]] = 1; }
+                    c0 = c1;
+                    continue;
+                }
+                const int64_t n_ph = (l + 31) / 32, width = flat && n_ph > 1 ? (l + n_ph - 1) / n_ph : l;
+                int64_t got = 0;
+                heap.clear();
+                ++blob;
+                while (got < need) {
+                    int32_t v = -1;
+                    while (!heap.empty()) {                      // the unassigned row most of the tile's rows point at (lowest position on a tie)
+                        std::pop_heap(heap.begin(), heap.end());
+                        const std::pair<int32_t, int32_t> top = heap.back();
+                        heap.pop_back();
+                        const int32_t u = -top.second;
+                        if (!assigned[(size_t)u] && cnt[(size_t)u] == top.first) { v = u; break; }   // (else: taken, or an older count of u)
+                    }
+                    if (v < 0) {                                 // (re)seed: the next unassigned row of the class
+                        int64_t &cu = cursor[(size_t)l];
+                        while (cu < cls_begin[(size_t)l + 1] && assigned[(size_t)cls_rows[(size_t)cu]]) ++cu;
+                        if (cu >= cls_begin[(size_t)l + 1]) break;   // (cannot happen: the class has exactly as many rows as positions)
+                        v = cls_rows[(size_t)cu];
+                    }
+                    assigned[(size_t)v] = 1;
+                    out[got++] = v;
+                    const int64_t vc = v / C, vi = v % C, vcs = s->chunk_ptrs[(size_t)vc];
+                    int64_t ja = 0, jb = l;
+                    if (width < l) {                             // the slots of one phase around the diagonal (the middle of the row when it has none)
+                        int64_t d = l / 2;
+                        for (int64_t j = 0; j < l; ++j)
+                            if (s->col_idxs[(size_t)(vcs + j * C + vi)] == v) { d = j; break; }
+                        ja = std::min(std::max<int64_t>(0, d - width / 2), l - width);
+                        jb = ja + width;
+                    }
+                    for (int64_t j = ja; j < jb; ++j) {
+                        const int64_t u = s->col_idxs[(size_t)(vcs + j * C + vi)];
+                        if (u >= lo && u < hi && !assigned[(size_t)u] && s->chunk_lengths[(size_t)(u / C)] == l) {
+                            if (stamp[(size_t)u] != blob) { stamp[(size_t)u] = blob; cnt[(size_t)u] = 0; }
+                            heap.emplace_back(++cnt[(size_t)u], (int32_t)-u);
+                            std::push_heap(heap.begin(), heap.end());
+                        }
+                    }
+                }
+                std::sort(out, out + got);                       // inside the run: position order (neighbouring lanes <-> neighbouring y rows)
+                c0 = c1;
+            }
+        }
+    }
+}
+
+// X rows the 64-row tiles of a sample (every `step`-th tile) touch under a row order: what a clustering is accepted or refused by
+static int64_t sample_tile_columns(const uspmv_scs *s, const std::vector<int32_t> &row_map, int64_t step) {
+    const int64_t C = s->C, nc = s->n_chunks, T = std::max<int64_t>(1, 64 / C), n_tiles = (nc + T - 1) / T;
+    int64_t total = 0;
+#pragma omp parallel reduction(+ : total)
+    {
+        std::vector<int32_t> cols;
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t t = 0; t < n_tiles; t += step) {
+            cols.clear();
+            for (int64_t c = t * T; c < std::min(nc, (t + 1) * T); ++c) {
+                const int64_t L = s->chunk_lengths[(size_t)c];
+                for (int64_t i = 0; i < C; ++i) {
+                    const int64_t v = row_map[(size_t)(c * C + i)], vcs = s->chunk_ptrs[(size_t)(v / C)], vi = v % C;
+                    for (int64_t j = 0; j < L; ++j) cols.push_back(s->col_idxs[(size_t)(vcs + j * C + vi)]);
+                }
+            }
+            std::sort(cols.begin(), cols.end());
+            total += (int64_t)(std::unique(cols.begin(), cols.end()) - cols.begin());
+        }
+    }
+    return total;
+}
+
+// Measurement aid (needs the caller's permutation and a known line stride): rows dealt to the tiles as FLAT bricks of `lines`
+// neighbouring mesh lines -- rows of a chunk-length class ordered by (block of `lines` lines, position in the line, line), cut into the
+// class's positions in order, every run of equal-length chunks of a tile then sorted by position.
+static bool brick_row_map(const uspmv_scs *s, int64_t stride, int64_t lines, std::vector<int32_t> *row_map) {
+    const int64_t C = s->C, nc = s->n_chunks, n_pad = nc * C;
+    if (stride < 1 || lines < 1 || (int64_t)s->new_to_old_idx.size() < s->n_rows) return false;
     int32_t max_len = 0;
     for (int64_t c = 0; c < nc; ++c) max_len = std::max(max_len, s->chunk_lengths[(size_t)c]);
-    // rows of every class in position order, and a cursor to the first one that may still be unassigned
     std::vector<int64_t> cls_begin((size_t)max_len + 2, 0);
     for (int64_t c = 0; c < nc; ++c) cls_begin[(size_t)s->chunk_lengths[(size_t)c] + 1] += C;
     for (size_t l = 0; l + 1 < cls_begin.size(); ++l) cls_begin[l + 1] += cls_begin[l];
-    std::vector<int32_t> cls_rows((size_t)n_pad);
+    std::vector<int32_t> cls_pos((size_t)n_pad);
     {
         std::vector<int64_t> fill(cls_begin.begin(), cls_begin.end() - 1);
         for (int64_t c = 0; c < nc; ++c) {
             const int32_t l = s->chunk_lengths[(size_t)c];
-            for (int64_t i = 0; i < C; ++i) cls_rows[(size_t)fill[(size_t)l]++] = (int32_t)(c * C + i);
+            for (int64_t i = 0; i < C; ++i) cls_pos[(size_t)fill[(size_t)l]++] = (int32_t)(c * C + i);
         }
     }
-    std::vector<int64_t> cursor(cls_begin.begin(), cls_begin.end() - 1);
-    std::vector<char> assigned((size_t)n_pad, 0);
-    std::vector<int32_t> stamp((size_t)n_pad, -1), queue;
+    const int32_t *n2o = s->new_to_old_idx.data();
+    const int64_t n_rows = s->n_rows, blk = lines * stride;
+    auto key = [&](int32_t q) -> int64_t {
+        if (q >= n_rows) return ((int64_t)1 << 60) | q;
+        const int64_t o = n2o[q];
+        return (o / blk) * blk + (o % stride) * lines + (o / stride) % lines;
+    };
+    std::vector<int32_t> rows(cls_pos);
+    for (size_t l = 1; l + 1 < cls_begin.size(); ++l) {
+        int32_t *b = rows.data() + cls_begin[l], *e = rows.data() + cls_begin[l + 1];
+        if (b == e) continue;
+        std::vector<std::pair<int64_t, int32_t>> kv((size_t)(e - b));
+#pragma omp parallel for schedule(static)
+        for (int64_t k = 0; k < (int64_t)kv.size(); ++k) kv[(size_t)k] = {key(b[k]), b[k]};
+        std::sort(kv.begin(), kv.end());
+        for (size_t k = 0; k < kv.size(); ++k) b[k] = kv[k].second;
+    }
+    for (int64_t k = 0; k < n_pad; ++k) (*row_map)[(size_t)cls_pos[(size_t)k]] = rows[(size_t)k];
     const int64_t T = std::max<int64_t>(1, 64 / C);
-    int32_t blob = 0;
     for (int64_t c0 = 0; c0 < nc;) {
         const int64_t tile_end = std::min(nc, (c0 / T + 1) * T);
         int64_t c1 = c0 + 1;
-        const int32_t l = s->chunk_lengths[(size_t)c0];
-        while (c1 < tile_end && s->chunk_lengths[(size_t)c1] == l) ++c1;
-        const int64_t need = (c1 - c0) * C;
-        int32_t *out = row_map->data() + c0 * C;
-        if (l == 0) {                                        // empty chunks: rows stay where they are
-            for (int64_t k = 0; k < need; ++k) { out[k] = (int32_t)(c0 * C + k); assigned[(size_t)out[k]] = 1; }
-            c0 = c1;
-            continue;
-        }
-        int64_t got = 0;
-        size_t head = 0;
-        queue.clear();
-        ++blob;
-        while (got < need) {
-            if (head == queue.size()) {                      // (re)seed: the next unassigned row of the class in position order
-                int64_t &cu = cursor[(size_t)l];
-                while (cu < cls_begin[(size_t)l + 1] && assigned[(size_t)cls_rows[(size_t)cu]]) ++cu;
-                if (cu >= cls_begin[(size_t)l + 1]) break;   // (cannot happen: the class has exactly as many rows as positions)
-                const int32_t seed = cls_rows[(size_t)cu];
-                stamp[(size_t)seed] = blob;
-                queue.push_back(seed);
-            }
-            const int32_t v = queue[head++];
-            if (assigned[(size_t)v]) continue;
-            assigned[(size_t)v] = 1;
-            out[got++] = v;
-            const int64_t vc = v / C, vi = v % C, vcs = s->chunk_ptrs[(size_t)vc];
-            for (int64_t j = 0; j < l; ++j) {
-                const int32_t u = s->col_idxs[(size_t)(vcs + j * C + vi)];
-                if ((int64_t)u < n_pad && !assigned[(size_t)u] && stamp[(size_t)u] != blob && s->chunk_lengths[(size_t)(u / C)] == l) {
-                    stamp[(size_t)u] = blob;
-                    queue.push_back(u);
-                }
-            }
-        }
-        std::sort(out, out + got);                           // inside the run: position order (neighbouring lanes <-> neighbouring y rows)
+        while (c1 < tile_end && s->chunk_lengths[(size_t)c1] == s->chunk_lengths[(size_t)c0]) ++c1;
+        std::sort(row_map->data() + c0 * C, row_map->data() + c1 * C);
         c0 = c1;
     }
+    return true;
+}
+
+int uspmv_scs_reorder_bricks(const uspmv_scs *s, int64_t stride, int64_t lines, uspmv_scs *r, std::vector<int32_t> *row_map) {
+    row_map->resize((size_t)(s->n_chunks * s->C));
+    if (!brick_row_map(s, stride, lines, row_map)) return uspmv_scs_reorder_rows(s, 1, r, row_map);
+    return uspmv_scs_reorder_rows(s, -1, r, row_map);
 }
 
 int uspmv_scs_reorder_ties(const uspmv_scs *s, uspmv_scs *r, std::vector<int32_t> *row_map) { return uspmv_scs_reorder_rows(s, 1, r, row_map); }
 
-// mode 1: tie re-ordering (below); mode 2: row clustering (above); mode -1: copy under the caller's row_map
-int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vector<int32_t> *row_map) {
-    if (mode == 2) {                                         // (on the caller's struct: there a column index IS a row position)
-        row_map->resize((size_t)(s->n_chunks * s->C));
-        cluster_row_map(s, row_map);
-        return uspmv_scs_reorder_rows(s, -1, r, row_map);
-    }
+// row_map of the tie re-ordering (mode 1); *window_chunks = chunks per window the rows were ordered in.  true when a row moved
+static bool tie_row_map(const uspmv_scs *s, std::vector<int32_t> *row_map, int64_t *window_chunks) {
     const int64_t C = s->C, nc = s->n_chunks, n_pad = nc * C;
     bool changed = false;
-    if (mode == -1) changed = true;                          // row_map given by the caller: only the copy below
-    else {
     row_map->resize((size_t)n_pad);
     for (int64_t q = 0; q < n_pad; ++q) (*row_map)[(size_t)q] = (int32_t)q;
     const bool have_perm = s->sigma > 1 && std::max<int64_t>(s->sigma, C) % C == 0 && (int64_t)s->new_to_old_idx.size() >= s->n_rows;
@@ -288,34 +391,62 @@ int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vect
     // uspmv_dmat_optimize_block_device): rows ordered by their first column inside runs of at most 16 equal-length chunks -- for
     // locally numbered (banded, stencil-like) matrices that is the original order again.
     const int64_t W = have_perm ? std::max<int64_t>(s->sigma, C) : 16 * C;
-    {
-        const int64_t cpw = W / C;
-        const int32_t *n2o = have_perm ? s->new_to_old_idx.data() : nullptr;
-        const int64_t n_rows = s->n_rows;
-        std::vector<char> ch((size_t)((nc + cpw - 1) / cpw), 0);
+    const int64_t cpw = W / C;
+    if (window_chunks) *window_chunks = cpw;
+    const int32_t *n2o = have_perm ? s->new_to_old_idx.data() : nullptr;
+    const int64_t n_rows = s->n_rows;
+    std::vector<char> ch((size_t)((nc + cpw - 1) / cpw), 0);
 #pragma omp parallel for schedule(dynamic, 64)
-        for (int64_t w = 0; w < (nc + cpw - 1) / cpw; ++w) {
-            const int64_t c_end = std::min(nc, (w + 1) * cpw);
-            int64_t c0 = w * cpw;
-            while (c0 < c_end) {
-                int64_t c1 = c0 + 1;
-                while (c1 < c_end && s->chunk_lengths[(size_t)c1] == s->chunk_lengths[(size_t)c0]) ++c1;
-                int32_t *b = row_map->data() + c0 * C, *e = row_map->data() + c1 * C;
-                auto key = [&](int32_t q) -> int64_t {
-                    if (n2o) return q < n_rows ? (int64_t)n2o[q] : (int64_t)INT32_MAX + q;
-                    const int64_t cq = q / C;
-                    return s->chunk_lengths[(size_t)cq] > 0 ? (int64_t)s->col_idxs[(size_t)(s->chunk_ptrs[(size_t)cq] + q % C)] : (int64_t)INT32_MAX + q;
-                };
-                auto less = [&](int32_t a, int32_t bb) { const int64_t ka = key(a), kb = key(bb); return ka < kb || (ka == kb && a < bb); };
-                if (!std::is_sorted(b, e, less)) {
-                    std::sort(b, e, less);
-                    ch[(size_t)w] = 1;
-                }
-                c0 = c1;
+    for (int64_t w = 0; w < (nc + cpw - 1) / cpw; ++w) {
+        const int64_t c_end = std::min(nc, (w + 1) * cpw);
+        int64_t c0 = w * cpw;
+        while (c0 < c_end) {
+            int64_t c1 = c0 + 1;
+            while (c1 < c_end && s->chunk_lengths[(size_t)c1] == s->chunk_lengths[(size_t)c0]) ++c1;
+            int32_t *b = row_map->data() + c0 * C, *e = row_map->data() + c1 * C;
+            auto key = [&](int32_t q) -> int64_t {
+                if (n2o) return q < n_rows ? (int64_t)n2o[q] : (int64_t)INT32_MAX + q;
+                const int64_t cq = q / C;
+                return s->chunk_lengths[(size_t)cq] > 0 ? (int64_t)s->col_idxs[(size_t)(s->chunk_ptrs[(size_t)cq] + q % C)] : (int64_t)INT32_MAX + q;
+            };
+            auto less = [&](int32_t a, int32_t bb) { const int64_t ka = key(a), kb = key(bb); return ka < kb || (ka == kb && a < bb); };
+            if (!std::is_sorted(b, e, less)) {
+                std::sort(b, e, less);
+                ch[(size_t)w] = 1;
             }
+            c0 = c1;
         }
-        for (char v : ch) changed = changed || v;
     }
+    for (char v : ch) changed = changed || v;
+    return changed;
+}
+
+// mode 1: tie re-ordering; mode 2 / 4: row clustering (balls / flat patches; kept only where a sample of tiles then touches fewer
+// X rows than under mode 1, which it falls back to); mode -1: copy under the caller's row_map
+int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vector<int32_t> *row_map) {
+    const int64_t C = s->C, nc = s->n_chunks;
+    bool changed = false;
+    const bool verbose = getenv("USPMV_VERBOSE") != nullptr;
+    double t_last = omp_get_wtime();
+    auto lap = [&](const char *what) { if (verbose) { const double t = omp_get_wtime(); fprintf(stderr, "[uspmv] block plan row order: %s %.2f s\n", what, t - t_last); t_last = t; } };
+    if (mode == -1) changed = true;                          // row_map given by the caller: only the copy below
+    else {
+        int64_t cpw = 1;
+        changed = tie_row_map(s, row_map, &cpw);
+        lap("ties undone");
+        // (clustering works on the caller's struct: there a column index below the row count IS a row position)
+        if ((mode == 2 || mode == 4) && nc * C <= (int64_t)INT32_MAX) {
+            std::vector<int32_t> cl((size_t)(nc * C));
+            cluster_row_map(s, *row_map, cpw, &cl, mode == 4);
+            const int64_t T = std::max<int64_t>(1, 64 / C), n_tiles = (nc + T - 1) / T, step = std::max<int64_t>(1, n_tiles / 2048);
+            lap("clusters grown");
+            const int64_t before = sample_tile_columns(s, *row_map, step), after = sample_tile_columns(s, cl, step);
+            if (getenv("USPMV_VERBOSE"))
+                fprintf(stderr, "[uspmv] block plan row clustering (mode %d): sampled tiles touch %lld X rows against %lld with the ties undone -> %s\n", mode,
+                        (long long)after, (long long)before, after * 100 < before * 95 ? "kept" : "not kept");
+            if (after * 100 < before * 95) { row_map->swap(cl); changed = true; }
+            lap("sample compared");
+        }
     }
     r->C = C; r->sigma = s->sigma; r->n_rows = s->n_rows; r->n_cols = s->n_cols; r->nnz = s->nnz; r->dtype = s->dtype;
     r->n_chunks = nc; r->n_rows_padded = s->n_rows_padded; r->n_elements = s->n_elements;
@@ -340,6 +471,7 @@ int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vect
             }
         }
     }
+    lap("entries copied");
     return changed ? 1 : 0;
 }
 
@@ -350,7 +482,7 @@ int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vect
 // 16-bit indices.  The workgroup stages one phase at a time (cap_rows * row bytes of LDS: 16 KB -> eight workgroups per CU) and
 // still walks every row's slots in order, so the FMA chains are unchanged.  An X row needed in two phases is staged twice; for
 // matrices whose rows are column-sorted the phases' row sets are (nearly) disjoint.
-int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_phased_plan *p, int line_shift) {
+int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_phased_plan *p, int line_shift, int phase_cost) {
     // line_shift > 0: the lists hold LINES of 2^line_shift consecutive X rows (what a column-major block vector is staged by: one
     // 128-byte line per list entry and column); a phase lists at most cap_rows >> line_shift lines and the local index of an entry
     // is (position of its line) << line_shift | (column & (2^line_shift - 1)).
@@ -406,6 +538,50 @@ int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_pha
                 rows.insert(rows.end(), cur.begin(), cur.end());
                 cur.clear();
             };
+            if (phase_cost > 0) {
+                // cuts by dynamic programming: least (staged items + phase_cost per phase) over all cuts with <= ngp groups and <= cap_items
+                // items per phase (the greedy form below fills every phase to the brim, which for column-sorted rows of a mesh
+                // cuts through the groups of slots that share their X rows)
+                std::vector<std::vector<int32_t>> gcols((size_t)ng);
+                for (int64_t g = 0; g < ng; ++g) {
+                    ++group_id;
+                    for (int64_t c = c0; c < c1; ++c) {
+                        const int64_t cs = s->chunk_ptrs[(size_t)c], L = s->chunk_lengths[(size_t)c];
+                        for (int64_t j = g * 4; j < std::min(g * 4 + 4, L); ++j)
+                            for (int64_t i = 0; i < C; ++i) {
+                                const int32_t col = s->col_idxs[(size_t)(cs + j * C + i)] >> line_shift;
+                                if (gstamp[(size_t)col] != group_id) { gstamp[(size_t)col] = group_id; gcols[(size_t)g].push_back(col); }
+                            }
+                    }
+                }
+                std::vector<int64_t> best((size_t)ng + 1, INT64_MAX);
+                std::vector<int32_t> from((size_t)ng + 1, -1);
+                best[0] = 0;
+                for (int64_t i = 0; i < ng; ++i) {
+                    if (best[(size_t)i] == INT64_MAX) continue;
+                    ++group_id;
+                    int64_t cnt = 0;
+                    for (int64_t j = i; j < std::min<int64_t>(ng, i + ngp); ++j) {
+                        for (int32_t col : gcols[(size_t)j])
+                            if (gstamp[(size_t)col] != group_id) { gstamp[(size_t)col] = group_id; ++cnt; }
+                        if (j > i && cnt > cap_items) break;
+                        const int64_t v = best[(size_t)i] + cnt + phase_cost;
+                        if (v < best[(size_t)j + 1]) { best[(size_t)j + 1] = v; from[(size_t)j + 1] = (int32_t)i; }
+                    }
+                }
+                std::vector<int32_t> cuts;
+                for (int64_t j = ng; j > 0; j = from[(size_t)j]) cuts.push_back((int32_t)j);
+                int64_t first = 0;
+                for (size_t k = cuts.size(); k-- > 0;) {
+                    ++phase_id;
+                    for (int64_t g = first; g < cuts[k]; ++g)
+                        for (int32_t col : gcols[(size_t)g])
+                            if (stamp[(size_t)col] != phase_id) { stamp[(size_t)col] = phase_id; cur.push_back(col); }
+                    close_phase(first, cuts[k]);
+                    first = cuts[k];
+                }
+                continue;
+            }
             int64_t first = 0;
             ++phase_id;
             for (int64_t g = 0; g < ng; ++g) {

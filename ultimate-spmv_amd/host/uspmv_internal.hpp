@@ -130,7 +130,7 @@ struct uspmv_phased_plan {
     std::vector<uint32_t> c16_ptrs;     // n_chunks+1
     std::vector<uint16_t> col16;        // [chunk][slot/4][row][slot%4], index into the list of the slot's phase
 };
-int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_phased_plan *plan, int line_shift = 0);   // host/tlc_plan.cpp
+int uspmv_build_phased_plan(const uspmv_scs *s, int cap_rows, int ngp, uspmv_phased_plan *plan, int line_shift = 0, int phase_cost = 0);   // host/tlc_plan.cpp
 
 int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *out);   // host/tlc_plan.cpp
 // per chunk 0 = no halo column, 1 = halo only through +0.0 padding entries on the one column *pad_col, 2 = other halo references (host/halo_plan.cpp)
@@ -141,6 +141,7 @@ int uspmv_scs_reorder_ties(const uspmv_scs *s, uspmv_scs *r, std::vector<int32_t
 // mode 1 = the above; mode 2 = rows re-dealt to the 64-row tiles as breadth-first balls of the matrix graph (per chunk-length
 // class, so the chunk structure is still untouched); mode -1 = copy under the caller's row_map
 int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vector<int32_t> *row_map);   // host/tlc_plan.cpp
+int uspmv_scs_reorder_bricks(const uspmv_scs *s, int64_t stride, int64_t lines, uspmv_scs *r, std::vector<int32_t> *row_map);   // host/tlc_plan.cpp (measurement aid)
 
 int uspmv_scs_layout(const uspmv_coo *m, int64_t C, int64_t sigma, int dtype, const int32_t *fixed_permutation,
                      uspmv_scs *s, std::vector<int64_t> *row_start, const char *who);   // host/scs_convert.cpp
