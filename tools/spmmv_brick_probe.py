@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Config 3, phased SpMMV kernel: the plan's private row order side by side -- 1 = ties undone (default, plan built on the device),
-2 = breadth-first balls, 3 = flat bricks of `lines` mesh lines (needs the line stride: measurement aid) -- with the phases cut
+"""Config 3, phased SpMMV kernel: the plan's private row order side by side -- 1 = ties undone (what the device-side builder does),
+2 = balls over all slots, 3 = flat bricks of `lines` mesh lines (needs the line stride: measurement aid), 4 = flat patches grown along the
+slots of one phase (the host planner's default) -- with the phases cut
 greedily or by dynamic programming (`spmmv_phase_dp`); both layouts, every line checked against the lane-per-row kernel."""
 import os, sys, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,9 +22,9 @@ for lay in (pkg.ROWWISE, pkg.COLWISE):
     pkg.set_tuning(spmmv_variant=3); y = torch.zeros_like(X); pkg.spmmv(A0, X, y, b, ld, lay); Y0[lay] = y
 pkg.set_tuning(spmmv_variant=0)
 del A0
-cases = [(1, 0, 4, 64, 256), (4, 24, 4, 64, 256), (4, 24, 4, 128, 256), (4, 24, 4, 128, 512), (3, 24, 8, 128, 512), (4, 24, 4, 64, 256), (1, 0, 4, 64, 256)]
-for reorder, dp, lines, tile, prow in cases:
-    pkg.set_tuning(spmmv_reorder=reorder, spmmv_phase_dp=dp, spmmv_brick_stride=3 * g, spmmv_brick_lines=lines, spmmv_phase_tile=tile, spmmv_phase_rows=prow)
+cases = [(1, 0, 4), (4, 24, 4), (3, 24, 4), (2, 24, 4), (1, 24, 4), (4, 0, 4), (4, 24, 4), (1, 0, 4)]
+for reorder, dp, lines in cases:
+    pkg.set_tuning(spmmv_reorder=reorder, spmmv_phase_dp=dp, spmmv_brick_stride=3 * g, spmmv_brick_lines=lines)
     t0 = time.time()
     A = pkg.DeviceMatrix(s, block_tlc=b)
     plan_s = time.time() - t0
@@ -32,6 +33,6 @@ for reorder, dp, lines, tile, prow in cases:
         same = bool(torch.equal(Y, Y0[lay]))
         B.time_launches(5, 20, A=A, x=X, y=Y, b=b, ld=ld, layout=lay)
         ms = sorted(B.time_launches(5, 40, A=A, x=X, y=Y, b=b, ld=ld, layout=lay) for _ in range(5))
-        print(json.dumps(dict(reorder=reorder, phase_dp=dp, lines=lines, tile=tile, phase_rows=prow, layout=nm, plan_s=round(plan_s, 1), bitexact=same, ms_min=round(ms[0], 4), ms_med=round(ms[2], 4))), flush=True)
+        print(json.dumps(dict(reorder=reorder, phase_dp=dp, lines=lines, rows_staged=A.block_plan_info()["rows_staged"], layout=nm, plan_s=round(plan_s, 1), bitexact=same, ms_min=round(ms[0], 4), ms_med=round(ms[2], 4))), flush=True)
     del A
-pkg.set_tuning(spmmv_reorder=1, spmmv_phase_dp=0, spmmv_brick_stride=0, spmmv_phase_tile=64, spmmv_phase_rows=256)
+pkg.set_tuning(spmmv_reorder=4, spmmv_phase_dp=24, spmmv_brick_stride=0)

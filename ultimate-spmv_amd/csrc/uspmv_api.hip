@@ -914,7 +914,9 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
     uspmv_scs r;                       // private copy with the sigma sort's ties undone (only kept when rows moved)
     std::vector<int32_t> row_map;
     const bool moved = g_tune.spmmv_reorder && (g_tune.spmmv_reorder == 3 ? uspmv_scs_reorder_bricks(s, g_tune.spmmv_brick_stride, g_tune.spmmv_brick_lines, &r, &row_map)
-                                                                          : uspmv_scs_reorder_rows(s, g_tune.spmmv_reorder == 2 ? 2 : g_tune.spmmv_reorder == 4 ? 4 : 1, &r, &row_map)) == 1;
+                                                                          : uspmv_scs_reorder_rows(s, g_tune.spmmv_reorder == 2 ? 2 : (g_tune.spmmv_reorder == 4 && !g_tune.spmmv_xline) ? 4 : 1, &r, &row_map)) == 1;
+    // (with the line plan requested -- "spmmv_xline": X staged by 128-byte lines of the column-major vector -- the rows stay in original order,
+    //  ties undone: a patch of several mesh lines touches more LINES of X than a run of consecutive rows)
     // 64-byte rows: the phased plan over the same (re-ordered) entries -- what uspmv_spmmv runs by default.  When the phased kernel
     // can take it (at most 512 rows per phase), the one-list-per-tile plan of the older kernels and its column-major copy of the entries
     // (8 + 6 bytes per non-zero of HBM, a second or two of planning) are only built on request ("spmmv_list_plan" 1).
