@@ -212,12 +212,15 @@ int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *o) {
 // staging one plane's patch) instead of 3 x 3 x 3 blocks (each phase staging three planes' worth).  Rows of one phase: all slots.
 // row_map[new position] = position in the caller's struct.  O(elements); the matrix is cut into segments of whole sigma windows that
 // are clustered independently (in parallel; a ball does not cross a segment's end).
-static void cluster_row_map(const uspmv_scs *s, const std::vector<int32_t> &base, int64_t window_chunks, std::vector<int32_t> *row_map, bool flat) {
+// seg_stride > 1: only every seg_stride-th segment is clustered (the others keep `base`): the trial run that decides whether the whole
+// matrix is worth it.  Returns the chunks per segment.
+static int64_t cluster_row_map(const uspmv_scs *s, const std::vector<int32_t> &base, int64_t window_chunks, std::vector<int32_t> *row_map, bool flat, int64_t seg_stride = 1) {
     const int64_t C = s->C, nc = s->n_chunks, n_pad = nc * C;
     const int64_t T = std::max<int64_t>(1, 64 / C);
     int64_t seg_chunks = std::max<int64_t>(window_chunks, T);
     while (seg_chunks * C < 65536) seg_chunks *= 2;
     const int64_t n_seg = (nc + seg_chunks - 1) / seg_chunks;
+    if (seg_stride > 1) *row_map = base;
     std::vector<char> assigned((size_t)n_pad, 0);
     std::vector<int32_t> stamp((size_t)n_pad, -1), cnt((size_t)n_pad, 0);
 #pragma omp parallel
@@ -226,7 +229,7 @@ static void cluster_row_map(const uspmv_scs *s, const std::vector<int32_t> &base
         std::vector<std::pair<int32_t, int32_t>> heap;      // (rows of the tile pointing at u, -u)
         std::vector<int64_t> cls_begin, cursor;
 #pragma omp for schedule(dynamic, 1)
-        for (int64_t sg = 0; sg < n_seg; ++sg) {
+        for (int64_t sg = seg_stride / 2; sg < n_seg; sg += seg_stride) {
             const int64_t cA = sg * seg_chunks, cB = std::min(nc, cA + seg_chunks), lo = cA * C, hi = cB * C;
             int32_t max_len = 0;
             for (int64_t c = cA; c < cB; ++c) max_len = std::max(max_len, s->chunk_lengths[(size_t)c]);
@@ -298,10 +301,12 @@ static void cluster_row_map(const uspmv_scs *s, const std::vector<int32_t> &base
             }
         }
     }
+    return seg_chunks;
 }
 
-// X rows the 64-row tiles of a sample (every `step`-th tile) touch under a row order: what a clustering is accepted or refused by
-static int64_t sample_tile_columns(const uspmv_scs *s, const std::vector<int32_t> &row_map, int64_t step) {
+// X rows the 64-row tiles of a sample (every `step`-th tile of every seg_stride-th segment of seg_tiles tiles) touch under a row order:
+// what a clustering is accepted or refused by
+static int64_t sample_tile_columns(const uspmv_scs *s, const std::vector<int32_t> &row_map, int64_t step, int64_t seg_tiles = 0, int64_t seg_stride = 1) {
     const int64_t C = s->C, nc = s->n_chunks, T = std::max<int64_t>(1, 64 / C), n_tiles = (nc + T - 1) / T;
     int64_t total = 0;
 #pragma omp parallel reduction(+ : total)
@@ -309,6 +314,7 @@ static int64_t sample_tile_columns(const uspmv_scs *s, const std::vector<int32_t
         std::vector<int32_t> cols;
 #pragma omp for schedule(dynamic, 4)
         for (int64_t t = 0; t < n_tiles; t += step) {
+            if (seg_stride > 1 && (t / seg_tiles) % seg_stride != seg_stride / 2) continue;
             cols.clear();
             for (int64_t c = t * T; c < std::min(nc, (t + 1) * T); ++c) {
                 const int64_t L = s->chunk_lengths[(size_t)c];
@@ -437,28 +443,60 @@ int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vect
         // (clustering works on the caller's struct: there a column index below the row count IS a row position)
         if ((mode == 2 || mode == 4) && nc * C <= (int64_t)INT32_MAX) {
             std::vector<int32_t> cl((size_t)(nc * C));
-            cluster_row_map(s, *row_map, cpw, &cl, mode == 4);
-            const int64_t T = std::max<int64_t>(1, 64 / C), n_tiles = (nc + T - 1) / T, step = std::max<int64_t>(1, n_tiles / 2048);
-            lap("clusters grown");
-            const int64_t before = sample_tile_columns(s, *row_map, step), after = sample_tile_columns(s, cl, step);
-            if (getenv("USPMV_VERBOSE"))
-                fprintf(stderr, "[uspmv] block plan row clustering (mode %d): sampled tiles touch %lld X rows against %lld with the ties undone -> %s\n", mode,
-                        (long long)after, (long long)before, after * 100 < before * 95 ? "kept" : "not kept");
-            if (after * 100 < before * 95) { row_map->swap(cl); changed = true; }
-            lap("sample compared");
+            const int64_t T = std::max<int64_t>(1, 64 / C), n_tiles = (nc + T - 1) / T;
+            // a trial on every 16th segment first (matrices of more than 32 segments): irregular matrices, which gain nothing, stop there
+            const int64_t seg_guess = (nc * C + 65535) / 65536;
+            bool worth = true;
+            if (seg_guess > 32) {
+                const int64_t seg_chunks = cluster_row_map(s, *row_map, cpw, &cl, mode == 4, 16), seg_tiles = std::max<int64_t>(1, seg_chunks / T);
+                const int64_t step = std::max<int64_t>(1, seg_tiles / 128);
+                const int64_t before = sample_tile_columns(s, *row_map, step, seg_tiles, 16), after = sample_tile_columns(s, cl, step, seg_tiles, 16);
+                worth = after * 100 < before * 95;
+                if (verbose) fprintf(stderr, "[uspmv] block plan row clustering (mode %d), trial on every 16th segment: %lld X rows against %lld with the ties undone -> %s\n",
+                                     mode, (long long)after, (long long)before, worth ? "go on" : "not worth it");
+                lap("trial segments");
+            }
+            if (worth) {
+                cluster_row_map(s, *row_map, cpw, &cl, mode == 4);
+                lap("clusters grown");
+                const int64_t step = std::max<int64_t>(1, n_tiles / 2048);
+                const int64_t before = sample_tile_columns(s, *row_map, step), after = sample_tile_columns(s, cl, step);
+                if (verbose)
+                    fprintf(stderr, "[uspmv] block plan row clustering (mode %d): sampled tiles touch %lld X rows against %lld with the ties undone -> %s\n", mode,
+                            (long long)after, (long long)before, after * 100 < before * 95 ? "kept" : "not kept");
+                if (after * 100 < before * 95) { row_map->swap(cl); changed = true; }
+                lap("sample compared");
+            }
         }
     }
     r->C = C; r->sigma = s->sigma; r->n_rows = s->n_rows; r->n_cols = s->n_cols; r->nnz = s->nnz; r->dtype = s->dtype;
     r->n_chunks = nc; r->n_rows_padded = s->n_rows_padded; r->n_elements = s->n_elements;
     r->chunk_ptrs = s->chunk_ptrs; r->chunk_lengths = s->chunk_lengths;
-    r->col_idxs.resize((size_t)s->n_elements);
+    uspmv_resize_huge(r->col_idxs, (size_t)s->n_elements);
     // (a struct rebuilt from device arrays may carry the indices only -- the values then stay on the device and the caller gathers them
     //  there under row_map: uspmv_dmat_optimize_block_device)
     const bool has_values = (int64_t)(s->dtype == USPMV_F64 ? s->values_f64.size() : s->values_f32.size()) == s->n_elements;
-    if (has_values) { if (s->dtype == USPMV_F64) r->values_f64.resize((size_t)s->n_elements); else r->values_f32.resize((size_t)s->n_elements); }
+    if (has_values) { if (s->dtype == USPMV_F64) uspmv_resize_huge(r->values_f64, (size_t)s->n_elements); else uspmv_resize_huge(r->values_f32, (size_t)s->n_elements); }
+    lap("copy allocated");
 #pragma omp parallel for schedule(static)
     for (int64_t c = 0; c < nc; ++c) {
         const int64_t cs = s->chunk_ptrs[(size_t)c], L = s->chunk_lengths[(size_t)c];
+        int64_t from[64];                                    // (C <= 64 wherever a block plan is built; wider chunks take the row loop below)
+        if (C <= 64) {
+            // slot by slot: the C destinations of a slot are contiguous and their sources sit in the few chunks the tile's rows come from
+            for (int64_t i = 0; i < C; ++i) {
+                const int64_t src_row = (*row_map)[(size_t)(c * C + i)];
+                from[i] = s->chunk_ptrs[(size_t)(src_row / C)] + src_row % C;
+            }
+            for (int64_t j = 0; j < L; ++j) {
+                const int64_t dst = cs + j * C, off = j * C;
+                for (int64_t i = 0; i < C; ++i) r->col_idxs[(size_t)(dst + i)] = s->col_idxs[(size_t)(from[i] + off)];
+                if (!has_values) continue;
+                if (s->dtype == USPMV_F64) for (int64_t i = 0; i < C; ++i) r->values_f64[(size_t)(dst + i)] = s->values_f64[(size_t)(from[i] + off)];
+                else for (int64_t i = 0; i < C; ++i) r->values_f32[(size_t)(dst + i)] = s->values_f32[(size_t)(from[i] + off)];
+            }
+            continue;
+        }
         for (int64_t i = 0; i < C; ++i) {
             const int64_t src_row = (*row_map)[(size_t)(c * C + i)];
             const int64_t sc = src_row / C, si = src_row % C, scs = s->chunk_ptrs[(size_t)sc];
