@@ -247,7 +247,7 @@ def other_configs(pkg, B, torch, args, which):
         cpu, same = _cpu_leg(2.0 * s.nnz, fr or fp, fp, yc, y.cpu().numpy(), args.cpu_seconds / 3, "spmv_omp_scs_adv<C=32,double>")
         kind, ntile, nplan = A.plan_info()
         line(config, workload + " scs -c 32 -s 512 -dp", {2: "scs_spmv_sweep<double> (column-window sweep)", 1: "scs_spmv_tlc<double,32>", 0: "scs_spmv_rows<double,32,8>"}[kind],
-             wall, k_ms, byts, 2.0 * s.nnz, same, cpu, setup, {"plan_kind": kind, "plan_tiles_planned": [nplan, ntile], "rows_per_tile": (s.n_rows_padded // ntile) if ntile else None})
+             wall, k_ms, byts, 2.0 * s.nnz, same, cpu, setup, {"plan_kind": kind, "plan_tiles_planned": [nplan, ntile], "rows_per_tile": (s.n_rows_padded // ntile) if ntile else None, "local_index_bits": A.index_bits() if kind == 1 else None})
         del A, s, a, x, y
         t.cuda.empty_cache()
 
@@ -1167,7 +1167,7 @@ def main():
         "dtype": "f64", "data": "synthetic" if not args.mtx else "file",
         "config": {"workload": workload, "C": args.chunk, "sigma": args.sigma, "n_rows": n_global, "nnz": total_nnz,
                    "beta": round(s.nnz / s.n_elements, 6), "x": "5.0 (DefaultValues)", "partition": "none", "halo_overlap": False,
-                   "kernel": {0: "lane-per-row gather", 1: "tile-local-column (LDS-staged x lines, 16-bit local indices)",
+                   "kernel": {0: "lane-per-row gather", 1: f"tile-local-column (LDS-staged x lines, {A.index_bits()}-bit local indices)",
                               2: "column-window sweep (LDS-staged x windows, compacted stream)"}[kind],
                    "plan_tiles_planned": [n_planned, n_tiles], "tuning": tuning},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

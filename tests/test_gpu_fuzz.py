@@ -138,6 +138,14 @@ def check_every_setup(pkg, orc, t, rng, m, C, sigma, f64, tag, expect=None):
     A.optimize(s); check_spmv(A, "host plan")
     A2 = pkg.DeviceMatrix(s); A2.optimize_device(); check_spmv(A2, "device plan")
     assert A.plan_info() == A2.plan_info(), tag
+    for i12 in (0, 2):                             # the plan's local indices as 16-bit words / packed to 12 bits wherever the tiles allow it
+        pkg.set_tuning(tlc_idx12=i12)
+        try:
+            A8 = pkg.DeviceMatrix(s); A8.optimize(s) if i12 else A8.optimize_device()
+        finally:
+            pkg.set_tuning(tlc_idx12=1)
+        assert A8.index_bits() in ((0, 16) if i12 == 0 else (0, 12, 16)), tag + (i12, A8.index_bits())
+        check_spmv(A8, f"plan with tlc_idx12 = {i12} ({A8.index_bits()}-bit local indices)")
     if "kind" in expect: assert A.plan_info()[0] == expect["kind"], tag + (A.plan_info(),)
     if "tile_rows" in expect:
         import ctypes

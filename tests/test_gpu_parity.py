@@ -724,10 +724,14 @@ def test_tile_local_column_kernel_bitexact(pkg, orc, torch_cuda, name):
             s, a, xp = _prep(pkg, m, Cc, sg, code, x0)
             y_or = orc.spmv_scs(Cc, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
             x = _dev(t, xp)
-            for max_lines, tile_rows in ((0, 256), (3, 256), (1, 512), (0, 512), (0, 1024), (5, 1024)):
-                pkg.set_tuning(tlc_tile_rows=tile_rows)
+            for max_lines, tile_rows, i12 in ((0, 256, 2), (0, 256, 0), (3, 256, 2), (1, 512, 1), (0, 512, 2), (0, 1024, 2), (5, 1024, 0)):
+                pkg.set_tuning(tlc_tile_rows=tile_rows, tlc_idx12=i12)      # local indices in 12 bits wherever they can be (2), by the library's rule (1), never (0)
                 A = pkg.DeviceMatrix(s, tlc=True, tlc_max_lines=max_lines)
-                pkg.set_tuning(tlc_tile_rows=0)
+                pkg.set_tuning(tlc_tile_rows=0, tlc_idx12=1)
+                bits = A.index_bits()
+                assert bits == (0 if not A.tlc_staged else 16 if i12 == 0 else bits) and bits in (0, 12, 16), (name, code, Cc, sg, max_lines, tile_rows, i12, bits)
+                pd = A.plan_download() if Cc >= 32 else None      # (narrow chunks: the plan sits on the internal C = 32 copy)
+                if pd is not None and i12 == 2: assert bits == (12 if pd["max_lines_used"] <= 256 else 16), (name, code, Cc, sg, max_lines, tile_rows, bits, pd["max_lines_used"])
                 if Cc < 32:      # narrow chunks are re-chunked to C = 32 internally (same row order)
                     nc32 = (s.n_chunks * Cc + 31) // 32
                     assert A.tlc_tiles in (0, (nc32 + tile_rows // 32 - 1) // (tile_rows // 32))
@@ -752,6 +756,44 @@ def test_tile_local_column_kernel_bitexact(pkg, orc, torch_cuda, name):
         s2 = pkg.convert_to_scs(m, 10, 3)          # C does not divide 256: no plan, still correct
         A2 = pkg.DeviceMatrix(s2, tlc=True)
         assert A2.tlc_tiles == 0
+
+
+def test_local_indices_in_12_bits_every_row_length(pkg, orc, torch_cuda):
+    """scs_spmv_tlc over the 12-bit index stream (pairs of slot groups in three dwords, an odd last group in a dword + a ushort, partial
+    last pairs): banded matrices whose chunk lengths run through every residue mod 8 from 1 to 41, C in {2 ... 256}, both precisions,
+    all tiles / a subset of tiles, bit-identical to the oracle and to the 16-bit stream."""
+    t = torch_cuda
+    rng = np.random.default_rng(12)
+    try:
+        for C in (2, 4, 16, 32, 64, 128, 256):
+            n = 3000
+            I, J = [], []
+            for r in range(n):
+                k = 1 + (r // 64) % 41                               # rows of a 64-row block share their length: every chunk length occurs
+                cols = np.unique(np.clip(r + rng.integers(-300, 301, 3 * k), 0, n - 1))[:k]
+                I += [r] * len(cols); J += cols.tolist()
+            V = rng.standard_normal(len(I))
+            m = pkg.Coo.from_arrays(n, n, np.array(I, np.int32), np.array(J, np.int32), V)
+            for code in (pkg.F64, pkg.F32):
+                s, a, xp = _prep(pkg, m, C, 1, code, rng.standard_normal(n))
+                y_or = orc.spmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], xp)
+                x = _dev(t, xp)
+                got = {}
+                for i12 in (0, 2):
+                    pkg.set_tuning(tlc_idx12=i12)
+                    A = pkg.DeviceMatrix(s, tlc=True)
+                    assert A.tlc_staged == A.tlc_tiles > 0 and A.index_bits() == (12 if i12 else 16), (C, code, i12, A.index_bits(), A.tlc_staged, A.tlc_tiles)
+                    y = t.full((s.n_rows_padded,), 9.0, dtype=A.torch_dtype, device="cuda")
+                    pkg.spmv(A, x, y)
+                    assert np.array_equal(y.cpu().numpy(), y_or), (C, code, i12)
+                    if C < 32: continue                              # (narrow chunks: the plan sits on the internal C = 32 copy, no tile subsets)
+                    ids = t.arange(A.tlc_tiles - 1, -1, -2, dtype=t.int32, device="cuda")     # every other tile, backwards
+                    y2 = t.full((s.n_rows_padded,), 9.0, dtype=A.torch_dtype, device="cuda")
+                    pkg.spmv_tiles(A, ids, x, y2)
+                    got[i12] = y2.cpu().numpy()
+                if C >= 32: assert np.array_equal(got[0], got[2]), (C, code)
+    finally:
+        pkg.set_tuning(tlc_idx12=1)
 
 
 def _random_coo(n, per_row, rng, empty_every=0, band=None):

@@ -85,6 +85,7 @@ _SIGS = {
     "uspmv_spmv_chunks": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "uspmv_spmv_tiles": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "uspmv_dmat_tile_rows": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "uspmv_dmat_index_bits": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "uspmv_dmat_optimize_device": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_optimize_device_ap": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_plan_download": (C.c_int, [_vp, C.POINTER(_i64), _vp, _vp, _vp, _vp]),
@@ -863,6 +864,12 @@ class DeviceMatrix:
         _ck(lib().uspmv_dmat_tile_rows(self.h, C.byref(tr)))
         self.tile_rows = tr.value
         return a.value, b.value
+
+    def index_bits(self):
+        """Bits per tile-local column index the plan's kernel streams (16 | 12; 0 without a plan): uspmv_dmat_index_bits."""
+        b = C.c_int()
+        _ck(lib().uspmv_dmat_index_bits(self.h, C.byref(b)))
+        return b.value
 
     def plan_download(self):
         """Host copies of the tile-local-column plan (tests): dict or None when the handle has no plan."""

@@ -212,6 +212,39 @@ __global__ void rechunk32_kernel(const long n_rows_old, const int C, const int *
     }
 }
 
+// 16-bit local indices -> 12-bit (uspmv_device.hpp: tlc_col12).  One thread per (chunk, row): the row's groups of four indices, two
+// groups to three dwords, an odd last group to a dword + a ushort.
+__global__ void __launch_bounds__(256) plan_pack12(const long n_chunks, const int C, const int *__restrict__ chunk_lengths,
+        const unsigned *__restrict__ c16_ptrs, const unsigned short *__restrict__ col16, const unsigned *__restrict__ c12_ptrs, unsigned *__restrict__ col12) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long c = row / C;
+    if (c >= n_chunks) return;
+    const int i = (int)(row - c * C);
+    const int L = chunk_lengths[c], ngt = (L + 3) >> 2, np = ngt >> 1;
+    const unsigned short *q = col16 + c16_ptrs[c];
+    unsigned *w = col12 + c12_ptrs[c];
+    auto idx = [&](int g, int k) -> unsigned { return (unsigned)q[((long)g * C + i) * 4 + k] & 0xFFFu; };
+    for (int p = 0; p < np; ++p) {
+        unsigned long long lo = 0; unsigned hi = 0;              // 96 bits: index u at bits [12u, 12u + 12)
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long v = idx(2 * p + (u >> 2), u & 3);
+            const int b = 12 * u;
+            if (b < 64) { lo |= v << b; if (b + 12 > 64) hi |= (unsigned)(v >> (64 - b)); }
+            else hi |= (unsigned)(v << (b - 64));
+        }
+        w[(long)(3 * p + 0) * C + i] = (unsigned)lo;
+        w[(long)(3 * p + 1) * C + i] = (unsigned)(lo >> 32);
+        w[(long)(3 * p + 2) * C + i] = hi;
+    }
+    if (ngt & 1) {
+        unsigned long long v48 = 0;
+        for (int k = 0; k < 4; ++k) v48 |= (unsigned long long)idx(ngt - 1, k) << (12 * k);
+        unsigned *t = w + (long)3 * np * C;
+        t[i] = (unsigned)v48;
+        ((unsigned short *)(t + C))[i] = (unsigned short)(v48 >> 32);
+    }
+}
+
 }  // namespace
 
 namespace uspmv_dev {
@@ -220,6 +253,15 @@ int launch_plan_count(const uspmv_dmat *A, long n_tiles, int max_lines, int *d_n
     hipLaunchKernelGGL(plan_count_lines, dim3((unsigned)n_tiles), dim3(256), 0, st, (long)A->n_chunks, (int)A->C, A->chunk_ptrs,
                        A->chunk_lengths, A->col_idxs, max_lines, d_n_lines, d_max_col, A2 ? A2->chunk_ptrs : nullptr,
                        A2 ? A2->chunk_lengths : nullptr, A2 ? A2->col_idxs : nullptr, tile_rows / 256);
+    HIP_TRY(hipGetLastError());
+    return USPMV_OK;
+}
+
+int launch_plan_pack12(const uspmv_dmat *A, const unsigned *d_c16_ptrs, const unsigned short *d_col16, const unsigned *d_c12_ptrs, unsigned *d_col12, hipStream_t st) {
+    const long rows = (long)A->n_chunks * A->C;
+    if (rows == 0) return USPMV_OK;
+    hipLaunchKernelGGL(plan_pack12, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (long)A->n_chunks, (int)A->C, A->chunk_lengths, d_c16_ptrs, d_col16,
+                       d_c12_ptrs, d_col12);
     HIP_TRY(hipGetLastError());
     return USPMV_OK;
 }

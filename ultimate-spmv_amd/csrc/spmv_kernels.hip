@@ -199,7 +199,9 @@ __device__ __forceinline__ float ld_sys(const float *p) {
     return __uint_as_float(__hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
 }
 
-template <typename VT, int CT, bool NT, bool IDS, int SYNC = 0>
+// I12: c16_ptrs / col16 are the handle's 12-BIT arrays (uspmv_device.hpp: tlc_c12_ptrs in dwords, tlc_col12): per pair of slot groups three
+// dwords per row (8 indices), an odd last group a dword + a ushort -- 1.5 instead of 2 bytes of index per non-zero.
+template <typename VT, int CT, bool NT, bool IDS, int SYNC = 0, bool I12 = false>
 __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const int C_rt, const int *__restrict__ chunk_ptrs,
         const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const VT *__restrict__ values,
         const VT *__restrict__ x_arg, VT *__restrict__ y, const int *__restrict__ tile_line_ptr,
@@ -280,6 +282,41 @@ __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const 
             *(vec_t *)(xs + k * 16 + sub * EPL) = v;
         }
         __syncthreads();
+        if constexpr (I12) {
+            if (L > 0) {
+                const VT *vp = values + (long)cs + i;
+                const unsigned *cw = (const unsigned *)col16 + q0 + i;
+                const int ngt = (L + 3) >> 2, np = ngt >> 1;
+#define TLC12_UNPACK(D0, D1, D2)                                                                                      \
+                const unsigned ix[8] = {(D0) & 0xFFFu, ((D0) >> 12) & 0xFFFu, ((D0) >> 24) | (((D1) & 0xFu) << 8), ((D1) >> 4) & 0xFFFu, \
+                                        ((D1) >> 16) & 0xFFFu, ((D1) >> 28) | (((D2) & 0xFFu) << 4), ((D2) >> 8) & 0xFFFu, (D2) >> 20};
+                int p = 0;
+                for (; 8 * p + 8 <= L; ++p) {
+                    VT v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = ld_stream<NT>(vp + (long)(8 * p + u) * C);
+                    const unsigned d0 = ld_stream<NT>(cw + (long)(3 * p) * C), d1 = ld_stream<NT>(cw + (long)(3 * p + 1) * C), d2 = ld_stream<NT>(cw + (long)(3 * p + 2) * C);
+                    TLC12_UNPACK(d0, d1, d2)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc = fma_t(v[u], xs[ix[u]], acc);
+                }
+                if (p < np) {                                    // the last pair holds fewer than eight slots of the row
+                    const unsigned d0 = ld_stream<NT>(cw + (long)(3 * p) * C), d1 = ld_stream<NT>(cw + (long)(3 * p + 1) * C), d2 = ld_stream<NT>(cw + (long)(3 * p + 2) * C);
+                    TLC12_UNPACK(d0, d1, d2)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (8 * p + u < L) acc = fma_t(ld_stream<NT>(vp + (long)(8 * p + u) * C), xs[ix[u]], acc);
+                } else if (ngt & 1) {                            // an odd last group: 48 bits per row
+                    const unsigned *t = (const unsigned *)col16 + q0 + (long)3 * np * C;
+                    const unsigned e0 = ld_stream<NT>(t + i), e1 = ld_stream<NT>((const unsigned short *)(t + C) + i);
+                    const unsigned jx[4] = {e0 & 0xFFFu, (e0 >> 12) & 0xFFFu, (e0 >> 24) | ((e1 & 0xFu) << 8), e1 >> 4};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (8 * np + u < L) acc = fma_t(ld_stream<NT>(vp + (long)(8 * np + u) * C), xs[jx[u]], acc);
+                }
+#undef TLC12_UNPACK
+            }
+        } else
         if (L > 0) {
             const VT *vp = values + (long)cs + i;
             const unsigned long long *cq = (const unsigned long long *)(col16 + q0) + i;
@@ -454,13 +491,16 @@ int launch_spmv_tlc(const uspmv_dmat *A, const int *tile_ids, long n_tiles, cons
     const int C = (int)A->C;
     const unsigned grid = (unsigned)n_tiles;
     const size_t lds = (size_t)A->tlc_max_lines * 16 * sizeof(VT);
+    const bool i12 = A->tlc_col12 != nullptr;                 // (12-bit local indices: uspmv_api.hip tlc_pack12)
+    const unsigned *iptrs = i12 ? A->tlc_c12_ptrs : A->tlc_c16_ptrs;
+    const unsigned short *idata = i12 ? (const unsigned short *)A->tlc_col12 : A->tlc_col16;
 #define TLC_LAUNCH(CTV, NTV, IDSV)                                                                                    \
     do {                                                                                                              \
-        auto kfn = scs_spmv_tlc<VT, CTV, NTV, IDSV>;                                                                 \
+        auto kfn = i12 ? scs_spmv_tlc<VT, CTV, NTV, IDSV, 0, true> : scs_spmv_tlc<VT, CTV, NTV, IDSV>;                \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(A->tlc_tile_rows), lds, st, (long)A->n_chunks, C, A->chunk_ptrs,        \
                            A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, A->tlc_line_ptr, A->tlc_lines,   \
-                           A->tlc_c16_ptrs, A->tlc_col16, (long)A->tlc_x_len, tile_ids, g_tune.xcd_remap, A->n_store, StepArgs{});  \
+                           iptrs, idata, (long)A->tlc_x_len, tile_ids, g_tune.xcd_remap, A->n_store, StepArgs{});  \
     } while (0)
 #define TLC_LAUNCH_C(NTV, IDSV) do { if (C == 32) TLC_LAUNCH(32, NTV, IDSV); else TLC_LAUNCH(0, NTV, IDSV); } while (0)
     if (tile_ids) { if (g_tune.nontemporal) TLC_LAUNCH_C(true, true); else TLC_LAUNCH_C(false, true); }
@@ -477,13 +517,16 @@ int launch_spmv_tlc_step(const uspmv_dmat *A, const int *step_ids, const StepArg
     if (n == 0) return USPMV_OK;
     const int C = (int)A->C;
     const size_t lds = (size_t)A->tlc_max_lines * 16 * sizeof(VT);
+    const bool i12 = A->tlc_col12 != nullptr;
+    const unsigned *iptrs = i12 ? A->tlc_c12_ptrs : A->tlc_c16_ptrs;
+    const unsigned short *idata = i12 ? (const unsigned short *)A->tlc_col12 : A->tlc_col16;
 #define TLC_STEP(CTV, SY)                                                                                             \
     do {                                                                                                              \
-        auto kfn = scs_spmv_tlc<VT, CTV, true, true, SY>;                                                             \
+        auto kfn = i12 ? scs_spmv_tlc<VT, CTV, true, true, SY, true> : scs_spmv_tlc<VT, CTV, true, true, SY>;         \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)n), dim3(A->tlc_tile_rows), lds, st, (long)A->n_chunks, C, A->chunk_ptrs,  \
                            A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, A->tlc_line_ptr, A->tlc_lines,   \
-                           A->tlc_c16_ptrs, A->tlc_col16, (long)A->tlc_x_len, step_ids, g_tune.xcd_remap, A->n_store, sa); \
+                           iptrs, idata, (long)A->tlc_x_len, step_ids, g_tune.xcd_remap, A->n_store, sa); \
     } while (0)
     if (sync == 1) { if (C == 32) TLC_STEP(32, 1); else TLC_STEP(0, 1); }
     else { if (C == 32) TLC_STEP(32, 2); else TLC_STEP(0, 2); }

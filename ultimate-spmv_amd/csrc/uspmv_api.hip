@@ -236,6 +236,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "rechunk")) g_tune.rechunk = value != 0;
     else if (!strcmp(key, "tlc_auto_tile")) g_tune.tlc_auto_tile = value != 0;
     else if (!strcmp(key, "tlc_measure_tile")) g_tune.tlc_measure_tile = value != 0;
+    else if (!strcmp(key, "tlc_idx12")) g_tune.tlc_idx12 = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (!strcmp(key, "tlc_tile_rows")) {
         if (value != 0 && value != 256 && value != 512 && value != 1024) return uspmv::fail(USPMV_ERR_INVALID, "tlc_tile_rows must be 0|256|512|1024");
         g_tune.tlc_tile_rows = value;
@@ -299,6 +300,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "tlc_tile_rows")) *value = g_tune.tlc_tile_rows;
     else if (!strcmp(key, "tlc_auto_tile")) *value = g_tune.tlc_auto_tile;
     else if (!strcmp(key, "tlc_measure_tile")) *value = g_tune.tlc_measure_tile;
+    else if (!strcmp(key, "tlc_idx12")) *value = g_tune.tlc_idx12;
     else return uspmv::fail(USPMV_ERR_INVALID, "uspmv_get_tuning: unknown key '%s'", key);
     return USPMV_OK;
 }
@@ -448,7 +450,8 @@ static int sweep_plan_install(uspmv_dmat_t *A, uspmv_dmat_t *B, const uspmv_scs_
                               int64_t *n_tiles, int64_t *n_sweep, const char *who);
 static void tlc_release(uspmv_dmat_t *A) {
     (void)hipFree(A->tlc_line_ptr); (void)hipFree(A->tlc_lines); (void)hipFree(A->tlc_c16_ptrs); (void)hipFree(A->tlc_col16);
-    A->tlc_line_ptr = A->tlc_lines = nullptr; A->tlc_c16_ptrs = nullptr; A->tlc_col16 = nullptr;
+    (void)hipFree(A->tlc_c12_ptrs); (void)hipFree(A->tlc_col12);
+    A->tlc_line_ptr = A->tlc_lines = nullptr; A->tlc_c16_ptrs = nullptr; A->tlc_col16 = nullptr; A->tlc_c12_ptrs = A->tlc_col12 = nullptr;
     A->tlc = false; A->tlc_plan_id = 0;
 }
 
@@ -549,6 +552,79 @@ static int measured_tile_rows(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, c
     return best;
 }
 
+// The plan's local indices once more in 12 bits (single structs whose tiles list at most 256 lines, i.e. local indices below 4096; even C):
+// what scs_spmv_tlc then streams instead of the 16-bit array -- 1.5 instead of 2 bytes per non-zero.  The 16-bit array stays (the
+// adaptive-precision kernels, uspmv_dmat_plan_download and the plan digests read it).  cl: the chunk lengths when the caller has them on
+// the host, else they are copied back (4 bytes per chunk).
+static int tlc_pack12(uspmv_dmat_t *A, const std::vector<int32_t> *cl, const char *who) {
+    if (!A->tlc || !g_tune.tlc_idx12 || A->tlc_max_lines > 256 || A->C < 2 || A->C % 2 != 0 || A->n_chunks < 1) return USPMV_OK;
+    std::vector<int32_t> own;
+    if (!cl || (int64_t)cl->size() != A->n_chunks) {
+        own.resize((size_t)A->n_chunks);
+        HIP_TRY(hipMemcpy(own.data(), A->chunk_lengths, 4 * (size_t)A->n_chunks, hipMemcpyDeviceToHost));
+        cl = &own;
+    }
+    const int64_t C = A->C, nc = A->n_chunks;
+    std::vector<uint32_t> p12((size_t)nc + 1);
+    int64_t tot = 0;                                             // dwords
+    for (int64_t c = 0; c < nc; ++c) {
+        p12[(size_t)c] = (uint32_t)tot;
+        const int64_t ngt = ((int64_t)(*cl)[(size_t)c] + 3) / 4;
+        tot += (ngt / 2) * 3 * C + (ngt & 1) * (C + C / 2);
+        if (tot > (int64_t)UINT32_MAX) return USPMV_OK;          // (too large for 32-bit offsets: the 16-bit array serves)
+    }
+    p12[(size_t)nc] = (uint32_t)tot;
+    hipError_t e = hipMalloc((void **)&A->tlc_c12_ptrs, 4 * ((size_t)nc + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&A->tlc_col12, 4 * (size_t)std::max<int64_t>(tot, 1));
+    if (e == hipSuccess) e = hipMemcpy(A->tlc_c12_ptrs, p12.data(), 4 * ((size_t)nc + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess && uspmv_dev::launch_plan_pack12(A, A->tlc_c16_ptrs, A->tlc_col16, A->tlc_c12_ptrs, A->tlc_col12, nullptr) != USPMV_OK) e = hipErrorUnknown;
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        (void)hipFree(A->tlc_c12_ptrs); (void)hipFree(A->tlc_col12); A->tlc_c12_ptrs = A->tlc_col12 = nullptr;
+        return uspmv::fail(USPMV_ERR_HIP, "%s: packing the local indices to 12 bits failed: %s", who, hipGetErrorString(e));
+    }
+    // Keep it?  The 12-bit stream costs more load instructions per row (three dwords per eight slots, a dword + a ushort for an odd last
+    // group, against one 8-byte load per four slots): rows of 27 and more entries gain 3-15 % (profiles/r04/idx12_probe.txt), rows of a
+    // dozen entries and the KKT matrix (rows of 5-28) lose 4 %.  Large matrices are timed both ways on the spot (where measuring is
+    // allowed: "tlc_measure_tile", not inside uspmv_dist_create*), the others decided by their mean row length.
+    auto drop = [&]() { (void)hipFree(A->tlc_c12_ptrs); (void)hipFree(A->tlc_col12); A->tlc_c12_ptrs = A->tlc_col12 = nullptr; };
+    const double mean_len = (double)A->n_elements / (double)(nc * C);
+    const bool measure = g_tune.tlc_measure_tile && uspmv_dev::tl_measure_off <= 0 && nc * C >= (int64_t)1 << 20;
+    if (g_tune.tlc_idx12 == 2) return USPMV_OK;                  // ("tlc_idx12" 2: kept wherever it can be built -- tests, probes)
+    if (!measure) {
+        if (mean_len < 16.0) drop();
+        return USPMV_OK;
+    }
+    const size_t vsz = A->dtype == USPMV_F64 ? 8 : 4;
+    void *x = nullptr, *y = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const size_t xb = vsz * (size_t)std::max<int64_t>(A->tlc_x_len + 16, 16), yb = vsz * (size_t)std::max<int64_t>(nc * C, 1);
+    bool ok = hipMalloc(&x, xb) == hipSuccess && hipMalloc(&y, yb) == hipSuccess && hipMemset(x, 0, xb) == hipSuccess &&
+              hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    float best[2] = {1e30f, 1e30f};                              // [0] 16-bit, [1] 12-bit
+    uint32_t *const c12 = A->tlc_col12;
+    for (int round = 0; round < 5 && ok; ++round) {              // (round 0 warms the clocks up)
+        const int which = round == 0 ? 1 : (round & 1);
+        A->tlc_col12 = which ? c12 : nullptr;
+        ok = hipEventRecord(e0, nullptr) == hipSuccess;
+        for (int l = 0; l < 3 && ok; ++l)
+            ok = (A->dtype == USPMV_F64 ? launch_spmv_tlc<double>(A, nullptr, (long)A->tlc_n_tiles, (const double *)x, (double *)y, nullptr)
+                                        : launch_spmv_tlc<float>(A, nullptr, (long)A->tlc_n_tiles, (const float *)x, (float *)y, nullptr)) == USPMV_OK;
+        float ms = 0;
+        ok = ok && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        if (ok && round > 0) best[which] = std::min(best[which], ms);
+    }
+    A->tlc_col12 = c12;
+    (void)hipFree(x); (void)hipFree(y);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (!ok) { (void)hipGetLastError(); if (mean_len < 16.0) drop(); return USPMV_OK; }
+    if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] %s: local indices in 12 bits %.4f ms per SpMV against %.4f in 16 bits -> %s\n", who, best[1] / 3, best[0] / 3,
+                                         best[1] < 0.99f * best[0] ? "12 bits" : "16 bits");
+    if (!(best[1] < 0.99f * best[0])) drop();
+    return USPMV_OK;
+}
+
 int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
     if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: NULL argument");
     if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: layout-only struct; the plan builder needs the host column indices");
@@ -612,7 +688,7 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     }
     A->tlc = true; A->tlc_tile_rows = p.tile_rows; A->tlc_max_lines = p.max_lines_used; A->tlc_x_len = p.x_len_min; A->tlc_n_tiles = p.n_tiles;
     A->tlc_staged = p.n_staged_tiles;
-    return USPMV_OK;
+    return tlc_pack12(A, &s->chunk_lengths, "uspmv_dmat_optimize");
 }
 
 // 16-bit index offsets per chunk from the chunk lengths (O(n_chunks) on the host); false: too large for 32-bit offsets
@@ -727,6 +803,7 @@ static int device_plan_install_rows(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_li
         M->tlc = true; M->tlc_tile_rows = R; M->tlc_max_lines = used; M->tlc_x_len = (int64_t)max_col + 1; M->tlc_n_tiles = nt;
         M->tlc_staged = staged; M->tlc_plan_id = id;
     }
+    if (!B) return tlc_pack12(A, nullptr, who);
     return USPMV_OK;
 }
 
@@ -1709,6 +1786,13 @@ int uspmv_dmat_block_plan_info(const uspmv_dmat_t *A, int64_t meta[10]) {
 int uspmv_dmat_tile_rows(const uspmv_dmat_t *A, int *tile_rows) {
     if (!A || !tile_rows) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_tile_rows: NULL argument");
     *tile_rows = A->tlc ? A->tlc_tile_rows : 0;
+    return USPMV_OK;
+}
+
+int uspmv_dmat_index_bits(const uspmv_dmat_t *A, int *bits) {
+    if (!A || !bits) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_index_bits: NULL argument");
+    const uspmv_dmat_t *M = (A->alt && g_tune.rechunk) ? A->alt : A;
+    *bits = !M->tlc ? 0 : M->tlc_col12 ? 12 : 16;
     return USPMV_OK;
 }
 

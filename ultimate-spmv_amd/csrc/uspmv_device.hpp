@@ -45,6 +45,10 @@ struct uspmv_dmat {
     int32_t *tlc_line_ptr = nullptr, *tlc_lines = nullptr;
     uint32_t *tlc_c16_ptrs = nullptr;
     uint16_t *tlc_col16 = nullptr;
+    // ... and the same local indices packed to 12 bits (plans of at most 256 lines per tile: 9.5 instead of 10 bytes per non-zero of the stream):
+    // per chunk, at tlc_c12_ptrs[c] dwords: for every PAIR of slot groups three planes of C dwords (96 bits per row = 8 indices), then
+    // for an odd last group one plane of C dwords + one of C ushorts (48 bits per row).  What scs_spmv_tlc reads when present.
+    uint32_t *tlc_c12_ptrs = nullptr, *tlc_col12 = nullptr;
     // block (SpMMV) plan: 64-row tiles, per tile the list of X rows it touches (uspmv_dmat_optimize_block)
     bool bt = false;
     int bt_max_rows = 0, bt_tile_rows = 64;
@@ -200,6 +204,8 @@ struct Tuning {
     int spmmv_phase_rows = 256;  // ... X rows per phase (256 | 512)
     int spmmv_list_plan = 0;   // NEXT optimize_block: also build the one-list-per-tile plan (variants 4 / 5 / 6) when the phased kernel can take the matrix
     int spmmv_idx8 = 1;        // NEXT optimize_block: one-byte phase-local indices when every phase lists <= 256 rows
+    int tlc_idx12 = 1;       // NEXT optimize: tile-local-column plans of <= 256 lines per tile also get their local indices packed to 12 bits: 0 = never,
+                             // 1 = kept where it measures (>= 2^20 rows) or is expected (mean row length >= 16) faster, 2 = kept wherever it can be built
     int spmmv_reorder = 4;  // block plan's private copy of the entries (host planner): 1 = rows of equal-length chunks of a sigma window back in original order;
                             // 4 = on top of that, rows re-dealt to the tiles as FLAT patches of the matrix graph (grown along the slots of one phase
                             // around the diagonal: 7.9 instead of 11.9 staged X rows per row on config 3; kept only where a sample of tiles
@@ -250,6 +256,7 @@ int launch_spmv_ap_chunks(const uspmv_dmat *dp, const uspmv_dmat *sp, const int 
 // (A2 / the *_2 arrays: optional second struct sharing the plan -- the sp part of an ap[dp_sp] pair)
 int launch_plan_count(const uspmv_dmat *A, long n_tiles, int max_lines, int *d_n_lines, int *d_max_col, hipStream_t st,
                       const uspmv_dmat *A2 = nullptr, int tile_rows = 256);                                               // plan_kernels.hip
+int launch_plan_pack12(const uspmv_dmat *A, const unsigned *d_c16_ptrs, const unsigned short *d_col16, const unsigned *d_c12_ptrs, unsigned *d_col12, hipStream_t st);   // plan_kernels.hip
 int launch_plan_write(const uspmv_dmat *A, long n_tiles, const int *d_tile_line_ptr, const unsigned *d_c16_ptrs, int *d_tile_lines,
                       unsigned short *d_col16, hipStream_t st, const uspmv_dmat *A2 = nullptr, const unsigned *d_c16_ptrs2 = nullptr,
                       unsigned short *d_col16_2 = nullptr, int tile_rows = 256);                                           // plan_kernels.hip
