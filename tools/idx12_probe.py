@@ -35,10 +35,8 @@ def main():
         H = {}
         pkg.set_tuning(tlc_measure_tile=0)                       # (no on-the-spot verdict: both forms are wanted here)
         for v in (0, 1):
-            pkg.set_tuning(tlc_idx12=v)
+            pkg.set_tuning(tlc_idx12=2 if v else 0)
             H[v] = pkg.DeviceMatrix(s, tlc=True)
-            if v and H[v].index_bits() != 12:                     # (the mean-row-length rule dropped it: pack regardless for the comparison)
-                print(json.dumps(dict(matrix=name, note="12-bit indices not kept by the mean-row-length rule", bits=H[v].index_bits())), flush=True)
         pkg.set_tuning(tlc_idx12=1, tlc_measure_tile=1)
         Hm = pkg.DeviceMatrix(s, tlc=True)                        # what the library decides on its own (measured on the spot for >= 2^20 rows)
         auto = dict(bits=Hm.index_bits(), tile_rows=Hm.tile_rows)

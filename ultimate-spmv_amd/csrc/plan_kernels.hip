@@ -213,7 +213,7 @@ __global__ void rechunk32_kernel(const long n_rows_old, const int C, const int *
 }
 
 // 16-bit local indices -> 12-bit (uspmv_device.hpp: tlc_col12).  One thread per (chunk, row): the row's groups of four indices, two
-// groups to three dwords, an odd last group to a dword + a ushort.
+// groups to three consecutive dwords, an odd last group to a dword + a ushort (in two planes of the chunk).
 __global__ void __launch_bounds__(256) plan_pack12(const long n_chunks, const int C, const int *__restrict__ chunk_lengths,
         const unsigned *__restrict__ c16_ptrs, const unsigned short *__restrict__ col16, const unsigned *__restrict__ c12_ptrs, unsigned *__restrict__ col12) {
     const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,9 +232,8 @@ __global__ void __launch_bounds__(256) plan_pack12(const long n_chunks, const in
             if (b < 64) { lo |= v << b; if (b + 12 > 64) hi |= (unsigned)(v >> (64 - b)); }
             else hi |= (unsigned)(v << (b - 64));
         }
-        w[(long)(3 * p + 0) * C + i] = (unsigned)lo;
-        w[(long)(3 * p + 1) * C + i] = (unsigned)(lo >> 32);
-        w[(long)(3 * p + 2) * C + i] = hi;
+        unsigned *t3 = w + ((long)p * C + i) * 3;
+        t3[0] = (unsigned)lo; t3[1] = (unsigned)(lo >> 32); t3[2] = hi;
     }
     if (ngt & 1) {
         unsigned long long v48 = 0;
@@ -258,9 +257,9 @@ int launch_plan_count(const uspmv_dmat *A, long n_tiles, int max_lines, int *d_n
 }
 
 int launch_plan_pack12(const uspmv_dmat *A, const unsigned *d_c16_ptrs, const unsigned short *d_col16, const unsigned *d_c12_ptrs, unsigned *d_col12, hipStream_t st) {
-    const long rows = (long)A->n_chunks * A->C;
-    if (rows == 0) return USPMV_OK;
-    hipLaunchKernelGGL(plan_pack12, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (long)A->n_chunks, (int)A->C, A->chunk_lengths, d_c16_ptrs, d_col16,
+    const long n_rows = (long)A->n_chunks * A->C;
+    if (n_rows == 0) return USPMV_OK;
+    hipLaunchKernelGGL(plan_pack12, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, (long)A->n_chunks, (int)A->C, A->chunk_lengths, d_c16_ptrs, d_col16,
                        d_c12_ptrs, d_col12);
     HIP_TRY(hipGetLastError());
     return USPMV_OK;

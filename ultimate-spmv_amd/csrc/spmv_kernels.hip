@@ -200,7 +200,8 @@ __device__ __forceinline__ float ld_sys(const float *p) {
 }
 
 // I12: c16_ptrs / col16 are the handle's 12-BIT arrays (uspmv_device.hpp: tlc_c12_ptrs in dwords, tlc_col12): per pair of slot groups three
-// dwords per row (8 indices), an odd last group a dword + a ushort -- 1.5 instead of 2 bytes of index per non-zero.
+// consecutive dwords per row (8 indices, one global_load_dwordx3), an odd last group a dword + a ushort -- 1.5 instead of 2 bytes of index
+// per non-zero.
 template <typename VT, int CT, bool NT, bool IDS, int SYNC = 0, bool I12 = false>
 __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const int C_rt, const int *__restrict__ chunk_ptrs,
         const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const VT *__restrict__ values,
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const 
         if constexpr (I12) {
             if (L > 0) {
                 const VT *vp = values + (long)cs + i;
-                const unsigned *cw = (const unsigned *)col16 + q0 + i;
+                const unsigned *cw = (const unsigned *)col16 + q0 + (long)i * 3;
                 const int ngt = (L + 3) >> 2, np = ngt >> 1;
 #define TLC12_UNPACK(D0, D1, D2)                                                                                      \
                 const unsigned ix[8] = {(D0) & 0xFFFu, ((D0) >> 12) & 0xFFFu, ((D0) >> 24) | (((D1) & 0xFu) << 8), ((D1) >> 4) & 0xFFFu, \
@@ -295,13 +296,15 @@ __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const 
                     VT v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) v[u] = ld_stream<NT>(vp + (long)(8 * p + u) * C);
-                    const unsigned d0 = ld_stream<NT>(cw + (long)(3 * p) * C), d1 = ld_stream<NT>(cw + (long)(3 * p + 1) * C), d2 = ld_stream<NT>(cw + (long)(3 * p + 2) * C);
+                    const unsigned *t3 = cw + (long)p * 3 * C;
+                    const unsigned d0 = ld_stream<NT>(t3), d1 = ld_stream<NT>(t3 + 1), d2 = ld_stream<NT>(t3 + 2);   // (one global_load_dwordx3)
                     TLC12_UNPACK(d0, d1, d2)
 #pragma unroll
                     for (int u = 0; u < 8; ++u) acc = fma_t(v[u], xs[ix[u]], acc);
                 }
                 if (p < np) {                                    // the last pair holds fewer than eight slots of the row
-                    const unsigned d0 = ld_stream<NT>(cw + (long)(3 * p) * C), d1 = ld_stream<NT>(cw + (long)(3 * p + 1) * C), d2 = ld_stream<NT>(cw + (long)(3 * p + 2) * C);
+                    const unsigned *t3 = cw + (long)p * 3 * C;
+                    const unsigned d0 = ld_stream<NT>(t3), d1 = ld_stream<NT>(t3 + 1), d2 = ld_stream<NT>(t3 + 2);   // (one global_load_dwordx3)
                     TLC12_UNPACK(d0, d1, d2)
 #pragma unroll
                     for (int u = 0; u < 8; ++u)

@@ -583,9 +583,8 @@ static int tlc_pack12(uspmv_dmat_t *A, const std::vector<int32_t> *cl, const cha
         (void)hipFree(A->tlc_c12_ptrs); (void)hipFree(A->tlc_col12); A->tlc_c12_ptrs = A->tlc_col12 = nullptr;
         return uspmv::fail(USPMV_ERR_HIP, "%s: packing the local indices to 12 bits failed: %s", who, hipGetErrorString(e));
     }
-    // Keep it?  The 12-bit stream costs more load instructions per row (three dwords per eight slots, a dword + a ushort for an odd last
-    // group, against one 8-byte load per four slots): rows of 27 and more entries gain 3-15 % (profiles/r04/idx12_probe.txt), rows of a
-    // dozen entries and the KKT matrix (rows of 5-28) lose 4 %.  Large matrices are timed both ways on the spot (where measuring is
+    // Keep it?  Not every matrix gains (profiles/r04/idx12_probe_*.txt: the 253^3 stencil 1.5-9.5 % depending on the box, the 304^3 one between
+    // -15 % and +2 %, rows of a dozen entries +-1 %).  Large matrices are timed both ways on the spot (where measuring is
     // allowed: "tlc_measure_tile", not inside uspmv_dist_create*), the others decided by their mean row length.
     auto drop = [&]() { (void)hipFree(A->tlc_c12_ptrs); (void)hipFree(A->tlc_col12); A->tlc_c12_ptrs = A->tlc_col12 = nullptr; };
     const double mean_len = (double)A->n_elements / (double)(nc * C);

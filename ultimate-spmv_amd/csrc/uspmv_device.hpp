@@ -46,8 +46,9 @@ struct uspmv_dmat {
     uint32_t *tlc_c16_ptrs = nullptr;
     uint16_t *tlc_col16 = nullptr;
     // ... and the same local indices packed to 12 bits (plans of at most 256 lines per tile: 9.5 instead of 10 bytes per non-zero of the stream):
-    // per chunk, at tlc_c12_ptrs[c] dwords: for every PAIR of slot groups three planes of C dwords (96 bits per row = 8 indices), then
-    // for an odd last group one plane of C dwords + one of C ushorts (48 bits per row).  What scs_spmv_tlc reads when present.
+    // per chunk, at tlc_c12_ptrs[c] dwords: for every PAIR of slot groups [row][3 dwords] (96 bits per row = 8 indices, one 12-byte load per
+    // lane; three planes of C dwords measured 3 % slower), then for an odd last group one plane of C dwords + one of C ushorts (48 bits per
+    // row).  What scs_spmv_tlc reads when present.
     uint32_t *tlc_c12_ptrs = nullptr, *tlc_col12 = nullptr;
     // block (SpMMV) plan: 64-row tiles, per tile the list of X rows it touches (uspmv_dmat_optimize_block)
     bool bt = false;
