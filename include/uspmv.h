@@ -251,7 +251,7 @@ int uspmv_dmat_plan_download(const uspmv_dmat_t *m, int64_t meta[4], int32_t *ti
 /* Rows per tile of the plan (256 | 512 | 1024; 0 = no plan).  A tile covers tile_rows/C consecutive chunks. */
 int uspmv_dmat_tile_rows(const uspmv_dmat_t *m, int *tile_rows);
 /* Bits per tile-local column index the plan's kernel streams: 16, or 12 where the plan packed them (tiles of at most 256 lines; kept when
- * it measured -- large matrices -- or is expected -- mean row length >= 16 -- to be faster; tuning key "tlc_idx12" 0 switches it off); 0 = no plan */
+ * the mean row length is >= 8; tuning key "tlc_idx12" 0 switches it off, 2 keeps it wherever it can be built); 0 = no plan */
 int uspmv_dmat_index_bits(const uspmv_dmat_t *m, int *bits);
 /* uspmv_spmv over a subset of tiles (d_tile_ids[n_ids]) of a handle with a plan: the interior /
  * boundary split of the halo-overlap scheme at tile granularity.  Entries < 0 are skipped (a list another kernel switches on or off). */

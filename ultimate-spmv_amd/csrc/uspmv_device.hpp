@@ -206,7 +206,7 @@ struct Tuning {
     int spmmv_list_plan = 0;   // NEXT optimize_block: also build the one-list-per-tile plan (variants 4 / 5 / 6) when the phased kernel can take the matrix
     int spmmv_idx8 = 1;        // NEXT optimize_block: one-byte phase-local indices when every phase lists <= 256 rows
     int tlc_idx12 = 1;       // NEXT optimize: tile-local-column plans of <= 256 lines per tile also get their local indices packed to 12 bits: 0 = never,
-                             // 1 = kept where it measures (>= 2^20 rows) or is expected (mean row length >= 16) faster, 2 = kept wherever it can be built
+                             // 1 = kept when the mean row length is >= 8, 2 = kept wherever it can be built
     int spmmv_reorder = 4;  // block plan's private copy of the entries (host planner): 1 = rows of equal-length chunks of a sigma window back in original order;
                             // 4 = on top of that, rows re-dealt to the tiles as FLAT patches of the matrix graph (grown along the slots of one phase
                             // around the diagonal: 7.9 instead of 11.9 staged X rows per row on config 3; kept only where a sample of tiles
