@@ -104,3 +104,30 @@ def test_solve_mode_with_the_conversion_on_the_device(pkg, tmp_path):
         assert r.returncode == 0 and "Total Gflops" in r.stdout, (extra, r.stdout, r.stderr)
     r = subprocess.run([EXE, mtx_path("bcsstk13"), "scs", "-c", "32", "-s", "512", "-ap[dp_sp]", "-ap_threshold_1", "1", "-convert", "device"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "one-precision" in (r.stdout + r.stderr)
+
+
+def test_tune_flag_passes_library_tuning_keys(pkg, tmp_path):
+    """-tune key=value (repeatable): the 12-bit / 16-bit index stream of the SpMV plan and the block plan's row order / phase cuts give the
+    goldens' bits in solve mode, single and block vectors; an unknown key or a malformed pair ends the run with the library's message."""
+    g = golden("solve.npz")
+    name, C, sg = "bcsstk13", 32, 64
+    jobs = []
+    for tag, tune, extra in (("i12off", ["-tune", "tlc_idx12=0"], []), ("i12on", ["-tune", "tlc_idx12=2"], []),
+                             ("ties", ["-tune", "spmmv_reorder=1", "-tune", "spmmv_phase_dp=0"], ["-block_vec_size", "8"]),
+                             ("patches", ["-tune", "spmmv_reorder=4", "-tune", "spmmv_phase_dp=24"], ["-block_vec_size", "8"])):
+        jobs.append((tag, [EXE, mtx_path(name), "scs", "-c", str(C), "-s", str(sg), "-mode", "s", "-rev", "3", "-rand_x", "1", "-dp", "-validate", "0"] + tune + extra))
+    done = _harness_runs(tmp_path, jobs)
+    want = g[f"{name}_scs_C{C}_s{sg}_f64_r1"]
+    for tag in ("i12off", "i12on"):
+        r, yf = done[tag]
+        assert r.returncode == 0, (tag, r.stdout, r.stderr)
+        assert np.array_equal(np.fromfile(yf, want.dtype), want), tag
+    ys = {}
+    for tag in ("ties", "patches"):
+        r, yf = done[tag]
+        assert r.returncode == 0, (tag, r.stdout, r.stderr)
+        ys[tag] = np.fromfile(yf, np.float64)
+    assert ys["ties"].size >= want.size and np.array_equal(ys["ties"], ys["patches"])
+    for bad in (["-tune", "no_such_key=1"], ["-tune", "tlc_idx12"]):
+        r = subprocess.run([EXE, mtx_path(name), "scs"] + bad, cwd=tmp_path, capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and ("unknown key" in (r.stdout + r.stderr) or "key=value" in (r.stdout + r.stderr)), (bad, r.stdout, r.stderr)

@@ -82,6 +82,7 @@ void usage() {
             "  -mpi_mode <singlevec|multivec|bulkvec>\n"
             "  -bench_steps <int> -bench_warmup <int> -json <file|-> (fixed-count protocol, JSON report)  -x_prepared <0|1> (bench mode, column-major block vectors: X re-laid out once)\n"
             "  -convert <host|device|device_stable> (where convert_to_scs runs; device_stable: ties of the sigma sort in original order)\n"
+            "  -tune <key>=<int> (a tuning key of the library, e.g. tlc_idx12=0, spmmv_reorder=1; repeatable)\n"
             "  multi-rank runs: -check_y <0|1> -step_form <auto|auto_all|overlap|plain|pad|fused>\n"
             "  -seg_metis [-part_file <file>]: graph partition (built-in level-set partitioner, or part ids from a gpmetis-style file)\n");
 }
@@ -130,6 +131,12 @@ Config parse(int argc, char **argv) {
         else if (a == "-check_y") c.check_y = atoi(need(i));
         else if (a == "-json") c.json = need(i);
         else if (a == "-x_prepared") c.x_prepared = atoi(need(i));
+        else if (a == "-tune") {                                // -tune key=value: a library tuning key (uspmv_set_tuning), applied at once; repeatable
+            const std::string kv = need(i);
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos || eq == 0 || eq + 1 >= kv.size()) die("tune takes key=value.");
+            if (uspmv_set_tuning(kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1)) != USPMV_OK) die(std::string("tune: ") + uspmv_last_error());
+        }
         else if (a == "-convert") { c.convert = need(i); if (c.convert != "host" && c.convert != "device" && c.convert != "device_stable") die("convert must be host, device or device_stable."); }
         else if (a == "-step_form") { c.step_form = need(i); if (c.step_form != "auto" && c.step_form != "auto_all" && c.step_form != "overlap" && c.step_form != "plain" && c.step_form != "pad" && c.step_form != "fused") die("step_form must be auto, auto_all, overlap, plain, pad or fused."); }
         else if (a == "-block_vec_layout") { std::string v = need(i); if (v == "colwise") c.layout = USPMV_COLWISE; else if (v == "rowwise") c.layout = USPMV_ROWWISE; else die("block_vec_layout must be colwise or rowwise."); }
