@@ -628,6 +628,7 @@ def cli_measure(args, parents, scaling, grid, timeout_s, host_exchange=False, ea
         env = dict(os.environ, OMP_NUM_THREADS=str(cores), USPMV_JOB_ID=job, USPMV_STAGES="1", RANK=str(r), WORLD_SIZE=str(world),
                    LOCAL_RANK=str(r) if parents.self_launch else os.environ.get("LOCAL_RANK", str(r)))
         env.setdefault("USPMV_HC_TIMEOUT", str(int(timeout_s)))     # (the children's rendezvous gives up with them, not an hour later)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # (dmabuf IPC: without it RCCL's hipIpcGetMemHandle fails on this driver)
         if host_exchange:
             env["USPMV_EXCHANGE"] = "host"
         if args.no_overlap:

@@ -110,7 +110,7 @@ def test_tune_flag_passes_library_tuning_keys(pkg, tmp_path):
     """-tune key=value (repeatable): the 12-bit / 16-bit index stream of the SpMV plan and the block plan's row order / phase cuts give the
     goldens' bits in solve mode, single and block vectors; an unknown key or a malformed pair ends the run with the library's message."""
     g = golden("solve.npz")
-    name, C, sg = "bcsstk13", 32, 64
+    name, C, sg = "impcol_e", 32, 64          # (the solve goldens hold FDM-2d-16 / matrix1 / impcol_e)
     jobs = []
     for tag, tune, extra in (("i12off", ["-tune", "tlc_idx12=0"], []), ("i12on", ["-tune", "tlc_idx12=2"], []),
                              ("ties", ["-tune", "spmmv_reorder=1", "-tune", "spmmv_phase_dp=0"], ["-block_vec_size", "8"]),
