@@ -127,7 +127,8 @@ def test_tune_flag_passes_library_tuning_keys(pkg, tmp_path):
         r, yf = done[tag]
         assert r.returncode == 0, (tag, r.stdout, r.stderr)
         ys[tag] = np.fromfile(yf, np.float64)
-    assert ys["ties"].size >= want.size and np.array_equal(ys["ties"], ys["patches"])
+    assert ys["ties"].size == 8 * want.size and np.array_equal(ys["ties"], ys["patches"])
+    assert np.array_equal(ys["ties"][:want.size], want)      # (column 0 of the block vector draws the x of the single-vector run)
     for bad in (["-tune", "no_such_key=1"], ["-tune", "tlc_idx12"]):
         r = subprocess.run([EXE, mtx_path(name), "scs"] + bad, cwd=tmp_path, capture_output=True, text=True, timeout=60)
         assert r.returncode != 0 and ("unknown key" in (r.stdout + r.stderr) or "key=value" in (r.stdout + r.stderr)), (bad, r.stdout, r.stderr)

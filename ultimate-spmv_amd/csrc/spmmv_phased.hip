@@ -335,9 +335,11 @@ bool launch_spmmv_quadph(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool 
 namespace uspmv_dev {
 
 bool spmmv_phased(const uspmv_dmat *A, const double *X, double *Y, long ld, bool ycol, int xmode, hipStream_t st) {
+    if (xmode == 0 && g_tune.spmmv_stream > 0 && A->ps_desc && spmmv_stream(A, X, Y, ld, ycol, st)) return true;
     return launch_spmmv_quadph<double, 8>(A, X, Y, ld, ycol, xmode, st);
 }
 bool spmmv_phased(const uspmv_dmat *A, const float *X, float *Y, long ld, bool ycol, int xmode, hipStream_t st) {
+    if (xmode == 0 && g_tune.spmmv_stream > 0 && A->ps_desc && spmmv_stream(A, X, Y, ld, ycol, st)) return true;
     return launch_spmmv_quadph<float, 16>(A, X, Y, ld, ycol, xmode, st);
 }
 

@@ -1,0 +1,262 @@
+// SpMMV over the phased block plan as a STREAM (64-byte X rows, C = 32, one-byte phase-local indices): persistent workgroups walk a flat
+// schedule of phase descriptors, and everything a phase needs is requested one phase (its X-row list: two, its descriptor: three) ahead --
+// the X rows by DMA into the other half of a double LDS buffer, the matrix entries into a second register set -- so that a workgroup's
+// round trips (descriptor -> list -> X rows + entries) lie behind the arithmetic of its OWN previous phase instead of only behind other
+// workgroups, and one barrier per phase is left.  The arithmetic is that of scs_spmmv_quadph (spmmv_phased.hip): four lanes per row, a
+// slot's (value, index) quad-broadcast, one ds_read_b128 per lane and slot, every row its slot-ordered FMA chain -- bit-identical to
+// block_spmv_omp_scs_general (code/kernels.hpp:306-398).
+#include "uspmv_device.hpp"
+#include <vector>
+
+using namespace uspmv_dev;
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_cvoid_t;
+
+// one phase of one tile, 32 bytes, in the order its workgroup meets it
+struct alignas(32) PhDesc {
+    unsigned va, vb;     // element offset (values and index bytes alike) of the phase's first group in the tile's two chunks
+    int lp, nl;          // the phase's X-row list: first entry, entries
+    unsigned pk;         // bits 0-3 / 4-7: full groups of chunk A / B in the phase; 8-9 / 10-11: slots of their partial last group when it lies in the phase; 12: first phase of its tile; 13: last
+    int tile;
+    int spare0, spare1;
+};
+constexpr unsigned PK_FIRST = 1u << 12, PK_LAST = 1u << 13;
+
+__global__ void __launch_bounds__(256) stream_desc_fill(const long n_tiles, const long n_chunks, const int *__restrict__ chunk_lengths,
+        const unsigned *__restrict__ c16_ptrs, const int *__restrict__ ph_ptr, const int *__restrict__ ph_g0, const int *__restrict__ ph_list_ptr,
+        const int *__restrict__ slot, PhDesc *__restrict__ out) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const long cA = 2 * t, cB = 2 * t + 1;
+    const int LA = cA < n_chunks ? chunk_lengths[cA] : 0, LB = cB < n_chunks ? chunk_lengths[cB] : 0;
+    const unsigned qA = cA < n_chunks ? c16_ptrs[cA] : 0u, qB = cB < n_chunks ? c16_ptrs[cB] : 0u;
+    const int fA = LA >> 2, rA = LA & 3, fB = LB >> 2, rB = LB & 3;
+    const int p0 = ph_ptr[t], p1 = ph_ptr[t + 1];
+    PhDesc *o = out + slot[t];
+    if (p0 >= p1) {                                          // a tile of empty rows: its y rows are still written
+        PhDesc d{0u, 0u, 0, 0, PK_FIRST | PK_LAST, (int)t, 0, 0};
+        *o = d;
+        return;
+    }
+    for (int ph = p0; ph < p1; ++ph) {
+        const int g0 = ph_g0[ph], g1 = ph + 1 < p1 ? ph_g0[ph + 1] : 0x7fffffff;
+        const int nfa = max(min(g1, fA) - g0, 0), nfb = max(min(g1, fB) - g0, 0);
+        const int ra = (rA && fA >= g0 && fA < g1) ? rA : 0, rb = (rB && fB >= g0 && fB < g1) ? rB : 0;
+        PhDesc d;
+        d.va = qA + (unsigned)g0 * 128u; d.vb = qB + (unsigned)g0 * 128u;
+        d.lp = ph_list_ptr[ph]; d.nl = ph_list_ptr[ph + 1] - d.lp;
+        d.pk = (unsigned)nfa | ((unsigned)nfb << 4) | ((unsigned)ra << 8) | ((unsigned)rb << 10) | (ph == p0 ? PK_FIRST : 0u) | (ph + 1 == p1 ? PK_LAST : 0u);
+        d.tile = (int)t; d.spare0 = d.spare1 = 0;
+        o[ph - p0] = d;
+    }
+}
+
+template <typename VT, int B, bool NT, bool YCOL, bool YNT, int ABL>
+__global__ void __launch_bounds__(256, 4) scs_spmmv_pstream(const PhDesc *__restrict__ desc, const int *__restrict__ wg_ptr,
+        const VT *__restrict__ values, const unsigned char *__restrict__ col8, const int *__restrict__ xrows, const VT *__restrict__ X,
+        VT *__restrict__ Y, const long ld, const long n_rows_pad, const long n_store, const int *__restrict__ row_map) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];     // two buffers of 256 X rows (16 KiB each)
+    constexpr int VW = 16 / (int)sizeof(VT);
+    static_assert(B == 4 * VW, "four 16-byte pieces per X row");
+    typedef VT vec_t __attribute__((ext_vector_type(VW)));
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int r = lane >> 2, q = lane & 3;
+    const int sel = wave >> 1, hoff = (wave & 1) * 64 + lane;                  // the wave's chunk of the tile; its lanes' element inside a group
+    const int d_beg = wg_ptr[blockIdx.x], d_end = wg_ptr[blockIdx.x + 1];
+    if (d_beg >= d_end) return;
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    // descriptors of phases s, s + 1, s + 2 as scalars: {va, vb, lp, nl, pk, tile, -, -}; dl = the one in flight (phase s + 3 once iteration s has
+    // asked for it): a VECTOR load of the same address by every lane, made scalar behind the next iteration's wait.  (A scalar load has to be
+    // waited for where it is used -- as plain C++ that was an immediate wait that also covered the X rows and entries just requested -- and by
+    // inline asm the register allocator copies its destination while the load is still in flight.)
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    v8i D0 = {0, 0, 0, 0, 0, 0, 0, 0}, D1 = D0, D2 = D0;
+    v4i dl0 = {0, 0, 0, 0};
+    v2i dl1 = {0, 0};
+    VT a[2][8];
+    unsigned ix[2][8];
+    int xr[4] = {-1, -1, -1, -1};
+    int y0 = -1, y1 = -1, y2 = -1;                                             // y rows of the lane for the tiles of phases s, s + 1, s + 2
+    vec_t acc;
+#pragma unroll
+    for (int w = 0; w < VW; ++w) acc[w] = VT(0);
+
+#define PS_STEP(UU, AV, IV)                                                                                   \
+    {                                                                                                         \
+        const VT aa = quad_bcast<UU>(AV);                                                                     \
+        const unsigned li = (unsigned)quad_bcast<UU>((int)(IV));                                              \
+        const vec_t xv = xs[li * 4u + (unsigned)q];                                                           \
+        _Pragma("unroll") for (int w = 0; w < VW; ++w) acc[w] = fma_t(aa, xv[w], acc[w]);                     \
+    }
+    // one iteration; P = register set that holds phase s (the other one receives phase s + 1)
+#define PS_BODY(P)                                                                                                                   \
+    {                                                                                                                                \
+        __builtin_amdgcn_s_waitcnt(0);                                 /* X rows and entries of phase s, list of s + 1, descriptor of s + 2 */ \
+        __syncthreads();                                               /* ... of every wave; and every wave is through with phase s - 1 */ \
+        D0 = D1; D1 = D2; y0 = y1; y1 = y2;                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) D2[j] = __builtin_amdgcn_readfirstlane(dl0[j]);                                \
+        D2[4] = __builtin_amdgcn_readfirstlane(dl1[0]); D2[5] = __builtin_amdgcn_readfirstlane(dl1[1]);                              \
+        if (s + 3 >= d_beg && s + 3 < d_end) {                                                                                       \
+            const int *dp = (const int *)(desc + (s + 3));                                                                           \
+            dl0 = *(const v4i *)dp; dl1 = *(const v2i *)(dp + 4);                                                                    \
+        }                                                                                                                            \
+        if (s + 1 >= d_beg && s + 1 < d_end) {                                                                                       \
+            unsigned char *buf = ps_smem + ((s + 1) & 1) * 16384;                                                                    \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                            \
+                if (!(ABL & 1) && xr[k] >= 0)                                                                                        \
+                    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(X + (long)xr[k] * B + q * VW), (lds_void_t *)(buf + (wave + 4 * k) * 1024), 16, 0, 0); \
+            const unsigned pk1 = (unsigned)D1[4];                                                                                    \
+            const unsigned vo = (unsigned)(sel ? D1[1] : D1[0]) + (unsigned)hoff;                                                    \
+            const int ngl = (int)((pk1 >> (4 * sel)) & 15u) + (((pk1 >> (8 + 2 * sel)) & 3u) ? 1 : 0);                               \
+            _Pragma("unroll") for (int d = 0; d < 8; ++d)                                                                            \
+                if (d < ngl) {                                                                                                       \
+                    if (!(ABL & 8)) ix[(P) ^ 1][d] = ld_stream<NT>(col8 + vo + d * 128);                                             \
+                    if (!(ABL & 4)) a[(P) ^ 1][d] = ld_stream<NT>(values + vo + d * 128);                                            \
+                }                                                                                                                    \
+        }                                                                                                                            \
+        if (s + 2 >= d_beg && s + 2 < d_end) {                                                                                       \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                          \
+                const int e = ((wave + 4 * k) * 64 + lane) >> 2;                                                                     \
+                xr[k] = -1;                                                                                                          \
+                if (e < D2[3]) xr[k] = xrows[D2[2] + e];                                                                             \
+            }                                                                                                                        \
+            y2 = y1;                                                                                                                 \
+            if ((unsigned)D2[4] & PK_FIRST) {                                                                                        \
+                const long row = (long)D2[5] * 64 + wave * 16 + r;                                                                   \
+                y2 = -1;                                                                                                             \
+                if (row < n_rows_pad) y2 = row_map ? row_map[row] : (int)row;                                                        \
+            }                                                                                                                        \
+        }                                                                                                                            \
+        if (s >= d_beg) {                                                                                                            \
+            const vec_t *xs = (const vec_t *)(ps_smem + (s & 1) * 16384);                                                            \
+            const unsigned pk0 = (unsigned)D0[4];                                                                                    \
+            const int nf = (int)((pk0 >> (4 * sel)) & 15u), rem = (int)((pk0 >> (8 + 2 * sel)) & 3u);                                \
+            if (!(ABL & 2)) {                                                                                                        \
+                _Pragma("unroll") for (int d = 0; d < 8; ++d) {                                                                      \
+                    if (d < nf) { PS_STEP(0, a[P][d], ix[P][d]) PS_STEP(1, a[P][d], ix[P][d]) PS_STEP(2, a[P][d], ix[P][d]) PS_STEP(3, a[P][d], ix[P][d]) } \
+                    else if (d == nf && rem) {                                                                                       \
+                        PS_STEP(0, a[P][d], ix[P][d])                                                                                \
+                        if (rem > 1) PS_STEP(1, a[P][d], ix[P][d])                                                                   \
+                        if (rem > 2) PS_STEP(2, a[P][d], ix[P][d])                                                                   \
+                    }                                                                                                                \
+                }                                                                                                                    \
+            }                                                                                                                        \
+            if (pk0 & PK_LAST) {                                                                                                     \
+                if (y0 >= 0 && y0 < n_store) {                                                                                       \
+                    if (YCOL) { _Pragma("unroll") for (int w = 0; w < VW; ++w) st_y<YNT>(Y + ((long)y0 + (long)(q * VW + w) * ld), acc[w]); } \
+                    else *((vec_t *)(Y + (long)y0 * B) + q) = acc;                                                                   \
+                }                                                                                                                    \
+                _Pragma("unroll") for (int w = 0; w < VW; ++w) acc[w] = VT(0);                                                       \
+            }                                                                                                                        \
+        }                                                                                                                            \
+        ++s;                                                                                                                         \
+    }
+
+    int s = d_beg - 3;
+    while (s < d_end) {
+        PS_BODY(0)
+        if (s >= d_end) break;
+        PS_BODY(1)
+    }
+#undef PS_BODY
+#undef PS_STEP
+}
+
+template <typename VT, int B>
+bool launch_pstream(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
+    if (!A->ps_desc || !A->ps_wg_ptr || A->ps_grid <= 0 || A->part || A->C != 32 || !A->pb_idx8 || A->pb_max_rows > 256 || A->pb_ngp > 8) return false;
+    const size_t lds = 2 * 16384;
+#define PS_ARGS (const PhDesc *)A->ps_desc, (const int *)A->ps_wg_ptr, (const VT *)A->pb_values, (const unsigned char *)A->pb_col16, (const int *)A->pb_xrows, X, Y, ld, \
+                (long)(A->n_chunks * A->C), (long)A->n_store, (const int *)A->bt_row_map
+#define PS_LAUNCH(NTV, YC, YN, AB) hipLaunchKernelGGL((scs_spmmv_pstream<VT, B, NTV, YC, YN, AB>), dim3((unsigned)A->ps_grid), dim3(256), lds, st, PS_ARGS)
+    if constexpr (sizeof(VT) == 8) {
+        if (g_tune.ablate >= 1 && !ycol) {          // measurement only (results wrong by construction)
+            switch (g_tune.ablate) {
+                case 1: PS_LAUNCH(true, false, true, 1); return true;
+                case 2: PS_LAUNCH(true, false, true, 2); return true;
+                case 4: PS_LAUNCH(true, false, true, 4); return true;
+                case 12: PS_LAUNCH(true, false, true, 12); return true;
+                case 13: PS_LAUNCH(true, false, true, 13); return true;
+                case 3: PS_LAUNCH(true, false, true, 3); return true;
+                default: break;
+            }
+        }
+    }
+    const bool nt = g_tune.nontemporal != 0, ynt = nt && (!ycol || g_tune.spmmv_ycol_nt);
+    if (nt) {
+        if (ycol) { if (ynt) PS_LAUNCH(true, true, true, 0); else PS_LAUNCH(true, true, false, 0); }
+        else PS_LAUNCH(true, false, true, 0);
+    } else {
+        if (ycol) PS_LAUNCH(false, true, false, 0); else PS_LAUNCH(false, false, false, 0);
+    }
+#undef PS_LAUNCH
+#undef PS_ARGS
+    return true;
+}
+
+}  // namespace
+
+namespace uspmv_dev {
+
+void dmat_stream_release(uspmv_dmat *A) {
+    (void)hipFree(A->ps_desc); (void)hipFree(A->ps_wg_ptr);
+    A->ps_desc = nullptr; A->ps_wg_ptr = nullptr; A->ps_grid = 0; A->ps_n_desc = 0;
+}
+
+// The flat schedule of the handle's phased plan for `wgs_per_cu` persistent workgroups per CU: workgroup w walks tiles w, w + G, w + 2G, ...
+// (the whole grid moves through the matrix as one front, like the one-tile-per-workgroup launch), its descriptors contiguous.
+int dmat_stream_schedule(uspmv_dmat *A, int wgs_per_cu) {
+    dmat_stream_release(A);
+    if (!A->pb || A->C != 32 || !A->pb_idx8 || A->pb_n_tiles <= 0 || wgs_per_cu <= 0) return USPMV_OK;
+    int dev = 0, cus = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t nt = A->pb_n_tiles;
+    const int G = (int)std::min<int64_t>((int64_t)std::max(cus, 1) * std::min(wgs_per_cu, 5), nt);
+    std::vector<int32_t> php((size_t)nt + 1), slot((size_t)nt), wgp((size_t)G + 1, 0);
+    HIP_TRY(hipMemcpy(php.data(), A->pb_ph_ptr, 4 * ((size_t)nt + 1), hipMemcpyDeviceToHost));
+    // workgroup w runs on XCD w % 8 (round-robin dispatch): with "spmmv_stream_xcd" the G / 8 workgroups of an XCD take CONSECUTIVE tiles of
+    // every super-block of G tiles -- neighbouring tiles share most of their X rows, which then meet in one L2 -- otherwise tile t goes to
+    // workgroup t % G
+    const bool by_xcd = g_tune.spmmv_stream_xcd && G % 8 == 0 && G >= 16;
+    const int per = G / 8;
+    int64_t pos = 0;
+    for (int w = 0; w < G; ++w) {
+        wgp[(size_t)w] = (int32_t)pos;
+        const int64_t first = by_xcd ? (int64_t)(w % 8) * per + w / 8 : w;
+        for (int64_t t = first; t < nt; t += G) {
+            slot[(size_t)t] = (int32_t)pos;
+            pos += std::max(php[(size_t)t + 1] - php[(size_t)t], 1);
+        }
+        if (pos > INT32_MAX - 8) return USPMV_OK;
+    }
+    wgp[(size_t)G] = (int32_t)pos;
+    int32_t *d_slot = nullptr;
+    hipError_t e = hipMalloc((void **)&d_slot, 4 * (size_t)nt);
+    if (e == hipSuccess) e = hipMemcpy(d_slot, slot.data(), 4 * (size_t)nt, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&A->ps_wg_ptr, 4 * ((size_t)G + 1));
+    if (e == hipSuccess) e = hipMemcpy(A->ps_wg_ptr, wgp.data(), 4 * ((size_t)G + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&A->ps_desc, sizeof(PhDesc) * (size_t)pos);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(stream_desc_fill, dim3(grid_for(nt, 256)), dim3(256), 0, nullptr, (long)nt, (long)A->n_chunks, A->chunk_lengths,
+                           (const unsigned *)A->pb_c16_ptrs, (const int *)A->pb_ph_ptr, (const int *)A->pb_g0, (const int *)A->pb_list_ptr, (const int *)d_slot, (PhDesc *)A->ps_desc);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    }
+    (void)hipFree(d_slot);
+    if (e != hipSuccess) {
+        dmat_stream_release(A);
+        return uspmv::fail(USPMV_ERR_HIP, "uspmv_dmat_optimize_block: stream schedule: %s", hipGetErrorString(e));
+    }
+    A->ps_grid = G; A->ps_n_desc = pos;
+    return USPMV_OK;
+}
+
+bool spmmv_stream(const uspmv_dmat *A, const double *X, double *Y, long ld, bool ycol, hipStream_t st) { return launch_pstream<double, 8>(A, X, Y, ld, ycol, st); }
+bool spmmv_stream(const uspmv_dmat *A, const float *X, float *Y, long ld, bool ycol, hipStream_t st) { return launch_pstream<float, 16>(A, X, Y, ld, ycol, st); }
+
+}  // namespace uspmv_dev

@@ -199,6 +199,8 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_brick_stride")) g_tune.spmmv_brick_stride = value < 0 ? 0 : (long)value;
     else if (!strcmp(key, "spmmv_brick_lines")) g_tune.spmmv_brick_lines = value < 1 ? 1 : (int)value;
     else if (!strcmp(key, "spmmv_phase_dp")) g_tune.spmmv_phase_dp = value < 0 ? 0 : (int)value;
+    else if (!strcmp(key, "spmmv_stream")) g_tune.spmmv_stream = value < 0 ? 0 : value > 5 ? 5 : (int)value;
+    else if (!strcmp(key, "spmmv_stream_xcd")) g_tune.spmmv_stream_xcd = value != 0;
     else if (!strcmp(key, "spmmv_phased")) g_tune.spmmv_phased = value != 0;
     else if (!strcmp(key, "spmmv_xcol")) g_tune.spmmv_xcol = value != 0;
     else if (!strcmp(key, "spmmv_ycol_nt")) g_tune.spmmv_ycol_nt = value != 0;
@@ -271,6 +273,8 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_brick_stride")) *value = g_tune.spmmv_brick_stride;
     else if (!strcmp(key, "spmmv_brick_lines")) *value = g_tune.spmmv_brick_lines;
     else if (!strcmp(key, "spmmv_phase_dp")) *value = g_tune.spmmv_phase_dp;
+    else if (!strcmp(key, "spmmv_stream")) *value = g_tune.spmmv_stream;
+    else if (!strcmp(key, "spmmv_stream_xcd")) *value = g_tune.spmmv_stream_xcd;
     else if (!strcmp(key, "spmmv_phased")) *value = g_tune.spmmv_phased;
     else if (!strcmp(key, "spmmv_xcol")) *value = g_tune.spmmv_xcol;
     else if (!strcmp(key, "spmmv_ycol_nt")) *value = g_tune.spmmv_ycol_nt;
@@ -925,6 +929,7 @@ static void bt_release(uspmv_dmat_t *A) {
     A->bt_values = nullptr; A->bt_cols = A->bt_row_map = nullptr;
     (void)hipFree(A->pb_ph_ptr); (void)hipFree(A->pb_g0); (void)hipFree(A->pb_list_ptr); (void)hipFree(A->pb_xrows); (void)hipFree(A->pb_c16_ptrs); (void)hipFree(A->pb_col16);
     (void)hipFree(A->pb_values); A->pb_values = nullptr; A->pb_idx8 = false; A->pb_device_built = false;
+    dmat_stream_release(A);
     A->pb_ph_ptr = A->pb_g0 = A->pb_list_ptr = A->pb_xrows = nullptr; A->pb_c16_ptrs = nullptr; A->pb_col16 = nullptr; A->pb = false;
     A->bt_line_ptr = A->bt_xrows = nullptr; A->bt_c16_ptrs = nullptr; A->bt_col16 = nullptr;
     A->bt = false;
@@ -1111,6 +1116,7 @@ int uspmv_dmat_optimize_block(uspmv_dmat_t *A, const uspmv_scs_t *s, int block_v
     if (pp.valid && pl.valid) { A->pl = true; A->pl_shift = pl.line_shift; A->pl_max_rows = pl.max_rows_used; A->pl_n_phases = pl.n_phases; A->pl_rows_staged = (int64_t)pl.xrows.size() << pl.line_shift; }
     if (pp.valid) { A->pb = true; A->pb_cap_rows = pp.cap_rows; A->pb_ngp = pp.ngp; A->pb_max_rows = pp.max_rows_used; A->pb_n_tiles = pp.n_tiles; A->pb_n_phases = pp.n_phases; A->pb_rows_staged = (int64_t)pp.xrows.size(); }
     if (list_plan && p.valid) { A->bt = true; A->bt_tile_rows = p.tile_rows; A->bt_max_rows = p.max_lines_used; A->bt_n_tiles = p.n_tiles; A->bt_staged = p.n_staged_tiles; }
+    if (A->pb && g_tune.spmmv_stream > 0) return dmat_stream_schedule(A, g_tune.spmmv_stream);
     return USPMV_OK;
 }
 
@@ -1190,6 +1196,7 @@ static int block_plan_install_device(uspmv_dmat_t *A, int block_vec_size, int64_
     A->pb = true; A->pb_idx8 = true; A->pb_device_built = true; A->pb_cap_rows = 256; A->pb_ngp = 8; A->pb_max_rows = max_rows; A->pb_n_tiles = nt; A->pb_n_phases = n_ph; A->pb_rows_staged = n_list;
     if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] phased block plan (device builder): tiles=%lld phases=%lld rows_total=%lld max_rows=%d rows %s\n",
                                          (long long)nt, (long long)n_ph, (long long)n_list, max_rows, changed ? "re-ordered" : "in the caller's order");
+    if (g_tune.spmmv_stream > 0) return dmat_stream_schedule(A, g_tune.spmmv_stream);
     return USPMV_OK;
 }
 

@@ -72,6 +72,11 @@ struct uspmv_dmat {
     uint16_t *pb_col16 = nullptr;       // phase-local indices; ONE BYTE each when pb_idx8 (no phase lists more than 256 rows)
     bool pb_idx8 = false;
     bool pb_device_built = false;       // the plan's index part was built by csrc/block_plan_kernels.hip
+    // the phased plan once more as a flat schedule of 32-byte phase descriptors for persistent workgroups (spmmv_stream.hip; "spmmv_stream")
+    int ps_grid = 0;
+    int64_t ps_n_desc = 0;
+    int32_t *ps_wg_ptr = nullptr;
+    void *ps_desc = nullptr;
     // the same plan once more with LINE lists (128 bytes of one column: 16 doubles / 32 floats) for column-major block vectors:
     // shares pb_values / pb_c16_ptrs / the row map; one-byte local indices (line << shift | row in line)
     bool pl = false;
@@ -216,6 +221,9 @@ struct Tuning {
     int spmmv_brick_lines = 4;
     int spmmv_phase_dp = 24;  // NEXT optimize_block (host planner): > 0 = phase cuts by dynamic programming (least staged rows + this many rows' worth per
                               // phase), 0 = every phase filled to the brim (what the device-side builder does)
+    int spmmv_stream = 0;   // NEXT optimize_block (64-byte rows, C = 32, one-byte indices): > 0 = also lay the phased plan out as a flat schedule for this many
+                            // persistent workgroups per CU (at most 5: 32 KiB of LDS each) and let uspmv_spmmv run the streaming kernel (spmmv_stream.hip)
+    int spmmv_stream_xcd = 1;  // ... 1 = the workgroups of an XCD take consecutive tiles, 0 = tile t goes to workgroup t % grid
     int spmmv_variant = 0;  // 0 = auto (= 3 where a B-specialised kernel exists); 1 = generic kernel; 2 = row-major with transposing X phase; 3 = row-major, lane per row
 };
 extern Tuning g_tune;   // uspmv_api.hip
@@ -246,6 +254,11 @@ int prepare_x(const uspmv_dmat *A, const VT *X, int b, long ld, hipStream_t st);
 // xmode: 0 = row-major X, 1 = column-major X assembled through registers, 2 = column-major X staged by 128-byte lines (line plan)
 bool spmmv_phased(const uspmv_dmat *A, const double *X, double *Y, long ld, bool ycol, int xmode, hipStream_t st);
 bool spmmv_phased(const uspmv_dmat *A, const float *X, float *Y, long ld, bool ycol, int xmode, hipStream_t st);
+// the same plan walked by persistent workgroups (spmmv_stream.hip); false: no schedule on the handle / shape not covered
+bool spmmv_stream(const uspmv_dmat *A, const double *X, double *Y, long ld, bool ycol, hipStream_t st);
+bool spmmv_stream(const uspmv_dmat *A, const float *X, float *Y, long ld, bool ycol, hipStream_t st);
+int dmat_stream_schedule(uspmv_dmat *A, int wgs_per_cu);
+void dmat_stream_release(uspmv_dmat *A);
 int launch_spmv_ap(const uspmv_dmat *dp, const uspmv_dmat *sp, const double *d_x, const float *d_x_sp, double *d_y,
                    hipStream_t stream);                                                                           // ap_kernels.hip
 template <typename VT>

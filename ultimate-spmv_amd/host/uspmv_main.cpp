@@ -47,7 +47,7 @@ struct Config {  // subset of the reference's Config (code/classes_structs.hpp:4
     double bench_time = 5.0, ap_threshold_1 = 0.0, ap_threshold_2 = 0.0, dropout_threshold = 0.0;
     std::string matrix_file_name, seg_method = "seg-rows", value_type = "dp", kernel_format = "scs";
     std::string output_filename_bench = "spmv_bench.txt";
-    std::string dump_y;          // -dump_y <file>: solve mode writes its result vector (original row order, raw VT) there
+    std::string dump_y;          // -dump_y <file>: solve mode writes its result vector (original row order, raw VT; block vectors column after column) there
     int layout = USPMV_COLWISE;  // run-time here; a make knob in the reference (Makefile:26-31)
     int tlc = 1;                 // build the tile-local-column plan (MI355X-specific, results unchanged)
     int use_graph = 1;           // bench loop replays hipGraphs of 64 launches
@@ -374,9 +374,11 @@ int run(const Config &c, uspmv_coo_t *coo) {
         std::vector<VT> hy((size_t)b * ld);
         for (unsigned long i = 0; i < c.n_repetitions; ++i) { r.exec(); if (i + 1 < c.n_repetitions) std::swap(r.x, r.y); }
         hk(hipMemcpy(hy.data(), r.y, sizeof(VT) * hy.size(), hipMemcpyDeviceToHost), "hipMemcpy y");
-        if (!c.dump_y.empty() && b == 1) {   // copy_back_result (code/utilities.hpp:3862): y_orig[i] = y[old_to_new[i]]
-            std::vector<VT> yo((size_t)n_rows);
-            for (int64_t i = 0; i < n_rows; ++i) yo[(size_t)i] = hy[(size_t)o2n[i]];
+        if (!c.dump_y.empty()) {   // copy_back_result (code/utilities.hpp:3862): y_orig[i] = y[old_to_new[i]]; block vectors: column after column
+            std::vector<VT> yo((size_t)n_rows * (size_t)b);
+            for (int v = 0; v < b; ++v)
+                for (int64_t i = 0; i < n_rows; ++i)
+                    yo[(size_t)v * (size_t)n_rows + (size_t)i] = c.layout == USPMV_ROWWISE ? hy[(size_t)o2n[i] * (size_t)b + (size_t)v] : hy[(size_t)v * (size_t)ld + (size_t)o2n[i]];
             std::ofstream fy(c.dump_y, std::ios::binary);
             fy.write((const char *)yo.data(), (std::streamsize)(sizeof(VT) * yo.size()));
             if (!fy) die("cannot write " + c.dump_y);
