@@ -220,6 +220,9 @@ int uspmv_dmat_plan_info(const uspmv_dmat_t *m, int *kind, int64_t *n_tiles, int
 int uspmv_dmat_block_plan_info(const uspmv_dmat_t *m, int64_t meta[10]);
 /* X rows the phased block plan stages per product (sum of its phases' lists; 0 without such a plan) */
 int uspmv_dmat_block_plan_staged(const uspmv_dmat_t *m, int64_t *rows_staged);
+/* the phased block plan laid out as a flat schedule for persistent workgroups (tuning "spmmv_stream" > 0 at plan time; the streaming form of
+ * block_spmv_omp_scs_general, code/kernels.hpp:306-398): meta[2] = workgroups of the launch (0: no schedule on the handle), phase descriptors */
+int uspmv_dmat_stream_info(const uspmv_dmat_t *m, int64_t meta[2]);
 /* FNV-1a digests of the phased block plan's device arrays: phase pointers, first groups, list pointers, X-row lists, index offsets,
  * local indices, the group-major values, the row map (tests: a plan built on the device equals the host planner's) */
 int uspmv_dmat_block_plan_digest(const uspmv_dmat_t *m, uint64_t digest[8]);

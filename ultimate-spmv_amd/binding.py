@@ -98,6 +98,7 @@ _SIGS = {
     "uspmv_dmat_block_plan_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dmat_block_plan_digest": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "uspmv_dmat_block_plan_staged": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "uspmv_dmat_stream_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dmat_optimize_sweep_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_sweep_plan_digest": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(_i64)]),
     "uspmv_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp]),
@@ -928,6 +929,9 @@ class DeviceMatrix:
         n = _i64()
         _ck(lib().uspmv_dmat_block_plan_staged(self.h, C.byref(n)))
         d["rows_staged"] = n.value
+        m2 = (_i64 * 2)()
+        _ck(lib().uspmv_dmat_stream_info(self.h, m2))
+        d["stream_grid"], d["stream_descriptors"] = int(m2[0]), int(m2[1])
         return d
 
     def optimize_block_device(self, block_vec_size):

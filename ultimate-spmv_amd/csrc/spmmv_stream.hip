@@ -57,8 +57,9 @@ __global__ void __launch_bounds__(256) stream_desc_fill(const long n_tiles, cons
 template <typename VT, int B, bool NT, bool YCOL, bool YNT, int ABL>
 __global__ void __launch_bounds__(256, 4) scs_spmmv_pstream(const PhDesc *__restrict__ desc, const int *__restrict__ wg_ptr,
         const VT *__restrict__ values, const unsigned char *__restrict__ col8, const int *__restrict__ xrows, const VT *__restrict__ X,
-        VT *__restrict__ Y, const long ld, const long n_rows_pad, const long n_store, const int *__restrict__ row_map) {
+        VT *__restrict__ Y, const long ld, const long n_rows_pad, const long n_store, const int *__restrict__ row_map, long long *__restrict__ wg_clock) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];     // two buffers of 256 X rows (16 KiB each)
+    if (wg_clock && threadIdx.x == 0) wg_clock[blockIdx.x] = (long long)wall_clock64();      // (measurement aid: USPMV_STREAM_CLOCK)
     constexpr int VW = 16 / (int)sizeof(VT);
     static_assert(B == 4 * VW, "four 16-byte pieces per X row");
     typedef VT vec_t __attribute__((ext_vector_type(VW)));
@@ -162,6 +163,7 @@ __global__ void __launch_bounds__(256, 4) scs_spmmv_pstream(const PhDesc *__rest
         if (s >= d_end) break;
         PS_BODY(1)
     }
+    if (wg_clock && threadIdx.x == 0) wg_clock[gridDim.x + blockIdx.x] = (long long)wall_clock64();
 #undef PS_BODY
 #undef PS_STEP
 }
@@ -170,8 +172,28 @@ template <typename VT, int B>
 bool launch_pstream(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
     if (!A->ps_desc || !A->ps_wg_ptr || A->ps_grid <= 0 || A->part || A->C != 32 || !A->pb_idx8 || A->pb_max_rows > 256 || A->pb_ngp > 8) return false;
     const size_t lds = 2 * 16384;
+    // measurement aid: USPMV_STREAM_CLOCK=<file> -- every workgroup's start and end time (100 MHz counter) of THIS launch, written as text
+    static const char *clock_file = getenv("USPMV_STREAM_CLOCK");
+    long long *d_clock = nullptr;
+    if (clock_file && hipMalloc((void **)&d_clock, 16 * (size_t)A->ps_grid) != hipSuccess) d_clock = nullptr;
+    struct ClockOut {
+        long long *d; int G; hipStream_t st; const char *file;
+        ~ClockOut() {
+            if (!d) return;
+            std::vector<long long> h(2 * (size_t)G);
+            if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), d, 16 * (size_t)G, hipMemcpyDeviceToHost) == hipSuccess) {
+                if (FILE *f = fopen(file, "w")) {
+                    long long t0 = h[0];
+                    for (int w = 0; w < G; ++w) t0 = std::min(t0, h[(size_t)w]);
+                    for (int w = 0; w < G; ++w) fprintf(f, "%d %lld %lld\n", w, h[(size_t)w] - t0, h[(size_t)G + w] - t0);
+                    fclose(f);
+                }
+            }
+            (void)hipFree(d);
+        }
+    } clock_out{d_clock, A->ps_grid, st, clock_file};
 #define PS_ARGS (const PhDesc *)A->ps_desc, (const int *)A->ps_wg_ptr, (const VT *)A->pb_values, (const unsigned char *)A->pb_col16, (const int *)A->pb_xrows, X, Y, ld, \
-                (long)(A->n_chunks * A->C), (long)A->n_store, (const int *)A->bt_row_map
+                (long)(A->n_chunks * A->C), (long)A->n_store, (const int *)A->bt_row_map, d_clock
 #define PS_LAUNCH(NTV, YC, YN, AB) hipLaunchKernelGGL((scs_spmmv_pstream<VT, B, NTV, YC, YN, AB>), dim3((unsigned)A->ps_grid), dim3(256), lds, st, PS_ARGS)
     if constexpr (sizeof(VT) == 8) {
         if (g_tune.ablate >= 1 && !ycol) {          // measurement only (results wrong by construction)

@@ -1759,6 +1759,13 @@ int uspmv_dmat_block_plan_info(const uspmv_dmat_t *A, int64_t meta[10]) {
     return USPMV_OK;
 }
 
+int uspmv_dmat_stream_info(const uspmv_dmat_t *A, int64_t meta[2]) {
+    if (!A || !meta) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_stream_info: NULL argument");
+    const uspmv_dmat_t *M = (A->alt && g_tune.rechunk) ? A->alt : A;
+    meta[0] = M->ps_desc ? M->ps_grid : 0; meta[1] = M->ps_desc ? M->ps_n_desc : 0;
+    return USPMV_OK;
+}
+
 int uspmv_dmat_tile_rows(const uspmv_dmat_t *A, int *tile_rows) {
     if (!A || !tile_rows) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_tile_rows: NULL argument");
     *tile_rows = A->tlc ? A->tlc_tile_rows : 0;
