@@ -197,6 +197,7 @@ def check_every_setup(pkg, orc, t, rng, m, C, sigma, f64, tag, expect=None):
     Ab = pkg.DeviceMatrix(s); Ab.optimize_block(s, b); handles.append(("host block plan", Ab))
     Ad = pkg.DeviceMatrix(s); Ad.optimize_block_device(b); handles.append(("device block plan", Ad))
     if b * (8 if f64 else 4) == 64 and C == 32:             # 64-byte X rows: the phased plan walked as a stream by persistent workgroups (both builders)
+        sdepth = int(rng.choice([1, 2]))
         pkg.set_tuning(spmmv_stream=int(rng.choice([1, 2, 3, 4, 5])), spmmv_stream_xcd=int(rng.choice([0, 1])))
         try:
             As = pkg.DeviceMatrix(s); As.optimize_block(s, b); handles.append(("host block plan, streamed", As))
@@ -222,7 +223,7 @@ def check_every_setup(pkg, orc, t, rng, m, C, sigma, f64, tag, expect=None):
         wantb = orc.spmmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, b, ld, rowwise)
         for what, H in handles:
             Y = t.full((b * ld,), 3.0, dtype=tdt, device="cuda")
-            pkg.set_tuning(spmmv_stream=1 if what.endswith("streamed") else 0)
+            pkg.set_tuning(spmmv_stream=1 if what.endswith("streamed") else 0, spmmv_stream_depth=sdepth if what.endswith("streamed") else 1)
             pkg.spmmv(H, _dev(t, X), Y, b, ld, lay_code)
             got = Y.cpu().numpy()
             n_out = s.n_rows_padded * b if rowwise else None
@@ -238,7 +239,7 @@ def check_every_setup(pkg, orc, t, rng, m, C, sigma, f64, tag, expect=None):
                 pkg.spmmv(H, dXp, Y2, b, ld, lay_code)
                 pkg.spmmv_x_release(H)
                 assert t.equal(Y2, Y), tag + (what, "colwise, X prepared", b)
-    pkg.set_tuning(spmmv_stream=0)
+    pkg.set_tuning(spmmv_stream=0, spmmv_stream_depth=1)
 
     # ---- adaptive precision pair (dp struct sorted on its own, sp struct placed with its permutation): plain, host plan, device plan
     if code == pkg.F64 and n >= C:

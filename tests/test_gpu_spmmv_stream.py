@@ -1,6 +1,6 @@
 """The phased SpMMV plan walked as a stream by persistent workgroups (tuning "spmmv_stream", csrc/spmmv_stream.hip): bit-identical to the reference's
 block_spmv_omp_scs_general (code/kernels.hpp:306-398) in both block-vector layouts, for every number of workgroups per CU, both tile -> workgroup
-mappings, rows with partial last groups, empty rows and tiles, leading dimensions beyond the padded rows, special values; shapes the streaming
+mappings, both prefetch depths (one phase ahead with a full wait per phase; two phases ahead with partial waits), rows with partial last groups, empty rows and tiles, leading dimensions beyond the padded rows, special values; shapes the streaming
 kernel does not cover (C != 32) fall back to the one-tile-per-workgroup kernel with the same bits."""
 import numpy as np
 import pytest
@@ -50,18 +50,19 @@ def matrix(pkg, name):
     return pkg.read_mtx(mtx_path(name))
 
 
-CASES = [("stencil3", 32, 512, 4, 1), ("stencil3", 32, 512, 3, 0), ("stencil3", 32, 1, 1, 1), ("stencil3", 32, 64, 5, 1), ("stencil1", 32, 512, 4, 1),
-         ("mesh2d", 32, 128, 2, 1), ("band", 32, 64, 4, 1), ("FDM-2d-16", 32, 16, 4, 1), ("impcol_e", 32, 64, 4, 0), ("stencil3", 64, 128, 4, 1)]
+CASES = [("stencil3", 32, 512, 4, 1, 1), ("stencil3", 32, 512, 3, 0, 2), ("stencil3", 32, 1, 1, 1, 2), ("stencil3", 32, 64, 5, 1, 1), ("stencil1", 32, 512, 4, 1, 2),
+         ("mesh2d", 32, 128, 2, 1, 1), ("band", 32, 64, 4, 1, 2), ("FDM-2d-16", 32, 16, 4, 1, 2), ("impcol_e", 32, 64, 4, 0, 2), ("impcol_e", 32, 64, 4, 0, 1),
+         ("stencil3", 64, 128, 4, 1, 1)]
 
 
-@pytest.mark.parametrize("name,C,sigma,wgs,by_xcd", CASES)
+@pytest.mark.parametrize("name,C,sigma,wgs,by_xcd,depth", CASES)
 @pytest.mark.parametrize("dt", ["f64", "f32"])
-def test_stream_kernel_bitexact_both_layouts(pkg, orc, t, name, C, sigma, wgs, by_xcd, dt):
+def test_stream_kernel_bitexact_both_layouts(pkg, orc, t, name, C, sigma, wgs, by_xcd, depth, dt):
     m = matrix(pkg, name)
     dtype = pkg.F64 if dt == "f64" else pkg.F32
     b = 8 if dt == "f64" else 16
     s, a, xp = prep(pkg, m, C, sigma, dtype)
-    pkg.set_tuning(spmmv_stream=wgs, spmmv_stream_xcd=by_xcd)
+    pkg.set_tuning(spmmv_stream=wgs, spmmv_stream_xcd=by_xcd, spmmv_stream_depth=depth)
     try:
         A = pkg.DeviceMatrix(s, block_tlc=b)
         info = A.block_plan_info()
@@ -88,7 +89,7 @@ def test_stream_kernel_bitexact_both_layouts(pkg, orc, t, name, C, sigma, wgs, b
                         assert np.all(got[v * ld + n:(v + 1) * ld] == -7.0)                      # rows beyond the matrix are left alone
         del A
     finally:
-        pkg.set_tuning(spmmv_stream=0, spmmv_stream_xcd=1)
+        pkg.set_tuning(spmmv_stream=0, spmmv_stream_xcd=1, spmmv_stream_depth=1)
 
 
 def test_stream_kernel_on_the_device_built_plan_and_special_values(pkg, orc, t):
@@ -102,7 +103,7 @@ def test_stream_kernel_on_the_device_built_plan_and_special_values(pkg, orc, t):
     sp = rng.choice(X.size, 200, replace=False)
     X[sp[:50]] = np.inf; X[sp[50:100]] = -np.inf; X[sp[100:150]] = np.nan; X[sp[150:]] = -0.0
     Yo = orc.spmmv_scs(32, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], X, b, ld, True)
-    pkg.set_tuning(spmmv_stream=4)
+    pkg.set_tuning(spmmv_stream=4, spmmv_stream_depth=2)
     try:
         A = pkg.DeviceMatrix(s)
         A.optimize_block_device(b)
@@ -113,7 +114,7 @@ def test_stream_kernel_on_the_device_built_plan_and_special_values(pkg, orc, t):
         t.cuda.synchronize()
         got = dY.cpu().numpy()
     finally:
-        pkg.set_tuning(spmmv_stream=0)
+        pkg.set_tuning(spmmv_stream=0, spmmv_stream_depth=1)
     both_nan = np.isnan(got) & np.isnan(Yo)
     assert np.array_equal(np.isnan(got), np.isnan(Yo))
     assert np.array_equal(got[~both_nan].view(np.uint64), Yo[~both_nan].view(np.uint64))

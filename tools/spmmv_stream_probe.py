@@ -21,13 +21,13 @@ def check_small():
             s = pkg.convert_to_scs(coo, 32, sigma, pkg.F64); a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"])
             b, ld = 8, s.n_rows_padded
             X = torch.rand(b * ld, dtype=torch.float64, device="cuda") - 0.5
-            for wgs in (1, 4):
+            for wgs, depth in ((1, 1), (4, 1), (1, 2), (3, 2)):
                 pkg.set_tuning(spmmv_stream=0, spmmv_variant=3)
                 A0 = pkg.DeviceMatrix(s)
                 ref = {}
                 for lay in (pkg.ROWWISE, pkg.COLWISE):
                     y = torch.zeros_like(X); pkg.spmmv(A0, X, y, b, ld, lay); ref[lay] = y
-                pkg.set_tuning(spmmv_variant=0, spmmv_stream=wgs)
+                pkg.set_tuning(spmmv_variant=0, spmmv_stream=wgs, spmmv_stream_depth=depth)
                 A = pkg.DeviceMatrix(s, block_tlc=b)
                 for lay in (pkg.ROWWISE, pkg.COLWISE):
                     Y = torch.full_like(X, -7.0); pkg.spmmv(A, X, Y, b, ld, lay)
@@ -35,9 +35,9 @@ def check_small():
                     if lay == pkg.COLWISE:
                         same = all(bool(torch.equal(Y[v * ld: v * ld + s.n_rows], ref[lay][v * ld: v * ld + s.n_rows])) for v in range(b))
                     ok &= same
-                    print(json.dumps(dict(check=name, sigma=sigma, wgs_per_cu=wgs, layout="row" if lay == pkg.ROWWISE else "col", bitexact=same)), flush=True)
+                    print(json.dumps(dict(check=name, sigma=sigma, wgs_per_cu=wgs, depth=depth, layout="row" if lay == pkg.ROWWISE else "col", bitexact=same)), flush=True)
                 del A, A0
-    pkg.set_tuning(spmmv_stream=0)
+    pkg.set_tuning(spmmv_stream=0, spmmv_stream_depth=1)
     return ok
 
 
@@ -58,18 +58,20 @@ for lay in (pkg.ROWWISE, pkg.COLWISE):
 pkg.set_tuning(spmmv_variant=0)
 del A0
 # cases: workgroups per CU (0 = the one-tile-per-workgroup kernel); a negative number = that many with tile t -> workgroup t % grid
-cases = [int(c) for c in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,4,3,5,2,0,4".split(","))]
+# "n:2" = depth 2 (X rows and entries two phases ahead, three LDS buffers, partial waits)
+raw_cases = sys.argv[2].split(",") if len(sys.argv) > 2 else "0,3,3:2,0,3:2".split(",")
+cases = [(int(c.split(":")[0]), int(c.split(":")[1]) if ":" in c else 1) for c in raw_cases]
 abl = [int(c) for c in (sys.argv[3].split(",") if len(sys.argv) > 3 else [])]
-for wgs in cases:
-    pkg.set_tuning(spmmv_stream=abs(wgs), spmmv_stream_xcd=1 if wgs >= 0 else 0)
+for wgs, depth in cases:
+    pkg.set_tuning(spmmv_stream=abs(wgs), spmmv_stream_xcd=1 if wgs >= 0 else 0, spmmv_stream_depth=depth)
     A = pkg.DeviceMatrix(s, block_tlc=b)
     for lay, nm in ((pkg.ROWWISE, "rowwise"), (pkg.COLWISE, "colwise")):
         Y.fill_(-1.0); pkg.spmmv(A, X, Y, b, ld, lay)
         same = bool(torch.equal(Y, Y0[lay]))
         B.time_launches(5, 20, A=A, x=X, y=Y, b=b, ld=ld, layout=lay)
         ms = sorted(B.time_launches(5, 40, A=A, x=X, y=Y, b=b, ld=ld, layout=lay) for _ in range(5))
-        print(json.dumps(dict(wgs_per_cu=wgs, kernel="pstream" if wgs else "quadph", layout=nm, bitexact=same, ms_min=round(ms[0], 4), ms_med=round(ms[2], 4))), flush=True)
-    if wgs:
+        print(json.dumps(dict(wgs_per_cu=wgs, depth=depth if wgs else 0, kernel="pstream" if wgs else "quadph", layout=nm, bitexact=same, ms_min=round(ms[0], 4), ms_med=round(ms[2], 4))), flush=True)
+    if wgs and depth == 1:
         for ab in abl:
             pkg.set_tuning(ablate=ab, spmmv_variant=8)
             B.time_launches(5, 20, A=A, x=X, y=Y, b=b, ld=ld, layout=pkg.ROWWISE)
@@ -77,4 +79,4 @@ for wgs in cases:
             print(json.dumps(dict(wgs_per_cu=wgs, ablate=ab, ms_min=round(ms[0], 4))), flush=True)
         pkg.set_tuning(ablate=0, spmmv_variant=0)
     del A
-pkg.set_tuning(spmmv_stream=0)
+pkg.set_tuning(spmmv_stream=0, spmmv_stream_depth=1)

@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(256) stream_desc_fill(const long n_tiles, cons
         const int nfa = max(min(g1, fA) - g0, 0), nfb = max(min(g1, fB) - g0, 0);
         const int ra = (rA && fA >= g0 && fA < g1) ? rA : 0, rb = (rB && fB >= g0 && fB < g1) ? rB : 0;
         PhDesc d;
-        d.va = qA + (unsigned)g0 * 128u; d.vb = qB + (unsigned)g0 * 128u;
+        d.va = nfa + ra > 0 ? qA + (unsigned)g0 * 128u : 0u;      // (0: nothing of the chunk in this phase -- the depth-2 kernel loads unconditionally, from a valid address)
+        d.vb = nfb + rb > 0 ? qB + (unsigned)g0 * 128u : 0u;
         d.lp = ph_list_ptr[ph]; d.nl = ph_list_ptr[ph + 1] - d.lp;
         d.pk = (unsigned)nfa | ((unsigned)nfb << 4) | ((unsigned)ra << 8) | ((unsigned)rb << 10) | (ph == p0 ? PK_FIRST : 0u) | (ph + 1 == p1 ? PK_LAST : 0u);
         d.tile = (int)t; d.spare0 = d.spare1 = 0;
@@ -168,6 +169,125 @@ __global__ void __launch_bounds__(256, 4) scs_spmmv_pstream(const PhDesc *__rest
 #undef PS_STEP
 }
 
+// Depth 2: the X rows and entries of phase s + 2 are requested while phase s is multiplied (three LDS buffers, three register sets), and the wait at the
+// top of an iteration is PARTIAL -- vmcnt(20): everything but the 4 DMA + 16 entry loads of the previous iteration -- so that a workgroup has
+// requests in flight also while it waits and while it computes (with depth 1 the workgroups of a CU fall into step: they wait together and compute
+// together, and the parts of the time add up, profiles/r04/stream/).  For the count to be a constant every load of an iteration is unconditional: list
+// entries, rows and groups beyond the phase's are fetched from valid dummy addresses and never used.  Order inside an iteration: the small loads
+// (descriptor, list, y row) first, the 20 large ones last -- loads complete in order, so "at most 20 outstanding" means every older one has landed.
+template <typename VT, int B, bool NT, bool YCOL, bool YNT, bool RM>
+__global__ void __launch_bounds__(256, 3) scs_spmmv_pstream2(const PhDesc *__restrict__ desc, const int *__restrict__ wg_ptr,
+        const VT *__restrict__ values, const unsigned char *__restrict__ col8, const int *__restrict__ xrows, const VT *__restrict__ X,
+        VT *__restrict__ Y, const long ld, const long n_rows_pad, const long n_store, const int *__restrict__ row_map, long long *__restrict__ wg_clock) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];     // three buffers of 256 X rows (16 KiB each)
+    if (wg_clock && threadIdx.x == 0) wg_clock[blockIdx.x] = (long long)wall_clock64();
+    constexpr int VW = 16 / (int)sizeof(VT);
+    static_assert(B == 4 * VW, "four 16-byte pieces per X row");
+    typedef VT vec_t __attribute__((ext_vector_type(VW)));
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int r = lane >> 2, q = lane & 3;
+    const int sel = wave >> 1, hoff = (wave & 1) * 64 + lane;
+    const int d_beg = wg_ptr[blockIdx.x], d_end = wg_ptr[blockIdx.x + 1];
+    if (d_beg >= d_end) return;
+    v8i D0 = {0, 0, 0, 0, 0, 0, 0, 0}, D1 = D0, D2 = D0, D3 = D0;               // descriptors of phases s .. s + 3
+    v4i dl0 = {0, 0, 0, 0};
+    v2i dl1 = {0, 0};
+    VT a[3][8];
+    unsigned ix[3][8];
+    int xr[4] = {0, 0, 0, 0};
+    int y0 = -1, y1 = -1, y2 = -1, y3 = -1;
+    vec_t acc;
+#pragma unroll
+    for (int w = 0; w < VW; ++w) acc[w] = VT(0);
+    const long row_last = n_rows_pad - 1;
+
+#define PS_STEP(UU, AV, IV)                                                                                   \
+    {                                                                                                         \
+        const VT aa = quad_bcast<UU>(AV);                                                                     \
+        const unsigned li = (unsigned)quad_bcast<UU>((int)(IV));                                              \
+        const vec_t xv = xs[li * 4u + (unsigned)q];                                                           \
+        _Pragma("unroll") for (int w = 0; w < VW; ++w) acc[w] = fma_t(aa, xv[w], acc[w]);                     \
+    }
+    // P = register set / LDS buffer of phase s; phase s + 2 goes to (P + 2) % 3
+#define PS2_BODY(P)                                                                                                                  \
+    {                                                                                                                                \
+        __builtin_amdgcn_s_waitcnt(0x4F74);                            /* vmcnt(20), the other counters left alone */                \
+        asm volatile("" ::: "memory");                                                                                               \
+        __builtin_amdgcn_s_barrier();                                                                                                \
+        asm volatile("" ::: "memory");                                                                                               \
+        D0 = D1; D1 = D2; D2 = D3; y0 = y1; y1 = y2; y2 = y3;                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) D3[j] = __builtin_amdgcn_readfirstlane(dl0[j]);                                \
+        D3[4] = __builtin_amdgcn_readfirstlane(dl1[0]); D3[5] = __builtin_amdgcn_readfirstlane(dl1[1]);                              \
+        int xu[4];                                                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) xu[k] = xr[k];                                                                 \
+        /* ---- the small loads: descriptor of s + 4, list of s + 3, y row of s + 3's tile */                                        \
+        {                                                                                                                            \
+            const int di = min(max(s + 4, d_beg), d_end - 1);                                                                        \
+            const int *dp = (const int *)(desc + di);                                                                                \
+            dl0 = *(const v4i *)dp; dl1 = *(const v2i *)(dp + 4);                                                                    \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                          \
+                const int e = ((wave + 4 * k) * 64 + lane) >> 2;                                                                     \
+                xr[k] = xrows[e < D3[3] ? D3[2] + e : 0];                                                                            \
+            }                                                                                                                        \
+            const long row = min((long)D3[5] * 64 + wave * 16 + r, row_last);                                                        \
+            y3 = RM ? row_map[row] : (int)row;                         /* (every phase asks for its tile's y row: no select on a value in flight) */ \
+        }                                                                                                                            \
+        /* ---- the large ones: X rows and entries of phase s + 2 (descriptor D2, list xu) */                                        \
+        {                                                                                                                            \
+            unsigned char *buf = ps_smem + (((P) + 2) % 3) * 16384;                                                                  \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                            \
+                __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(X + (long)xu[k] * B + q * VW), (lds_void_t *)(buf + (wave + 4 * k) * 1024), 16, 0, 0); \
+            const unsigned pk2 = (unsigned)D2[4];                                                                                    \
+            const unsigned vo = (unsigned)(sel ? D2[1] : D2[0]) + (unsigned)hoff;                                                    \
+            const int ngl = (int)((pk2 >> (4 * sel)) & 15u) + (((pk2 >> (8 + 2 * sel)) & 3u) ? 1 : 0);                               \
+            _Pragma("unroll") for (int d = 0; d < 8; ++d) {                                                                          \
+                const unsigned od = vo + (d < ngl ? d * 128u : 0u);                                                                  \
+                ix[((P) + 2) % 3][d] = ld_stream<NT>(col8 + od);                                                                     \
+                a[((P) + 2) % 3][d] = ld_stream<NT>(values + od);                                                                    \
+            }                                                                                                                        \
+        }                                                                                                                            \
+        if (s >= d_beg) {                                                                                                            \
+            const vec_t *xs = (const vec_t *)(ps_smem + (P) * 16384);                                                                \
+            const unsigned pk0 = (unsigned)D0[4];                                                                                    \
+            const int nf = (int)((pk0 >> (4 * sel)) & 15u), rem = (int)((pk0 >> (8 + 2 * sel)) & 3u);                                \
+            _Pragma("unroll") for (int d = 0; d < 8; ++d) {                                                                          \
+                if (d < nf) { PS_STEP(0, a[P][d], ix[P][d]) PS_STEP(1, a[P][d], ix[P][d]) PS_STEP(2, a[P][d], ix[P][d]) PS_STEP(3, a[P][d], ix[P][d]) } \
+                else if (d == nf && rem) {                                                                                           \
+                    PS_STEP(0, a[P][d], ix[P][d])                                                                                    \
+                    if (rem > 1) PS_STEP(1, a[P][d], ix[P][d])                                                                       \
+                    if (rem > 2) PS_STEP(2, a[P][d], ix[P][d])                                                                       \
+                }                                                                                                                    \
+            }                                                                                                                        \
+            if (pk0 & PK_LAST) {                                                                                                     \
+                if ((long)D0[5] * 64 + wave * 16 + r <= row_last && y0 < n_store) {                                                  \
+                    if (YCOL) { _Pragma("unroll") for (int w = 0; w < VW; ++w) st_y<YNT>(Y + ((long)y0 + (long)(q * VW + w) * ld), acc[w]); } \
+                    else *((vec_t *)(Y + (long)y0 * B) + q) = acc;                                                                   \
+                }                                                                                                                    \
+                _Pragma("unroll") for (int w = 0; w < VW; ++w) acc[w] = VT(0);                                                       \
+            }                                                                                                                        \
+        }                                                                                                                            \
+        ++s;                                                                                                                         \
+    }
+
+    // iteration s asks for the descriptor of s + 4, the list of s + 3, the rows and entries of s + 2 and multiplies phase s: five iterations of
+    // lead-in (their loads go to clamped, valid addresses; nothing is multiplied or stored before s = d_beg)
+    int s = d_beg - 5;
+    s -= ((s - d_beg) % 3 + 3) % 3;                                        // (phase d_beg + 3k in register set 0)
+    while (s < d_end) {
+        PS2_BODY(0)
+        if (s >= d_end) break;
+        PS2_BODY(1)
+        if (s >= d_end) break;
+        PS2_BODY(2)
+    }
+#undef PS2_BODY
+#undef PS_STEP
+    if (wg_clock && threadIdx.x == 0) wg_clock[gridDim.x + blockIdx.x] = (long long)wall_clock64();
+}
+
 template <typename VT, int B>
 bool launch_pstream(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
     if (!A->ps_desc || !A->ps_wg_ptr || A->ps_grid <= 0 || A->part || A->C != 32 || !A->pb_idx8 || A->pb_max_rows > 256 || A->pb_ngp > 8) return false;
@@ -209,6 +329,19 @@ bool launch_pstream(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol,
         }
     }
     const bool nt = g_tune.nontemporal != 0, ynt = nt && (!ycol || g_tune.spmmv_ycol_nt);
+    if (g_tune.spmmv_stream_depth >= 2) {
+        const size_t lds3 = 3 * 16384;
+#define PS2_LAUNCH(NTV, YC, YN) do { if (A->bt_row_map) hipLaunchKernelGGL((scs_spmmv_pstream2<VT, B, NTV, YC, YN, true>), dim3((unsigned)A->ps_grid), dim3(256), lds3, st, PS_ARGS); \
+                                     else hipLaunchKernelGGL((scs_spmmv_pstream2<VT, B, NTV, YC, YN, false>), dim3((unsigned)A->ps_grid), dim3(256), lds3, st, PS_ARGS); } while (0)
+        if (nt) {
+            if (ycol) { if (ynt) PS2_LAUNCH(true, true, true); else PS2_LAUNCH(true, true, false); }
+            else PS2_LAUNCH(true, false, true);
+        } else {
+            if (ycol) PS2_LAUNCH(false, true, false); else PS2_LAUNCH(false, false, false);
+        }
+#undef PS2_LAUNCH
+        return true;
+    }
     if (nt) {
         if (ycol) { if (ynt) PS_LAUNCH(true, true, true, 0); else PS_LAUNCH(true, true, false, 0); }
         else PS_LAUNCH(true, false, true, 0);

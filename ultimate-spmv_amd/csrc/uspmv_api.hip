@@ -201,6 +201,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_phase_dp")) g_tune.spmmv_phase_dp = value < 0 ? 0 : (int)value;
     else if (!strcmp(key, "spmmv_stream")) g_tune.spmmv_stream = value < 0 ? 0 : value > 5 ? 5 : (int)value;
     else if (!strcmp(key, "spmmv_stream_xcd")) g_tune.spmmv_stream_xcd = value != 0;
+    else if (!strcmp(key, "spmmv_stream_depth")) g_tune.spmmv_stream_depth = value >= 2 ? 2 : 1;
     else if (!strcmp(key, "spmmv_phased")) g_tune.spmmv_phased = value != 0;
     else if (!strcmp(key, "spmmv_xcol")) g_tune.spmmv_xcol = value != 0;
     else if (!strcmp(key, "spmmv_ycol_nt")) g_tune.spmmv_ycol_nt = value != 0;
@@ -275,6 +276,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_phase_dp")) *value = g_tune.spmmv_phase_dp;
     else if (!strcmp(key, "spmmv_stream")) *value = g_tune.spmmv_stream;
     else if (!strcmp(key, "spmmv_stream_xcd")) *value = g_tune.spmmv_stream_xcd;
+    else if (!strcmp(key, "spmmv_stream_depth")) *value = g_tune.spmmv_stream_depth;
     else if (!strcmp(key, "spmmv_phased")) *value = g_tune.spmmv_phased;
     else if (!strcmp(key, "spmmv_xcol")) *value = g_tune.spmmv_xcol;
     else if (!strcmp(key, "spmmv_ycol_nt")) *value = g_tune.spmmv_ycol_nt;

@@ -223,6 +223,7 @@ struct Tuning {
                               // phase), 0 = every phase filled to the brim (what the device-side builder does)
     int spmmv_stream = 0;   // NEXT optimize_block (64-byte rows, C = 32, one-byte indices): > 0 = also lay the phased plan out as a flat schedule for this many
                             // persistent workgroups per CU (at most 5: 32 KiB of LDS each) and let uspmv_spmmv run the streaming kernel (spmmv_stream.hip)
+    int spmmv_stream_depth = 1;  // ... 1 = X rows and entries one phase ahead (two LDS buffers, full wait per phase); 2 = two phases ahead (three buffers, partial wait)
     int spmmv_stream_xcd = 1;  // ... 1 = the workgroups of an XCD take consecutive tiles, 0 = tile t goes to workgroup t % grid
     int spmmv_variant = 0;  // 0 = auto (= 3 where a B-specialised kernel exists); 1 = generic kernel; 2 = row-major with transposing X phase; 3 = row-major, lane per row
 };
