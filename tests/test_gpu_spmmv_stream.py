@@ -52,7 +52,7 @@ def matrix(pkg, name):
 
 CASES = [("stencil3", 32, 512, 4, 1, 1), ("stencil3", 32, 512, 3, 0, 2), ("stencil3", 32, 1, 1, 1, 2), ("stencil3", 32, 64, 5, 1, 1), ("stencil1", 32, 512, 4, 1, 2),
          ("mesh2d", 32, 128, 2, 1, 1), ("band", 32, 64, 4, 1, 2), ("FDM-2d-16", 32, 16, 4, 1, 2), ("impcol_e", 32, 64, 4, 0, 2), ("impcol_e", 32, 64, 4, 0, 1),
-         ("stencil3", 64, 128, 4, 1, 1)]
+         ("stencil3", 64, 128, 4, 1, 1), ("stencil3", 32, 512, 99, 1, 1), ("mesh2d", 32, 128, 99, 1, 1), ("impcol_e", 32, 64, 99, 1, 1)]
 
 
 @pytest.mark.parametrize("name,C,sigma,wgs,by_xcd,depth", CASES)

@@ -21,7 +21,7 @@ def check_small():
             s = pkg.convert_to_scs(coo, 32, sigma, pkg.F64); a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"])
             b, ld = 8, s.n_rows_padded
             X = torch.rand(b * ld, dtype=torch.float64, device="cuda") - 0.5
-            for wgs, depth in ((1, 1), (4, 1), (1, 2), (3, 2)):
+            for wgs, depth in ((1, 1), (4, 1), (1, 2), (3, 2), (99, 1)):
                 pkg.set_tuning(spmmv_stream=0, spmmv_variant=3)
                 A0 = pkg.DeviceMatrix(s)
                 ref = {}
@@ -37,7 +37,7 @@ def check_small():
                     ok &= same
                     print(json.dumps(dict(check=name, sigma=sigma, wgs_per_cu=wgs, depth=depth, layout="row" if lay == pkg.ROWWISE else "col", bitexact=same)), flush=True)
                 del A, A0
-    pkg.set_tuning(spmmv_stream=0, spmmv_stream_depth=1)
+    pkg.set_tuning(spmmv_stream=0, spmmv_stream_depth=1, spmmv_stream_waves=4)
     return ok
 
 
@@ -60,17 +60,21 @@ del A0
 # cases: workgroups per CU (0 = the one-tile-per-workgroup kernel); a negative number = that many with tile t -> workgroup t % grid
 # "n:2" = depth 2 (X rows and entries two phases ahead, three LDS buffers, partial waits)
 raw_cases = sys.argv[2].split(",") if len(sys.argv) > 2 else "0,3,3:2,0,3:2".split(",")
-cases = [(int(c.split(":")[0]), int(c.split(":")[1]) if ":" in c else 1) for c in raw_cases]
+# "99" = one tile per workgroup (only the phases of a tile pipelined); "n:1:5" = register budget of five waves per SIMD
+def _case(c):
+    f = c.split(":")
+    return int(f[0]), int(f[1]) if len(f) > 1 else 1, int(f[2]) if len(f) > 2 else 4
+cases = [_case(c) for c in raw_cases]
 abl = [int(c) for c in (sys.argv[3].split(",") if len(sys.argv) > 3 else [])]
-for wgs, depth in cases:
-    pkg.set_tuning(spmmv_stream=abs(wgs), spmmv_stream_xcd=1 if wgs >= 0 else 0, spmmv_stream_depth=depth)
+for wgs, depth, waves in cases:
+    pkg.set_tuning(spmmv_stream=abs(wgs), spmmv_stream_xcd=1 if wgs >= 0 else 0, spmmv_stream_depth=depth, spmmv_stream_waves=waves)
     A = pkg.DeviceMatrix(s, block_tlc=b)
     for lay, nm in ((pkg.ROWWISE, "rowwise"), (pkg.COLWISE, "colwise")):
         Y.fill_(-1.0); pkg.spmmv(A, X, Y, b, ld, lay)
         same = bool(torch.equal(Y, Y0[lay]))
         B.time_launches(5, 20, A=A, x=X, y=Y, b=b, ld=ld, layout=lay)
         ms = sorted(B.time_launches(5, 40, A=A, x=X, y=Y, b=b, ld=ld, layout=lay) for _ in range(5))
-        print(json.dumps(dict(wgs_per_cu=wgs, depth=depth if wgs else 0, kernel="pstream" if wgs else "quadph", layout=nm, bitexact=same, ms_min=round(ms[0], 4), ms_med=round(ms[2], 4))), flush=True)
+        print(json.dumps(dict(wgs_per_cu=wgs, depth=depth if wgs else 0, waves=waves if wgs else 0, kernel="pstream" if wgs else "quadph", layout=nm, bitexact=same, ms_min=round(ms[0], 4), ms_med=round(ms[2], 4))), flush=True)
     if wgs and depth == 1:
         for ab in abl:
             pkg.set_tuning(ablate=ab, spmmv_variant=8)
@@ -79,4 +83,4 @@ for wgs, depth in cases:
             print(json.dumps(dict(wgs_per_cu=wgs, ablate=ab, ms_min=round(ms[0], 4))), flush=True)
         pkg.set_tuning(ablate=0, spmmv_variant=0)
     del A
-pkg.set_tuning(spmmv_stream=0, spmmv_stream_depth=1)
+pkg.set_tuning(spmmv_stream=0, spmmv_stream_depth=1, spmmv_stream_waves=4)

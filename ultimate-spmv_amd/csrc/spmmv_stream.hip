@@ -55,10 +55,14 @@ __global__ void __launch_bounds__(256) stream_desc_fill(const long n_tiles, cons
     }
 }
 
-template <typename VT, int B, bool NT, bool YCOL, bool YNT, int ABL>
-__global__ void __launch_bounds__(256, 4) scs_spmmv_pstream(const PhDesc *__restrict__ desc, const int *__restrict__ wg_ptr,
+// MW: waves per SIMD the register allocation aims at (4: four workgroups per CU; 5: five, the most 32 KiB of LDS each allow).  xcd_remap != 0: the
+// schedule has ONE TILE PER WORKGROUP ("spmmv_stream" 99: the hardware deals the tiles out as workgroups finish, like the default kernel, and only the
+// phases of a tile are pipelined) and workgroup b takes entry remap_block(b) of it.
+template <typename VT, int B, bool NT, bool YCOL, bool YNT, int ABL, int MW = 4>
+__global__ void __launch_bounds__(256, MW) scs_spmmv_pstream(const PhDesc *__restrict__ desc, const int *__restrict__ wg_ptr,
         const VT *__restrict__ values, const unsigned char *__restrict__ col8, const int *__restrict__ xrows, const VT *__restrict__ X,
-        VT *__restrict__ Y, const long ld, const long n_rows_pad, const long n_store, const int *__restrict__ row_map, long long *__restrict__ wg_clock) {
+        VT *__restrict__ Y, const long ld, const long n_rows_pad, const long n_store, const int *__restrict__ row_map, long long *__restrict__ wg_clock,
+        const int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];     // two buffers of 256 X rows (16 KiB each)
     if (wg_clock && threadIdx.x == 0) wg_clock[blockIdx.x] = (long long)wall_clock64();      // (measurement aid: USPMV_STREAM_CLOCK)
     constexpr int VW = 16 / (int)sizeof(VT);
@@ -67,7 +71,8 @@ __global__ void __launch_bounds__(256, 4) scs_spmmv_pstream(const PhDesc *__rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int r = lane >> 2, q = lane & 3;
     const int sel = wave >> 1, hoff = (wave & 1) * 64 + lane;                  // the wave's chunk of the tile; its lanes' element inside a group
-    const int d_beg = wg_ptr[blockIdx.x], d_end = wg_ptr[blockIdx.x + 1];
+    const unsigned wg = xcd_remap ? remap_block(blockIdx.x, gridDim.x, xcd_remap) : blockIdx.x;
+    const int d_beg = wg_ptr[wg], d_end = wg_ptr[wg + 1];
     if (d_beg >= d_end) return;
     typedef int v8i __attribute__((ext_vector_type(8)));
     // descriptors of phases s, s + 1, s + 2 as scalars: {va, vb, lp, nl, pk, tile, -, -}; dl = the one in flight (phase s + 3 once iteration s has
@@ -178,7 +183,8 @@ __global__ void __launch_bounds__(256, 4) scs_spmmv_pstream(const PhDesc *__rest
 template <typename VT, int B, bool NT, bool YCOL, bool YNT, bool RM>
 __global__ void __launch_bounds__(256, 3) scs_spmmv_pstream2(const PhDesc *__restrict__ desc, const int *__restrict__ wg_ptr,
         const VT *__restrict__ values, const unsigned char *__restrict__ col8, const int *__restrict__ xrows, const VT *__restrict__ X,
-        VT *__restrict__ Y, const long ld, const long n_rows_pad, const long n_store, const int *__restrict__ row_map, long long *__restrict__ wg_clock) {
+        VT *__restrict__ Y, const long ld, const long n_rows_pad, const long n_store, const int *__restrict__ row_map, long long *__restrict__ wg_clock,
+        const int /*xcd_remap*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];     // three buffers of 256 X rows (16 KiB each)
     if (wg_clock && threadIdx.x == 0) wg_clock[blockIdx.x] = (long long)wall_clock64();
     constexpr int VW = 16 / (int)sizeof(VT);
@@ -292,6 +298,7 @@ template <typename VT, int B>
 bool launch_pstream(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol, hipStream_t st) {
     if (!A->ps_desc || !A->ps_wg_ptr || A->ps_grid <= 0 || A->part || A->C != 32 || !A->pb_idx8 || A->pb_max_rows > 256 || A->pb_ngp > 8) return false;
     const size_t lds = 2 * 16384;
+    const bool per_tile = (int64_t)A->ps_grid == A->pb_n_tiles && A->ps_per_tile;
     // measurement aid: USPMV_STREAM_CLOCK=<file> -- every workgroup's start and end time (100 MHz counter) of THIS launch, written as text
     static const char *clock_file = getenv("USPMV_STREAM_CLOCK");
     long long *d_clock = nullptr;
@@ -313,7 +320,7 @@ bool launch_pstream(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol,
         }
     } clock_out{d_clock, A->ps_grid, st, clock_file};
 #define PS_ARGS (const PhDesc *)A->ps_desc, (const int *)A->ps_wg_ptr, (const VT *)A->pb_values, (const unsigned char *)A->pb_col16, (const int *)A->pb_xrows, X, Y, ld, \
-                (long)(A->n_chunks * A->C), (long)A->n_store, (const int *)A->bt_row_map, d_clock
+                (long)(A->n_chunks * A->C), (long)A->n_store, (const int *)A->bt_row_map, d_clock, per_tile ? g_tune.xcd_remap : 0
 #define PS_LAUNCH(NTV, YC, YN, AB) hipLaunchKernelGGL((scs_spmmv_pstream<VT, B, NTV, YC, YN, AB>), dim3((unsigned)A->ps_grid), dim3(256), lds, st, PS_ARGS)
     if constexpr (sizeof(VT) == 8) {
         if (g_tune.ablate >= 1 && !ycol) {          // measurement only (results wrong by construction)
@@ -342,7 +349,12 @@ bool launch_pstream(const uspmv_dmat *A, const VT *X, VT *Y, long ld, bool ycol,
 #undef PS2_LAUNCH
         return true;
     }
-    if (nt) {
+    if (nt && g_tune.spmmv_stream_waves >= 5) {
+#define PS_LAUNCH5(NTV, YC, YN) hipLaunchKernelGGL((scs_spmmv_pstream<VT, B, NTV, YC, YN, 0, 5>), dim3((unsigned)A->ps_grid), dim3(256), lds, st, PS_ARGS)
+        if (ycol) { if (ynt) PS_LAUNCH5(true, true, true); else PS_LAUNCH5(true, true, false); }
+        else PS_LAUNCH5(true, false, true);
+#undef PS_LAUNCH5
+    } else if (nt) {
         if (ycol) { if (ynt) PS_LAUNCH(true, true, true, 0); else PS_LAUNCH(true, true, false, 0); }
         else PS_LAUNCH(true, false, true, 0);
     } else {
@@ -359,7 +371,7 @@ namespace uspmv_dev {
 
 void dmat_stream_release(uspmv_dmat *A) {
     (void)hipFree(A->ps_desc); (void)hipFree(A->ps_wg_ptr);
-    A->ps_desc = nullptr; A->ps_wg_ptr = nullptr; A->ps_grid = 0; A->ps_n_desc = 0;
+    A->ps_desc = nullptr; A->ps_wg_ptr = nullptr; A->ps_grid = 0; A->ps_n_desc = 0; A->ps_per_tile = false;
 }
 
 // The flat schedule of the handle's phased plan for `wgs_per_cu` persistent workgroups per CU: workgroup w walks tiles w, w + G, w + 2G, ...
@@ -371,13 +383,14 @@ int dmat_stream_schedule(uspmv_dmat *A, int wgs_per_cu) {
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t nt = A->pb_n_tiles;
-    const int G = (int)std::min<int64_t>((int64_t)std::max(cus, 1) * std::min(wgs_per_cu, 5), nt);
+    const bool per_tile = wgs_per_cu >= 99 && nt <= INT32_MAX;          // one tile per workgroup: only the phases of a tile are pipelined
+    const int G = per_tile ? (int)nt : (int)std::min<int64_t>((int64_t)std::max(cus, 1) * std::min(wgs_per_cu, 5), nt);
     std::vector<int32_t> php((size_t)nt + 1), slot((size_t)nt), wgp((size_t)G + 1, 0);
     HIP_TRY(hipMemcpy(php.data(), A->pb_ph_ptr, 4 * ((size_t)nt + 1), hipMemcpyDeviceToHost));
     // workgroup w runs on XCD w % 8 (round-robin dispatch): with "spmmv_stream_xcd" the G / 8 workgroups of an XCD take CONSECUTIVE tiles of
     // every super-block of G tiles -- neighbouring tiles share most of their X rows, which then meet in one L2 -- otherwise tile t goes to
     // workgroup t % G
-    const bool by_xcd = g_tune.spmmv_stream_xcd && G % 8 == 0 && G >= 16;
+    const bool by_xcd = !per_tile && g_tune.spmmv_stream_xcd && G % 8 == 0 && G >= 16;
     const int per = G / 8;
     int64_t pos = 0;
     for (int w = 0; w < G; ++w) {
@@ -407,7 +420,7 @@ int dmat_stream_schedule(uspmv_dmat *A, int wgs_per_cu) {
         dmat_stream_release(A);
         return uspmv::fail(USPMV_ERR_HIP, "uspmv_dmat_optimize_block: stream schedule: %s", hipGetErrorString(e));
     }
-    A->ps_grid = G; A->ps_n_desc = pos;
+    A->ps_grid = G; A->ps_n_desc = pos; A->ps_per_tile = per_tile;
     return USPMV_OK;
 }
 

@@ -199,7 +199,8 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_brick_stride")) g_tune.spmmv_brick_stride = value < 0 ? 0 : (long)value;
     else if (!strcmp(key, "spmmv_brick_lines")) g_tune.spmmv_brick_lines = value < 1 ? 1 : (int)value;
     else if (!strcmp(key, "spmmv_phase_dp")) g_tune.spmmv_phase_dp = value < 0 ? 0 : (int)value;
-    else if (!strcmp(key, "spmmv_stream")) g_tune.spmmv_stream = value < 0 ? 0 : value > 5 ? 5 : (int)value;
+    else if (!strcmp(key, "spmmv_stream")) g_tune.spmmv_stream = value < 0 ? 0 : value >= 99 ? 99 : value > 5 ? 5 : (int)value;
+    else if (!strcmp(key, "spmmv_stream_waves")) g_tune.spmmv_stream_waves = value >= 5 ? 5 : 4;
     else if (!strcmp(key, "spmmv_stream_xcd")) g_tune.spmmv_stream_xcd = value != 0;
     else if (!strcmp(key, "spmmv_stream_depth")) g_tune.spmmv_stream_depth = value >= 2 ? 2 : 1;
     else if (!strcmp(key, "spmmv_phased")) g_tune.spmmv_phased = value != 0;
@@ -276,6 +277,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_phase_dp")) *value = g_tune.spmmv_phase_dp;
     else if (!strcmp(key, "spmmv_stream")) *value = g_tune.spmmv_stream;
     else if (!strcmp(key, "spmmv_stream_xcd")) *value = g_tune.spmmv_stream_xcd;
+    else if (!strcmp(key, "spmmv_stream_waves")) *value = g_tune.spmmv_stream_waves;
     else if (!strcmp(key, "spmmv_stream_depth")) *value = g_tune.spmmv_stream_depth;
     else if (!strcmp(key, "spmmv_phased")) *value = g_tune.spmmv_phased;
     else if (!strcmp(key, "spmmv_xcol")) *value = g_tune.spmmv_xcol;

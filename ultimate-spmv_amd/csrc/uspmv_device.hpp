@@ -74,6 +74,7 @@ struct uspmv_dmat {
     bool pb_device_built = false;       // the plan's index part was built by csrc/block_plan_kernels.hip
     // the phased plan once more as a flat schedule of 32-byte phase descriptors for persistent workgroups (spmmv_stream.hip; "spmmv_stream")
     int ps_grid = 0;
+    bool ps_per_tile = false;           // the schedule has one tile per workgroup ("spmmv_stream" 99)
     int64_t ps_n_desc = 0;
     int32_t *ps_wg_ptr = nullptr;
     void *ps_desc = nullptr;
@@ -223,6 +224,7 @@ struct Tuning {
                               // phase), 0 = every phase filled to the brim (what the device-side builder does)
     int spmmv_stream = 0;   // NEXT optimize_block (64-byte rows, C = 32, one-byte indices): > 0 = also lay the phased plan out as a flat schedule for this many
                             // persistent workgroups per CU (at most 5: 32 KiB of LDS each) and let uspmv_spmmv run the streaming kernel (spmmv_stream.hip)
+    int spmmv_stream_waves = 4;  // ... depth 1: register budget of the kernel in waves per SIMD (4 | 5)
     int spmmv_stream_depth = 1;  // ... 1 = X rows and entries one phase ahead (two LDS buffers, full wait per phase); 2 = two phases ahead (three buffers, partial wait)
     int spmmv_stream_xcd = 1;  // ... 1 = the workgroups of an XCD take consecutive tiles, 0 = tile t goes to workgroup t % grid
     int spmmv_variant = 0;  // 0 = auto (= 3 where a B-specialised kernel exists); 1 = generic kernel; 2 = row-major with transposing X phase; 3 = row-major, lane per row
