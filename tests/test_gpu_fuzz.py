@@ -198,7 +198,7 @@ def check_every_setup(pkg, orc, t, rng, m, C, sigma, f64, tag, expect=None):
     Ad = pkg.DeviceMatrix(s); Ad.optimize_block_device(b); handles.append(("device block plan", Ad))
     if b * (8 if f64 else 4) == 64 and C == 32:             # 64-byte X rows: the phased plan walked as a stream by persistent workgroups (both builders)
         sdepth = int(rng.choice([1, 2]))
-        pkg.set_tuning(spmmv_stream=int(rng.choice([1, 2, 3, 4, 5])), spmmv_stream_xcd=int(rng.choice([0, 1])))
+        pkg.set_tuning(spmmv_stream=int(rng.choice([1, 2, 3, 4, 5, 99])), spmmv_stream_xcd=int(rng.choice([0, 1])))
         try:
             As = pkg.DeviceMatrix(s); As.optimize_block(s, b); handles.append(("host block plan, streamed", As))
             At = pkg.DeviceMatrix(s); At.optimize_block_device(b); handles.append(("device block plan, streamed", At))
