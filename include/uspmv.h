@@ -220,6 +220,10 @@ int uspmv_dmat_plan_info(const uspmv_dmat_t *m, int *kind, int64_t *n_tiles, int
 int uspmv_dmat_block_plan_info(const uspmv_dmat_t *m, int64_t meta[10]);
 /* X rows the phased block plan stages per product (sum of its phases' lists; 0 without such a plan) */
 int uspmv_dmat_block_plan_staged(const uspmv_dmat_t *m, int64_t *rows_staged);
+/* x elements per entry of the tile-local-column plan's lists: 16 (128-byte lines, the default), 1 (single elements: the plan uspmv_dmat_optimize falls
+ * to when a tile's columns are scattered over too many lines -- row numberings that are only locally coherent), 0 without such a plan.  Same kernel
+ * arithmetic as scs_impl_cpu (code/kernels.hpp:218-258) either way. */
+int uspmv_dmat_plan_granularity(const uspmv_dmat_t *m, int *elements_per_list_entry);
 /* the phased block plan laid out as a flat schedule for persistent workgroups (tuning "spmmv_stream" > 0 at plan time; the streaming form of
  * block_spmv_omp_scs_general, code/kernels.hpp:306-398): meta[2] = workgroups of the launch (0: no schedule on the handle), phase descriptors */
 int uspmv_dmat_stream_info(const uspmv_dmat_t *m, int64_t meta[2]);

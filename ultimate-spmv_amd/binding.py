@@ -99,6 +99,7 @@ _SIGS = {
     "uspmv_dmat_block_plan_digest": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "uspmv_dmat_block_plan_staged": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dmat_stream_info": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "uspmv_dmat_plan_granularity": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "uspmv_dmat_optimize_sweep_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_sweep_plan_digest": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(_i64)]),
     "uspmv_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp]),
@@ -865,6 +866,12 @@ class DeviceMatrix:
         _ck(lib().uspmv_dmat_tile_rows(self.h, C.byref(tr)))
         self.tile_rows = tr.value
         return a.value, b.value
+
+    def plan_granularity(self):
+        """x elements per list entry of the tile-local-column plan: 16 (lines), 1 (single elements), 0 (no plan): uspmv_dmat_plan_granularity."""
+        g = C.c_int()
+        _ck(lib().uspmv_dmat_plan_granularity(self.h, C.byref(g)))
+        return g.value
 
     def index_bits(self):
         """Bits per tile-local column index the plan's kernel streams (16 | 12; 0 without a plan): uspmv_dmat_index_bits."""

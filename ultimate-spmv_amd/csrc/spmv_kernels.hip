@@ -202,7 +202,9 @@ __device__ __forceinline__ float ld_sys(const float *p) {
 // I12: c16_ptrs / col16 are the handle's 12-BIT arrays (uspmv_device.hpp: tlc_c12_ptrs in dwords, tlc_col12): per pair of slot groups three
 // consecutive dwords per row (8 indices, one global_load_dwordx3), an odd last group a dword + a ushort -- 1.5 instead of 2 bytes of index
 // per non-zero.
-template <typename VT, int CT, bool NT, bool IDS, int SYNC = 0, bool I12 = false>
+// ELEM: the tile's list holds single x ELEMENTS (uspmv_build_tlc_plan with line_shift 0): thread k gathers element k of the list into LDS -- one
+// 8-byte gather per DISTINCT column of the tile instead of one per entry; local indices = positions in the list.
+template <typename VT, int CT, bool NT, bool IDS, int SYNC = 0, bool I12 = false, bool ELEM = false>
 __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const int C_rt, const int *__restrict__ chunk_ptrs,
         const int *__restrict__ chunk_lengths, const int *__restrict__ col_idxs, const VT *__restrict__ values,
         const VT *__restrict__ x_arg, VT *__restrict__ y, const int *__restrict__ tile_line_ptr,
@@ -268,6 +270,12 @@ __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const 
     VT acc = VT(0);
     if (nl > 0) {
         const int sub = threadIdx.x % LPL, lk = threadIdx.x / LPL;
+        if constexpr (ELEM) {
+            for (int k = threadIdx.x; k < nl; k += blockDim.x) {
+                const long idx = tile_lines[lp0 + k];
+                xs[k] = idx < x_len ? x[idx] : VT(0);
+            }
+        } else
         for (int k = lk; k < nl; k += blockDim.x / LPL) {
             const long idx = (long)tile_lines[lp0 + k] * 16 + sub * EPL;
             vec_t v;
@@ -493,13 +501,15 @@ int launch_spmv_tlc(const uspmv_dmat *A, const int *tile_ids, long n_tiles, cons
     if (n_tiles == 0) return USPMV_OK;
     const int C = (int)A->C;
     const unsigned grid = (unsigned)n_tiles;
-    const size_t lds = (size_t)A->tlc_max_lines * 16 * sizeof(VT);
+    const bool elem = A->tlc_elem;
+    const size_t lds = (size_t)A->tlc_max_lines * (elem ? 1 : 16) * sizeof(VT);
     const bool i12 = A->tlc_col12 != nullptr;                 // (12-bit local indices: uspmv_api.hip tlc_pack12)
     const unsigned *iptrs = i12 ? A->tlc_c12_ptrs : A->tlc_c16_ptrs;
     const unsigned short *idata = i12 ? (const unsigned short *)A->tlc_col12 : A->tlc_col16;
 #define TLC_LAUNCH(CTV, NTV, IDSV)                                                                                    \
     do {                                                                                                              \
         auto kfn = i12 ? scs_spmv_tlc<VT, CTV, NTV, IDSV, 0, true> : scs_spmv_tlc<VT, CTV, NTV, IDSV>;                \
+        if (elem) kfn = i12 ? scs_spmv_tlc<VT, CTV, NTV, IDSV, 0, true, true> : scs_spmv_tlc<VT, CTV, NTV, IDSV, 0, false, true>; \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(A->tlc_tile_rows), lds, st, (long)A->n_chunks, C, A->chunk_ptrs,        \
                            A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, A->tlc_line_ptr, A->tlc_lines,   \
@@ -518,6 +528,7 @@ template <typename VT>
 int launch_spmv_tlc_step(const uspmv_dmat *A, const int *step_ids, const StepArgs &sa, int sync, const VT *x, VT *y, hipStream_t st) {
     const long n = sync == 1 ? sa.n_early + sa.n_real + sa.n_cond : sa.n_real + sa.n_cond;
     if (n == 0) return USPMV_OK;
+    if (A->tlc_elem) return uspmv::fail(USPMV_ERR_UNSUPPORTED, "one-launch distributed step: not on a plan over single x elements");
     const int C = (int)A->C;
     const size_t lds = (size_t)A->tlc_max_lines * 16 * sizeof(VT);
     const bool i12 = A->tlc_col12 != nullptr;

@@ -199,6 +199,8 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_brick_stride")) g_tune.spmmv_brick_stride = value < 0 ? 0 : (long)value;
     else if (!strcmp(key, "spmmv_brick_lines")) g_tune.spmmv_brick_lines = value < 1 ? 1 : (int)value;
     else if (!strcmp(key, "spmmv_phase_dp")) g_tune.spmmv_phase_dp = value < 0 ? 0 : (int)value;
+    else if (!strcmp(key, "tlc_elem")) g_tune.tlc_elem = value < 0 ? 0 : value > 2 ? 2 : (int)value;
+    else if (!strcmp(key, "tlc_elem_cap")) g_tune.tlc_elem_cap = value < 64 ? 64 : value > 16384 ? 16384 : (int)value;
     else if (!strcmp(key, "spmmv_stream")) g_tune.spmmv_stream = value < 0 ? 0 : value >= 99 ? 99 : value > 5 ? 5 : (int)value;
     else if (!strcmp(key, "spmmv_stream_waves")) g_tune.spmmv_stream_waves = value >= 5 ? 5 : 4;
     else if (!strcmp(key, "spmmv_stream_xcd")) g_tune.spmmv_stream_xcd = value != 0;
@@ -275,6 +277,8 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_brick_stride")) *value = g_tune.spmmv_brick_stride;
     else if (!strcmp(key, "spmmv_brick_lines")) *value = g_tune.spmmv_brick_lines;
     else if (!strcmp(key, "spmmv_phase_dp")) *value = g_tune.spmmv_phase_dp;
+    else if (!strcmp(key, "tlc_elem")) *value = g_tune.tlc_elem;
+    else if (!strcmp(key, "tlc_elem_cap")) *value = g_tune.tlc_elem_cap;
     else if (!strcmp(key, "spmmv_stream")) *value = g_tune.spmmv_stream;
     else if (!strcmp(key, "spmmv_stream_xcd")) *value = g_tune.spmmv_stream_xcd;
     else if (!strcmp(key, "spmmv_stream_waves")) *value = g_tune.spmmv_stream_waves;
@@ -460,6 +464,7 @@ static void tlc_release(uspmv_dmat_t *A) {
     (void)hipFree(A->tlc_line_ptr); (void)hipFree(A->tlc_lines); (void)hipFree(A->tlc_c16_ptrs); (void)hipFree(A->tlc_col16);
     (void)hipFree(A->tlc_c12_ptrs); (void)hipFree(A->tlc_col12);
     A->tlc_line_ptr = A->tlc_lines = nullptr; A->tlc_c16_ptrs = nullptr; A->tlc_col16 = nullptr; A->tlc_c12_ptrs = A->tlc_col12 = nullptr;
+    A->tlc_elem = false;
     A->tlc = false; A->tlc_plan_id = 0;
 }
 
@@ -565,7 +570,7 @@ static int measured_tile_rows(uspmv_dmat_t *A, uspmv_dmat_t *B, int max_lines, c
 // adaptive-precision kernels, uspmv_dmat_plan_download and the plan digests read it).  cl: the chunk lengths when the caller has them on
 // the host, else they are copied back (4 bytes per chunk).
 static int tlc_pack12(uspmv_dmat_t *A, const std::vector<int32_t> *cl, const char *who) {
-    if (!A->tlc || !g_tune.tlc_idx12 || A->tlc_max_lines > 256 || A->C < 2 || A->C % 2 != 0 || A->n_chunks < 1) return USPMV_OK;
+    if (!A->tlc || !g_tune.tlc_idx12 || (A->tlc_elem ? A->tlc_max_lines > 4096 : A->tlc_max_lines > 256) || A->C < 2 || A->C % 2 != 0 || A->n_chunks < 1) return USPMV_OK;
     std::vector<int32_t> own;
     if (!cl || (int64_t)cl->size() != A->n_chunks) {
         own.resize((size_t)A->n_chunks);
@@ -624,6 +629,7 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
             return USPMV_OK;
         }
     }
+    const bool own_budget = max_lines > 0;                     // (a caller with a line budget of its own keeps the line plan: no element fallback)
     if (max_lines <= 0) max_lines = 512;                       // 64 KiB of doubles: 2 workgroups per CU at worst
     const int cap = (int)(160 * 1024 / (16 * (s->dtype == USPMV_F64 ? 8 : 4)));
     if (max_lines > cap) max_lines = cap;
@@ -641,7 +647,26 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] tlc plan: tile_rows=%d tiles=%lld staged=%lld max_lines=%d lines_total=%zu col16=%zu\n",
                                          p.tile_rows, (long long)p.n_tiles, (long long)p.n_staged_tiles, p.max_lines_used, p.tile_lines.size(), p.col16.size());
     if (A->sw) sw_release(A);
-    if ((!p.valid || p.n_staged_tiles * 2 < p.n_tiles) && g_tune.sweep) {
+    bool elem = false;
+    if (((!own_budget && (!p.valid || p.n_staged_tiles * 10 < p.n_tiles * 9)) || g_tune.tlc_elem == 2) && g_tune.tlc_elem && uspmv_dev::tl_measure_off == 0) {   // (2: measurement aid, always try)
+        // columns scattered over many lines (x in a numbering that is only loosely related to the rows'): the line plan leaves a tenth of the tiles or
+        // more to the gather path.  List the tile's distinct ELEMENTS instead -- taken when (nearly) every tile fits and an element serves four
+        // entries or more on average (else the line plan stays, or the column-window sweep takes over below).  Measured (tools/numbering_probe.py,
+        // profiles/r04/numbering_probe_*.txt): 27-point x 3 dof stencil with x renumbered at random inside blocks of 1 000 / 5 000 / 20 000 nodes 0.97 / 0.90 /
+        // 0.89 of the roofline against 0.74 (line plan, 69 % of the tiles staged) / 0.70 / 0.61 (sweep); 1 dof, 4.2 entries per element: 0.65 against 0.59;
+        // on a regular numbering the line plan is 20 % ahead (0.683 against 0.819 ms on the 253^3 stencil), which is why this is a fallback only.
+        uspmv_tlc_plan q;
+        const int ecap = std::min(g_tune.tlc_elem_cap, (int)(64 * 1024 / (s->dtype == USPMV_F64 ? 8 : 4)));
+        if (int rc = uspmv_build_tlc_plan(s, nullptr, ecap, 256, &q, /*line_shift=*/0)) return rc;
+        if (q.valid && tile_rows_accept(q.n_tiles, q.n_staged_tiles) && ((double)q.tile_lines.size() * 4.0 <= (double)s->n_elements || g_tune.tlc_elem == 2)) {
+            p = std::move(q); elem = true;
+            if (n_tiles) *n_tiles = p.n_tiles;
+            if (n_staged) *n_staged = p.n_staged_tiles;
+            if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] tlc plan over single x elements: tiles=%lld staged=%lld max_elements=%d elements_total=%zu (%.1f entries per element)\n",
+                                                 (long long)p.n_tiles, (long long)p.n_staged_tiles, p.max_lines_used, p.tile_lines.size(), (double)s->n_elements / (double)std::max<size_t>(p.tile_lines.size(), 1));
+        }
+    }
+    if (!elem && (!p.valid || p.n_staged_tiles * 2 < p.n_tiles) && g_tune.sweep) {
         // wide, irregular rows: most tiles touch too many x lines to stage them.  Try the column-window sweep; it takes over
         // when it covers at least half of the rows.
         int64_t swt = 0, sws = 0;
@@ -664,7 +689,7 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
         return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize: device copy failed: %s", hipGetErrorString(e));
     }
     A->tlc = true; A->tlc_tile_rows = p.tile_rows; A->tlc_max_lines = p.max_lines_used; A->tlc_x_len = p.x_len_min; A->tlc_n_tiles = p.n_tiles;
-    A->tlc_staged = p.n_staged_tiles;
+    A->tlc_staged = p.n_staged_tiles; A->tlc_elem = elem;
     return tlc_pack12(A, &s->chunk_lengths, "uspmv_dmat_optimize");
 }
 
@@ -1760,6 +1785,13 @@ int uspmv_dmat_block_plan_info(const uspmv_dmat_t *A, int64_t meta[10]) {
     const uspmv_dmat_t *M = (A->alt && g_tune.rechunk) ? A->alt : A;
     meta[0] = M->bt; meta[1] = M->pb; meta[2] = M->pl; meta[3] = M->pb_n_tiles; meta[4] = M->pb_n_phases; meta[5] = M->pl_n_phases;
     meta[6] = M->pl_rows_staged; meta[7] = M->pb_idx8; meta[8] = M->pb_device_built; meta[9] = M->pb_max_rows;
+    return USPMV_OK;
+}
+
+int uspmv_dmat_plan_granularity(const uspmv_dmat_t *A, int *elements_per_list_entry) {
+    if (!A || !elements_per_list_entry) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_plan_granularity: NULL argument");
+    const uspmv_dmat_t *M = (A->alt && g_tune.rechunk) ? A->alt : A;
+    *elements_per_list_entry = !M->tlc ? 0 : M->tlc_elem ? 1 : 16;
     return USPMV_OK;
 }
 

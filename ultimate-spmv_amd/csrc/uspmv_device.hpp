@@ -39,6 +39,8 @@ struct uspmv_dmat {
     long part_split = 0;
     // tile-local-column plan (host/tlc_plan.cpp), device copies owned by the handle
     bool tlc = false;
+    bool tlc_elem = false;   // the plan lists single x ELEMENTS instead of 16-element lines (tlc_max_lines counts elements): rows whose columns are scattered
+                             // (a numbering that is only locally coherent) -- uspmv_dmat_optimize falls to it when the line plan stages too few tiles
     int tlc_max_lines = 0, tlc_tile_rows = 256;
     int64_t tlc_x_len = 0, tlc_n_tiles = 0, tlc_staged = 0;
     uint64_t tlc_plan_id = 0;   // structs planned together (ap pair) carry the same non-zero id
@@ -211,6 +213,9 @@ struct Tuning {
     int spmmv_phase_rows = 256;  // ... X rows per phase (256 | 512)
     int spmmv_list_plan = 0;   // NEXT optimize_block: also build the one-list-per-tile plan (variants 4 / 5 / 6) when the phased kernel can take the matrix
     int spmmv_idx8 = 1;        // NEXT optimize_block: one-byte phase-local indices when every phase lists <= 256 rows
+    int tlc_elem = 1;        // NEXT uspmv_dmat_optimize (host planner, one struct): when the 16-element-line plan stages fewer than half of the tiles, try the
+                             // plan over single x elements (each distinct column of a tile gathered once into LDS) before the column-window sweep
+    int tlc_elem_cap = 4096; // ... most elements a tile may list (4096: 32 KiB of doubles, local indices still fit 12 bits)
     int tlc_idx12 = 1;       // NEXT optimize: tile-local-column plans of <= 256 lines per tile also get their local indices packed to 12 bits: 0 = never,
                              // 1 = kept when the mean row length is >= 8, 2 = kept wherever it can be built
     int spmmv_reorder = 4;  // block plan's private copy of the entries (host planner): 1 = rows of equal-length chunks of a sigma window back in original order;
