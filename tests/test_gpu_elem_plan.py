@@ -18,8 +18,9 @@ def t(pkg):
     return torch
 
 
-def scrambled_columns(pkg, g, dof, K, seed=3):
-    """27-point x dof stencil on g^3 nodes with the COLUMNS' nodes renumbered at random inside consecutive blocks of K nodes (rows keep their order)."""
+def scrambled_columns(pkg, g, dof, K, seed=3, rows_too=False):
+    """27-point x dof stencil on g^3 nodes with the COLUMNS' nodes renumbered at random inside consecutive blocks of K nodes (rows keep their order
+    unless rows_too: then the permutation is symmetric)."""
     base = pkg.gen_stencil27(g, g, g, dof=dof)
     I, J, V = (np.array(a) for a in base.arrays())
     n = base.n_rows
@@ -29,8 +30,9 @@ def scrambled_columns(pkg, g, dof, K, seed=3):
     for s0 in range(0, nn, K):
         seg = p[s0:s0 + K].copy(); rng.shuffle(seg); p[s0:s0 + K] = seg
     J2 = (p[J // dof] * dof + J % dof).astype(np.int32)
-    o = np.lexsort((J2, I))
-    return pkg.Coo.from_arrays(n, n, I[o], J2[o], V[o])
+    I2 = (p[I // dof] * dof + I % dof).astype(np.int32) if rows_too else I
+    o = np.lexsort((J2, I2))
+    return pkg.Coo.from_arrays(n, n, I2[o], J2[o], V[o])
 
 
 @pytest.fixture(scope="module")
@@ -89,3 +91,31 @@ def test_regular_numbering_keeps_the_line_plan_unless_forced(pkg, orc, t):
         dy = t.zeros(s.n_rows_padded, dtype=t.float64, device="cuda")
         pkg.spmv(H, t.from_numpy(x).cuda(), dy)
         assert np.array_equal(dy.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("C,sigma,dt", [(32, 512, "f64"), (32, 64, "f32"), (64, 128, "f64")])
+def test_rows_dealt_by_the_matrix_graph_then_the_element_plan(pkg, orc, t, C, sigma, dt):
+    """Rows AND columns renumbered alike: a tile of consecutive rows is no compact piece of the mesh any more.  uspmv_dmat_optimize deals the rows to the tiles
+    by the matrix graph (a private copy of the values, y through a row map) and lists single x elements: bit-identical to the oracle, every row of y."""
+    m = scrambled_columns(pkg, 40, 3, 8000, rows_too=True)
+    dtype = pkg.F64 if dt == "f64" else pkg.F32
+    s = pkg.convert_to_scs(m, C, sigma, dtype)
+    a = s.arrays(); pkg.permute_scs_cols(s, a["old_to_new_idx"]); a = s.arrays()
+    x = np.zeros(s.n_rows_padded, a["values"].dtype)
+    x[:s.n_rows] = pkg.apply_permutation(make_x(s.n_rows).astype(a["values"].dtype), a["new_to_old_idx"])
+    want = orc.spmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], x)
+    A = pkg.DeviceMatrix(s, tlc=True)
+    assert A.plan_granularity() == 1 and A.tlc_staged * 20 >= A.tlc_tiles * 19, (A.plan_granularity(), A.tlc_staged, A.tlc_tiles)
+    dx = t.from_numpy(x).cuda()
+    for _ in range(2):
+        dy = t.full((s.n_rows_padded,), -3.0, dtype=dx.dtype, device="cuda")
+        pkg.spmv(A, dx, dy)
+        assert np.array_equal(dy.cpu().numpy()[:s.n_rows], want[:s.n_rows])
+    pkg.set_tuning(tlc_elem_rows=0)                       # without the row dealing the other plans answer -- same bits
+    try:
+        A0 = pkg.DeviceMatrix(s, tlc=True)
+    finally:
+        pkg.set_tuning(tlc_elem_rows=1)
+    dy = t.full((s.n_rows_padded,), -3.0, dtype=dx.dtype, device="cuda")
+    pkg.spmv(A0, dx, dy)
+    assert np.array_equal(dy.cpu().numpy()[:s.n_rows], want[:s.n_rows])

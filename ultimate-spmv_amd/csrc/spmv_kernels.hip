@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const 
         const VT *__restrict__ x_arg, VT *__restrict__ y, const int *__restrict__ tile_line_ptr,
         const int *__restrict__ tile_lines, const unsigned *__restrict__ c16_ptrs,
         const unsigned short *__restrict__ col16, const long x_len, const int *__restrict__ tile_ids,
-        const int xcd_remap, const long n_store, const StepArgs sa) {
+        const int xcd_remap, const long n_store, const StepArgs sa, const int *__restrict__ row_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tlc_smem[];
     VT *xs = (VT *)tlc_smem;
     constexpr int EPL = 16 / (int)sizeof(VT);   // elements per 16-byte load
@@ -375,6 +375,12 @@ __global__ void __launch_bounds__(1024) scs_spmv_tlc(const long n_chunks, const 
             acc = fma_t(ld_stream<NT>(vp + (long)j * C), (SYNC == 1 && coh) ? ld_sys(x + cj) : x[cj], acc);
         }
     }
+    if constexpr (ELEM) {
+        if (row_map) {                                       // rows dealt to the tiles by the matrix graph: y through the plan's row map (plain stores: the L2 merges them)
+            if (valid) { const long yr = row_map[row]; if (yr < n_store) y[yr] = acc; }
+            return;
+        }
+    }
     if (valid && row < n_store) st_y<NT>(y + row, acc);
 }
 
@@ -512,8 +518,8 @@ int launch_spmv_tlc(const uspmv_dmat *A, const int *tile_ids, long n_tiles, cons
         if (elem) kfn = i12 ? scs_spmv_tlc<VT, CTV, NTV, IDSV, 0, true, true> : scs_spmv_tlc<VT, CTV, NTV, IDSV, 0, false, true>; \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(A->tlc_tile_rows), lds, st, (long)A->n_chunks, C, A->chunk_ptrs,        \
-                           A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, A->tlc_line_ptr, A->tlc_lines,   \
-                           iptrs, idata, (long)A->tlc_x_len, tile_ids, g_tune.xcd_remap, A->n_store, StepArgs{});  \
+                           A->chunk_lengths, A->tlc_cols ? A->tlc_cols : A->col_idxs, (const VT *)(A->tlc_values ? A->tlc_values : A->values), x, y, A->tlc_line_ptr, A->tlc_lines,   \
+                           iptrs, idata, (long)A->tlc_x_len, tile_ids, g_tune.xcd_remap, A->n_store, StepArgs{}, (const int *)A->tlc_row_map);  \
     } while (0)
 #define TLC_LAUNCH_C(NTV, IDSV) do { if (C == 32) TLC_LAUNCH(32, NTV, IDSV); else TLC_LAUNCH(0, NTV, IDSV); } while (0)
     if (tile_ids) { if (g_tune.nontemporal) TLC_LAUNCH_C(true, true); else TLC_LAUNCH_C(false, true); }
@@ -540,7 +546,7 @@ int launch_spmv_tlc_step(const uspmv_dmat *A, const int *step_ids, const StepArg
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kfn, dim3((unsigned)n), dim3(A->tlc_tile_rows), lds, st, (long)A->n_chunks, C, A->chunk_ptrs,  \
                            A->chunk_lengths, A->col_idxs, (const VT *)A->values, x, y, A->tlc_line_ptr, A->tlc_lines,   \
-                           iptrs, idata, (long)A->tlc_x_len, step_ids, g_tune.xcd_remap, A->n_store, sa); \
+                           iptrs, idata, (long)A->tlc_x_len, step_ids, g_tune.xcd_remap, A->n_store, sa, (const int *)nullptr); \
     } while (0)
     if (sync == 1) { if (C == 32) TLC_STEP(32, 1); else TLC_STEP(0, 1); }
     else { if (C == 32) TLC_STEP(32, 2); else TLC_STEP(0, 2); }

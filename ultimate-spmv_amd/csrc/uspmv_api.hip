@@ -200,6 +200,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_brick_lines")) g_tune.spmmv_brick_lines = value < 1 ? 1 : (int)value;
     else if (!strcmp(key, "spmmv_phase_dp")) g_tune.spmmv_phase_dp = value < 0 ? 0 : (int)value;
     else if (!strcmp(key, "tlc_elem")) g_tune.tlc_elem = value < 0 ? 0 : value > 2 ? 2 : (int)value;
+    else if (!strcmp(key, "tlc_elem_rows")) g_tune.tlc_elem_rows = value != 0;
     else if (!strcmp(key, "tlc_elem_cap")) g_tune.tlc_elem_cap = value < 64 ? 64 : value > 16384 ? 16384 : (int)value;
     else if (!strcmp(key, "spmmv_stream")) g_tune.spmmv_stream = value < 0 ? 0 : value >= 99 ? 99 : value > 5 ? 5 : (int)value;
     else if (!strcmp(key, "spmmv_stream_waves")) g_tune.spmmv_stream_waves = value >= 5 ? 5 : 4;
@@ -278,6 +279,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_brick_lines")) *value = g_tune.spmmv_brick_lines;
     else if (!strcmp(key, "spmmv_phase_dp")) *value = g_tune.spmmv_phase_dp;
     else if (!strcmp(key, "tlc_elem")) *value = g_tune.tlc_elem;
+    else if (!strcmp(key, "tlc_elem_rows")) *value = g_tune.tlc_elem_rows;
     else if (!strcmp(key, "tlc_elem_cap")) *value = g_tune.tlc_elem_cap;
     else if (!strcmp(key, "spmmv_stream")) *value = g_tune.spmmv_stream;
     else if (!strcmp(key, "spmmv_stream_xcd")) *value = g_tune.spmmv_stream_xcd;
@@ -465,6 +467,7 @@ static void tlc_release(uspmv_dmat_t *A) {
     (void)hipFree(A->tlc_c12_ptrs); (void)hipFree(A->tlc_col12);
     A->tlc_line_ptr = A->tlc_lines = nullptr; A->tlc_c16_ptrs = nullptr; A->tlc_col16 = nullptr; A->tlc_c12_ptrs = A->tlc_col12 = nullptr;
     A->tlc_elem = false;
+    (void)hipFree(A->tlc_values); (void)hipFree(A->tlc_row_map); (void)hipFree(A->tlc_cols); A->tlc_values = nullptr; A->tlc_row_map = A->tlc_cols = nullptr;
     A->tlc = false; A->tlc_plan_id = 0;
 }
 
@@ -666,6 +669,29 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
                                                  (long long)p.n_tiles, (long long)p.n_staged_tiles, p.max_lines_used, p.tile_lines.size(), (double)s->n_elements / (double)std::max<size_t>(p.tile_lines.size(), 1));
         }
     }
+    // ... and when the ROWS of a tile are scattered as well (rows and columns renumbered alike: a tile of 256 consecutive rows is no compact piece of the
+    // mesh any more): deal the rows to the tiles by the matrix graph first, as the block plan does (uspmv_scs_reorder_rows mode 4: rows change places
+    // only with rows of equal-length chunks, every row keeps its slot sequence), then the element plan on that order -- a private copy of the values
+    // (8 / 4 bytes per element of HBM), of the column indices (for the few tiles that do not stage) and a row map for y.
+    uspmv_scs rr;
+    std::vector<int32_t> rr_map;
+    bool reordered = false;
+    if (!elem && !own_budget && (!p.valid || p.n_staged_tiles * 10 < p.n_tiles * 9) && g_tune.tlc_elem && g_tune.tlc_elem_rows && uspmv_dev::tl_measure_off == 0 &&
+        s->n_rows == s->n_cols && uspmv_scs_reorder_rows(s, 4, &rr, &rr_map) == 1) {
+        uspmv_tlc_plan q;
+        const int ecap = std::min(g_tune.tlc_elem_cap, (int)(64 * 1024 / (s->dtype == USPMV_F64 ? 8 : 4)));
+        if (int rc = uspmv_build_tlc_plan(&rr, nullptr, ecap, 256, &q, /*line_shift=*/0)) return rc;
+        if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] element plan on the graph-dealt rows: valid=%d tiles=%lld staged=%lld max_elements=%d (cap %d) elements_total=%zu\n", (int)q.valid,
+                                             (long long)q.n_tiles, (long long)q.n_staged_tiles, q.max_lines_used, ecap, q.tile_lines.size());
+        // (19 of 20 tiles staged is enough here: what would run instead -- sweep or gather kernel -- is 2 x slower on such matrices)
+        if (q.valid && q.n_staged_tiles * 20 >= q.n_tiles * 19 && (double)q.tile_lines.size() * 4.0 <= (double)s->n_elements) {
+            p = std::move(q); elem = true; reordered = true;
+            if (n_tiles) *n_tiles = p.n_tiles;
+            if (n_staged) *n_staged = p.n_staged_tiles;
+            if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] tlc plan over single x elements, rows dealt to the tiles by the matrix graph: tiles=%lld max_elements=%d elements_total=%zu (%.1f entries per element)\n",
+                                                 (long long)p.n_tiles, p.max_lines_used, p.tile_lines.size(), (double)s->n_elements / (double)std::max<size_t>(p.tile_lines.size(), 1));
+        }
+    }
     if (!elem && (!p.valid || p.n_staged_tiles * 2 < p.n_tiles) && g_tune.sweep) {
         // wide, irregular rows: most tiles touch too many x lines to stage them.  Try the column-window sweep; it takes over
         // when it covers at least half of the rows.
@@ -684,6 +710,11 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     if (e == hipSuccess) e = up(p.tile_lines.data(), p.tile_lines.size() * 4, (void **)&A->tlc_lines);
     if (e == hipSuccess) e = up(p.c16_ptrs.data(), p.c16_ptrs.size() * 4, (void **)&A->tlc_c16_ptrs);
     if (e == hipSuccess) e = up(p.col16.data(), p.col16.size() * 2, (void **)&A->tlc_col16);
+    if (e == hipSuccess && reordered) {
+        e = up(rr.values_ptr(), (size_t)rr.n_elements * (rr.dtype == USPMV_F64 ? 8 : 4), &A->tlc_values);
+        if (e == hipSuccess) e = up(rr_map.data(), rr_map.size() * 4, (void **)&A->tlc_row_map);
+        if (e == hipSuccess && p.n_staged_tiles < p.n_tiles) e = up(rr.col_idxs.data(), (size_t)rr.n_elements * 4, (void **)&A->tlc_cols);
+    }
     if (e != hipSuccess) {
         tlc_release(A);
         return uspmv::fail(USPMV_ERR_ALLOC, "uspmv_dmat_optimize: device copy failed: %s", hipGetErrorString(e));

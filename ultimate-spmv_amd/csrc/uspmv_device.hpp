@@ -52,6 +52,10 @@ struct uspmv_dmat {
     // lane; three planes of C dwords measured 3 % slower), then for an odd last group one plane of C dwords + one of C ushorts (48 bits per
     // row).  What scs_spmv_tlc reads when present.
     uint32_t *tlc_c12_ptrs = nullptr, *tlc_col12 = nullptr;
+    // element plan over rows DEALT TO THE TILES BY THE MATRIX GRAPH (uspmv_scs_reorder_rows mode 4, as for the block plan): a private copy of the values in that
+    // order and row_map[plan row] = row of y.  Null when the caller's row order is kept.
+    void *tlc_values = nullptr;
+    int32_t *tlc_row_map = nullptr, *tlc_cols = nullptr;     // (tlc_cols: the column indices in that order, for the few tiles that do not stage)
     // block (SpMMV) plan: 64-row tiles, per tile the list of X rows it touches (uspmv_dmat_optimize_block)
     bool bt = false;
     int bt_max_rows = 0, bt_tile_rows = 64;
@@ -215,6 +219,7 @@ struct Tuning {
     int spmmv_idx8 = 1;        // NEXT optimize_block: one-byte phase-local indices when every phase lists <= 256 rows
     int tlc_elem = 1;        // NEXT uspmv_dmat_optimize (host planner, one struct): when the 16-element-line plan stages fewer than half of the tiles, try the
                              // plan over single x elements (each distinct column of a tile gathered once into LDS) before the column-window sweep
+    int tlc_elem_rows = 1;   // ... when the element plan over the caller's row order fails too: 1 = deal the rows to the tiles by the matrix graph first (private value copy + row map)
     int tlc_elem_cap = 4096; // ... most elements a tile may list (4096: 32 KiB of doubles, local indices still fit 12 bits)
     int tlc_idx12 = 1;       // NEXT optimize: tile-local-column plans of <= 256 lines per tile also get their local indices packed to 12 bits: 0 = never,
                              // 1 = kept when the mean row length is >= 8, 2 = kept wherever it can be built
