@@ -200,7 +200,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_brick_lines")) g_tune.spmmv_brick_lines = value < 1 ? 1 : (int)value;
     else if (!strcmp(key, "spmmv_phase_dp")) g_tune.spmmv_phase_dp = value < 0 ? 0 : (int)value;
     else if (!strcmp(key, "tlc_elem")) g_tune.tlc_elem = value < 0 ? 0 : value > 2 ? 2 : (int)value;
-    else if (!strcmp(key, "tlc_elem_rows")) g_tune.tlc_elem_rows = value != 0;
+    else if (!strcmp(key, "tlc_elem_rows")) g_tune.tlc_elem_rows = value < 0 ? 0 : (int)value;
     else if (!strcmp(key, "tlc_elem_cap")) g_tune.tlc_elem_cap = value < 64 ? 64 : value > 16384 ? 16384 : (int)value;
     else if (!strcmp(key, "spmmv_stream")) g_tune.spmmv_stream = value < 0 ? 0 : value >= 99 ? 99 : value > 5 ? 5 : (int)value;
     else if (!strcmp(key, "spmmv_stream_waves")) g_tune.spmmv_stream_waves = value >= 5 ? 5 : 4;
@@ -677,7 +677,7 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     std::vector<int32_t> rr_map;
     bool reordered = false;
     if (!elem && !own_budget && (!p.valid || p.n_staged_tiles * 10 < p.n_tiles * 9) && g_tune.tlc_elem && g_tune.tlc_elem_rows && uspmv_dev::tl_measure_off == 0 &&
-        s->n_rows == s->n_cols && uspmv_scs_reorder_rows(s, 4, &rr, &rr_map) == 1) {
+        s->n_rows == s->n_cols && uspmv_scs_reorder_rows(s, g_tune.tlc_elem_rows == 4 ? 4 : 2, &rr, &rr_map, g_tune.tlc_elem_rows == 4 ? 64 : 256) == 1) {   // (balls for 256-row tiles; 4: the block plan's flat 64-row patches)
         uspmv_tlc_plan q;
         const int ecap = std::min(g_tune.tlc_elem_cap, (int)(64 * 1024 / (s->dtype == USPMV_F64 ? 8 : 4)));
         if (int rc = uspmv_build_tlc_plan(&rr, nullptr, ecap, 256, &q, /*line_shift=*/0)) return rc;

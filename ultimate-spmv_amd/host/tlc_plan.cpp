@@ -214,9 +214,10 @@ int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *o) {
 // are clustered independently (in parallel; a ball does not cross a segment's end).
 // seg_stride > 1: only every seg_stride-th segment is clustered (the others keep `base`): the trial run that decides whether the whole
 // matrix is worth it.  Returns the chunks per segment.
-static int64_t cluster_row_map(const uspmv_scs *s, const std::vector<int32_t> &base, int64_t window_chunks, std::vector<int32_t> *row_map, bool flat, int64_t seg_stride = 1) {
+static int64_t cluster_row_map(const uspmv_scs *s, const std::vector<int32_t> &base, int64_t window_chunks, std::vector<int32_t> *row_map, bool flat, int64_t seg_stride = 1,
+                               int64_t tile_rows = 64) {
     const int64_t C = s->C, nc = s->n_chunks, n_pad = nc * C;
-    const int64_t T = std::max<int64_t>(1, 64 / C);
+    const int64_t T = std::max<int64_t>(1, tile_rows / C);
     int64_t seg_chunks = std::max<int64_t>(window_chunks, T);
     while (seg_chunks * C < 65536) seg_chunks *= 2;
     const int64_t n_seg = (nc + seg_chunks - 1) / seg_chunks;
@@ -306,8 +307,8 @@ static int64_t cluster_row_map(const uspmv_scs *s, const std::vector<int32_t> &b
 
 // X rows the 64-row tiles of a sample (every `step`-th tile of every seg_stride-th segment of seg_tiles tiles) touch under a row order:
 // what a clustering is accepted or refused by
-static int64_t sample_tile_columns(const uspmv_scs *s, const std::vector<int32_t> &row_map, int64_t step, int64_t seg_tiles = 0, int64_t seg_stride = 1) {
-    const int64_t C = s->C, nc = s->n_chunks, T = std::max<int64_t>(1, 64 / C), n_tiles = (nc + T - 1) / T;
+static int64_t sample_tile_columns(const uspmv_scs *s, const std::vector<int32_t> &row_map, int64_t step, int64_t seg_tiles = 0, int64_t seg_stride = 1, int64_t tile_rows = 64) {
+    const int64_t C = s->C, nc = s->n_chunks, T = std::max<int64_t>(1, tile_rows / C), n_tiles = (nc + T - 1) / T;
     int64_t total = 0;
 #pragma omp parallel reduction(+ : total)
     {
@@ -429,7 +430,9 @@ static bool tie_row_map(const uspmv_scs *s, std::vector<int32_t> *row_map, int64
 
 // mode 1: tie re-ordering; mode 2 / 4: row clustering (balls / flat patches; kept only where a sample of tiles then touches fewer
 // X rows than under mode 1, which it falls back to); mode -1: copy under the caller's row_map
-int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vector<int32_t> *row_map) {
+// tile_rows: rows of the tiles the clusters are grown for (64: the block plan's; 256: the SpMV plan's, uspmv_dmat_optimize's fallback for unfriendly numberings)
+int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vector<int32_t> *row_map, int tile_rows) {
+    if (tile_rows < 64 || tile_rows % 64 != 0) tile_rows = 64;
     const int64_t C = s->C, nc = s->n_chunks;
     bool changed = false;
     const bool verbose = getenv("USPMV_VERBOSE") != nullptr;
@@ -443,24 +446,24 @@ int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vect
         // (clustering works on the caller's struct: there a column index below the row count IS a row position)
         if ((mode == 2 || mode == 4) && nc * C <= (int64_t)INT32_MAX) {
             std::vector<int32_t> cl((size_t)(nc * C));
-            const int64_t T = std::max<int64_t>(1, 64 / C), n_tiles = (nc + T - 1) / T;
+            const int64_t T = std::max<int64_t>(1, (int64_t)tile_rows / C), n_tiles = (nc + T - 1) / T;
             // a trial on every 16th segment first (matrices of more than 32 segments): irregular matrices, which gain nothing, stop there
             const int64_t seg_guess = (nc * C + 65535) / 65536;
             bool worth = true;
             if (seg_guess > 32) {
-                const int64_t seg_chunks = cluster_row_map(s, *row_map, cpw, &cl, mode == 4, 16), seg_tiles = std::max<int64_t>(1, seg_chunks / T);
+                const int64_t seg_chunks = cluster_row_map(s, *row_map, cpw, &cl, mode == 4, 16, tile_rows), seg_tiles = std::max<int64_t>(1, seg_chunks / T);
                 const int64_t step = std::max<int64_t>(1, seg_tiles / 128);
-                const int64_t before = sample_tile_columns(s, *row_map, step, seg_tiles, 16), after = sample_tile_columns(s, cl, step, seg_tiles, 16);
+                const int64_t before = sample_tile_columns(s, *row_map, step, seg_tiles, 16, tile_rows), after = sample_tile_columns(s, cl, step, seg_tiles, 16, tile_rows);
                 worth = after * 100 < before * 95;
                 if (verbose) fprintf(stderr, "[uspmv] block plan row clustering (mode %d), trial on every 16th segment: %lld X rows against %lld with the ties undone -> %s\n",
                                      mode, (long long)after, (long long)before, worth ? "go on" : "not worth it");
                 lap("trial segments");
             }
             if (worth) {
-                cluster_row_map(s, *row_map, cpw, &cl, mode == 4);
+                cluster_row_map(s, *row_map, cpw, &cl, mode == 4, 1, tile_rows);
                 lap("clusters grown");
                 const int64_t step = std::max<int64_t>(1, n_tiles / 2048);
-                const int64_t before = sample_tile_columns(s, *row_map, step), after = sample_tile_columns(s, cl, step);
+                const int64_t before = sample_tile_columns(s, *row_map, step, 0, 1, tile_rows), after = sample_tile_columns(s, cl, step, 0, 1, tile_rows);
                 if (verbose)
                     fprintf(stderr, "[uspmv] block plan row clustering (mode %d): sampled tiles touch %lld X rows against %lld with the ties undone -> %s\n", mode,
                             (long long)after, (long long)before, after * 100 < before * 95 ? "kept" : "not kept");
