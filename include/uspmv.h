@@ -179,7 +179,11 @@ void uspmv_dmat_free(uspmv_dmat_t *m);
  * from: per 256-row tile the list of 16-element x lines it touches plus 16-bit LDS-local
  * column indices.  uspmv_spmv then stages the x lines of a tile in LDS and streams 2-byte instead of
  * 4-byte indices (results unchanged, bit for bit).  Tiles touching more than max_lines lines (0 = default
- * 512) keep the gather path.  n_tiles / n_staged report the outcome (may be NULL). */
+ * 512) keep the gather path.  n_tiles / n_staged report the outcome (may be NULL).
+ * With max_lines = 0 the planner has three fallbacks when the line plan leaves a tenth of the tiles or more unstaged: the same
+ * plan over single x ELEMENTS (uspmv_dmat_plan_granularity = 1); that plan on rows dealt to the tiles by the matrix graph (a private copy of the values
+ * in HBM, y stored through a row map -- for matrices whose rows and columns are numbered alike but not coherently); the column-window sweep for wide
+ * irregular rows.  Every one of them walks each row's slots in the reference's order (scs_impl_cpu, code/kernels.hpp:218-258): same bits. */
 int uspmv_dmat_optimize(uspmv_dmat_t *m, const uspmv_scs_t *s, int max_lines, int64_t *n_tiles, int64_t *n_staged);
 /* Same for an ap[dp_sp] pair (structs with identical row layout): one shared line list per tile, 16-bit
  * indices for both structs; uspmv_spmv_ap then streams 10 + 6 instead of 12 + 8 bytes per non-zero. */
