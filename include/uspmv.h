@@ -228,6 +228,8 @@ int uspmv_dmat_block_plan_staged(const uspmv_dmat_t *m, int64_t *rows_staged);
  * to when a tile's columns are scattered over too many lines -- row numberings that are only locally coherent), 0 without such a plan.  Same kernel
  * arithmetic as scs_impl_cpu (code/kernels.hpp:218-258) either way. */
 int uspmv_dmat_plan_granularity(const uspmv_dmat_t *m, int *elements_per_list_entry);
+/* 1 when that plan runs on rows dealt to its tiles by the matrix graph (private value copy in HBM, y stored through a row map), else 0 */
+int uspmv_dmat_plan_rows_dealt(const uspmv_dmat_t *m, int *dealt);
 /* the phased block plan laid out as a flat schedule for persistent workgroups (tuning "spmmv_stream" > 0 at plan time; the streaming form of
  * block_spmv_omp_scs_general, code/kernels.hpp:306-398): meta[2] = workgroups of the launch (0: no schedule on the handle), phase descriptors */
 int uspmv_dmat_stream_info(const uspmv_dmat_t *m, int64_t meta[2]);

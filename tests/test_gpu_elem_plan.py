@@ -105,7 +105,7 @@ def test_rows_dealt_by_the_matrix_graph_then_the_element_plan(pkg, orc, t, C, si
     x[:s.n_rows] = pkg.apply_permutation(make_x(s.n_rows).astype(a["values"].dtype), a["new_to_old_idx"])
     want = orc.spmv_scs(C, s.n_chunks, a["chunk_ptrs"], a["chunk_lengths"], a["col_idxs"], a["values"], x)
     A = pkg.DeviceMatrix(s, tlc=True)
-    assert A.plan_granularity() == 1 and A.tlc_staged * 20 >= A.tlc_tiles * 19, (A.plan_granularity(), A.tlc_staged, A.tlc_tiles)
+    assert A.plan_granularity() == 1 and A.plan_rows_dealt() and A.tlc_staged * 20 >= A.tlc_tiles * 19, (A.plan_granularity(), A.tlc_staged, A.tlc_tiles)
     dx = t.from_numpy(x).cuda()
     for _ in range(2):
         dy = t.full((s.n_rows_padded,), -3.0, dtype=dx.dtype, device="cuda")
@@ -116,6 +116,7 @@ def test_rows_dealt_by_the_matrix_graph_then_the_element_plan(pkg, orc, t, C, si
         A0 = pkg.DeviceMatrix(s, tlc=True)
     finally:
         pkg.set_tuning(tlc_elem_rows=1)
+    assert not A0.plan_rows_dealt()
     dy = t.full((s.n_rows_padded,), -3.0, dtype=dx.dtype, device="cuda")
     pkg.spmv(A0, dx, dy)
     assert np.array_equal(dy.cpu().numpy()[:s.n_rows], want[:s.n_rows])

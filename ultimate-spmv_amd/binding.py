@@ -100,6 +100,7 @@ _SIGS = {
     "uspmv_dmat_block_plan_staged": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dmat_stream_info": (C.c_int, [_vp, C.POINTER(_i64)]),
     "uspmv_dmat_plan_granularity": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "uspmv_dmat_plan_rows_dealt": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "uspmv_dmat_optimize_sweep_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "uspmv_dmat_sweep_plan_digest": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(_i64)]),
     "uspmv_spmmv": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp]),
@@ -872,6 +873,12 @@ class DeviceMatrix:
         g = C.c_int()
         _ck(lib().uspmv_dmat_plan_granularity(self.h, C.byref(g)))
         return g.value
+
+    def plan_rows_dealt(self):
+        """True when the tile-local-column plan runs on rows dealt to its tiles by the matrix graph (uspmv_dmat_plan_rows_dealt)."""
+        g = C.c_int()
+        _ck(lib().uspmv_dmat_plan_rows_dealt(self.h, C.byref(g)))
+        return bool(g.value)
 
     def index_bits(self):
         """Bits per tile-local column index the plan's kernel streams (16 | 12; 0 without a plan): uspmv_dmat_index_bits."""

@@ -1826,6 +1826,13 @@ int uspmv_dmat_plan_granularity(const uspmv_dmat_t *A, int *elements_per_list_en
     return USPMV_OK;
 }
 
+int uspmv_dmat_plan_rows_dealt(const uspmv_dmat_t *A, int *dealt) {
+    if (!A || !dealt) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_plan_rows_dealt: NULL argument");
+    const uspmv_dmat_t *M = (A->alt && g_tune.rechunk) ? A->alt : A;
+    *dealt = M->tlc && M->tlc_row_map != nullptr;
+    return USPMV_OK;
+}
+
 int uspmv_dmat_stream_info(const uspmv_dmat_t *A, int64_t meta[2]) {
     if (!A || !meta) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_stream_info: NULL argument");
     const uspmv_dmat_t *M = (A->alt && g_tune.rechunk) ? A->alt : A;

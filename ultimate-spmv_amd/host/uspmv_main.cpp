@@ -300,7 +300,10 @@ int run(const Config &c, uspmv_coo_t *coo) {
         if (ap) ck(uspmv_dmat_optimize_ap(r.A, r.A_sp, scs, scs_sp, 0, &nt, &ns), "uspmv_dmat_optimize_ap");
         else if (device_A) ck(uspmv_dmat_optimize_device(r.A, 0, &nt, &ns), "uspmv_dmat_optimize_device");   // (no host entries: the plan is built on the device too)
         else ck(uspmv_dmat_optimize(r.A, scs, 0, &nt, &ns), "uspmv_dmat_optimize");
-        printf("tile-local-column plan: %ld of %ld tiles staged in LDS\n", (long)ns, (long)nt);
+        int gran = 0, dealt = 0;
+        (void)uspmv_dmat_plan_granularity(r.A, &gran); (void)uspmv_dmat_plan_rows_dealt(r.A, &dealt);
+        printf("tile-local-column plan: %ld of %ld tiles staged in LDS%s%s\n", (long)ns, (long)nt, gran == 1 ? " (lists of single x elements)" : "",
+               dealt ? ", rows dealt to the tiles by the matrix graph" : "");
     } else if (c.tlc && b > 1 && !ap && (size_t)b * sizeof(VT) <= 32) {   // block plan pays for rows of <= 32 bytes
         int64_t nt = 0, ns = 0;
         if (device_A) ck(uspmv_dmat_optimize_block_device(r.A, b, &nt, &ns), "uspmv_dmat_optimize_block_device");
