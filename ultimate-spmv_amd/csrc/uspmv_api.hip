@@ -610,6 +610,23 @@ static int tlc_pack12(uspmv_dmat_t *A, const std::vector<int32_t> *cl, const cha
     return USPMV_OK;
 }
 
+// A quick look before an element plan is built in full (a sort per tile over all entries): of ~64 tiles spread over the struct, how many list more distinct
+// columns than `cap`?  true: more than a tenth of them -- the element plan would be turned down anyway (wide irregular rows: the sweep's matrices).
+static bool elements_over_cap(const uspmv_scs_t *s, int cap, int tile_rows) {
+    const int64_t C = s->C, T = std::max<int64_t>(1, tile_rows / C), nt = (s->n_chunks + T - 1) / T;
+    const int64_t step = std::max<int64_t>(1, nt / 64);
+    int64_t seen = 0, over = 0;
+    std::vector<int32_t> cols;
+    for (int64_t t = step / 2; t < nt; t += step) {
+        const int64_t c0 = t * T, c1 = std::min<int64_t>(c0 + T, s->n_chunks);
+        cols.assign(s->col_idxs.begin() + s->chunk_ptrs[(size_t)c0], s->col_idxs.begin() + s->chunk_ptrs[(size_t)c1]);
+        std::sort(cols.begin(), cols.end());
+        const int64_t n = (int64_t)(std::unique(cols.begin(), cols.end()) - cols.begin());
+        ++seen; over += n > cap;
+    }
+    return seen > 0 && over * 10 > seen;
+}
+
 int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
     if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: NULL argument");
     if (!uspmv::scs_has_entries(s)) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: layout-only struct; the plan builder needs the host column indices");
@@ -660,7 +677,8 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
         // on a regular numbering the line plan is 20 % ahead (0.683 against 0.819 ms on the 253^3 stencil), which is why this is a fallback only.
         uspmv_tlc_plan q;
         const int ecap = std::min(g_tune.tlc_elem_cap, (int)(64 * 1024 / (s->dtype == USPMV_F64 ? 8 : 4)));
-        if (int rc = uspmv_build_tlc_plan(s, nullptr, ecap, 256, &q, /*line_shift=*/0)) return rc;
+        if (!elements_over_cap(s, ecap, 256))
+            if (int rc = uspmv_build_tlc_plan(s, nullptr, ecap, 256, &q, /*line_shift=*/0)) return rc;
         if (q.valid && tile_rows_accept(q.n_tiles, q.n_staged_tiles) && ((double)q.tile_lines.size() * 4.0 <= (double)s->n_elements || g_tune.tlc_elem == 2)) {
             p = std::move(q); elem = true;
             if (n_tiles) *n_tiles = p.n_tiles;
@@ -680,7 +698,8 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
         s->n_rows == s->n_cols && uspmv_scs_reorder_rows(s, g_tune.tlc_elem_rows == 4 ? 4 : 2, &rr, &rr_map, g_tune.tlc_elem_rows == 4 ? 64 : 256) == 1) {   // (balls for 256-row tiles; 4: the block plan's flat 64-row patches)
         uspmv_tlc_plan q;
         const int ecap = std::min(g_tune.tlc_elem_cap, (int)(64 * 1024 / (s->dtype == USPMV_F64 ? 8 : 4)));
-        if (int rc = uspmv_build_tlc_plan(&rr, nullptr, ecap, 256, &q, /*line_shift=*/0)) return rc;
+        if (!elements_over_cap(&rr, ecap, 256))
+            if (int rc = uspmv_build_tlc_plan(&rr, nullptr, ecap, 256, &q, /*line_shift=*/0)) return rc;
         if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] element plan on the graph-dealt rows: valid=%d tiles=%lld staged=%lld max_elements=%d (cap %d) elements_total=%zu\n", (int)q.valid,
                                              (long long)q.n_tiles, (long long)q.n_staged_tiles, q.max_lines_used, ecap, q.tile_lines.size());
         // (19 of 20 tiles staged is enough here: what would run instead -- sweep or gather kernel -- is 2 x slower on such matrices)
