@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--tune", default="", help="key=value,... forwarded to uspmv_set_tuning")
     ap.add_argument("--no-tlc", action="store_true", help="skip the tile-local-column plan (plain gather kernel)")
     ap.add_argument("--no-traffic", action="store_true", help="N = 1: do not run the two rocprofv3 PMC child passes (roofline.traffic then comes from profiles/traffic.json)")
-    ap.add_argument("--other-configs", default="3,4b,2k,5one", help="N = 1: further configurations measured after the headline and reported under \"other_configs\" (3 = Queen_4147-class SpMMV b = 8, both layouts; 4b = HV15R-class ap[dp_sp] and dp; 2k = nlpkkt200-class KKT matrix; 5one = config 5's 304^3 matrix on one GPU); \"\" = none")
+    ap.add_argument("--other-configs", default="3,4b,2k,3s,5one", help="N = 1: further configurations measured after the headline and reported under \"other_configs\" (3 = Queen_4147-class SpMMV b = 8, both layouts; 4b = HV15R-class ap[dp_sp] and dp; 2k = nlpkkt200-class KKT matrix; 3s = the Queen-class stencil in a numbering scrambled inside blocks of 20 000 nodes, SpMV; 5one = config 5's 304^3 matrix on one GPU); \"\" = none")
     ap.add_argument("--kkt", type=int, default=200, help="config 2k: grid edge N of uspmv_gen_kkt")
     ap.add_argument("--grid5", type=int, default=304, help="config 5one: stencil grid edge")
     ap.add_argument("--grid3", type=int, default=111, help="config 3: nodes per edge (3 dof per node)")
@@ -247,7 +247,8 @@ def other_configs(pkg, B, torch, args, which):
         cpu, same = _cpu_leg(2.0 * s.nnz, fr or fp, fp, yc, y.cpu().numpy(), args.cpu_seconds / 3, "spmv_omp_scs_adv<C=32,double>")
         kind, ntile, nplan = A.plan_info()
         line(config, workload + " scs -c 32 -s 512 -dp", {2: "scs_spmv_sweep<double> (column-window sweep)", 1: "scs_spmv_tlc<double,32>", 0: "scs_spmv_rows<double,32,8>"}[kind],
-             wall, k_ms, byts, 2.0 * s.nnz, same, cpu, setup, {"plan_kind": kind, "plan_tiles_planned": [nplan, ntile], "rows_per_tile": (s.n_rows_padded // ntile) if ntile else None, "local_index_bits": A.index_bits() if kind == 1 else None})
+             wall, k_ms, byts, 2.0 * s.nnz, same, cpu, setup, {"plan_kind": kind, "plan_tiles_planned": [nplan, ntile], "rows_per_tile": (s.n_rows_padded // ntile) if ntile else None, "local_index_bits": A.index_bits() if kind == 1 else None,
+              "x_elements_per_list_entry": A.plan_granularity() if kind == 1 else None, "rows_dealt_by_the_matrix_graph": A.plan_rows_dealt() if kind == 1 else None})
         del A, s, a, x, y
         t.cuda.empty_cache()
 
@@ -336,6 +337,28 @@ def other_configs(pkg, B, torch, args, which):
         coo = pkg.gen_kkt(N)
         spmv_config("2k", f"nlpkkt200-class KKT [H A^T; A 0] synthetic (uspmv_gen_kkt N={N}: n={coo.n_rows}, nnz={coo.nnz}, rows of 5-28 entries in two index ranges N^3 apart)", coo)
         del coo
+    if "3s" in which:
+        # the Queen_4147-class stencil (80^3 nodes x 3 dof) with its NODES renumbered at random inside consecutive blocks of 20 000 nodes, rows and columns
+        # alike: a numbering that is only locally coherent.  SpMV: the planner deals the rows to the tiles by the matrix graph and lists
+        # single x elements.  A failure here costs this line only.
+        try:
+            g3s, dof, Kb = 80, 3, 20000
+            base = pkg.gen_stencil27(g3s, g3s, g3s, dof=dof)
+            I0, J0, V0 = (np.array(v) for v in base.arrays())
+            nrow = base.n_rows
+            del base
+            rng = np.random.default_rng(7)
+            pn = np.arange(nrow // dof, dtype=np.int64)
+            for s0 in range(0, pn.size, Kb):
+                seg = pn[s0:s0 + Kb].copy(); rng.shuffle(seg); pn[s0:s0 + Kb] = seg
+            I1 = (pn[I0 // dof] * dof + I0 % dof).astype(np.int32); J1 = (pn[J0 // dof] * dof + J0 % dof).astype(np.int32)
+            o = np.lexsort((J1, I1))
+            coo = pkg.Coo.from_arrays(nrow, nrow, I1[o], J1[o], V0[o])
+            del I0, J0, V0, I1, J1, o
+            spmv_config("3s", f"Queen_4147-class stencil ({g3s}^3 nodes x {dof} dof, n={coo.n_rows}, nnz={coo.nnz}) with its nodes renumbered at random inside blocks of {Kb} nodes (rows and columns alike), single vector", coo)
+            del coo
+        except Exception as e:   # noqa: BLE001 -- an informational line must not take the others with it
+            res.append({"config": "3s", "error": f"{type(e).__name__}: {e}"})
     if "5one" in which:
         g = args.grid5
         coo = pkg.gen_stencil27(g, g, g)
