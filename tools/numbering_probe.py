@@ -13,6 +13,7 @@ pkg = ge.load_package()
 from ultimate_spmv_amd import binding as B
 torch.cuda.set_device(0)
 if os.environ.get("TLC_ELEM") is not None: pkg.set_tuning(tlc_elem=int(os.environ["TLC_ELEM"]))
+if os.environ.get("TLC_ELEM_SEG") is not None: pkg.set_tuning(tlc_elem_seg_rows=int(os.environ["TLC_ELEM_SEG"]))
 if os.environ.get("TLC_ELEM_ROWS") is not None: pkg.set_tuning(tlc_elem_rows=int(os.environ["TLC_ELEM_ROWS"]))      # 1: balls for 256-row tiles, 4: the block plan's 64-row patches, 0: off
 g = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 Ks = [int(k) for k in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,64,1000,20000".split(","))]

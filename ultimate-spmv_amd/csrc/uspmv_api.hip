@@ -201,6 +201,7 @@ int uspmv_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "spmmv_phase_dp")) g_tune.spmmv_phase_dp = value < 0 ? 0 : (int)value;
     else if (!strcmp(key, "tlc_elem")) g_tune.tlc_elem = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (!strcmp(key, "tlc_elem_rows")) g_tune.tlc_elem_rows = value < 0 ? 0 : (int)value;
+    else if (!strcmp(key, "tlc_elem_seg_rows")) g_tune.tlc_elem_seg_rows = value < 65536 ? 65536 : (int)value;
     else if (!strcmp(key, "tlc_elem_cap")) g_tune.tlc_elem_cap = value < 64 ? 64 : value > 16384 ? 16384 : (int)value;
     else if (!strcmp(key, "spmmv_stream")) g_tune.spmmv_stream = value < 0 ? 0 : value >= 99 ? 99 : value > 5 ? 5 : (int)value;
     else if (!strcmp(key, "spmmv_stream_waves")) g_tune.spmmv_stream_waves = value >= 5 ? 5 : 4;
@@ -280,6 +281,7 @@ int uspmv_get_tuning(const char *key, int *value) {
     else if (!strcmp(key, "spmmv_phase_dp")) *value = g_tune.spmmv_phase_dp;
     else if (!strcmp(key, "tlc_elem")) *value = g_tune.tlc_elem;
     else if (!strcmp(key, "tlc_elem_rows")) *value = g_tune.tlc_elem_rows;
+    else if (!strcmp(key, "tlc_elem_seg_rows")) *value = g_tune.tlc_elem_seg_rows;
     else if (!strcmp(key, "tlc_elem_cap")) *value = g_tune.tlc_elem_cap;
     else if (!strcmp(key, "spmmv_stream")) *value = g_tune.spmmv_stream;
     else if (!strcmp(key, "spmmv_stream_xcd")) *value = g_tune.spmmv_stream_xcd;
@@ -612,7 +614,7 @@ static int tlc_pack12(uspmv_dmat_t *A, const std::vector<int32_t> *cl, const cha
 
 // A quick look before an element plan is built in full (a sort per tile over all entries): of ~64 tiles spread over the struct, how many list more distinct
 // columns than `cap`?  true: more than a tenth of them -- the element plan would be turned down anyway (wide irregular rows: the sweep's matrices).
-static bool elements_over_cap(const uspmv_scs_t *s, int cap, int tile_rows) {
+static double elements_over_cap_frac(const uspmv_scs_t *s, int cap, int tile_rows) {
     const int64_t C = s->C, T = std::max<int64_t>(1, tile_rows / C), nt = (s->n_chunks + T - 1) / T;
     const int64_t step = std::max<int64_t>(1, nt / 64);
     int64_t seen = 0, over = 0;
@@ -624,8 +626,9 @@ static bool elements_over_cap(const uspmv_scs_t *s, int cap, int tile_rows) {
         const int64_t n = (int64_t)(std::unique(cols.begin(), cols.end()) - cols.begin());
         ++seen; over += n > cap;
     }
-    return seen > 0 && over * 10 > seen;
+    return seen > 0 ? (double)over / (double)seen : 1.0;
 }
+static bool elements_over_cap(const uspmv_scs_t *s, int cap, int tile_rows) { return elements_over_cap_frac(s, cap, tile_rows) > 0.1; }
 
 int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, int64_t *n_tiles, int64_t *n_staged) {
     if (!A || !s) return uspmv::fail(USPMV_ERR_INVALID, "uspmv_dmat_optimize: NULL argument");
@@ -694,21 +697,29 @@ int uspmv_dmat_optimize(uspmv_dmat_t *A, const uspmv_scs_t *s, int max_lines, in
     uspmv_scs rr;
     std::vector<int32_t> rr_map;
     bool reordered = false;
-    if (!elem && !own_budget && (!p.valid || p.n_staged_tiles * 10 < p.n_tiles * 9) && g_tune.tlc_elem && g_tune.tlc_elem_rows && uspmv_dev::tl_measure_off == 0 &&
-        s->n_rows == s->n_cols && uspmv_scs_reorder_rows(s, g_tune.tlc_elem_rows == 4 ? 4 : 2, &rr, &rr_map, g_tune.tlc_elem_rows == 4 ? 64 : 256) == 1) {   // (balls for 256-row tiles; 4: the block plan's flat 64-row patches)
-        uspmv_tlc_plan q;
+    if (!elem && !own_budget && (!p.valid || p.n_staged_tiles * 10 < p.n_tiles * 9) && g_tune.tlc_elem && g_tune.tlc_elem_rows && uspmv_dev::tl_measure_off == 0 && s->n_rows == s->n_cols) {
         const int ecap = std::min(g_tune.tlc_elem_cap, (int)(64 * 1024 / (s->dtype == USPMV_F64 ? 8 : 4)));
-        if (!elements_over_cap(&rr, ecap, 256))
-            if (int rc = uspmv_build_tlc_plan(&rr, nullptr, ecap, 256, &q, /*line_shift=*/0)) return rc;
-        if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] element plan on the graph-dealt rows: valid=%d tiles=%lld staged=%lld max_elements=%d (cap %d) elements_total=%zu\n", (int)q.valid,
-                                             (long long)q.n_tiles, (long long)q.n_staged_tiles, q.max_lines_used, ecap, q.tile_lines.size());
-        // (19 of 20 tiles staged is enough here: what would run instead -- sweep or gather kernel -- is 2 x slower on such matrices)
-        if (q.valid && q.n_staged_tiles * 20 >= q.n_tiles * 19 && (double)q.tile_lines.size() * 4.0 <= (double)s->n_elements) {
-            p = std::move(q); elem = true; reordered = true;
-            if (n_tiles) *n_tiles = p.n_tiles;
-            if (n_staged) *n_staged = p.n_staged_tiles;
-            if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] tlc plan over single x elements, rows dealt to the tiles by the matrix graph: tiles=%lld max_elements=%d elements_total=%zu (%.1f entries per element)\n",
-                                                 (long long)p.n_tiles, p.max_lines_used, p.tile_lines.size(), (double)s->n_elements / (double)std::max<size_t>(p.tile_lines.size(), 1));
+        // first with the clusters confined to segments of tlc_elem_seg_rows rows (64 Ki: many segments in parallel, and a trial on a sample of them that stops
+        // irregular matrices early); when that leaves some, but not most, of the sampled tiles over the cap -- related rows further apart than a segment --
+        // once more with segments of 2^20 rows (a second or more of clustering per million rows on few threads: only where it looks promising)
+        const int64_t seg_stage[2] = {(int64_t)g_tune.tlc_elem_seg_rows, (int64_t)1 << 20};
+        for (int stage = 0; stage < 2 && !reordered; ++stage) {
+            if (stage == 1 && seg_stage[1] <= seg_stage[0]) break;
+            if (uspmv_scs_reorder_rows(s, g_tune.tlc_elem_rows == 4 ? 4 : 2, &rr, &rr_map, g_tune.tlc_elem_rows == 4 ? 64 : 256, seg_stage[stage]) != 1) break;
+            const double over = elements_over_cap_frac(&rr, ecap, 256);
+            uspmv_tlc_plan q;
+            if (over <= 0.1)
+                if (int rc = uspmv_build_tlc_plan(&rr, nullptr, ecap, 256, &q, /*line_shift=*/0)) return rc;
+            if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] element plan on the graph-dealt rows (segments of %lld rows): %.0f %% of the sampled tiles over the cap; valid=%d tiles=%lld staged=%lld max_elements=%d (cap %d) elements_total=%zu\n",
+                                                 (long long)seg_stage[stage], 100.0 * over, (int)q.valid, (long long)q.n_tiles, (long long)q.n_staged_tiles, q.max_lines_used, ecap, q.tile_lines.size());
+            // (19 of 20 tiles staged is enough here: what would run instead -- sweep or gather kernel -- is 2 x slower on such matrices)
+            if (q.valid && q.n_staged_tiles * 20 >= q.n_tiles * 19 && (double)q.tile_lines.size() * 4.0 <= (double)s->n_elements) {
+                p = std::move(q); elem = true; reordered = true;
+                if (n_tiles) *n_tiles = p.n_tiles;
+                if (n_staged) *n_staged = p.n_staged_tiles;
+                if (getenv("USPMV_VERBOSE")) fprintf(stderr, "[uspmv] tlc plan over single x elements, rows dealt to the tiles by the matrix graph: tiles=%lld max_elements=%d elements_total=%zu (%.1f entries per element)\n",
+                                                     (long long)p.n_tiles, p.max_lines_used, p.tile_lines.size(), (double)s->n_elements / (double)std::max<size_t>(p.tile_lines.size(), 1));
+            } else if (over > 0.6) break;                    // most tiles far over the cap: larger segments will not repair that
         }
     }
     if (!elem && (!p.valid || p.n_staged_tiles * 2 < p.n_tiles) && g_tune.sweep) {

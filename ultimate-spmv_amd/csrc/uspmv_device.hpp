@@ -220,6 +220,7 @@ struct Tuning {
     int tlc_elem = 1;        // NEXT uspmv_dmat_optimize (host planner, one struct): when the 16-element-line plan stages fewer than half of the tiles, try the
                              // plan over single x elements (each distinct column of a tile gathered once into LDS) before the column-window sweep
     int tlc_elem_rows = 1;   // ... when the element plan over the caller's row order fails too: 1 = deal the rows to the tiles by the matrix graph first (private value copy + row map)
+    int tlc_elem_seg_rows = 65536;  // ... rows of the segments the row dealing clusters independently (larger: numberings that scatter related rows further apart)
     int tlc_elem_cap = 4096; // ... most elements a tile may list (4096: 32 KiB of doubles, local indices still fit 12 bits)
     int tlc_idx12 = 1;       // NEXT optimize: tile-local-column plans of <= 256 lines per tile also get their local indices packed to 12 bits: 0 = never,
                              // 1 = kept when the mean row length is >= 8, 2 = kept wherever it can be built

@@ -215,11 +215,11 @@ int uspmv_scs_rechunk32(const uspmv_scs *s, uspmv_scs *o) {
 // seg_stride > 1: only every seg_stride-th segment is clustered (the others keep `base`): the trial run that decides whether the whole
 // matrix is worth it.  Returns the chunks per segment.
 static int64_t cluster_row_map(const uspmv_scs *s, const std::vector<int32_t> &base, int64_t window_chunks, std::vector<int32_t> *row_map, bool flat, int64_t seg_stride = 1,
-                               int64_t tile_rows = 64) {
+                               int64_t tile_rows = 64, int64_t seg_rows = 65536) {
     const int64_t C = s->C, nc = s->n_chunks, n_pad = nc * C;
     const int64_t T = std::max<int64_t>(1, tile_rows / C);
     int64_t seg_chunks = std::max<int64_t>(window_chunks, T);
-    while (seg_chunks * C < 65536) seg_chunks *= 2;
+    while (seg_chunks * C < seg_rows) seg_chunks *= 2;
     const int64_t n_seg = (nc + seg_chunks - 1) / seg_chunks;
     if (seg_stride > 1) *row_map = base;
     std::vector<char> assigned((size_t)n_pad, 0);
@@ -431,8 +431,11 @@ static bool tie_row_map(const uspmv_scs *s, std::vector<int32_t> *row_map, int64
 // mode 1: tie re-ordering; mode 2 / 4: row clustering (balls / flat patches; kept only where a sample of tiles then touches fewer
 // X rows than under mode 1, which it falls back to); mode -1: copy under the caller's row_map
 // tile_rows: rows of the tiles the clusters are grown for (64: the block plan's; 256: the SpMV plan's, uspmv_dmat_optimize's fallback for unfriendly numberings)
-int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vector<int32_t> *row_map, int tile_rows) {
+// seg_rows: rows of the segments that are clustered independently of each other (a cluster does not cross a segment's end; 64 Ki by default: many
+// segments in parallel; larger: numberings that scatter related rows further apart, fewer threads at work)
+int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vector<int32_t> *row_map, int tile_rows, int64_t seg_rows) {
     if (tile_rows < 64 || tile_rows % 64 != 0) tile_rows = 64;
+    if (seg_rows < 65536) seg_rows = 65536;
     const int64_t C = s->C, nc = s->n_chunks;
     bool changed = false;
     const bool verbose = getenv("USPMV_VERBOSE") != nullptr;
@@ -448,10 +451,10 @@ int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vect
             std::vector<int32_t> cl((size_t)(nc * C));
             const int64_t T = std::max<int64_t>(1, (int64_t)tile_rows / C), n_tiles = (nc + T - 1) / T;
             // a trial on every 16th segment first (matrices of more than 32 segments): irregular matrices, which gain nothing, stop there
-            const int64_t seg_guess = (nc * C + 65535) / 65536;
+            const int64_t seg_guess = (nc * C + seg_rows - 1) / seg_rows;
             bool worth = true;
             if (seg_guess > 32) {
-                const int64_t seg_chunks = cluster_row_map(s, *row_map, cpw, &cl, mode == 4, 16, tile_rows), seg_tiles = std::max<int64_t>(1, seg_chunks / T);
+                const int64_t seg_chunks = cluster_row_map(s, *row_map, cpw, &cl, mode == 4, 16, tile_rows, seg_rows), seg_tiles = std::max<int64_t>(1, seg_chunks / T);
                 const int64_t step = std::max<int64_t>(1, seg_tiles / 128);
                 const int64_t before = sample_tile_columns(s, *row_map, step, seg_tiles, 16, tile_rows), after = sample_tile_columns(s, cl, step, seg_tiles, 16, tile_rows);
                 worth = after * 100 < before * 95;
@@ -460,7 +463,7 @@ int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vect
                 lap("trial segments");
             }
             if (worth) {
-                cluster_row_map(s, *row_map, cpw, &cl, mode == 4, 1, tile_rows);
+                cluster_row_map(s, *row_map, cpw, &cl, mode == 4, 1, tile_rows, seg_rows);
                 lap("clusters grown");
                 const int64_t step = std::max<int64_t>(1, n_tiles / 2048);
                 const int64_t before = sample_tile_columns(s, *row_map, step, 0, 1, tile_rows), after = sample_tile_columns(s, cl, step, 0, 1, tile_rows);

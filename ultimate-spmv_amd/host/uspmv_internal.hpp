@@ -158,7 +158,7 @@ int uspmv_scs_classify_chunks(const uspmv_scs *s, int64_t n_local, std::vector<u
 int uspmv_scs_reorder_ties(const uspmv_scs *s, uspmv_scs *r, std::vector<int32_t> *row_map);   // host/tlc_plan.cpp
 // mode 1 = the above; mode 2 = rows re-dealt to the 64-row tiles as breadth-first balls of the matrix graph (per chunk-length
 // class, so the chunk structure is still untouched); mode -1 = copy under the caller's row_map
-int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vector<int32_t> *row_map, int tile_rows = 64);   // host/tlc_plan.cpp
+int uspmv_scs_reorder_rows(const uspmv_scs *s, int mode, uspmv_scs *r, std::vector<int32_t> *row_map, int tile_rows = 64, int64_t seg_rows = 65536);   // host/tlc_plan.cpp
 int uspmv_scs_reorder_bricks(const uspmv_scs *s, int64_t stride, int64_t lines, uspmv_scs *r, std::vector<int32_t> *row_map);   // host/tlc_plan.cpp (measurement aid)
 
 int uspmv_scs_layout(const uspmv_coo *m, int64_t C, int64_t sigma, int dtype, const int32_t *fixed_permutation,
